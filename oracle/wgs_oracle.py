@@ -1,0 +1,188 @@
+"""wgs_oracle.py — TEST INFRASTRUCTURE (oracle).
+
+Plain PyTorch-CPU fp32 restatements of the reference algorithms on the hot path.  Functional style:
+every function takes the weights as a dict keyed exactly like the reference's `state_dict()` so the
+same tensors can be fed to the reference modules (when generating golden vectors in the build
+container, tools/make_golden.py), to this oracle, and to the HIP product path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Citations are file:line under the reference tree.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# =================================================================================================
+# RBF warping field — lib/support_sets.py:81-101
+# =================================================================================================
+def support_sets_forward(sd, mask, z, learn_gammas, gamma):
+    """sd: {'SUPPORT_SETS','ALPHAS','LOGGAMMA'}; mask [B,K] one-hot; z [B,d] -> unit field [B,d]."""
+    K, two_n_d = sd['SUPPORT_SETS'].shape
+    n2 = sd['ALPHAS'].shape[1]
+    d = two_n_d // n2
+    sv = (mask @ sd['SUPPORT_SETS']).reshape(-1, n2, d)              # :83-84
+    alphas = (mask @ sd['ALPHAS']).unsqueeze(2)                       # :87
+    if learn_gammas:
+        gammas = torch.exp(mask @ sd['LOGGAMMA']).unsqueeze(2)        # :90-91
+    else:
+        gammas = gamma * torch.ones(z.shape[0], n2, 1)                # :93
+    D = z.unsqueeze(1).repeat(1, n2, 1) - sv                          # :96
+    r2 = (torch.norm(D, dim=2) ** 2).unsqueeze(2)
+    grad_f = -2 * (alphas * gammas * torch.exp(-gammas * r2) * D).sum(dim=1)   # :97-98
+    return grad_f / torch.norm(grad_f, dim=1, keepdim=True)          # :101
+
+
+def support_sets_init(K, N, d, gamma, generator=None):
+    """State dict with the reference's initialisation law (lib/support_sets.py:35-79): radii
+    arange(1,4,3/K), N random antipodal pairs per set, alphas +1/-1, loggamma = log(gamma)."""
+    radii = torch.arange(1.0, 4.0, 3.0 / K)[:K]
+    v = torch.randn(K, N, d, generator=generator)
+    v = v / v.norm(dim=2, keepdim=True)
+    sv = torch.stack([v, -v], dim=2).reshape(K, 2 * N, d) * radii.view(K, 1, 1)
+    alphas = torch.tensor([1.0, -1.0]).repeat(N).unsqueeze(0).repeat(K, 1)
+    return {'SUPPORT_SETS': sv.reshape(K, 2 * N * d).contiguous(), 'ALPHAS': alphas.contiguous(),
+            'LOGGAMMA': math.log(gamma) * torch.ones(K, 1)}
+
+
+_rbf_c = None
+
+
+def rbf_c_lib():
+    """The plain-C fp64 restatement (oracle/rbf_ref.c), built by __graft_entry__.build()."""
+    global _rbf_c
+    if _rbf_c is None:
+        path = os.path.join(_HERE, '_build', 'librbf_ref.so')
+        if not os.path.isfile(path):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            import subprocess
+            subprocess.check_call(['gcc', '-O2', '-shared', '-fPIC', os.path.join(_HERE, 'rbf_ref.c'),
+                                   '-o', path, '-lm'])
+        _rbf_c = ctypes.CDLL(path)
+    return _rbf_c
+
+
+def _np32(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+
+
+def rbf_c_forward(sd, idx, z, learn_gammas, gamma):
+    lib = rbf_c_lib()
+    table, alphas = _np32(sd['SUPPORT_SETS']), _np32(sd['ALPHAS'])
+    lg = _np32(sd['LOGGAMMA'].reshape(-1)) if learn_gammas else None
+    idx = np.ascontiguousarray(idx.cpu().numpy().astype(np.int64))
+    zz = _np32(z)
+    B, d = zz.shape
+    K, n2 = alphas.shape
+    out = np.zeros((B, d), np.float64)
+    graw = np.zeros((B, d), np.float64)
+    P = ctypes.c_void_p
+    lib.rbf_ref_forward(P(table.ctypes.data), P(alphas.ctypes.data), P(lg.ctypes.data if lg is not None else 0),
+                        ctypes.c_double(gamma), P(idx.ctypes.data), P(zz.ctypes.data), P(out.ctypes.data),
+                        P(graw.ctypes.data), B, K, n2, d)
+    return out, graw
+
+
+def rbf_c_backward(sd, idx, z, gout, learn_gammas, gamma):
+    lib = rbf_c_lib()
+    table, alphas = _np32(sd['SUPPORT_SETS']), _np32(sd['ALPHAS'])
+    lg = _np32(sd['LOGGAMMA'].reshape(-1)) if learn_gammas else None
+    idx = np.ascontiguousarray(idx.cpu().numpy().astype(np.int64))
+    zz, go = _np32(z), _np32(gout)
+    B, d = zz.shape
+    K, n2 = alphas.shape
+    dtable = np.zeros((K, n2 * d), np.float64)
+    dal = np.zeros((K, n2), np.float64)
+    dlg = np.zeros((K,), np.float64)
+    dz = np.zeros((B, d), np.float64)
+    P = ctypes.c_void_p
+    lib.rbf_ref_backward(P(table.ctypes.data), P(alphas.ctypes.data), P(lg.ctypes.data if lg is not None else 0),
+                         ctypes.c_double(gamma), P(idx.ctypes.data), P(zz.ctypes.data), P(go.ctypes.data),
+                         P(dtable.ctypes.data), P(dal.ctypes.data), P(dlg.ctypes.data), P(dz.ctypes.data),
+                         B, K, n2, d)
+    return dtable, dal, dlg, dz
+
+
+def traverse_paths(sd, codes, eps, T, learn_gammas, gamma):
+    """All-K latent walks, traverse_latent_space.py:361-438 with shift_leap = 1:
+    returns (path [n,K,2T+1,d], shift [n,K,2T+1,d])."""
+    K = sd['ALPHAS'].shape[0]
+    n, d = codes.shape
+    path = torch.zeros(n, K, 2 * T + 1, d)
+    shift = torch.zeros(n, K, 2 * T + 1, d)
+    for c in range(n):
+        for k in range(K):
+            mask = torch.zeros(1, K)
+            mask[0, k] = 1.0
+            path[c, k, T] = codes[c]
+            for sign, step_idx in ((1.0, lambda t: T + t), (-1.0, lambda t: T - t)):
+                zc = codes[c:c + 1].clone()
+                for t in range(1, T + 1):
+                    sh = sign * eps * support_sets_forward(sd, mask, zc, learn_gammas, gamma)
+                    zc = zc + sh
+                    path[c, k, step_idx(t)] = zc[0]
+                    shift[c, k, step_idx(t)] = sh[0]
+    return path, shift
+
+
+# =================================================================================================
+# StyleGAN2 native ops — models/StyleGAN2/op/*
+# =================================================================================================
+def fused_bias_act(x, bias=None, ref=None, act=3, grad=0, alpha=0.2, scale=2 ** 0.5):
+    """fused_bias_act_kernel.cu:25-47: y = act(x + b[channel dim 1]) * scale."""
+    if bias is not None and bias.numel():
+        x = x + bias.view(1, -1, *([1] * (x.ndim - 2)))
+    mode = act * 10 + grad
+    if mode in (10, 11):
+        y = x
+    elif mode in (12, 32):
+        y = torch.zeros_like(x)
+    elif mode == 30:
+        y = torch.where(x > 0, x, x * alpha)
+    elif mode == 31:
+        y = torch.where(ref > 0, x, x * alpha)
+    else:
+        y = x
+    return y * scale
+
+
+def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """FusedLeakyReLUFunction.forward, op/fused_act.py:51-59 (autograd of these torch ops is the
+    same function the reference's hand-written backward computes, :19-48)."""
+    return F.leaky_relu(x + bias.view(1, -1, *([1] * (x.ndim - 2))), negative_slope) * scale
+
+
+def upfirdn2d_mhwc(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """Semantics of upfirdn2d_native (op/upfirdn2d.py:152-186) on the op's [major, h, w, minor]
+    layout, written from its definition: zero-insert upsample, pad (negative pad = crop), correlate
+    every (major, minor) plane with the FLIPPED kernel, keep every down-th sample."""
+    major, in_h, in_w, minor = x.shape
+    kh, kw = kernel.shape
+    planes = x.permute(0, 3, 1, 2).reshape(major * minor, 1, in_h, in_w)
+    up = planes.new_zeros(major * minor, 1, in_h * up_y, in_w * up_x)
+    up[:, :, ::up_y, ::up_x] = planes                       # sample (iy,ix) sits at (iy*up_y, ix*up_x)
+    up = F.pad(up, [pad_x0, pad_x1, pad_y0, pad_y1])        # F.pad crops for negative amounts
+    full = F.conv2d(up, torch.flip(kernel, [0, 1]).reshape(1, 1, kh, kw))
+    full = full[:, :, ::down_y, ::down_x]
+    oh, ow = full.shape[2], full.shape[3]
+    return full.reshape(major, minor, oh, ow).permute(0, 2, 3, 1).contiguous()
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """upfirdn2d(), op/upfirdn2d.py:144-149, on NCHW input."""
+    b, c, h, w = x.shape
+    out = upfirdn2d_mhwc(x.reshape(-1, h, w, 1), kernel, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+    return out.reshape(b, c, out.shape[1], out.shape[2])
+
+
+def make_blur_kernel(k=(1, 3, 3, 1)):
+    """make_kernel, models/StyleGAN2/model.py:18-26."""
+    k = torch.tensor(k, dtype=torch.float32)
+    k = k[None, :] * k[:, None]
+    return k / k.sum()

@@ -1,0 +1,34 @@
+"""CPU: the C-ABI library loads and exports every symbol include/wgs.h declares (no compute calls)."""
+import ctypes
+import os
+
+from warpedganspace_amd import _lib as L
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.isfile(L.LIB_PATH), "libwgs_hip.so not built: run __graft_entry__.build()"
+    h = ctypes.CDLL(L.LIB_PATH)
+    syms = L.header_symbols()
+    assert len(syms) >= 6
+    missing = [s for s in syms if not hasattr(h, s)]
+    assert not missing, missing
+
+
+def test_abi_version_and_error_text():
+    h = L.lib()
+    assert h.wgs_abi_version() >= 1
+    # argument validation happens on the host before any launch: safe without a GPU
+    rc = h.wgs_rbf_fwd(None, None, None, ctypes.c_float(0.1), None, None, None, None, None, 1, 1, 2, 8, None)
+    assert rc != 0
+    assert b"null pointer" in h.wgs_last_error()
+
+
+def test_product_path_rejects_cpu_tensors():
+    import pytest
+    import torch
+    from warpedganspace_amd.support_sets import SupportSets
+    S = SupportSets(4, 2, 8, learn_gammas=True)
+    mask = torch.zeros(2, 4)
+    mask[:, 1] = 1
+    with pytest.raises(L.WgsError):
+        S(mask, torch.randn(2, 8))

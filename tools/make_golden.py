@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by IMPORTING THE REFERENCE (build container only).
+
+Works from a scratch copy of /root/reference (never writes into it), with bytecode disabled, and
+with `models.StyleGAN2.op` pre-stubbed so importing models/StyleGAN2/model.py does not JIT-build
+(hipify) the reference's CUDA extension (SURVEY.md hazard note).  The stub's `upfirdn2d` is the
+reference's OWN pure-PyTorch statement of the op, `upfirdn2d_native` (models/StyleGAN2/op/
+upfirdn2d.py:152-186), extracted with `ast` from the copied file and executed with `F` injected
+(the reference forgot the import); `fused_leaky_relu` is restated from fused_bias_act_kernel.cu:25-47.
+
+Nothing from the reference is stored: only numeric outputs for seeded inputs (tests/golden_inputs.py).
+Usage:  python tools/make_golden.py [--only support_sets,native_ops,stylegan2,...]
+"""
+import argparse
+import ast
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from tests import golden_inputs as GI  # noqa: E402
+
+REF = '/root/reference'
+GOLD = os.path.join(REPO, 'tests', 'golden')
+
+
+def stage_reference():
+    tmp = tempfile.mkdtemp(prefix='refcopy_')
+    for sub in ('lib', 'models'):
+        shutil.copytree(os.path.join(REF, sub), os.path.join(tmp, sub),
+                        ignore=shutil.ignore_patterns('__pycache__', '*.pyc', 'pretrained'))
+    sys.path.insert(0, tmp)
+    return tmp
+
+
+def load_module_from(path, name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def reference_upfirdn2d_native(tmp):
+    src = open(os.path.join(tmp, 'models', 'StyleGAN2', 'op', 'upfirdn2d.py')).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'upfirdn2d_native'][0]
+    ns = {'torch': torch, 'F': F}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'upfirdn2d_native', 'exec'), ns)
+    return ns['upfirdn2d_native']
+
+
+def install_stylegan2_op_stub(tmp):
+    native = reference_upfirdn2d_native(tmp)
+
+    def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+        b, c, h, w = x.shape
+        out = native(x.reshape(-1, h, w, 1), kernel, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+        return out.reshape(b, c, out.shape[1], out.shape[2])
+
+    def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
+        return F.leaky_relu(x + bias.view(1, -1, *([1] * (x.ndim - 2))), negative_slope) * scale
+
+    class FusedLeakyReLU(torch.nn.Module):
+        def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+            super().__init__()
+            self.bias = torch.nn.Parameter(torch.zeros(channel))
+            self.negative_slope, self.scale = negative_slope, scale
+
+        def forward(self, x):
+            return fused_leaky_relu(x, self.bias, self.negative_slope, self.scale)
+
+    stub = types.ModuleType('models.StyleGAN2.op')
+    stub.upfirdn2d, stub.fused_leaky_relu, stub.FusedLeakyReLU = upfirdn2d, fused_leaky_relu, FusedLeakyReLU
+    sys.modules['models.StyleGAN2.op'] = stub
+    return native
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_support_sets(tmp):
+    ss = load_module_from(os.path.join(tmp, 'lib', 'support_sets.py'), 'ref_support_sets')
+    out = {}
+    cases = {'tiny': (4, 2, 8, 3, 11), 'cfg1': (32, 8, 128, 4, 12), 'cfg3': (128, 32, 512, 4, 13),
+             'cfg4': (16, 4, 120, 5, 14)}
+    for name, (K, N, d, B, seed) in cases.items():
+        for lg in (True, False):
+            c = GI.support_sets_case(K, N, d, B, seed, learn_gammas=lg)
+            m = ss.SupportSets(K, N, d, learn_alphas=True, learn_gammas=lg, gamma=c['gamma'])
+            m.load_state_dict(c['sd'])
+            z = c['z'].clone().requires_grad_(True)
+            y = m(GI.one_hot(c['idx'], K), z)
+            (y * c['gout']).sum().backward()
+            tag = '%s_%s' % (name, 'lg' if lg else 'cg')
+            out[tag + '_out'] = y.detach().numpy()
+            out[tag + '_dz'] = z.grad.numpy()
+            out[tag + '_dalphas'] = m.ALPHAS.grad.numpy()
+            if lg:
+                out[tag + '_dloggamma'] = m.LOGGAMMA.grad.numpy()
+            g = m.SUPPORT_SETS.grad
+            if name in ('tiny', 'cfg4'):
+                out[tag + '_dtable'] = g.numpy()
+            else:  # store only the selected rows (all others are exactly zero in the reference too)
+                rows = torch.unique(c['idx'])
+                gr = g[rows]
+                out[tag + '_dtable_rows_sub16'] = gr[:, ::16].numpy()
+                out[tag + '_dtable_vecnorm'] = gr.reshape(len(rows), 2 * N, d).norm(dim=2).numpy()
+                out[tag + '_dtable_rest_absmax'] = np.float32(
+                    g[[k for k in range(K) if k not in set(rows.tolist())]].abs().max().item())
+    # traversal (traverse_latent_space.py:361-438), K=6, T=3
+    c = GI.support_sets_case(6, 3, 16, 2, 21, learn_gammas=True)
+    m = ss.SupportSets(6, 3, 16, learn_alphas=False, learn_gammas=True, gamma=c['gamma'])
+    m.load_state_dict(c['sd'])
+    eps, T = 0.2, 3
+    path = np.zeros((2, 6, 2 * T + 1, 16), np.float32)
+    with torch.no_grad():
+        for ci in range(2):
+            for k in range(6):
+                mask = torch.zeros(1, 6)
+                mask[0, k] = 1.0
+                path[ci, k, T] = c['z'][ci].numpy()
+                for sign in (1.0, -1.0):
+                    zc = c['z'][ci:ci + 1].clone()
+                    for t in range(1, T + 1):
+                        zc = zc + sign * eps * m(mask, zc)
+                        path[ci, k, T + int(sign) * t] = zc[0].numpy()
+    out['traverse_path'] = path
+    np.savez_compressed(os.path.join(GOLD, 'support_sets.npz'), **out)
+    print('support_sets.npz', len(out), 'arrays')
+
+
+def gen_native_ops(tmp, native):
+    out = {}
+    k1 = torch.tensor([1., 3., 3., 1.])
+    k = k1[None, :] * k1[:, None]
+    k = k / k.sum()
+    for i, c in enumerate(GI.UPFIRDN_CASES):
+        x = GI.rt(100 + i, c['major'], c['h'], c['w'], c['minor'])
+        kk = k * c['gain']
+        if c['name'] == 'up3_down2':
+            kk = GI.rt(777, 5, 3)
+        y = native(x, kk, c['up'], c['up'], c['down'], c['down'], *c['pad'])
+        out['upfirdn_' + c['name']] = y.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'native_ops.npz'), **out)
+    print('native_ops.npz', len(out), 'arrays')
+
+
+def gen_stylegan2(tmp):
+    from models.StyleGAN2.model import Generator, ModulatedConv2d
+    out = {}
+    torch.manual_seed(0)
+    # --- ModulatedConv2d blocks (resolution-agnostic)
+    for name, (cin, cout, ks, up, demod, hw) in {
+            'plain': (16, 24, 3, False, True, 8), 'up': (16, 8, 3, True, True, 5),
+            'rgb': (16, 3, 1, False, False, 8)}.items():
+        m = ModulatedConv2d(cin, cout, ks, 32, demodulate=demod, upsample=up)
+        m.load_state_dict(GI.fill_state_dict(m.state_dict(), 300 + len(name)))
+        x = GI.rt(310, 2, cin, hw, hw).requires_grad_(True)
+        s = GI.rt(311, 2, 32).requires_grad_(True)
+        y = m(x, s)
+        probe = GI.rt(312, *y.shape)
+        (y * probe).sum().backward()
+        out['modconv_%s_y' % name] = y.detach().numpy()
+        out['modconv_%s_dx' % name] = x.grad.numpy()
+        out['modconv_%s_ds' % name] = s.grad.numpy()
+    # --- full generators, Z-space forward + gradient w.r.t. the shift
+    for size, B in ((32, 2), (256, 2)):
+        G = Generator(size, 512, 8)
+        G.load_state_dict(GI.fill_state_dict(G.state_dict(), 400 + size))
+        G.eval()
+        z = GI.rt(410 + size, B, 512)
+        shift = (GI.rt(411 + size, B, 512) * 0.02).requires_grad_(True)
+        img = G([z + shift], input_is_latent=False)[0]
+        probe = GI.rt(412 + size, *img.shape)
+        (img * probe).sum().backward()
+        w = G.get_latent(z).detach()
+        tag = 'g%d_' % size
+        if size == 32:
+            out[tag + 'img'] = img.detach().numpy()
+        else:
+            out[tag + 'img_pool8'] = F.avg_pool2d(img.detach(), 8).numpy()
+            out[tag + 'img_crop'] = img.detach()[:, :, 100:116, 60:76].numpy()
+            out[tag + 'img_absmean'] = np.float32(img.detach().abs().mean().item())
+        out[tag + 'w'] = w.numpy()
+        out[tag + 'dshift'] = shift.grad.numpy()
+        # W-space: image from w + shift and gradient w.r.t. that shift
+        shw = (GI.rt(413 + size, B, 512) * 0.05).requires_grad_(True)
+        imgw = G([w + shw], input_is_latent=True)[0]
+        (imgw * probe).sum().backward()
+        out[tag + 'w_dshift'] = shw.grad.numpy()
+        if size == 32:
+            out[tag + 'w_img'] = imgw.detach().numpy()
+        else:
+            out[tag + 'w_img_pool8'] = F.avg_pool2d(imgw.detach(), 8).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'stylegan2.npz'), **out)
+    print('stylegan2.npz', len(out), 'arrays')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(',')))
+    os.makedirs(GOLD, exist_ok=True)
+    tmp = stage_reference()
+    try:
+        native = install_stylegan2_op_stub(tmp)
+        gens = {'support_sets': lambda: gen_support_sets(tmp), 'native_ops': lambda: gen_native_ops(tmp, native),
+                'stylegan2': lambda: gen_stylegan2(tmp)}
+        for extra in ('gen_reconstructor', 'gen_generators', 'gen_step'):
+            if extra in globals():
+                gens[extra[4:]] = (lambda f: (lambda: f(tmp)))(globals()[extra])
+        for name, fn in gens.items():
+            if not only or name in only:
+                fn()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    main()

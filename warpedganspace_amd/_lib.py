@@ -1,0 +1,76 @@
+"""ctypes binding of libwgs_hip.so (the C ABI declared in include/wgs.h).
+
+The product path has NO CPU / PyTorch fallback: if the HIP library is missing, or a tensor is not
+a contiguous fp32 device tensor, the call raises.  PyTorch only provides device memory and streams.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwgs_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wgs.h")
+
+_lib = None
+
+
+class WgsError(RuntimeError):
+    pass
+
+
+def header_symbols(header_path=HEADER_PATH):
+    """Names of every function declared in include/wgs.h (used by the CPU export test)."""
+    src = open(header_path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wgs_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises WgsError when the extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise WgsError(
+                "libwgs_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or warpedganspace_amd/csrc/build.sh. There is no CPU fallback." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.wgs_last_error.restype = ctypes.c_char_p
+        _lib.wgs_rbf_ws_floats.restype = ctypes.c_int64
+        for name in ("wgs_conv_ws_bytes",):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = ctypes.c_int64
+    return _lib
+
+
+def check(rc, what="wgs"):
+    if rc != 0:
+        raise WgsError("%s failed (rc=%d): %s" % (what, rc, lib().wgs_last_error().decode()))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32, name="tensor"):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise WgsError("%s must be a GPU tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise WgsError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise WgsError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def rawptr(t):
+    """Device pointer without layout checks (caller guarantees the memory layout)."""
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_int64 = ctypes.c_int64

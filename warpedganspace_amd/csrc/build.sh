@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Build libwgs_hip.so for gfx950 (MI355X) in-tree.  No torch headers, no pybind: a plain C-ABI library.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function"
+OBJS=()
+for src in *.hip; do
+  obj="build/${src%.hip}.o"
+  mkdir -p build
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ wgs_common.h -nt "$obj" ] || [ ../../include/wgs.h -nt "$obj" ] \
+     || { [ -f "${src%.hip}.inc" ] && [ "${src%.hip}.inc" -nt "$obj" ]; }; then
+    echo "[hipcc] $src"
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
+  fi
+  OBJS+=("$obj")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libwgs_hip.so "${OBJS[@]}"
+echo "built $(cd .. && pwd)/libwgs_hip.so"

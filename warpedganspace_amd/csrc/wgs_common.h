@@ -1,0 +1,64 @@
+// Common device/host helpers for libwgs_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define WGS_OK 0
+#define WGS_EINVAL (-22)
+#define WGS_ELAUNCH (-5)
+
+// Thread-local error text (read back through wgs_last_error()).
+void wgs_set_error(const char* fmt, ...);
+
+#define WGS_CHECK_ARG(cond, ...)                    \
+    do {                                            \
+        if (!(cond)) {                              \
+            wgs_set_error(__VA_ARGS__);             \
+            return WGS_EINVAL;                      \
+        }                                           \
+    } while (0)
+
+#define WGS_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            wgs_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return WGS_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline int wgs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 reductions (gfx950: wavefront = 64 lanes) -------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x = 64*NW threads; `red` is LDS scratch of >= NW floats.
+// Every thread gets the total. Contains two __syncthreads().
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
