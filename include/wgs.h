@@ -97,6 +97,58 @@ int wgs_upfirdn2d(const float* x, const float* kernel, float* y, int major, int 
                   int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                   int pad_x1, int pad_y0, int pad_y1, wgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the matrix cores (exact fp32 MFMA) — the dense contractions behind
+ * F.conv2d / F.conv_transpose2d in ModulatedConv2d.forward (models/StyleGAN2/model.py:187-228),
+ * the generator blocks of models/ProgGAN/model.py:35-62 and models/SNGAN/sn_gen_resnet.py:24-54, and
+ * the Reconstructor's torchvision ResNet-18 / LeNet convs (lib/reconstructor.py:21-33,54-60) with
+ * their autograd backward.  Activations are NHWC.
+ *
+ * One launch computes, for every GEMM pixel m = (b, gy, gx) of a Hg x Wg grid and every n < Co:
+ *   acc = sum_{t < ntaps} sum_{k < Ci} A(b, gy*isy + dy[t], gx*isx + dx[t], k) * w[wt[t]*w_tap_stride + n*w_row_stride + k]
+ *   A(b,iy,ix,k) = x[b,iy,ix,k] * (a_scale ? a_scale[b*Ci + k] : 1)   (0 outside the image)
+ *   v   = acc * (col_scale ? col_scale[b*Co + n] : 1) + (noise ? noise_w[0]*noise[oy*Wo+ox] : 0) + (bias ? bias[n] : 0)
+ *   y[b, oy, ox, n] = (v > 0 ? v : v*act_slope) * gain,   oy = gy*osy + oy0, ox = gx*osx + ox0
+ * Plain conv: Hg=Ho, isy=stride, osy=1.  Stride-2 transposed conv / dgrad of strided conv: one launch
+ * per output parity phase (osy=2, oy0=phase) with that phase's tap subset.
+ * Requirements: Ci % 8 == 0, 16-B aligned rows, ntaps <= 64.
+ */
+typedef struct wgs_conv_desc {
+    const float* x;          /* [B,Hi,Wi,Ci] */
+    const float* w;          /* packed weights, see formula */
+    float* y;                /* [B,Ho,Wo,Co] */
+    const float* a_scale;    /* [B,Ci] or NULL  (StyleGAN2 style modulation / dgrad demod) */
+    const float* col_scale;  /* [B,Co] or NULL  (StyleGAN2 demodulation) */
+    const float* bias;       /* [Co] or NULL */
+    const float* noise;      /* [Ho*Wo] or NULL (StyleGAN2 NoiseInjection buffer) */
+    const float* noise_w;    /* device scalar (NoiseInjection.weight) or NULL */
+    int32_t B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps;
+    int64_t w_tap_stride, w_row_stride;
+    float act_slope, gain;   /* identity: 1,1;  relu: 0,1;  fused lrelu: 0.2,sqrt(2) */
+    int8_t dy[64], dx[64];
+    int16_t wt[64];
+} wgs_conv_desc;
+int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
+
+/* Weight gradient of a (strided) conv:  dw[co*w_row_stride + wt[t]*w_tap_stride + ci] +=
+ *   sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*isy + dy[t], ox*isx + dx[t], ci]
+ * ACCUMULATED (atomicAdd across the K splits) into the caller-zeroed `dw`.
+ * ksplit <= 0 lets the library choose.  Ci % 4 == 0, Co % 4 == 0.
+ */
+typedef struct wgs_wgrad_desc {
+    const float* x;   /* [B,Hi,Wi,Ci] */
+    const float* dy;  /* [B,Ho,Wo,Co] */
+    float* dw;
+    int32_t B, Hi, Wi, Ci, Ho, Wo, Co, isy, isx, ntaps, ksplit;
+    int64_t w_tap_stride, w_row_stride;
+    int8_t dy_t[64], dx_t[64];
+    int16_t wt[64];
+} wgs_wgrad_desc;
+int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
+
+/* dst[t][ci][co] = src[co][t][ci]  (pack [Cout,T,Cin] weights for the dgrad contraction). */
+int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,461 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// One kernel family covers every dense contraction of the hot path:
+//   * plain / strided conv forward              (Reconstructor, generator convs)
+//   * stride-2 transposed conv as 4 sub-pixel phase GEMMs (StyleGAN2 up-convs, models/StyleGAN2/
+//     model.py:201-212) and dgrad of strided convs (same structure)
+//   * dgrad of stride-1 convs (taps mirrored, weights packed [tap][Cin][Cout])
+//   * weight gradients (igemm_wgrad below), contracting over pixels
+// GEMM view (forward): M = B*Hg*Wg pixels, N = Cout, K = taps*Cin.  Activations are NHWC so a K-chunk
+// of one tap is a contiguous BK-float run per pixel row; weights are addressed as
+// w[wt[t]*tap_stride + n*row_stride + k] so PyTorch's channels_last [Cout,kh,kw,Cin] storage is used
+// in place.  The StyleGAN2 modulation is folded in: A rows are scaled by style[b,ci] while being
+// staged (a_scale), accumulators by demod[b,co] in the epilogue (col_scale) — the per-sample
+// weight tensor of model.py:190-199 is never materialised.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN (128x128 default), each wave a (BM/WAVES_M) x
+// (BN/WAVES_N) sub-tile of 32x32 MFMA tiles (64 accumulator VGPRs at 64x64).  K is consumed in
+// BK-float chunks, double-buffered in LDS with a register-staged prefetch of the next chunk issued
+// before the MFMAs of the current one (one barrier per chunk).  LDS rows are padded to BK+1 floats:
+// the per-lane operand reads (lane -> row, fixed k) are then bank-conflict free.
+#include "wgs_common.h"
+#include "../../include/wgs.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    float* y;
+    const float* a_scale;
+    const float* col_scale;
+    const float* bias;
+    const float* noise;
+    const float* noise_w;
+    int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M;
+    long w_tap_stride, w_row_stride;
+    float act_slope, gain;
+    signed char dy[64], dx[64];
+    short wt[64];
+};
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool ASCALE>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
+    constexpr int LD = BK + 1;
+    constexpr int CPR = BK / 4;       // float4 chunks per tile row
+    constexpr int RPP = 256 / CPR;    // tile rows filled per pass of the 256 threads
+    constexpr int PA = (BM + RPP - 1) / RPP;
+    constexpr int PB = (BN + RPP - 1) / RPP;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "bad wave layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM*LD]
+    float* Bs = smem + 2 * BM * LD;   // [2][BN*LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = (p.Co + BN - 1) / BN;
+    const int bid = blockIdx.x;
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+
+    const int q = tid % CPR, r0 = tid / CPR;
+    int a_iy0[PA], a_ix0[PA], a_pix[PA], a_b[PA];
+#pragma unroll
+    for (int pa = 0; pa < PA; ++pa) {
+        const int row = r0 + pa * RPP;
+        const int m = m0 + row;
+        const bool ok = (row < BM) && (m < p.M);
+        const int mm = ok ? m : 0;
+        const int gx = mm % p.Wg;
+        const int t = mm / p.Wg;
+        const int gy = t % p.Hg;
+        const int b = t / p.Hg;
+        a_iy0[pa] = ok ? gy * p.isy : -100000;  // invalid rows fail every bounds test
+        a_ix0[pa] = gx * p.isx;
+        a_pix[pa] = b * p.Hi * p.Wi;
+        a_b[pa] = b;
+    }
+
+    float4 ra[PA], rb[PB];
+    const int cpt = p.Ci / BK;  // K-chunks per tap
+    const int nk = p.ntaps * cpt;
+
+    auto load_tile = [&](int kt) {
+        const int t = kt / cpt;
+        const int ci0 = (kt - t * cpt) * BK + q * 4;
+        const int dy = p.dy[t], dx = p.dx[t];
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
+            const bool v = (r0 + pa * RPP < BM) && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v) {
+                val = *reinterpret_cast<const float4*>(p.x + ((size_t)(a_pix[pa] + iy * p.Wi + ix)) * p.Ci + ci0);
+                if (ASCALE) {
+                    const float4 s = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.Ci + ci0);
+                    val.x *= s.x; val.y *= s.y; val.z *= s.z; val.w *= s.w;
+                }
+            }
+            ra[pa] = val;
+        }
+        const float* wt = p.w + (size_t)p.wt[t] * p.w_tap_stride + ci0;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int n = r0 + pb * RPP;
+            const bool v = (n < BN) && (n0 + n < p.Co);
+            rb[pb] = v ? *reinterpret_cast<const float4*>(wt + (size_t)(n0 + n) * p.w_row_stride)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * LD;
+        float* b = Bs + buf * BN * LD;
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            const int row = r0 + pa * RPP;
+            if (row < BM) {
+                float* d = a + row * LD + q * 4;
+                d[0] = ra[pa].x; d[1] = ra[pa].y; d[2] = ra[pa].z; d[3] = ra[pa].w;
+            }
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int row = r0 + pb * RPP;
+            if (row < BN) {
+                float* d = b + row * LD + q * 4;
+                d[0] = rb[pb].x; d[1] = rb[pb].y; d[2] = rb[pb].z; d[3] = rb[pb].w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* a = As + cur * BM * LD + (wm * WM + l31) * LD + lh;
+        const float* b = Bs + cur * BN * LD + (wn * WN + l31) * LD + lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = a[i * 32 * LD + 2 * kk];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = b[j * 32 * LD + 2 * kk];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: per-row output addressing staged once in LDS (tile buffers are free now) ----
+    int* r_pix = reinterpret_cast<int*>(smem);   // output pixel index (b*Ho+oy)*Wo+ox, or -1
+    int* r_b = r_pix + BM;                       // sample index
+    int* r_hw = r_b + BM;                        // oy*Wo+ox (noise index)
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, bb = 0, hw = 0;
+        if (m < p.M) {
+            const int gx = m % p.Wg;
+            const int t = m / p.Wg;
+            const int gy = t % p.Hg;
+            bb = t / p.Hg;
+            hw = (gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
+            pix = bb * p.Ho * p.Wo + hw;
+        }
+        r_pix[tid] = pix; r_b[tid] = bb; r_hw[tid] = hw;
+    }
+    __syncthreads();
+    const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        const bool nok = n < p.Co;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int pix = r_pix[row];
+                if (pix >= 0 && nok) {
+                    float v = acc[i][j][r];
+                    if (p.col_scale) v *= p.col_scale[(size_t)r_b[row] * p.Co + n];
+                    if (p.noise) v = fmaf(nw, p.noise[r_hw[row]], v);
+                    v += bias;
+                    v = (v > 0.f ? v : v * p.act_slope) * p.gain;
+                    p.y[(size_t)pix * p.Co + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][t][ci] (+)= sum over output pixels m of dy[m][co] * x[pix_t(m)][ci].
+// GEMM view: M' = Cout, N' = Cin, K' = pixels.  Both operands are "k-major" in memory (a pixel row is
+// contiguous over channels), so tiles are staged as [k][i] rows: float4 global loads, float4 LDS
+// writes, conflict-free per-lane reads.  grid = (co tiles * ci tiles, taps, K splits); K splits
+// combine with atomicAdd into the caller-zeroed gradient.
+struct WgradArgs {
+    const float* x;   // [B,Hi,Wi,Ci]
+    const float* dy;  // [B,Ho,Wo,Co]
+    float* dw;        // dw[co*row_stride + wt[t]*tap_stride + ci]
+    int B, Hi, Wi, Ci, Ho, Wo, Co, isy, isx, ntaps, M, ksplit;
+    long w_tap_stride, w_row_stride;
+    signed char dy_[64], dx_[64];
+    short wt[64];
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
+    constexpr int BK = 32;                 // pixels per chunk
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int NW = WAVES_M * WAVES_N;  // waves that own accumulators (<= 4)
+    constexpr int CA = BM / 4, CB = BN / 4;             // float4 per staged row
+    constexpr int PA = (BK * CA + 255) / 256, PB = (BK * CB + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = (p.Ci + BN - 1) / BN;
+    const int co0 = (blockIdx.x / ntn) * BM, ci0 = (blockIdx.x % ntn) * BN;
+    const int t = blockIdx.y;
+    const int dyt = p.dy_[t], dxt = p.dx_[t];
+    const int nchunks = (p.M + BK - 1) / BK;
+    const int per = (nchunks + p.ksplit - 1) / p.ksplit;
+    const int c_begin = blockIdx.z * per, c_end = min(nchunks, c_begin + per);
+    if (c_begin >= c_end) return;
+
+    float4 ra[PA], rb[PB];
+    auto load_tile = [&](int c) {
+        const int mbase = c * BK;
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            const int e = tid + pa * 256;
+            const int k = e / CA, c4 = e % CA;
+            const int m = mbase + k;
+            const int co = co0 + c4 * 4;
+            const bool v = (e < BK * CA) && (m < p.M) && (co < p.Co);
+            ra[pa] = v ? *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.Co + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int e = tid + pb * 256;
+            const int k = e / CB, c4 = e % CB;
+            const int m = mbase + k;
+            const int ci = ci0 + c4 * 4;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((e < BK * CB) && (m < p.M) && (ci < p.Ci)) {
+                const int ox = m % p.Wo;
+                const int tt = m / p.Wo;
+                const int oy = tt % p.Ho;
+                const int b = tt / p.Ho;
+                const int iy = oy * p.isy + dyt, ix = ox * p.isx + dxt;
+                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                    val = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci);
+            }
+            rb[pb] = val;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            const int e = tid + pa * 256;
+            if (e < BK * CA) *reinterpret_cast<float4*>(&As[buf][(e / CA) * BM + (e % CA) * 4]) = ra[pa];
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int e = tid + pb * 256;
+            if (e < BK * CB) *reinterpret_cast<float4*>(&Bs[buf][(e / CB) * BN + (e % CB) * 4]) = rb[pb];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(c_begin);
+    store_tile(0);
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        if (c + 1 < c_end) load_tile(c + 1);
+        if (wave < NW) {
+            const float* a = &As[cur][lh * BM + wm * WM + l31];
+            const float* b = &Bs[cur][lh * BN + wn * WN + l31];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = a[2 * kk * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[j] = b[2 * kk * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < c_end) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    if (wave >= NW) return;
+    float* out = p.dw + (size_t)p.wt[t] * p.w_tap_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + wn * WN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Co && ci < p.Ci) {
+                    float* d = out + (size_t)co * p.w_row_stride + ci;
+                    unsafeAtomicAdd(d, acc[i][j][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+int launch_nt(const ConvArgs& a, hipStream_t st) {
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
+    const size_t smem = (size_t)2 * (BM + BN) * (BK + 1) * sizeof(float);
+    const size_t smem_epi = (size_t)3 * BM * sizeof(int);
+    const size_t sm = smem > smem_epi ? smem : smem_epi;
+    dim3 grid((unsigned)(ntm * ntn)), block(256);
+    if (a.a_scale) {
+        auto k = igemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>;
+        if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+    } else {
+        auto k = igemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>;
+        if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void repack_w_t_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int Co, int T, int Ci) {
+    // dst[t][ci][co] = src[co][t][ci]; 32x32 LDS transpose per (t, ci-tile, co-tile)
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Co && ci < Ci) ? src[((size_t)co * T + t) * Ci + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Ci && co < Co) dst[((size_t)t * Ci + ci) * Co + co] = tile[tx][r];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream) {
+    WGS_CHECK_ARG(src && dst && Co > 0 && T > 0 && Ci > 0, "wgs_repack_w_t: bad arguments");
+    dim3 grid((Ci + 31) / 32, (Co + 31) / 32, T);
+    hipLaunchKernelGGL(repack_w_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, Co, T, Ci);
+    WGS_CHECK_LAUNCH("repack_w_t_kernel");
+    return WGS_OK;
+}
+
+int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
+    WGS_CHECK_ARG(d && d->x && d->w && d->y, "wgs_conv_igemm: null pointer");
+    WGS_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hg > 0 && d->Wg > 0 && d->Ho > 0 && d->Wo > 0,
+                  "wgs_conv_igemm: bad spatial sizes");
+    WGS_CHECK_ARG(d->Ci > 0 && d->Ci % 8 == 0, "wgs_conv_igemm: Ci=%d must be a multiple of 8", d->Ci);
+    WGS_CHECK_ARG(d->Co > 0, "wgs_conv_igemm: Co=%d", d->Co);
+    WGS_CHECK_ARG(d->ntaps > 0 && d->ntaps <= 64, "wgs_conv_igemm: ntaps=%d out of range (1..64)", d->ntaps);
+    WGS_CHECK_ARG((long)d->B * d->Hg * d->Wg < (1L << 31) && (long)d->B * d->Ho * d->Wo < (1L << 31),
+                  "wgs_conv_igemm: pixel count overflows int32");
+    ConvArgs a;
+    a.x = d->x; a.w = d->w; a.y = d->y; a.a_scale = d->a_scale; a.col_scale = d->col_scale;
+    a.bias = d->bias; a.noise = d->noise; a.noise_w = d->noise_w;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Hg = d->Hg; a.Wg = d->Wg;
+    a.isy = d->isy; a.isx = d->isx; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.osy = d->osy; a.osx = d->osx; a.oy0 = d->oy0; a.ox0 = d->ox0; a.ntaps = d->ntaps;
+    a.M = d->B * d->Hg * d->Wg;
+    a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
+    a.act_slope = d->act_slope; a.gain = d->gain;
+    for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool k32 = (d->Ci % 32 == 0);
+    if (d->Co > 64) {
+        if (k32) launch_nt<128, 128, 32, 2, 2>(a, st); else launch_nt<128, 128, 8, 2, 2>(a, st);
+    } else if (d->Co > 32) {
+        if (k32) launch_nt<128, 64, 32, 2, 2>(a, st); else launch_nt<128, 64, 8, 2, 2>(a, st);
+    } else {
+        if (k32) launch_nt<128, 32, 32, 4, 1>(a, st); else launch_nt<128, 32, 8, 4, 1>(a, st);
+    }
+    WGS_CHECK_LAUNCH("igemm_nt_kernel");
+    return WGS_OK;
+}
+
+int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
+    WGS_CHECK_ARG(d && d->x && d->dy && d->dw, "wgs_conv_wgrad: null pointer");
+    WGS_CHECK_ARG(d->Ci > 0 && d->Ci % 4 == 0 && d->Co > 0 && d->Co % 4 == 0,
+                  "wgs_conv_wgrad: Ci=%d, Co=%d must be multiples of 4", d->Ci, d->Co);
+    WGS_CHECK_ARG(d->ntaps > 0 && d->ntaps <= 64, "wgs_conv_wgrad: ntaps=%d out of range", d->ntaps);
+    WGS_CHECK_ARG((long)d->B * d->Ho * d->Wo < (1L << 31), "wgs_conv_wgrad: pixel count overflows int32");
+    WgradArgs a;
+    a.x = d->x; a.dy = d->dy; a.dw = d->dw;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
+    a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
+    for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
+    const int BM = d->Co >= 128 ? 128 : 64;
+    const int BN = d->Ci >= 128 ? 128 : (d->Ci >= 64 ? 64 : 32);
+    const int tiles = ((d->Co + BM - 1) / BM) * ((d->Ci + BN - 1) / BN);
+    const int nchunks = (a.M + 31) / 32;
+    int ks = d->ksplit;
+    if (ks <= 0) {
+        ks = (1024 + tiles * d->ntaps - 1) / (tiles * d->ntaps);
+        if (ks > nchunks / 4) ks = nchunks / 4;
+        if (ks < 1) ks = 1;
+    }
+    a.ksplit = ks;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)tiles, (unsigned)d->ntaps, (unsigned)ks), block(256);
+    if (BM == 128 && BN == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, block, 0, st, a);
+    else if (BM == 128 && BN == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, block, 0, st, a);
+    else if (BM == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, block, 0, st, a);
+    else if (BN == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 128, 2, 2>), grid, block, 0, st, a);
+    else if (BN == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 32, 2, 1>), grid, block, 0, st, a);
+    WGS_CHECK_LAUNCH("igemm_wgrad_kernel");
+    return WGS_OK;
+}
+
+}  // extern "C"
