@@ -1,0 +1,109 @@
+"""GPU: implicit-GEMM MFMA convolution kernels vs torch-CPU fp64 convolution (the oracle's op)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel_err
+from warpedganspace_amd import conv as C
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CASES = [  # B, Ci, Co, H, W, k, stride, pad
+    (2, 32, 64, 9, 7, 3, 1, 1),
+    (3, 64, 128, 8, 8, 3, 1, 1),
+    (2, 128, 160, 6, 6, 3, 1, 1),      # Co not a multiple of the tile
+    (2, 64, 128, 9, 9, 3, 2, 1),
+    (2, 64, 128, 8, 8, 1, 2, 0),
+    (2, 8, 64, 20, 20, 7, 2, 3),       # ResNet conv1 shape (6 channels padded to 8)
+    (1, 512, 512, 4, 4, 3, 1, 1),
+    (2, 40, 24, 5, 5, 5, 1, 0),        # LeNet-like 5x5, Ci % 8 == 0
+    (5, 32, 32, 3, 3, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W,k,s,p', CASES)
+def test_conv_fwd_dgrad_wgrad(dev, B, Ci, Co, H, W, k, s, p):
+    torch.manual_seed(B * 1000 + Ci + Co)
+    x = torch.randn(B, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, k, k, dtype=torch.float64) / (Ci * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+
+    xd = nhwc(x.detach().float()).to(dev)
+    wp = C.pack_weight(w.detach().float()).to(dev)
+    yd = C.conv2d(xd, wp, k, stride=s, pad=p)
+    assert rel_err(nchw(yd), y.detach()) < 2e-6
+    gd = nhwc(g.float()).to(dev)
+    wt = C.repack_w_t(wp, Co, k * k, Ci)
+    assert torch.equal(wt.cpu(), wp.cpu().permute(1, 2, 0).contiguous())
+    dx = C.conv2d_dgrad(gd, wt, (H, W), k, stride=s, pad=p)
+    assert rel_err(nchw(dx), x.grad) < 2e-6
+    if Ci % 4 == 0 and Co % 4 == 0:
+        dw_ref = w.grad.permute(0, 2, 3, 1).reshape(Co, k * k, Ci)
+        dw = torch.zeros_like(wp)
+        C.conv2d_wgrad(xd, gd, dw, k, stride=s, pad=p)
+        assert rel_err(dw, dw_ref) < 5e-6
+        dw1 = torch.zeros_like(wp)
+        C.conv2d_wgrad(xd, gd, dw1, k, stride=s, pad=p, ksplit=1)
+        assert rel_err(dw1, dw_ref) < 5e-6
+
+
+def test_conv_epilogue_and_prologue(dev):
+    """StyleGAN2 fusion: a_scale (style), col_scale (demod), noise, bias, leaky-relu*sqrt(2)."""
+    torch.manual_seed(5)
+    B, Ci, Co, H = 3, 64, 96, 8
+    x = torch.randn(B, Ci, H, H)
+    w = torch.randn(Co, Ci, 3, 3) / (Ci * 9) ** 0.5
+    s = torch.randn(B, Ci) + 1.0
+    dm = torch.rand(B, Co) + 0.5
+    bias = torch.randn(Co)
+    noise = torch.randn(H, H)
+    nw = torch.tensor([0.37])
+    ref = (F.conv2d(x * s[:, :, None, None], w, padding=1) * dm[:, :, None, None] + nw * noise[None, None]
+           + bias[None, :, None, None])
+    ref = F.leaky_relu(ref, 0.2) * 2 ** 0.5
+    y = C.conv2d(nhwc(x).to(dev), C.pack_weight(w).to(dev), 3, pad=1, a_scale=s.to(dev), col_scale=dm.to(dev),
+                 bias=bias.to(dev), noise=noise.to(dev), noise_w=nw.to(dev), act_slope=0.2, gain=2 ** 0.5)
+    assert rel_err(nchw(y), ref) < 3e-6
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(2, 64, 32, 5), (1, 32, 64, 4), (3, 128, 128, 8)])
+def test_conv_transpose_s2(dev, B, Ci, Co, H):
+    torch.manual_seed(H)
+    x = torch.randn(B, Ci, H, H, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Ci, Co, 3, 3, dtype=torch.float64) / (Ci * 9) ** 0.5   # conv_transpose2d layout [in,out,k,k]
+    y = F.conv_transpose2d(x, w, stride=2, padding=0)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    wp = C.pack_weight(w.permute(1, 0, 2, 3).float()).to(dev)     # [Co, 9, Ci]
+    yd = C.conv_transpose2d_s2(nhwc(x.detach().float()).to(dev), wp)
+    assert tuple(yd.shape) == (B, 2 * H + 1, 2 * H + 1, Co)
+    assert rel_err(nchw(yd), y.detach()) < 2e-6
+    wt = C.repack_w_t(wp, Co, 9, Ci)
+    dx = C.conv_transpose2d_s2_dgrad(nhwc(g.float()).to(dev), wt)
+    assert rel_err(nchw(dx), x.grad) < 2e-6
+
+
+def test_conv_large_matches_blockwise(dev):
+    """A BASELINE-size layer (128->128 @ 64x64, B=4): compare with the CPU conv on one sample, and
+    linearity conv(a*x1 + x2) = a*conv(x1) + conv(x2) on the full tensor."""
+    torch.manual_seed(1)
+    B, Cc, H = 4, 128, 64
+    w = torch.randn(Cc, Cc, 3, 3) / (Cc * 9) ** 0.5
+    x1, x2 = torch.randn(B, H, H, Cc, device=dev), torch.randn(B, H, H, Cc, device=dev)
+    wp = C.pack_weight(w).to(dev)
+    y1, y2 = C.conv2d(x1, wp, 3, pad=1), C.conv2d(x2, wp, 3, pad=1)
+    y3 = C.conv2d(0.5 * x1 + x2, wp, 3, pad=1)
+    assert rel_err(y3, 0.5 * y1 + y2) < 1e-5
+    ref = F.conv2d(x1[:1].cpu().permute(0, 3, 1, 2), w, padding=1)
+    assert rel_err(nchw(y1[:1]), ref) < 3e-6

@@ -1,0 +1,152 @@
+"""Host-side launch helpers for the implicit-GEMM convolution kernels (wgs_conv_igemm /
+wgs_conv_wgrad / wgs_repack_w_t).  All activations are NHWC tensors of shape [B, H, W, C];
+weights are "packed" as [Cout, T, Cin] (T = kh*kw taps; this is the memory of a PyTorch
+[Cout, Cin, kh, kw] tensor in channels_last format) or, for dgrad contractions, [T, Cin, Cout].
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                ('a_scale', ctypes.c_void_p), ('col_scale', ctypes.c_void_p), ('bias', ctypes.c_void_p),
+                ('noise', ctypes.c_void_p), ('noise_w', ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ('B', 'Hi', 'Wi', 'Ci', 'Hg', 'Wg', 'isy', 'isx', 'Ho', 'Wo', 'Co',
+                                              'osy', 'osx', 'oy0', 'ox0', 'ntaps')] + \
+               [('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
+                ('act_slope', ctypes.c_float), ('gain', ctypes.c_float),
+                ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ('B', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'isy', 'isx', 'ntaps',
+                                              'ksplit')] + \
+               [('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
+                ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
+           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0):
+    """taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
+    if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
+        raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
+    d = ConvDesc()
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.a_scale, d.col_scale, d.bias = _p(a_scale), _p(col_scale), _p(bias)
+    d.noise, d.noise_w = _p(noise), _p(noise_w)
+    d.B, d.Hi, d.Wi, d.Ci = x.shape
+    d.Hg, d.Wg, d.isy, d.isx = Hg, Wg, isy, isy
+    _, d.Ho, d.Wo, d.Co = y.shape
+    d.osy, d.osx, d.oy0, d.ox0 = osy, osy, oy0, ox0
+    d.ntaps = len(taps)
+    d.w_tap_stride, d.w_row_stride = w_tap_stride, w_row_stride
+    d.act_slope, d.gain = act_slope, gain
+    for i, (ty, tx, ti) in enumerate(taps):
+        d.dy[i], d.dx[i], d.wt[i] = ty, tx, ti
+    L.check(L.lib().wgs_conv_igemm(ctypes.byref(d), L.stream()), 'wgs_conv_igemm')
+    return y
+
+
+def conv2d(x, w_packed, k, stride=1, pad=0, out=None, **epi):
+    """Forward conv. w_packed: [Co, k*k, Ci] memory."""
+    B, Hi, Wi, Ci = x.shape
+    Co = w_packed.shape[0]
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    Wo = (Wi + 2 * pad - k) // stride + 1
+    y = out if out is not None else torch.empty(B, Ho, Wo, Co, device=x.device, dtype=x.dtype)
+    taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
+    return launch(x, w_packed, y, taps, Ho, Wo, isy=stride, w_tap_stride=Ci, w_row_stride=k * k * Ci, **epi)
+
+
+def conv2d_dgrad(dy, wt_packed, in_hw, k, stride=1, pad=0, **epi):
+    """Gradient w.r.t. the conv input. dy [B,Ho,Wo,Co]; wt_packed [k*k, Ci, Co] memory (repack_w_t)."""
+    B, Ho, Wo, Co = dy.shape
+    Hi, Wi = in_hw
+    Ci = wt_packed.shape[1]
+    if stride == 1:
+        dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=dy.dtype)
+        taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
+        return launch(dy, wt_packed, dx, taps, Hi, Wi, w_tap_stride=Ci * Co, w_row_stride=Co, **epi)
+    if stride != 2:
+        raise L.WgsError("conv2d_dgrad: stride must be 1 or 2")
+    phases = []
+    for py in range(2):
+        for px in range(2):
+            taps = [((py + pad - ky) // 2, (px + pad - kx) // 2, ky * k + kx)
+                    for ky in range(k) if (py + pad - ky) % 2 == 0
+                    for kx in range(k) if (px + pad - kx) % 2 == 0]
+            phases.append((py, px, taps))
+    # pixels never reached by any tap (e.g. 1x1 stride-2) and pixels past the last window get zero
+    dx = torch.zeros(B, Hi, Wi, Ci, device=dy.device, dtype=dy.dtype)
+    for py, px, taps in phases:
+        Hg, Wg = (Hi - py + 1) // 2, (Wi - px + 1) // 2
+        if not taps or Hg <= 0 or Wg <= 0:
+            continue
+        launch(dy, wt_packed, dx, taps, Hg, Wg, osy=2, oy0=py, ox0=px, w_tap_stride=Ci * Co, w_row_stride=Co, **epi)
+    return dx
+
+
+def conv_transpose2d_s2(x, w_packed, k=3, out=None, **epi):
+    """F.conv_transpose2d(x, W[in,out,k,k], stride=2, padding=0) on NHWC, as 4 sub-pixel phase GEMMs.
+    w_packed [Co, k*k, Ci] memory with out[y,x,co] += x[iy,ix,ci]*w[co, ky*k+kx, ci] at y = 2*iy+ky."""
+    B, Hi, Wi, Ci = x.shape
+    Co = w_packed.shape[0]
+    Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
+    y = out if out is not None else torch.empty(B, Ho, Wo, Co, device=x.device, dtype=x.dtype)
+    for py in range(2):
+        for px in range(2):
+            taps = [((py - ky) // 2, (px - kx) // 2, ky * k + kx)
+                    for ky in range(k) if (py - ky) % 2 == 0 for kx in range(k) if (px - kx) % 2 == 0]
+            Hg, Wg = (Ho - py + 1) // 2, (Wo - px + 1) // 2
+            launch(x, w_packed, y, taps, Hg, Wg, osy=2, oy0=py, ox0=px, w_tap_stride=Ci, w_row_stride=k * k * Ci,
+                   **epi)
+    return y
+
+
+def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
+    """Gradient of conv_transpose2d_s2 w.r.t. its input = stride-2 conv over dy. wt_packed [k*k, Ci, Co]."""
+    B, Ho, Wo, Co = dy.shape
+    Ci = wt_packed.shape[1]
+    Hi, Wi = (Ho - k) // 2 + 1, (Wo - k) // 2 + 1
+    dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=dy.dtype)
+    taps = [(ky, kx, ky * k + kx) for ky in range(k) for kx in range(k)]
+    return launch(dy, wt_packed, dx, taps, Hi, Wi, isy=2, w_tap_stride=Ci * Co, w_row_stride=Co, **epi)
+
+
+def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0):
+    """Accumulate the weight gradient into the zero-initialised dw_packed [Co, k*k, Ci] memory."""
+    B, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    d = WgradDesc()
+    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw_packed.data_ptr()
+    d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = B, Hi, Wi, Ci, Ho, Wo, Co
+    d.isy, d.isx, d.ntaps, d.ksplit = stride, stride, k * k, ksplit
+    d.w_tap_stride, d.w_row_stride = Ci, k * k * Ci
+    i = 0
+    for ky in range(k):
+        for kx in range(k):
+            d.dy_t[i], d.dx_t[i], d.wt[i] = ky - pad, kx - pad, i
+            i += 1
+    L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad')
+    return dw_packed
+
+
+def repack_w_t(w_packed, Co, T, Ci, out=None):
+    """[Co,T,Ci] -> [T,Ci,Co] (weights for dgrad contractions)."""
+    dst = out if out is not None else torch.empty(T, Ci, Co, device=w_packed.device, dtype=w_packed.dtype)
+    L.check(L.lib().wgs_repack_w_t(L.rawptr(w_packed), L.rawptr(dst), Co, T, Ci, L.stream()), 'wgs_repack_w_t')
+    return dst
+
+
+def pack_weight(w):
+    """PyTorch [Co,Ci,kh,kw] -> contiguous [Co, kh*kw, Ci] (host-side, one-off for frozen weights)."""
+    Co, Ci, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(Co, kh * kw, Ci).contiguous()
