@@ -106,8 +106,8 @@ int wgs_upfirdn2d(const float* x, const float* kernel, float* y, int major, int 
  *
  * One launch computes, for every GEMM pixel m = (b, gy, gx) of a Hg x Wg grid and every n < Co:
  *   acc = sum_{t < ntaps} sum_{k < Ci} A(b, gy*isy + dy[t], gx*isx + dx[t], k) * w[wt[t]*w_tap_stride + n*w_row_stride + k]
- *   A(b,iy,ix,k) = x[b,iy,ix,k] * (a_scale ? a_scale[b*Ci + k] : 1)   (0 outside the image)
- *   v   = acc * (col_scale ? col_scale[b*Co + n] : 1) + (noise ? noise_w[0]*noise[oy*Wo+ox] : 0) + (bias ? bias[n] : 0)
+ *   A(b,iy,ix,k) = x[b,iy,ix,k] * (a_scale ? a_scale[b*a_ld + k] : 1)   (0 outside the image)
+ *   v   = acc * (col_scale ? col_scale[b*col_ld + n] : 1) + (noise ? noise_w[0]*noise[oy*Wo+ox] : 0) + (bias ? bias[n] : 0)
  *   y[b, oy, ox, n] = (v > 0 ? v : v*act_slope) * gain,   oy = gy*osy + oy0, ox = gx*osx + ox0
  * Plain conv: Hg=Ho, isy=stride, osy=1.  Stride-2 transposed conv / dgrad of strided conv: one launch
  * per output parity phase (osy=2, oy0=phase) with that phase's tap subset.
@@ -123,6 +123,7 @@ typedef struct wgs_conv_desc {
     const float* noise;      /* [Ho*Wo] or NULL (StyleGAN2 NoiseInjection buffer) */
     const float* noise_w;    /* device scalar (NoiseInjection.weight) or NULL */
     int32_t B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps;
+    int32_t a_ld, col_ld;    /* row strides of a_scale / col_scale (0 = Ci / Co) */
     int64_t w_tap_stride, w_row_stride;
     float act_slope, gain;   /* identity: 1,1;  relu: 0,1;  fused lrelu: 0.2,sqrt(2) */
     int8_t dy[64], dx[64];
@@ -148,6 +149,54 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
 
 /* dst[t][ci][co] = src[co][t][ci]  (pack [Cout,T,Cin] weights for the dgrad contraction). */
 int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * StyleGAN2 generator glue (models/StyleGAN2/model.py) — everything that is not a 3x3 contraction.
+ */
+/* PixelNorm (:9-15) over `rows` rows of length d: y = x * rsqrt(mean(x^2) + eps); and its backward. */
+int wgs_pixelnorm_fwd(const float* x, float* y, int rows, int d, float eps, wgs_stream_t stream);
+int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream);
+
+/* EqualLinear (:110-136) and friends, M = batch rows:
+ *   y[m*ldy + n] = out_gain * epi( wscale * sum_k f(x[m*ldx + k]) * w[n*K + k] + bscale * bias[n] )
+ * f = square when in_square (demodulation sum, :194);  epilogue 0 none, 1 leaky-relu(0.2)*sqrt(2)
+ * (fused_leaky_relu, :127-129), 2 rsqrt(v + eps) (demod, :195).  K % 4 == 0, K <= 2048. */
+int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx,
+                   int ldy, float wscale, float bscale, int in_square, int epilogue, float eps, float out_gain,
+                   wgs_stream_t stream);
+/* gx[m*ldx + k] (+)= wscale * sum_n gy[m*ldg + n] * gate(gate_y[m*ldg + n]) * w[n*K + k];
+ * gate(v) = v > 0 ? gain : gain*slope when gate_y != NULL (backward of the fused leaky-relu), else 1. */
+int wgs_linear_dgrad(const float* gy, const float* w, const float* gate_y, float* gx, int M, int N, int K, int ldg,
+                     int ldx, float wscale, float gate_slope, float gate_gain, int accumulate, wgs_stream_t stream);
+/* dw[n*K+k] = sum_m gy[m*N+n] x[m*K+k];  db[n] = sum_m gy[m*N+n] (db may be NULL). */
+int wgs_linear_wgrad(const float* gy, const float* x, float* dw, float* db, int M, int N, int K, wgs_stream_t stream);
+
+/* Blur(4x4, pad (1,1)) after the transposed conv (:165,212) fused with NoiseInjection (:231-241) and
+ * FusedLeakyReLU (:264): x [B,Ho+1,Wo+1,C] NHWC -> y [B,Ho,Wo,C]. */
+int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const float* noise, const float* noise_w,
+                                const float* bias, float* y, int B, int Ho, int Wo, int C, wgs_stream_t stream);
+
+/* ToRGB (:270-282): img[b,o,p] = wscale * sum_c x[b,p,c] s[b,c] w[o,c] + bias[o] + (skip ? skip[b,o,p] : 0).
+ * x NHWC [B,P,C]; img/skip NCHW [B,3,P]. C power of two. */
+int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip, float* img,
+                      int B, int P, int C, float wscale, wgs_stream_t stream);
+
+/* Backward through one StyledConv output `out` [B,P,C] (post-activation, saved by the forward):
+ *   dOut = sA*gA + sR*(sum_o drgb[b,o,p]*wR[o,c]*rscale);  dy = dOut * lrelu'(out)*sqrt(2)  -> dy [B,P,C]
+ *   num[b,c] += sum_p dy*ypre  (ypre = conv output before noise/bias/activation, recovered from `out`)
+ *   dsA[b,c] += sum_p out*gA ;  dsR[b,c] += sum_p out*gR       (caller zeroes num/dsA/dsR)
+ * gA = UN-scaled dgrad of the consumer conv (or NULL at the last layer), drgb = image gradient (or NULL). */
+int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
+                    const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
+                    float* dy, float* num, float* dsA, float* dsR, int B, int P, int C, wgs_stream_t stream);
+/* ds[b,c] += sum_p x[(x_batched ? b : 0), p, c] * g[b,p,c] */
+int wgs_xg_reduce(const float* x, int x_batched, const float* g, float* ds, int B, int P, int C, wgs_stream_t stream);
+/* dstyle[b*ld_out + i] = dsdir[b*Ci + i] - s[b*ld_s + i]*scale2 * sum_o num[b,o]*demod[b,o]^2*wsq[o,i]
+ * (demod == NULL: no demodulation, dstyle = dsdir). */
+int wgs_sg2_style_grad(const float* num, const float* demod, const float* s, const float* dsdir, const float* wsq,
+                       float scale2, float* dstyle, int B, int Co, int Ci, int ld_s, int ld_out, wgs_stream_t stream);
+/* wsq[o,i] = sum_t w[o,t,i]^2 for packed [Co,T,Ci] weights. */
+int wgs_sg2_wsq(const float* w_packed, float* wsq, int Co, int T, int Ci, wgs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -186,3 +186,86 @@ def make_blur_kernel(k=(1, 3, 3, 1)):
     k = torch.tensor(k, dtype=torch.float32)
     k = k[None, :] * k[:, None]
     return k / k.sum()
+
+
+# =================================================================================================
+# StyleGAN2 generator — models/StyleGAN2/model.py, functional over the reference state_dict
+# =================================================================================================
+def sg2_pixel_norm(x):
+    """PixelNorm.forward, model.py:14-15."""
+    return x * torch.rsqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def sg2_equal_linear(x, weight, bias, lr_mul=1.0, activation=False):
+    """EqualLinear.forward, model.py:126-131."""
+    scale = (1 / math.sqrt(weight.shape[1])) * lr_mul
+    if activation:
+        return fused_leaky_relu(F.linear(x, weight * scale), bias * lr_mul)
+    return F.linear(x, weight * scale, bias=bias * lr_mul)
+
+
+def sg2_mapping(sd, z, n_mlp=8, lr_mlp=0.01):
+    """Generator.style (model.py:290-295): PixelNorm then n_mlp activated EqualLinears."""
+    x = sg2_pixel_norm(z)
+    for i in range(1, n_mlp + 1):
+        x = sg2_equal_linear(x, sd['style.%d.weight' % i], sd['style.%d.bias' % i], lr_mul=lr_mlp, activation=True)
+    return x
+
+
+def sg2_modulated_conv(sd, prefix, x, style, demodulate=True, upsample=False):
+    """ModulatedConv2d.forward, model.py:187-228 — as written in the reference: per-sample weights
+    are materialised and applied with a grouped convolution (groups = batch)."""
+    weight = sd[prefix + '.weight']                       # [1, Co, Ci, k, k]
+    _, co, ci, k, _ = weight.shape
+    b, _, h, w = x.shape
+    s = sg2_equal_linear(style, sd[prefix + '.modulation.weight'], sd[prefix + '.modulation.bias']).view(b, 1, ci, 1, 1)
+    wgt = (1 / math.sqrt(ci * k * k)) * weight * s        # :191
+    if demodulate:
+        demod = torch.rsqrt(wgt.pow(2).sum([2, 3, 4]) + 1e-8)      # :194
+        wgt = wgt * demod.view(b, co, 1, 1, 1)
+    if upsample:
+        xin = x.reshape(1, b * ci, h, w)
+        wt = wgt.transpose(1, 2).reshape(b * ci, co, k, k)
+        out = F.conv_transpose2d(xin, wt, padding=0, stride=2, groups=b)       # :209
+        out = out.view(b, co, out.shape[2], out.shape[3])
+        return upfirdn2d(out, sd[prefix + '.blur.kernel'], pad=(1, 1))        # Blur pad: p=(4-2)-(3-1)=0 -> (1,1), :160-165
+    xin = x.reshape(1, b * ci, h, w)
+    out = F.conv2d(xin, wgt.view(b * co, ci, k, k), padding=k // 2, groups=b)  # :224
+    return out.view(b, co, out.shape[2], out.shape[3])
+
+
+def sg2_styled_conv(sd, prefix, x, style, noise, upsample=False):
+    """StyledConv.forward, model.py:266-267: activate(noise(conv(x, style)))."""
+    out = sg2_modulated_conv(sd, prefix + '.conv', x, style, upsample=upsample)
+    out = out + sd[prefix + '.noise.weight'] * noise                             # NoiseInjection :236-241
+    return fused_leaky_relu(out, sd[prefix + '.activate.bias'])
+
+
+def sg2_to_rgb(sd, prefix, x, style, skip=None):
+    """ToRGB.forward, model.py:278-282."""
+    out = sg2_modulated_conv(sd, prefix + '.conv', x, style, demodulate=False) + sd[prefix + '.bias']
+    if skip is not None:
+        out = out + upfirdn2d(skip, sd[prefix + '.upsample.kernel'], up=2, pad=(2, 1))
+    return out
+
+
+def sg2_synthesis(sd, w, size):
+    """Generator.forward with input_is_latent=True, one style, registered noise (model.py:364-403)."""
+    log_size = int(math.log(size, 2))
+    b = w.shape[0]
+    out = sd['input.input'].repeat(b, 1, 1, 1)
+    out = sg2_styled_conv(sd, 'conv1', out, w, sd['noises.noise_0'])
+    skip = sg2_to_rgb(sd, 'to_rgb1', out, w)
+    for j in range(log_size - 2):
+        out = sg2_styled_conv(sd, 'convs.%d' % (2 * j), out, w, sd['noises.noise_%d' % (2 * j + 1)], upsample=True)
+        out = sg2_styled_conv(sd, 'convs.%d' % (2 * j + 1), out, w, sd['noises.noise_%d' % (2 * j + 2)])
+        skip = sg2_to_rgb(sd, 'to_rgbs.%d' % j, out, w, skip)
+    return skip
+
+
+def sg2_generate(sd, z, size, shift=None, shift_in_w_space=False):
+    """StyleGAN2Wrapper.forward, models/gan_load.py:157-179."""
+    if shift_in_w_space:
+        w = sg2_mapping(sd, z)
+        return sg2_synthesis(sd, w if shift is None else w + shift, size)
+    return sg2_synthesis(sd, sg2_mapping(sd, z if shift is None else z + shift), size)

@@ -75,3 +75,66 @@ def test_upfirdn2d_oracle_vs_reference_native(golden):
         ref = g['upfirdn_' + c['name']]
         assert tuple(y.shape) == ref.shape, c['name']
         assert rel_err(y, ref) < 1e-6, c['name']
+
+
+def _sg2_sd(size, seed):
+    """State dict with the reference Generator's keys/shapes, filled from the shared seeded recipe.
+    The key/shape manifest comes from the product module (checked against the reference's own
+    state_dict by tests/golden/stylegan2.npz's manifest hash in test_stylegan2_manifest)."""
+    from warpedganspace_amd.stylegan2 import Generator
+    G = Generator(size, 512, 8)
+    return GI.fill_state_dict(G.state_dict(), seed)
+
+
+def test_stylegan2_oracle_vs_reference_g32(golden):
+    g = golden('stylegan2')
+    sd = _sg2_sd(32, 400 + 32)
+    z = GI.rt(410 + 32, 2, 512)
+    shift = (GI.rt(411 + 32, 2, 512) * 0.02).requires_grad_(True)
+    img = O.sg2_generate(sd, z, 32, shift)
+    probe = GI.rt(412 + 32, *img.shape)
+    (img * probe).sum().backward()
+    assert rel_err(img, g['g32_img']) < 1e-5
+    assert rel_err(O.sg2_mapping(sd, z), g['g32_w']) < 1e-5
+    assert rel_err(shift.grad, g['g32_dshift']) < 1e-4
+    w = O.sg2_mapping(sd, z).detach()
+    shw = (GI.rt(413 + 32, 2, 512) * 0.05).requires_grad_(True)
+    imgw = O.sg2_synthesis(sd, w + shw, 32)
+    (imgw * probe).sum().backward()
+    assert rel_err(imgw, g['g32_w_img']) < 1e-5
+    assert rel_err(shw.grad, g['g32_w_dshift']) < 1e-4
+
+
+def test_stylegan2_oracle_vs_reference_g256(golden):
+    g = golden('stylegan2')
+    sd = _sg2_sd(256, 400 + 256)
+    z = GI.rt(410 + 256, 2, 512)
+    shift = GI.rt(411 + 256, 2, 512) * 0.02
+    with torch.no_grad():
+        img = O.sg2_generate(sd, z, 256, shift)
+    assert rel_err(torch.nn.functional.avg_pool2d(img, 8), g['g256_img_pool8']) < 1e-5
+    assert rel_err(img[:, :, 100:116, 60:76], g['g256_img_crop']) < 1e-5
+    assert abs(img.abs().mean().item() - float(g['g256_img_absmean'])) < 1e-5 * float(g['g256_img_absmean'])
+
+
+@pytest.mark.parametrize('name,cin,cout,ks,up,demod,hw', [('plain', 16, 24, 3, False, True, 8),
+                                                            ('up', 16, 8, 3, True, True, 5),
+                                                            ('rgb', 16, 3, 1, False, False, 8)])
+def test_modulated_conv_oracle_vs_reference(golden, name, cin, cout, ks, up, demod, hw):
+    """ModulatedConv2d blocks (model.py:187-228): output, d/dx and d/dstyle against the reference."""
+    from collections import OrderedDict
+    g = golden('stylegan2')
+    tmpl = OrderedDict()
+    tmpl['weight'] = torch.zeros(1, cout, cin, ks, ks)
+    if up:
+        tmpl['blur.kernel'] = O.make_blur_kernel() * 4
+    tmpl['modulation.weight'] = torch.zeros(cin, 32)
+    tmpl['modulation.bias'] = torch.zeros(cin)
+    sd = {'m.' + k: v for k, v in GI.fill_state_dict(tmpl, 300 + len(name)).items()}
+    x = GI.rt(310, 2, cin, hw, hw).requires_grad_(True)
+    s = GI.rt(311, 2, 32).requires_grad_(True)
+    y = O.sg2_modulated_conv(sd, 'm', x, s, demodulate=demod, upsample=up)
+    (y * GI.rt(312, *y.shape)).sum().backward()
+    assert rel_err(y, g['modconv_%s_y' % name]) < 1e-5
+    assert rel_err(x.grad, g['modconv_%s_dx' % name]) < 1e-5
+    assert rel_err(s.grad, g['modconv_%s_ds' % name]) < 1e-5

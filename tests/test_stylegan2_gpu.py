@@ -1,0 +1,78 @@
+"""GPU: HIP StyleGAN2 generator (forward + input gradient) vs the reference golden vectors and the oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import wgs_oracle as O
+from tests import golden_inputs as GI
+from tests.util import rel_err, l2_rel
+from warpedganspace_amd.gan_load import StyleGAN2Wrapper
+from warpedganspace_amd.stylegan2 import Generator
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3   # north_star: within 1e-3 relative fp32 of the reference path (measured values are ~1e-5)
+
+
+def build(size, seed, dev):
+    G = Generator(size, 512, 8)
+    sd = GI.fill_state_dict(G.state_dict(), seed)
+    G.load_state_dict(sd)
+    return G.to(dev), sd
+
+
+@pytest.mark.parametrize('size', [32, 256])
+def test_generator_vs_reference_golden(dev, golden, size):
+    g = golden('stylegan2')
+    G, sd = build(size, 400 + size, dev)
+    tag = 'g%d_' % size
+    z = GI.rt(410 + size, 2, 512).to(dev)
+    shift = (GI.rt(411 + size, 2, 512) * 0.02).to(dev).requires_grad_(True)
+    wrap = StyleGAN2Wrapper(G, shift_in_w_space=False)
+    img = wrap(z, shift)
+    probe = GI.rt(412 + size, *img.shape).to(dev)
+    (img * probe).sum().backward()
+    w = wrap.get_w(z)
+    assert rel_err(w, g[tag + 'w']) < 1e-5
+    if size == 32:
+        e = rel_err(img, g[tag + 'img'])
+    else:
+        e = max(rel_err(F.avg_pool2d(img.detach(), 8), g[tag + 'img_pool8']),
+                rel_err(img.detach()[:, :, 100:116, 60:76], g[tag + 'img_crop']))
+    assert e < 1e-4, e
+    assert rel_err(shift.grad, g[tag + 'dshift']) < TOL
+    # W space
+    wrapw = StyleGAN2Wrapper(G, shift_in_w_space=True)
+    shw = (GI.rt(413 + size, 2, 512) * 0.05).to(dev).requires_grad_(True)
+    imgw = wrapw(z, shw)
+    (imgw * probe).sum().backward()
+    if size == 32:
+        assert rel_err(imgw, g[tag + 'w_img']) < 1e-4
+    else:
+        assert rel_err(F.avg_pool2d(imgw.detach(), 8), g[tag + 'w_img_pool8']) < 1e-4
+    assert rel_err(shw.grad, g[tag + 'w_dshift']) < TOL
+    # latent_is_w path (traverse_latent_space.py:457-462)
+    imgw2 = wrapw(w.detach(), shw.detach(), latent_is_w=True)
+    assert rel_err(imgw2, imgw) < 1e-6
+
+
+def test_generator_vs_oracle_64_batch5(dev):
+    """Another size / batch against the CPU oracle (full image + gradient)."""
+    G, sd = build(64, 777, dev)
+    z = GI.rt(778, 5, 512)
+    shift = (GI.rt(779, 5, 512) * 0.3).requires_grad_(True)
+    img_o = O.sg2_generate(sd, z, 64, shift)
+    probe = GI.rt(780, *img_o.shape)
+    (img_o * probe).sum().backward()
+    sh = shift.detach().to(dev).requires_grad_(True)
+    img = StyleGAN2Wrapper(G, False)(z.to(dev), sh)
+    (img * probe.to(dev)).sum().backward()
+    assert rel_err(img, img_o) < 1e-4
+    assert l2_rel(sh.grad, shift.grad) < TOL
+    assert rel_err(sh.grad, shift.grad) < TOL
+
+
+def test_no_grad_forward_saves_nothing(dev):
+    G, _ = build(32, 5, dev)
+    with torch.no_grad():
+        img = StyleGAN2Wrapper(G, False)(torch.randn(3, 512, device=dev))
+    assert img.shape == (3, 3, 32, 32) and not img.requires_grad

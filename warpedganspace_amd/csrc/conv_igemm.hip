@@ -34,7 +34,7 @@ struct ConvArgs {
     const float* bias;
     const float* noise;
     const float* noise_w;
-    int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M;
+    int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M, a_ld, col_ld;
     long w_tap_stride, w_row_stride;
     float act_slope, gain;
     signed char dy[64], dx[64];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
             if (v) {
                 val = *reinterpret_cast<const float4*>(p.x + ((size_t)(a_pix[pa] + iy * p.Wi + ix)) * p.Ci + ci0);
                 if (ASCALE) {
-                    const float4 s = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.Ci + ci0);
+                    const float4 s = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
                     val.x *= s.x; val.y *= s.y; val.z *= s.z; val.w *= s.w;
                 }
             }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
                 const int pix = r_pix[row];
                 if (pix >= 0 && nok) {
                     float v = acc[i][j][r];
-                    if (p.col_scale) v *= p.col_scale[(size_t)r_b[row] * p.Co + n];
+                    if (p.col_scale) v *= p.col_scale[(size_t)r_b[row] * p.col_ld + n];
                     if (p.noise) v = fmaf(nw, p.noise[r_hw[row]], v);
                     v += bias;
                     v = (v > 0.f ? v : v * p.act_slope) * p.gain;
@@ -407,6 +407,8 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     a.isy = d->isy; a.isx = d->isx; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.osy = d->osy; a.osx = d->osx; a.oy0 = d->oy0; a.ox0 = d->ox0; a.ntaps = d->ntaps;
     a.M = d->B * d->Hg * d->Wg;
+    a.a_ld = d->a_ld > 0 ? d->a_ld : d->Ci;
+    a.col_ld = d->col_ld > 0 ? d->col_ld : d->Co;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
     a.act_slope = d->act_slope; a.gain = d->gain;
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }

@@ -1,0 +1,471 @@
+// StyleGAN2 generator glue kernels (everything in models/StyleGAN2/model.py that is not a dense
+// 3x3 contraction): PixelNorm :9-15, EqualLinear :110-136 (mapping MLP + per-layer modulation),
+// demodulation :194-195, Blur + NoiseInjection + FusedLeakyReLU fused :67-81,231-241,264, ToRGB
+// :270-282, and the hand-derived backward of the shifted branch (dgrad only; G is frozen).
+// All HBM-/latency-bound: float4 accesses over the channel (NHWC minor) axis, wave64 reductions.
+#include "wgs_common.h"
+#include "../../include/wgs.h"
+
+namespace {
+
+constexpr float SQRT2 = 1.41421356237309504880f;
+
+// ---- PixelNorm over rows of length d -------------------------------------------------------------
+__global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int rows, int d, float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * d;
+    float s = 0.f;
+    for (int j = lane; j < d; j += 64) s = fmaf(xr[j], xr[j], s);
+    s = wave_sum(s);
+    const float f = rsqrtf(s / d + eps);
+    for (int j = lane; j < d; j += 64) y[(size_t)r * d + j] = xr[j] * f;
+}
+// y = x * f, f = (mean(x^2)+eps)^-1/2  =>  gx = f*gy - x * f^3 * (x.gy)/d
+__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                            float* __restrict__ gx, int rows, int d, float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * d;
+    const float* gr = gy + (size_t)r * d;
+    float s = 0.f, t = 0.f;
+    for (int j = lane; j < d; j += 64) { s = fmaf(xr[j], xr[j], s); t = fmaf(xr[j], gr[j], t); }
+    s = wave_sum(s); t = wave_sum(t);
+    const float f = rsqrtf(s / d + eps);
+    const float c = f * f * f * t / d;
+    for (int j = lane; j < d; j += 64) gx[(size_t)r * d + j] = f * gr[j] - xr[j] * c;
+}
+
+// ---- small dense layers (M = batch rows <= a few hundred) ----------------------------------------
+// y[m,n] = epi( wscale * sum_k f(x[m,k]) w[n,k] + bscale*bias[n] ), one wave per output column n.
+//   f = identity or square (in_square);  epi: 0 none, 1 leaky-relu(0.2)*sqrt(2), 2 rsqrt(v + eps)
+template <int NT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int M, int N, int K, int ldx, int ldy, float wscale,
+                                                         float bscale, int in_square, int epi, float eps, float out_gain) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float4 wr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int k = 4 * lane + 256 * t;
+        wr[t] = (k < K) ? *reinterpret_cast<const float4*>(w + (size_t)n * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float b = bias ? bias[n] * bscale : 0.f;
+    for (int m = 0; m < M; ++m) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = 4 * lane + 256 * t;
+            if (k < K) {
+                float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k);
+                if (in_square) { xv.x *= xv.x; xv.y *= xv.y; xv.z *= xv.z; xv.w *= xv.w; }
+                acc = fmaf(xv.x, wr[t].x, acc); acc = fmaf(xv.y, wr[t].y, acc);
+                acc = fmaf(xv.z, wr[t].z, acc); acc = fmaf(xv.w, wr[t].w, acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = fmaf(acc, wscale, b);
+            if (epi == 1) v = (v > 0.f ? v : 0.2f * v) * SQRT2;
+            else if (epi == 2) v = rsqrtf(v + eps);
+            y[(size_t)m * ldy + n] = v * out_gain;
+        }
+    }
+}
+
+// gx[m,k] (+)= wscale * sum_n g'[m,n] w[n,k],  g' = gy * (gate ? (gate[m,n] > 0 ? gain : gain*slope) : 1)
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                           const float* __restrict__ gate, float* __restrict__ gx,
+                                                           int M, int N, int K, int ldg, int ldx, float wscale,
+                                                           float slope, float gain, int accumulate) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (k >= K) return;
+    const float* g = gy + (size_t)m * ldg;
+    const float* gt = gate ? gate + (size_t)m * ldg : nullptr;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float gv = g[n];
+        if (gt) gv *= (gt[n] > 0.f ? gain : gain * slope);
+        acc = fmaf(gv, w[(size_t)n * K + k], acc);
+    }
+    float* o = gx + (size_t)m * ldx + k;
+    *o = accumulate ? (*o + acc * wscale) : acc * wscale;
+}
+
+// dW[n,k] = sum_m gy[m,n] x[m,k] ; db[n] = sum_m gy[m,n]   (Reconstructor heads; M = batch)
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                           float* __restrict__ dw, float* __restrict__ db, int M,
+                                                           int N, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (k >= K) return;
+    float acc = 0.f, accb = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float g = gy[(size_t)m * N + n];
+        acc = fmaf(g, x[(size_t)m * K + k], acc);
+        accb += g;
+    }
+    dw[(size_t)n * K + k] = acc;
+    if (db && k == 0) db[n] = accb;
+}
+
+// ---- Blur(4x4, pad (1,1)) + noise + bias + leaky-relu*sqrt(2) on NHWC ------------------------------
+// in [B, Hin, Win, C] (Hin = Ho+1), out [B, Ho, Wo, C].  The separable [1,3,3,1] kernel (outer product,
+// normalised, times up^2 = 4) is symmetric, so flipping is a no-op: k2[a][b] = k1[a]*k1[b]*4/64.
+__global__ __launch_bounds__(256) void blur_nba_kernel(const float* __restrict__ x, const float* __restrict__ kern,
+                                                       const float* __restrict__ noise, const float* __restrict__ noise_w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                       int Ho, int Wo, int C) {
+    __shared__ float sk[16];
+    if (threadIdx.x < 16) sk[threadIdx.x] = kern[15 - threadIdx.x];  // flipped (upfirdn2d correlates with flip)
+    __syncthreads();
+    const int Hin = Ho + 1, Win = Wo + 1;
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)B * Ho * Wo * c4n;
+    const float nw = noise ? noise_w[0] : 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e;
+        const int c = (int)(r % c4n) * 4; r /= c4n;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int iy = oy + ky - 1;
+            if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int ix = ox + kx - 1;
+                if (ix < 0 || ix >= Win) continue;
+                const float wv = sk[ky * 4 + kx];
+                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * Hin + iy) * Win + ix) * C + c);
+                acc.x = fmaf(v.x, wv, acc.x); acc.y = fmaf(v.y, wv, acc.y);
+                acc.z = fmaf(v.z, wv, acc.z); acc.w = fmaf(v.w, wv, acc.w);
+            }
+        }
+        const float nz = noise ? nw * noise[oy * Wo + ox] : 0.f;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+        float4 o;
+        o.x = acc.x + nz + bv.x; o.y = acc.y + nz + bv.y; o.z = acc.z + nz + bv.z; o.w = acc.w + nz + bv.w;
+        o.x = (o.x > 0.f ? o.x : 0.2f * o.x) * SQRT2; o.y = (o.y > 0.f ? o.y : 0.2f * o.y) * SQRT2;
+        o.z = (o.z > 0.f ? o.z : 0.2f * o.z) * SQRT2; o.w = (o.w > 0.f ? o.w : 0.2f * o.w) * SQRT2;
+        *reinterpret_cast<float4*>(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = o;
+    }
+}
+
+// ---- ToRGB: 1x1 modulated conv to 3 channels, no demod, + bias + up-sampled skip -> NCHW image ------
+// img[b,o,p] = wscale * sum_c x[b,p,c] s[b,c] W[o,c] + bias[o] + skip[b,o,p]
+// One block = 256 consecutive pixels of one sample; each wave walks its 64 pixels with LPP lanes per
+// pixel (float4 over channels), shuffle-reduces, stages results in LDS, then writes coalesced planes.
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ skip, float* __restrict__ img,
+                                                        int P, int C, float wscale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wm = sm;               // [3][C] modulated weights W[o,c]*s[b,c]*wscale
+    float* res = sm + 3 * C;      // [3][256]
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * 256;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) wm[i] = w[i] * s[(size_t)b * C + (i % C)] * wscale;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c4n = C >> 2;
+    const int lpp = c4n < 64 ? c4n : 64;   // lanes per pixel (power of two: C in {32..512})
+    const int ppw = 64 / lpp;              // pixels per wave iteration
+    const int sub = lane / lpp, cl = lane % lpp;
+    for (int it = 0; it < 64; it += ppw) {
+        const int pl = wave * 64 + it + sub;
+        const int p = p0 + pl;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if (p < P) {
+            const float* xp = x + ((size_t)b * P + p) * C;
+            for (int c = cl * 4; c < C; c += lpp * 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + c);
+                const float4 w0 = *reinterpret_cast<const float4*>(wm + c);
+                const float4 w1 = *reinterpret_cast<const float4*>(wm + C + c);
+                const float4 w2 = *reinterpret_cast<const float4*>(wm + 2 * C + c);
+                a0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+                a1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+                a2 += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+            }
+        }
+        for (int off = lpp >> 1; off > 0; off >>= 1) {
+            a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64);
+        }
+        if (cl == 0) { res[pl] = a0; res[256 + pl] = a1; res[512 + pl] = a2; }
+    }
+    __syncthreads();
+    const int p = p0 + threadIdx.x;
+    if (p < P) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const size_t off = ((size_t)b * 3 + o) * P + p;
+            float v = res[o * 256 + threadIdx.x] + bias[o];
+            if (skip) v += skip[off];
+            img[off] = v;
+        }
+    }
+}
+
+// ---- backward of one StyledConv's output tensor ----------------------------------------------------
+// `out` [B,P,C] is the saved post-activation output of a StyledConv, consumed by (A) the next modulated
+// conv with style sA [B,C], whose dgrad produced the UN-scaled gA [B,P,C], and optionally (R) the
+// ToRGB at this resolution (style sR, weight wR [3,C]*rscale) with image gradient drgb [B,3,P].
+//   dOut = sA*gA + sR * (sum_o drgb[b,o,p] wR[o,c] rscale)
+//   dy   = dOut * (out > 0 ? sqrt2 : 0.2*sqrt2)                               -> written [B,P,C]
+//   ypre = (out > 0 ? out/sqrt2 : out/(0.2 sqrt2)) - nw*noise[p] - bias[c]      (pre-noise conv output)
+//   num[b,c]  += sum_p dy*ypre      (d demod numerator: ddemod = num/demod)
+//   dsA[b,c]  += sum_p out*gA       (direct style gradient of the consumer conv)
+//   dsR[b,c]  += sum_p out*gR       (direct style gradient of the ToRGB)
+// grid = (pixel chunks, B); thread -> fixed float4 channel group, strides over the chunk's pixels.
+__global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
+    const float* __restrict__ out, const float* __restrict__ gA, const float* __restrict__ sA,
+    const float* __restrict__ drgb, const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
+    const float* __restrict__ noise, const float* __restrict__ noise_w, const float* __restrict__ bias,
+    float* __restrict__ dy, float* __restrict__ num, float* __restrict__ dsA, float* __restrict__ dsR, int P, int C,
+    int chunk) {
+    __shared__ float4 red[3][256];
+    const int b = blockIdx.y;
+    const int c4n = C >> 2;
+    const int tpp = c4n < 256 ? c4n : 256;  // threads per pixel
+    const int ppi = 256 / tpp;              // pixels per block iteration
+    const int cl = threadIdx.x % tpp, sub = threadIdx.x / tpp;
+    const int p_begin = blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
+    const float nw = noise ? noise_w[0] : 0.f;
+    for (int c = cl * 4; c < C; c += tpp * 4) {
+        float4 sa = gA ? *reinterpret_cast<const float4*>(sA + (size_t)b * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sr = make_float4(0.f, 0.f, 0.f, 0.f), w0 = sr, w1 = sr, w2 = sr;
+        if (drgb) {
+            sr = *reinterpret_cast<const float4*>(sR + (size_t)b * C + c);
+            w0 = *reinterpret_cast<const float4*>(wR + c);
+            w1 = *reinterpret_cast<const float4*>(wR + C + c);
+            w2 = *reinterpret_cast<const float4*>(wR + 2 * C + c);
+        }
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+        float4 r_num = make_float4(0.f, 0.f, 0.f, 0.f), r_a = r_num, r_r = r_num;
+        for (int p = p_begin + sub; p < p_end; p += ppi) {
+            const size_t off = ((size_t)b * P + p) * C + c;
+            const float4 o = *reinterpret_cast<const float4*>(out + off);
+            float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gA) ga = *reinterpret_cast<const float4*>(gA + off);
+            float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (drgb) {
+                const float d0 = drgb[((size_t)b * 3 + 0) * P + p] * rscale;
+                const float d1 = drgb[((size_t)b * 3 + 1) * P + p] * rscale;
+                const float d2 = drgb[((size_t)b * 3 + 2) * P + p] * rscale;
+                gr.x = d0 * w0.x + d1 * w1.x + d2 * w2.x; gr.y = d0 * w0.y + d1 * w1.y + d2 * w2.y;
+                gr.z = d0 * w0.z + d1 * w1.z + d2 * w2.z; gr.w = d0 * w0.w + d1 * w1.w + d2 * w2.w;
+            }
+            const float nz = noise ? nw * noise[p] : 0.f;
+            float4 d;
+#define WGS_ONE(f)                                                                  \
+    {                                                                               \
+        const float dout = sa.f * ga.f + sr.f * gr.f;                               \
+        const bool pos = o.f > 0.f;                                                 \
+        d.f = dout * (pos ? SQRT2 : 0.2f * SQRT2);                                  \
+        const float ypre = (pos ? o.f * (1.f / SQRT2) : o.f * (1.f / (0.2f * SQRT2))) - nz - bv.f; \
+        r_num.f = fmaf(d.f, ypre, r_num.f);                                         \
+        r_a.f = fmaf(o.f, ga.f, r_a.f);                                             \
+        r_r.f = fmaf(o.f, gr.f, r_r.f);                                             \
+    }
+            WGS_ONE(x) WGS_ONE(y) WGS_ONE(z) WGS_ONE(w)
+#undef WGS_ONE
+            *reinterpret_cast<float4*>(dy + off) = d;
+        }
+        // combine the `ppi` pixel sub-streams that share this channel group
+        __syncthreads();
+        red[0][threadIdx.x] = r_num; red[1][threadIdx.x] = r_a; red[2][threadIdx.x] = r_r;
+        __syncthreads();
+        if (sub == 0) {
+            for (int s2 = 1; s2 < ppi; ++s2) {
+                const float4 a = red[0][s2 * tpp + cl], bb = red[1][s2 * tpp + cl], cc = red[2][s2 * tpp + cl];
+                r_num.x += a.x; r_num.y += a.y; r_num.z += a.z; r_num.w += a.w;
+                r_a.x += bb.x; r_a.y += bb.y; r_a.z += bb.z; r_a.w += bb.w;
+                r_r.x += cc.x; r_r.y += cc.y; r_r.z += cc.z; r_r.w += cc.w;
+            }
+            float* pn = num + (size_t)b * C + c;
+            unsafeAtomicAdd(pn + 0, r_num.x); unsafeAtomicAdd(pn + 1, r_num.y);
+            unsafeAtomicAdd(pn + 2, r_num.z); unsafeAtomicAdd(pn + 3, r_num.w);
+            if (gA) {
+                float* pa = dsA + (size_t)b * C + c;
+                unsafeAtomicAdd(pa + 0, r_a.x); unsafeAtomicAdd(pa + 1, r_a.y);
+                unsafeAtomicAdd(pa + 2, r_a.z); unsafeAtomicAdd(pa + 3, r_a.w);
+            }
+            if (drgb) {
+                float* pr = dsR + (size_t)b * C + c;
+                unsafeAtomicAdd(pr + 0, r_r.x); unsafeAtomicAdd(pr + 1, r_r.y);
+                unsafeAtomicAdd(pr + 2, r_r.z); unsafeAtomicAdd(pr + 3, r_r.w);
+            }
+        }
+    }
+}
+
+// ds[b,c] += sum_p x[(xb ? b : 0), p, c] * g[b,p,c]   (direct style gradient of the first conv, whose
+// input is the batch-independent ConstantInput)
+__global__ __launch_bounds__(256) void xg_reduce_kernel(const float* __restrict__ x, int x_batched,
+                                                        const float* __restrict__ g, float* __restrict__ ds, int P,
+                                                        int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* xp = x + (x_batched ? (size_t)b * P * C : 0);
+    const float* gp = g + (size_t)b * P * C;
+    float acc = 0.f;
+    for (int p = 0; p < P; ++p) acc = fmaf(xp[(size_t)p * C + c], gp[(size_t)p * C + c], acc);
+    ds[(size_t)b * C + c] += acc;
+}
+
+// dstyle[b,i] = dsdir[b,i] - s[b,i]*scale2 * sum_o num[b,o]*demod[b,o]^2 * wsq[o,i]
+// (style gradient of a demodulated conv: direct term + the path through demod = rsqrt(scale2*sum s^2 wsq + eps))
+__global__ __launch_bounds__(256) void sg2_style_grad_kernel(const float* __restrict__ num, const float* __restrict__ demod,
+                                                             const float* __restrict__ s, const float* __restrict__ dsdir,
+                                                             const float* __restrict__ wsq, float scale2,
+                                                             float* __restrict__ dstyle, int Co, int Ci, int lds_,
+                                                             int ldo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= Ci) return;
+    float acc = 0.f;
+    if (demod) {
+        for (int o = 0; o < Co; ++o) {
+            const float dm = demod[(size_t)b * Co + o];
+            acc = fmaf(num[(size_t)b * Co + o] * dm * dm, wsq[(size_t)o * Ci + i], acc);
+        }
+    }
+    dstyle[(size_t)b * ldo + i] = dsdir[(size_t)b * Ci + i] - s[(size_t)b * lds_ + i] * scale2 * acc;
+}
+
+// wsq[o,i] = sum_t w[o,t,i]^2   (w packed [Co,T,Ci]; one-off for the frozen generator)
+__global__ __launch_bounds__(256) void wsq_kernel(const float* __restrict__ w, float* __restrict__ wsq, int Co, int T, int Ci) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int o = blockIdx.y;
+    if (i >= Ci) return;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) { const float v = w[((size_t)o * T + t) * Ci + i]; acc = fmaf(v, v, acc); }
+    wsq[(size_t)o * Ci + i] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wgs_pixelnorm_fwd(const float* x, float* y, int rows, int d, float eps, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && y && rows > 0 && d > 0, "wgs_pixelnorm_fwd: bad arguments");
+    hipLaunchKernelGGL(pixelnorm_fwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, d, eps);
+    WGS_CHECK_LAUNCH("pixelnorm_fwd_kernel");
+    return WGS_OK;
+}
+int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && gy && gx && rows > 0 && d > 0, "wgs_pixelnorm_bwd: bad arguments");
+    hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, rows, d, eps);
+    WGS_CHECK_LAUNCH("pixelnorm_bwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx,
+                   int ldy, float wscale, float bscale, int in_square, int epilogue, float eps, float out_gain,
+                   wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && w && y, "wgs_linear_fwd: null pointer");
+    WGS_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0 && K <= 2048 && ldx % 4 == 0,
+                  "wgs_linear_fwd: need K %% 4 == 0, K <= 2048, ldx %% 4 == 0 (M=%d N=%d K=%d ldx=%d)", M, N, K, ldx);
+    dim3 grid(wgs_cdiv(N, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define WGS_LIN(NT) hipLaunchKernelGGL(linear_fwd_kernel<NT>, grid, block, 0, st, x, w, bias, y, M, N, K, ldx, ldy, wscale, bscale, in_square, epilogue, eps, out_gain)
+    if (K <= 256) WGS_LIN(1); else if (K <= 512) WGS_LIN(2); else if (K <= 1024) WGS_LIN(4); else WGS_LIN(8);
+#undef WGS_LIN
+    WGS_CHECK_LAUNCH("linear_fwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_linear_dgrad(const float* gy, const float* w, const float* gate_y, float* gx, int M, int N, int K, int ldg,
+                     int ldx, float wscale, float gate_slope, float gate_gain, int accumulate, wgs_stream_t stream) {
+    WGS_CHECK_ARG(gy && w && gx && M > 0 && N > 0 && K > 0, "wgs_linear_dgrad: bad arguments");
+    hipLaunchKernelGGL(linear_dgrad_kernel, dim3(wgs_cdiv(K, 256), M), dim3(256), 0, (hipStream_t)stream, gy, w, gate_y,
+                       gx, M, N, K, ldg, ldx, wscale, gate_slope, gate_gain, accumulate);
+    WGS_CHECK_LAUNCH("linear_dgrad_kernel");
+    return WGS_OK;
+}
+
+int wgs_linear_wgrad(const float* gy, const float* x, float* dw, float* db, int M, int N, int K, wgs_stream_t stream) {
+    WGS_CHECK_ARG(gy && x && dw && M > 0 && N > 0 && K > 0, "wgs_linear_wgrad: bad arguments");
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(wgs_cdiv(K, 256), N), dim3(256), 0, (hipStream_t)stream, gy, x, dw, db, M, N, K);
+    WGS_CHECK_LAUNCH("linear_wgrad_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const float* noise, const float* noise_w,
+                                const float* bias, float* y, int B, int Ho, int Wo, int C, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && kernel4x4 && bias && y, "wgs_sg2_blur_noise_bias_act: null pointer");
+    WGS_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "wgs_sg2_blur_noise_bias_act: bad sizes (C %% 4)");
+    WGS_CHECK_ARG(!noise || noise_w, "wgs_sg2_blur_noise_bias_act: noise needs noise_w");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    int grid = wgs_cdiv(total, 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(blur_nba_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, kernel4x4, noise, noise_w, bias, y, B, Ho, Wo, C);
+    WGS_CHECK_LAUNCH("blur_nba_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip, float* img,
+                      int B, int P, int C, float wscale, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && s && w && bias && img, "wgs_sg2_torgb_fwd: null pointer");
+    WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && (C & (C - 1)) == 0, "wgs_sg2_torgb_fwd: C=%d must be a power of two >= 4", C);
+    const size_t smem = (size_t)(3 * C + 3 * 256) * sizeof(float);
+    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, 256), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale);
+    WGS_CHECK_LAUNCH("torgb_fwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
+                    const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
+                    float* dy, float* num, float* dsA, float* dsR, int B, int P, int C, wgs_stream_t stream) {
+    WGS_CHECK_ARG(out && bias && dy && num, "wgs_sg2_act_bwd: null pointer");
+    WGS_CHECK_ARG(gA || drgb, "wgs_sg2_act_bwd: needs at least one gradient source");
+    WGS_CHECK_ARG(!gA || (sA && dsA), "wgs_sg2_act_bwd: gA needs sA and dsA");
+    WGS_CHECK_ARG(!drgb || (wR && sR && dsR), "wgs_sg2_act_bwd: drgb needs wR, sR, dsR");
+    WGS_CHECK_ARG(!noise || noise_w, "wgs_sg2_act_bwd: noise needs noise_w");
+    WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && (C & (C - 1)) == 0, "wgs_sg2_act_bwd: C=%d must be a power of two >= 4", C);
+    // ~2048 blocks in total; each block owns `chunk` pixels of one sample
+    int chunks = wgs_cdiv(2048, B);
+    int chunk = wgs_cdiv(P, chunks);
+    if (chunk < 16) chunk = 16;
+    chunks = wgs_cdiv(P, chunk);
+    hipLaunchKernelGGL(sg2_act_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
+                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, P, C, chunk);
+    WGS_CHECK_LAUNCH("sg2_act_bwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_xg_reduce(const float* x, int x_batched, const float* g, float* ds, int B, int P, int C, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && g && ds && B > 0 && P > 0 && C > 0, "wgs_xg_reduce: bad arguments");
+    hipLaunchKernelGGL(xg_reduce_kernel, dim3(wgs_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, x, x_batched, g, ds, P, C);
+    WGS_CHECK_LAUNCH("xg_reduce_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_style_grad(const float* num, const float* demod, const float* s, const float* dsdir, const float* wsq,
+                       float scale2, float* dstyle, int B, int Co, int Ci, int ld_s, int ld_out, wgs_stream_t stream) {
+    WGS_CHECK_ARG(s && dsdir && dstyle && B > 0 && Co > 0 && Ci > 0, "wgs_sg2_style_grad: bad arguments");
+    WGS_CHECK_ARG(!demod || (num && wsq), "wgs_sg2_style_grad: demod needs num and wsq");
+    hipLaunchKernelGGL(sg2_style_grad_kernel, dim3(wgs_cdiv(Ci, 256), B), dim3(256), 0, (hipStream_t)stream, num, demod, s,
+                       dsdir, wsq, scale2, dstyle, Co, Ci, ld_s, ld_out);
+    WGS_CHECK_LAUNCH("sg2_style_grad_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_wsq(const float* w_packed, float* wsq, int Co, int T, int Ci, wgs_stream_t stream) {
+    WGS_CHECK_ARG(w_packed && wsq && Co > 0 && T > 0 && Ci > 0, "wgs_sg2_wsq: bad arguments");
+    hipLaunchKernelGGL(wsq_kernel, dim3(wgs_cdiv(Ci, 256), Co), dim3(256), 0, (hipStream_t)stream, w_packed, wsq, Co, T, Ci);
+    WGS_CHECK_LAUNCH("wsq_kernel");
+    return WGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+"""Generator wrappers with the reference's uniform API `G(z, shift=None)`, `G.dim_z`, `G.get_w(z)`
+(models/gan_load.py:21-28,65-81,109-120,137-179) on top of the HIP generators.
+
+Pre-trained weights are not available offline; `build_*` accept `pretrained_gan_weights=None`
+(random init exactly as the reference constructors do) or a path in the reference's file formats.
+"""
+import torch
+from torch import nn
+
+from .stylegan2 import Generator as StyleGAN2Generator
+
+
+class StyleGAN2Wrapper(nn.Module):
+    """models/gan_load.py:137-179."""
+
+    def __init__(self, G, shift_in_w_space):
+        super().__init__()
+        self.G = G
+        self.shift_in_w_space = shift_in_w_space
+        self.dim_z = 512
+        self.dim_w = self.G.style_dim if self.shift_in_w_space else self.dim_z
+
+    def get_w(self, z):
+        """Z-space codes [B,512] -> W-space codes [B,512] (mapping network)."""
+        return self.G.get_latent(z)
+
+    def forward(self, z, shift=None, latent_is_w=False):
+        """z: latent codes (Z space, or W space when `latent_is_w`); shift: shift vectors in the space
+        selected by `shift_in_w_space`.  Returns images [B, 3, res, res] (NCHW, un-clamped)."""
+        if self.shift_in_w_space:
+            if latent_is_w:
+                return self.G([z if shift is None else z + shift], input_is_latent=True)[0]
+            w = self.G.get_latent(z)
+            return self.G([w if shift is None else w + shift], input_is_latent=True)[0]
+        return self.G([z if shift is None else z + shift], input_is_latent=False)[0]
+
+
+def build_stylegan2(pretrained_gan_weights=None, resolution=1024, shift_in_w_space=False):
+    """models/gan_load.py:182-188 (checkpoint key 'g_ema', strict=False)."""
+    G = StyleGAN2Generator(resolution, 512, 8)
+    if pretrained_gan_weights is not None:
+        G.load_state_dict(torch.load(pretrained_gan_weights, map_location='cpu')['g_ema'], strict=False)
+    return StyleGAN2Wrapper(G, shift_in_w_space=shift_in_w_space)

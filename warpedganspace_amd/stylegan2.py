@@ -1,0 +1,402 @@
+"""StyleGAN2 generator on the HIP kernels — host-side mirror of models/StyleGAN2/model.py.
+
+The module tree reproduces the reference's parameter / buffer names and shapes exactly (so a
+`g_ema` checkpoint loads with `load_state_dict`, models/gan_load.py:186), but `forward` is an explicit
+kernel schedule instead of nn.Module calls:
+
+  * activations are NHWC; the modulated conv never materialises per-sample weights
+    (model.py:190-199): style scales the A operand while it is staged, demodulation scales the
+    accumulators, noise + bias + leaky-relu*sqrt(2) run in the GEMM epilogue (csrc/conv_igemm.hip);
+  * the stride-2 transposed conv (model.py:201-212) is 4 sub-pixel phase GEMMs followed by one fused
+    blur + noise + bias + activation pass;
+  * all 20 modulation EqualLinears are one [B,512] x [512, sum(Cin)] product;
+  * backward is hand-derived and propagates ONLY the input gradient (G is frozen, lib/trainer.py
+    never uses its weight gradients): d image -> d latent -> (Z space) d z.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import conv as C
+from . import ops
+
+SQRT2 = 2 ** 0.5
+
+
+def make_kernel(k):
+    """Normalised outer-product FIR kernel (model.py:18-26)."""
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+# ---- parameter containers (names/shapes = reference state_dict) -----------------------------------
+class _Blur(nn.Module):
+    def __init__(self, kernel):
+        super().__init__()
+        self.register_buffer('kernel', kernel)
+
+
+class _EqualLinear(nn.Module):
+    """EqualLinear parameters (model.py:110-136)."""
+
+    def __init__(self, in_dim, out_dim, bias_init=0.0, lr_mul=1.0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init))
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+
+class _ModulatedConv2d(nn.Module):
+    """ModulatedConv2d parameters (model.py:148-185)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.in_channel, self.out_channel, self.kernel_size = in_channel, out_channel, kernel_size
+        self.upsample, self.demodulate = upsample, demodulate
+        if upsample:
+            self.blur = _Blur(make_kernel(blur_kernel) * 4)     # Blur(..., upsample_factor=2), pad (1,1)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = _EqualLinear(style_dim, in_channel, bias_init=1)
+
+
+class _NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+
+class _Bias(nn.Module):
+    def __init__(self, channel):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+
+
+class _ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+
+class _StyledConv(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False):
+        super().__init__()
+        self.conv = _ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample)
+        self.noise = _NoiseInjection()
+        self.activate = _Bias(out_channel)
+
+
+class _ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True):
+        super().__init__()
+        if upsample:
+            self.upsample = _Blur(make_kernel((1, 3, 3, 1)) * 4)   # Upsample(factor 2): pad (2,1)
+        self.conv = _ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+
+class _Noises(nn.Module):
+    pass
+
+
+# ---- autograd glue -----------------------------------------------------------------------------------
+class _Mapping(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, G, z):
+        w, saved = G._mapping_fwd(z, save=ctx.needs_input_grad[1])
+        ctx.G, ctx.saved = G, saved
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        return None, ctx.G._mapping_bwd(ctx.saved, gw.contiguous())
+
+
+class _Synthesis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, G, w):
+        img, saved = G._synthesis_fwd(w, save=ctx.needs_input_grad[1])
+        ctx.G, ctx.saved = G, saved
+        return img
+
+    @staticmethod
+    def backward(ctx, gimg):
+        return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous())
+
+
+class Generator(nn.Module):
+    """Generator(size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1,3,3,1], lr_mlp=0.01)
+    — same signature as the reference (model.py:285-333)."""
+
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=(1, 3, 3, 1), lr_mlp=0.01):
+        super().__init__()
+        if tuple(blur_kernel) != (1, 3, 3, 1):
+            raise NotImplementedError("only the reference's [1,3,3,1] blur kernel is implemented")
+        self.size, self.style_dim = size, style_dim
+        layers = [nn.Identity()]                      # index 0 is PixelNorm in the reference (no params)
+        for _ in range(n_mlp):
+            layers.append(_EqualLinear(style_dim, style_dim, lr_mul=lr_mlp))
+        self.style = nn.Sequential(*layers)
+        self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier,
+                         128: 128 * channel_multiplier, 256: 64 * channel_multiplier,
+                         512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        self.input = _ConstantInput(self.channels[4])
+        self.conv1 = _StyledConv(self.channels[4], self.channels[4], 3, style_dim)
+        self.to_rgb1 = _ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.convs, self.to_rgbs = nn.ModuleList(), nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.noises = _Noises()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer('noise_{}'.format(layer_idx), torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_channel = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.convs.append(_StyledConv(in_channel, out_channel, 3, style_dim, upsample=True))
+            self.convs.append(_StyledConv(out_channel, out_channel, 3, style_dim))
+            self.to_rgbs.append(_ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - 2
+        for p in self.parameters():       # G is frozen on this path (lib/trainer.py:143-150 puts it in eval)
+            p.requires_grad_(False)
+        self._prep = None
+
+    # -- derived, device-resident packed weights (rebuilt after load_state_dict / .to()) -----------
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def refresh(self):
+        self._prep = None
+
+    def _prepare(self):
+        dev = self.input.input.device
+        if self._prep is not None and self._prep['dev'] == dev:
+            return self._prep
+        if dev.type != 'cuda':
+            raise L.WgsError("StyleGAN2 Generator runs on the HIP kernels only: move it to the GPU (no CPU fallback)")
+        styled = [self.conv1] + list(self.convs)
+        rgbs = [self.to_rgb1] + list(self.to_rgbs)
+        mods, offs, off = [], [], 0
+        P = {'dev': dev, 'layers': [], 'rgbs': []}
+        with torch.no_grad():
+            for i, sc in enumerate(styled):
+                m = sc.conv
+                wp = C.pack_weight(m.weight[0].float())             # [Co, 9, Ci]
+                wt = C.repack_w_t(wp, m.out_channel, 9, m.in_channel)
+                wsq = torch.empty(m.out_channel, m.in_channel, device=dev)
+                L.check(L.lib().wgs_sg2_wsq(L.ptr(wp), L.ptr(wsq), m.out_channel, 9, m.in_channel, L.stream()), 'wsq')
+                P['layers'].append(dict(
+                    wp=wp, wt=wt, wsq=wsq, Ci=m.in_channel, Co=m.out_channel, up=m.upsample, scale=m.scale, off=off,
+                    noise=getattr(self.noises, 'noise_{}'.format(i)).reshape(-1).contiguous(),
+                    noise_w=sc.noise.weight.contiguous(), bias=sc.activate.bias.contiguous(),
+                    blur=(m.blur.kernel.contiguous() if m.upsample else None),
+                    blur_f=(torch.flip(m.blur.kernel, [0, 1]).contiguous() if m.upsample else None)))
+                mods.append(m.modulation)
+                off += m.in_channel
+                # ToRGB sits after conv1 and after every second conv of `convs`
+                if i % 2 == 0:
+                    r = rgbs[i // 2]
+                    P['rgbs'].append(dict(w=r.conv.weight.reshape(3, r.conv.in_channel).contiguous(),
+                                          bias=r.bias.reshape(3).contiguous(), scale=r.conv.scale, off=off,
+                                          C=r.conv.in_channel,
+                                          upk=(r.upsample.kernel.contiguous() if hasattr(r, 'upsample') else None),
+                                          upk_f=(torch.flip(r.upsample.kernel, [0, 1]).contiguous()
+                                                 if hasattr(r, 'upsample') else None)))
+                    mods.append(r.conv.modulation)
+                    off += r.conv.in_channel
+            P['wmod'] = torch.cat([m.weight for m in mods], 0).contiguous()     # [sumC, style_dim]
+            P['bmod'] = torch.cat([m.bias for m in mods], 0).contiguous()
+            P['mod_scale'], P['sumC'] = mods[0].scale, off
+            P['map'] = [(l.weight.contiguous(), l.bias.contiguous(), l.scale, l.lr_mul) for l in list(self.style)[1:]]
+            P['const'] = self.input.input[0].permute(1, 2, 0).contiguous()       # [4,4,C] NHWC
+        self._prep = P
+        return P
+
+    # -- mapping network: PixelNorm + n_mlp x (EqualLinear + fused leaky-relu), model.py:288-295 -------
+    def _mapping_fwd(self, z, save):
+        P = self._prepare()
+        z = z.contiguous()
+        B, d = z.shape
+        lib, st = L.lib(), L.stream()
+        x = torch.empty_like(z)
+        L.check(lib.wgs_pixelnorm_fwd(L.ptr(z), L.ptr(x), B, d, L.c_float(1e-8), st), 'pixelnorm')
+        acts = [x]
+        for (w, b, scale, lr_mul) in P['map']:
+            y = torch.empty(B, w.shape[0], device=z.device)
+            L.check(lib.wgs_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, w.shape[0], w.shape[1], d, w.shape[0],
+                                       L.c_float(scale), L.c_float(lr_mul), 0, 1, L.c_float(0.0), L.c_float(1.0), st),
+                    'linear_fwd')
+            acts.append(y)
+            x = y
+        return x, ((z, acts) if save else None)
+
+    def _mapping_bwd(self, saved, gw):
+        P = self._prepare()
+        z, acts = saved
+        B, d = z.shape
+        lib, st = L.lib(), L.stream()
+        g = gw
+        for i in range(len(P['map']) - 1, -1, -1):
+            w, _, scale, _ = P['map'][i]
+            gx = torch.empty(B, w.shape[1], device=z.device)
+            L.check(lib.wgs_linear_dgrad(L.ptr(g), L.ptr(w), L.ptr(acts[i + 1]), L.ptr(gx), B, w.shape[0], w.shape[1],
+                                         w.shape[0], w.shape[1], L.c_float(scale), L.c_float(0.2), L.c_float(SQRT2), 0, st),
+                    'linear_dgrad')
+            g = gx
+        gz = torch.empty_like(z)
+        L.check(lib.wgs_pixelnorm_bwd(L.ptr(z), L.ptr(g), L.ptr(gz), B, d, L.c_float(1e-8), st), 'pixelnorm_bwd')
+        return gz
+
+    # -- synthesis network, model.py:389-403 ---------------------------------------------------------------
+    def _synthesis_fwd(self, w, save):
+        P = self._prepare()
+        lib, st = L.lib(), L.stream()
+        w = w.contiguous()
+        B = w.shape[0]
+        dev = w.device
+        sumC = P['sumC']
+        S = torch.empty(B, sumC, device=dev)      # every layer's modulation output s[b, ci] (bias_init = 1)
+        L.check(lib.wgs_linear_fwd(L.ptr(w), L.ptr(P['wmod']), L.ptr(P['bmod']), L.ptr(S), B, sumC, self.style_dim,
+                                   self.style_dim, sumC, L.c_float(P['mod_scale']), L.c_float(1.0), 0, 0,
+                                   L.c_float(0.0), L.c_float(1.0), st), 'modulation')
+        x = P['const'].unsqueeze(0).expand(B, -1, -1, -1).contiguous()
+        outs, demods = [], []
+        skip = None
+        for i, ly in enumerate(P['layers']):
+            Ci, Co = ly['Ci'], ly['Co']
+            s_view = S[:, ly['off']:]
+            demod = torch.empty(B, Co, device=dev)   # scale * rsqrt(scale^2 * sum_i s^2 wsq + 1e-8)
+            L.check(lib.wgs_linear_fwd(L.rawptr(s_view), L.ptr(ly['wsq']), None, L.ptr(demod), B, Co, Ci, sumC, Co,
+                                       L.c_float(ly['scale'] ** 2), L.c_float(0.0), 1, 2, L.c_float(1e-8),
+                                       L.c_float(ly['scale']), st), 'demod')
+            H = x.shape[1]
+            if ly['up']:
+                t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod)
+                y = torch.empty(B, 2 * H, 2 * H, Co, device=dev)
+                L.check(lib.wgs_sg2_blur_noise_bias_act(L.ptr(t), L.ptr(ly['blur']), L.ptr(ly['noise']),
+                                                        L.ptr(ly['noise_w']), L.ptr(ly['bias']), L.ptr(y), B, 2 * H, 2 * H,
+                                                        Co, st), 'blur_nba')
+                del t
+            else:
+                y = C.conv2d(x, ly['wp'], 3, pad=1, a_scale=s_view, a_ld=sumC, col_scale=demod, noise=ly['noise'],
+                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2)
+            outs.append(y)
+            demods.append(demod)
+            x = y
+            if i % 2 == 0:
+                r = P['rgbs'][i // 2]
+                Hc = x.shape[1]
+                if skip is not None:
+                    up = ops.upfirdn2d_mhwc(skip.reshape(B * 3, Hc // 2, Hc // 2, 1), r['upk'], 2, 2, 1, 1, 2, 1, 2, 1)
+                    skip_up = up.reshape(B, 3, Hc, Hc)
+                else:
+                    skip_up = None
+                img = torch.empty(B, 3, Hc, Hc, device=dev)
+                # the ToRGB kernel reads its style with row stride C: hand it a compact copy of the slice
+                s_rgb = S[:, r['off']:r['off'] + r['C']].contiguous()
+                L.check(lib.wgs_sg2_torgb_fwd(L.ptr(x), L.ptr(s_rgb), L.ptr(r['w']), L.ptr(r['bias']), L.ptr(skip_up),
+                                              L.ptr(img), B, Hc * Hc, r['C'], L.c_float(r['scale']), st), 'torgb')
+                skip = img
+        saved = (S, outs, demods, B) if save else None
+        return skip, saved
+
+    def _synthesis_bwd(self, saved, dimg):
+        """d image [B,3,S,S] -> d latent [B, style_dim] (all n_latent copies of w summed)."""
+        P = self._prepare()
+        lib, st = L.lib(), L.stream()
+        S, outs, demods, B = saved
+        dev = dimg.device
+        sumC = P['sumC']
+        layers, rgbs = P['layers'], P['rgbs']
+        dS = torch.zeros(B, sumC, device=dev)       # d loss / d modulation outputs, all layers
+        dskip = dimg
+        gA, sA_off, cons = None, None, None          # un-scaled dgrad of the consumer conv, its style slice
+        num_next = None
+        for i in range(len(layers) - 1, -1, -1):
+            ly = layers[i]
+            Co = ly['Co']
+            out = outs[i]
+            Hc = out.shape[1]
+            Pn = Hc * Hc
+            has_rgb = (i % 2 == 0)
+            r = rgbs[i // 2] if has_rgb else None
+            dy = torch.empty_like(out)
+            num = torch.zeros(B, Co, device=dev)
+            dsA = torch.zeros(B, Co, device=dev) if gA is not None else None
+            dsR = torch.zeros(B, Co, device=dev) if has_rgb else None
+            sA = S[:, sA_off:sA_off + Co].contiguous() if gA is not None else None
+            sR = S[:, r['off']:r['off'] + Co].contiguous() if has_rgb else None
+            L.check(lib.wgs_sg2_act_bwd(L.ptr(out), L.ptr(gA), L.ptr(sA), L.ptr(dskip if has_rgb else None),
+                                        L.ptr(r['w']) if has_rgb else None, L.ptr(sR),
+                                        L.c_float(r['scale'] if has_rgb else 0.0), L.ptr(ly['noise']), L.ptr(ly['noise_w']),
+                                        L.ptr(ly['bias']), L.ptr(dy), L.ptr(num), L.ptr(dsA), L.ptr(dsR), B, Pn, Co, st),
+                    'sg2_act_bwd')
+            # style gradient of the consumer conv (layer i+1) is now complete: direct term dsA + demod path
+            if gA is not None:
+                c = layers[i + 1]
+                self._style_grad(lib, st, num_next, demods[i + 1], S, c, dsA, dS, B, sumC)
+            if has_rgb:
+                L.check(lib.wgs_sg2_style_grad(None, None, L.rawptr(S[:, r['off']:]), L.ptr(dsR), None, L.c_float(1.0),
+                                               L.rawptr(dS[:, r['off']:]), B, 3, Co, sumC, sumC, st), 'style_grad_rgb')
+                if i > 0:   # gradient of the up-sampled skip w.r.t. the lower-resolution image (upfirdn2d.py:110-115)
+                    g = ops.upfirdn2d_mhwc(dskip.reshape(B * 3, Hc, Hc, 1), r['upk_f'], 1, 1, 2, 2, 1, 1, 1, 1)
+                    dskip = g.reshape(B, 3, Hc // 2, Hc // 2)
+            # input gradient of this layer (un-scaled by its own style: the producer applies it)
+            if ly['up']:
+                dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)
+                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], a_scale=demods[i])
+                del dt
+            else:
+                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, a_scale=demods[i])
+            del dy
+            sA_off, num_next = ly['off'], num
+        # bottom layer: its input is the ConstantInput -> only the style gradient remains
+        ly = layers[0]
+        ds0 = torch.zeros(B, ly['Ci'], device=dev)
+        L.check(lib.wgs_xg_reduce(L.ptr(P['const']), 0, L.ptr(gA), L.ptr(ds0), B, 16, ly['Ci'], st), 'xg_reduce')
+        self._style_grad(lib, st, num_next, demods[0], S, ly, ds0, dS, B, sumC)
+        dw = torch.empty(B, self.style_dim, device=dev)
+        L.check(lib.wgs_linear_dgrad(L.ptr(dS), L.ptr(P['wmod']), None, L.ptr(dw), B, sumC, self.style_dim, sumC,
+                                     self.style_dim, L.c_float(P['mod_scale']), L.c_float(1.0), L.c_float(1.0), 0, st),
+                'dlatent')
+        return dw
+
+    @staticmethod
+    def _style_grad(lib, st, num, demod, S, ly, dsdir, dS, B, sumC):
+        # stored demod already carries the conv's weight scale, so scale2 = 1 here (see _synthesis_fwd)
+        L.check(lib.wgs_sg2_style_grad(L.ptr(num), L.ptr(demod), L.rawptr(S[:, ly['off']:]), L.ptr(dsdir), L.ptr(ly['wsq']),
+                                       L.c_float(1.0), L.rawptr(dS[:, ly['off']:]), B, ly['Co'], ly['Ci'], sumC, sumC, st),
+                'style_grad')
+
+    # -- reference-facing API -------------------------------------------------------------------------------
+    def get_latent(self, input):
+        return _Mapping.apply(self, input)
+
+    def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=False):
+        """Same call signature as the reference (model.py:359-408).  Supported on the HIP path: a single
+        style code, the registered noise buffers, no truncation — i.e. exactly what StyleGAN2Wrapper
+        (models/gan_load.py:157-179) issues."""
+        if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise or truncation < 1:
+            raise NotImplementedError("HIP StyleGAN2 path supports one style code, registered noise, truncation=1")
+        s = styles[0]
+        if s.ndim != 2:
+            raise NotImplementedError("per-layer (W+) latents are not supported on the HIP path")
+        w = s if input_is_latent else _Mapping.apply(self, s)
+        img = _Synthesis.apply(self, w)
+        if return_latents:
+            return img, w.unsqueeze(1).repeat(1, self.n_latent, 1)
+        return img, None
