@@ -201,6 +201,16 @@ def gen_stylegan2(tmp):
             out[tag + 'w_img'] = imgw.detach().numpy()
         else:
             out[tag + 'w_img_pool8'] = F.avg_pool2d(imgw.detach(), 8).numpy()
+        # the same gradients from the reference modules run in float64: the fp32 reference itself is
+        # ~1e-3 away from these (ill-conditioned random mapping net), so tests measure against fp64
+        G64 = G.double()
+        sh64 = shift.detach().double().requires_grad_(True)
+        (G64([z.double() + sh64], input_is_latent=False)[0] * probe.double()).sum().backward()
+        out[tag + 'dshift64'] = sh64.grad.numpy()
+        shw64 = shw.detach().double().requires_grad_(True)
+        w64 = G64.get_latent(z.double()).detach()
+        (G64([w64 + shw64], input_is_latent=True)[0] * probe.double()).sum().backward()
+        out[tag + 'w_dshift64'] = shw64.grad.numpy()
     np.savez_compressed(os.path.join(GOLD, 'stylegan2.npz'), **out)
     print('stylegan2.npz', len(out), 'arrays')
 
