@@ -89,14 +89,17 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
     if (k >= K) return;
     const float* g = gy + (size_t)m * ldg;
     const float* gt = gate ? gate + (size_t)m * ldg : nullptr;
-    float acc = 0.f;
+    // fp64 accumulation: these reductions run over up to ~6000 terms (all modulation layers) and feed
+    // the ill-conditioned mapping-network Jacobian; the kernel is latency-bound either way.
+    double acc = 0.0;
     for (int n = 0; n < N; ++n) {
         float gv = g[n];
         if (gt) gv *= (gt[n] > 0.f ? gain : gain * slope);
-        acc = fmaf(gv, w[(size_t)n * K + k], acc);
+        acc = fma((double)gv, (double)w[(size_t)n * K + k], acc);
     }
     float* o = gx + (size_t)m * ldx + k;
-    *o = accumulate ? (*o + acc * wscale) : acc * wscale;
+    const float r = (float)(acc * (double)wscale);
+    *o = accumulate ? (*o + r) : r;
 }
 
 // dW[n,k] = sum_m gy[m,n] x[m,k] ; db[n] = sum_m gy[m,n]   (Reconstructor heads; M = batch)
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     const float* __restrict__ noise, const float* __restrict__ noise_w, const float* __restrict__ bias,
     float* __restrict__ dy, float* __restrict__ num, float* __restrict__ dsA, float* __restrict__ dsR, int P, int C,
     int chunk) {
-    __shared__ float4 red[3][256];
+    __shared__ double red[3][256][4];
     const int b = blockIdx.y;
     const int c4n = C >> 2;
     const int tpp = c4n < 256 ? c4n : 256;  // threads per pixel
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
             w2 = *reinterpret_cast<const float4*>(wR + 2 * C + c);
         }
         const float4 bv = *reinterpret_cast<const float4*>(bias + c);
-        float4 r_num = make_float4(0.f, 0.f, 0.f, 0.f), r_a = r_num, r_r = r_num;
+        // fp64 partial sums: these reductions run over up to 65536 pixels with heavy cancellation
+        double r_num[4] = {0, 0, 0, 0}, r_a[4] = {0, 0, 0, 0}, r_r[4] = {0, 0, 0, 0};
         for (int p = p_begin + sub; p < p_end; p += ppi) {
             const size_t off = ((size_t)b * P + p) * C + c;
             const float4 o = *reinterpret_cast<const float4*>(out + off);
@@ -266,43 +270,48 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
             }
             const float nz = noise ? nw * noise[p] : 0.f;
             float4 d;
-#define WGS_ONE(f)                                                                  \
+#define WGS_ONE(f, q)                                                               \
     {                                                                               \
         const float dout = sa.f * ga.f + sr.f * gr.f;                               \
         const bool pos = o.f > 0.f;                                                 \
         d.f = dout * (pos ? SQRT2 : 0.2f * SQRT2);                                  \
         const float ypre = (pos ? o.f * (1.f / SQRT2) : o.f * (1.f / (0.2f * SQRT2))) - nz - bv.f; \
-        r_num.f = fmaf(d.f, ypre, r_num.f);                                         \
-        r_a.f = fmaf(o.f, ga.f, r_a.f);                                             \
-        r_r.f = fmaf(o.f, gr.f, r_r.f);                                             \
+        r_num[q] += (double)(d.f * ypre);                                           \
+        r_a[q] += (double)(o.f * ga.f);                                             \
+        r_r[q] += (double)(o.f * gr.f);                                             \
     }
-            WGS_ONE(x) WGS_ONE(y) WGS_ONE(z) WGS_ONE(w)
+            WGS_ONE(x, 0) WGS_ONE(y, 1) WGS_ONE(z, 2) WGS_ONE(w, 3)
 #undef WGS_ONE
             *reinterpret_cast<float4*>(dy + off) = d;
         }
         // combine the `ppi` pixel sub-streams that share this channel group
         __syncthreads();
-        red[0][threadIdx.x] = r_num; red[1][threadIdx.x] = r_a; red[2][threadIdx.x] = r_r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            red[0][threadIdx.x][q] = r_num[q]; red[1][threadIdx.x][q] = r_a[q]; red[2][threadIdx.x][q] = r_r[q];
+        }
         __syncthreads();
         if (sub == 0) {
             for (int s2 = 1; s2 < ppi; ++s2) {
-                const float4 a = red[0][s2 * tpp + cl], bb = red[1][s2 * tpp + cl], cc = red[2][s2 * tpp + cl];
-                r_num.x += a.x; r_num.y += a.y; r_num.z += a.z; r_num.w += a.w;
-                r_a.x += bb.x; r_a.y += bb.y; r_a.z += bb.z; r_a.w += bb.w;
-                r_r.x += cc.x; r_r.y += cc.y; r_r.z += cc.z; r_r.w += cc.w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r_num[q] += red[0][s2 * tpp + cl][q];
+                    r_a[q] += red[1][s2 * tpp + cl][q];
+                    r_r[q] += red[2][s2 * tpp + cl][q];
+                }
             }
             float* pn = num + (size_t)b * C + c;
-            unsafeAtomicAdd(pn + 0, r_num.x); unsafeAtomicAdd(pn + 1, r_num.y);
-            unsafeAtomicAdd(pn + 2, r_num.z); unsafeAtomicAdd(pn + 3, r_num.w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) unsafeAtomicAdd(pn + q, (float)r_num[q]);
             if (gA) {
                 float* pa = dsA + (size_t)b * C + c;
-                unsafeAtomicAdd(pa + 0, r_a.x); unsafeAtomicAdd(pa + 1, r_a.y);
-                unsafeAtomicAdd(pa + 2, r_a.z); unsafeAtomicAdd(pa + 3, r_a.w);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) unsafeAtomicAdd(pa + q, (float)r_a[q]);
             }
             if (drgb) {
                 float* pr = dsR + (size_t)b * C + c;
-                unsafeAtomicAdd(pr + 0, r_r.x); unsafeAtomicAdd(pr + 1, r_r.y);
-                unsafeAtomicAdd(pr + 2, r_r.z); unsafeAtomicAdd(pr + 3, r_r.w);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) unsafeAtomicAdd(pr + q, (float)r_r[q]);
             }
         }
     }
@@ -333,14 +342,14 @@ __global__ __launch_bounds__(256) void sg2_style_grad_kernel(const float* __rest
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= Ci) return;
-    float acc = 0.f;
+    double acc = 0.0;
     if (demod) {
         for (int o = 0; o < Co; ++o) {
-            const float dm = demod[(size_t)b * Co + o];
-            acc = fmaf(num[(size_t)b * Co + o] * dm * dm, wsq[(size_t)o * Ci + i], acc);
+            const double dm = demod[(size_t)b * Co + o];
+            acc = fma((double)num[(size_t)b * Co + o] * dm * dm, (double)wsq[(size_t)o * Ci + i], acc);
         }
     }
-    dstyle[(size_t)b * ldo + i] = dsdir[(size_t)b * Ci + i] - s[(size_t)b * lds_ + i] * scale2 * acc;
+    dstyle[(size_t)b * ldo + i] = (float)((double)dsdir[(size_t)b * Ci + i] - (double)s[(size_t)b * lds_ + i] * scale2 * acc);
 }
 
 // wsq[o,i] = sum_t w[o,t,i]^2   (w packed [Co,T,Ci]; one-off for the frozen generator)
