@@ -198,6 +198,55 @@ int wgs_sg2_style_grad(const float* num, const float* demod, const float* s, con
 /* wsq[o,i] = sum_t w[o,t,i]^2 for packed [Co,T,Ci] weights. */
 int wgs_sg2_wsq(const float* w_packed, float* wsq, int Co, int T, int Ci, wgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Reconstructor glue (lib/reconstructor.py + torchvision ResNet-18 BasicBlocks / LeNet), NHWC.
+ */
+/* torch.cat([x1, x2], dim=1) (lib/reconstructor.py:73,77) of two NCHW [B,c,H,W] images into one NHWC
+ * [B,H,W,Cp] tensor, channels [x1 | x2 | zero padding] (Cp >= 2c, Cp % 8 == 0 for the conv kernel);
+ * and the gradient of that w.r.t. x1 / x2 (either may be NULL). */
+int wgs_pack_pair_nhwc(const float* x1, const float* x2, float* y, int B, int c, int HW, int Cp, wgs_stream_t stream);
+int wgs_unpack_pair_grad(const float* dy, float* d1, float* d2, int B, int c, int HW, int Cp, wgs_stream_t stream);
+
+/* nn.BatchNorm2d / BatchNorm1d on [N rows, C] (N = B*H*W) fused with the residual add and ReLU of a
+ * BasicBlock:  y = relu?( (x - mean)*invstd*gamma + beta (+ residual) ).
+ * train != 0: batch statistics (biased variance), running stats updated with `momentum` and the unbiased
+ * variance, num_batches_tracked += 1 (all three may be NULL); else running statistics are used.
+ * save_mean / save_invstd [C] are written for the backward; ws = 2*C doubles of scratch. C % 4 == 0. */
+int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
+               float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
+               int64_t N, int C, float eps, float momentum, int relu, int train, wgs_stream_t stream);
+/* Backward: g = (dyA + (dyB ? dyB : 0)) * (out ? out > 0 : 1)   [out = the saved post-ReLU output]
+ *   dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) (train) ;  dgamma = sum g*xhat ; dbeta = sum g ;
+ *   dres (optional) = g  (gradient of the residual branch). */
+int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* out, const float* save_mean,
+               const float* save_invstd, const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta,
+               double* ws, int64_t N, int C, int train, wgs_stream_t stream);
+
+/* nn.MaxPool2d(k, stride s, padding p) on NHWC; idx [B,Ho,Wo,C] bytes = window position of the first
+ * maximum (torch tie-breaking); backward gathers through idx. */
+int wgs_maxpool_fwd(const float* x, float* y, unsigned char* idx, int B, int Hi, int Wi, int C, int k, int s, int p,
+                    wgs_stream_t stream);
+int wgs_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int Hi, int Wi, int C, int k, int s, int p,
+                    wgs_stream_t stream);
+/* AdaptiveAvgPool2d(1) / features.mean([-1,-2]) (lib/reconstructor.py:74,78): [B,P,C] -> [B,C]. */
+int wgs_avgpool_fwd(const float* x, float* y, int B, int P, int C, wgs_stream_t stream);
+int wgs_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, wgs_stream_t stream);
+/* out[c] = sum over rows of x[N,C] (conv bias gradient); ws = 2*C doubles. */
+int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_stream_t stream);
+
+/* Loss of lib/trainer.py:245-249 and the statistics of :257-261:
+ *   ce = CrossEntropy(logits, target) (mean), l1 = mean|mag_pred - mag_target|, total = lambda_cls*ce + lambda_reg*l1
+ *   stats[0..3] = (ce, l1, total, accuracy);  argmax[b] = first index of max logits[b,:] (int64)
+ *   dlogits = d total / d logits, dmag = d total / d mag_pred.   ws: 2*B floats. */
+int wgs_ce_l1_loss(const float* logits, const int64_t* target, const float* mag_pred, const float* mag_target, float lambda_cls,
+                   float lambda_reg, float* dlogits, float* dmag, float* stats, int64_t* argmax, float* ws, int B, int K,
+                   wgs_stream_t stream);
+
+/* torch.optim.Adam (defaults: betas given, eps, no weight decay / amsgrad) on one flat buffer, update
+ * number `step` (1-based); the gradient is multiplied by grad_scale first (1/world after an all-reduce sum). */
+int wgs_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale, wgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,3 +269,82 @@ def sg2_generate(sd, z, size, shift=None, shift_in_w_space=False):
         w = sg2_mapping(sd, z)
         return sg2_synthesis(sd, w if shift is None else w + shift, size)
     return sg2_synthesis(sd, sg2_mapping(sd, z if shift is None else z + shift), size)
+
+
+# =================================================================================================
+# Reconstructor — lib/reconstructor.py:10-79, functional over the reference state_dict
+# =================================================================================================
+def _bn(sd, prefix, x, training=True):
+    """nn.BatchNorm2d/1d forward; updates the running statistics in `sd` in place like the module does."""
+    rm, rv = sd[prefix + '.running_mean'], sd[prefix + '.running_var']
+    if training and (prefix + '.num_batches_tracked') in sd:
+        sd[prefix + '.num_batches_tracked'] += 1
+    return F.batch_norm(x, rm, rv, sd[prefix + '.weight'], sd[prefix + '.bias'], training=training, momentum=0.1, eps=1e-5)
+
+
+def resnet18_features(sd, x, prefix='features_extractor', training=True):
+    """torchvision ResNet-18 (BasicBlock x [2,2,2,2]) up to and including the global average pool, the
+    tensor the reference captures with its avgpool forward hook (lib/reconstructor.py:6-7,62-63,78).
+    The arithmetic lives in the un-vendored torchvision dependency; this follows its public definition:
+    conv7x7/2(pad 3, no bias) - BN - ReLU - maxpool3/2(pad 1) - stages (64,128,256,512), stride 2 from the
+    second stage with a 1x1/2 conv + BN shortcut - AdaptiveAvgPool2d(1)."""
+    p = prefix + '.'
+    h = F.conv2d(x, sd[p + 'conv1.weight'], stride=2, padding=3)
+    h = F.relu(_bn(sd, p + 'bn1', h, training))
+    h = F.max_pool2d(h, 3, 2, 1)
+    for li in range(1, 5):
+        for bi in range(2):
+            q = '%slayer%d.%d.' % (p, li, bi)
+            stride = 2 if (li > 1 and bi == 0) else 1
+            out = F.conv2d(h, sd[q + 'conv1.weight'], stride=stride, padding=1)
+            out = F.relu(_bn(sd, q + 'bn1', out, training))
+            out = F.conv2d(out, sd[q + 'conv2.weight'], stride=1, padding=1)
+            out = _bn(sd, q + 'bn2', out, training)
+            if (q + 'downsample.0.weight') in sd:
+                ident = _bn(sd, q + 'downsample.1', F.conv2d(h, sd[q + 'downsample.0.weight'], stride=stride), training)
+            else:
+                ident = h
+            h = F.relu(out + ident)
+    return F.adaptive_avg_pool2d(h, 1).flatten(1)
+
+
+def reconstructor_resnet(sd, x1, x2, training=True):
+    """Reconstructor.forward, ResNet branch (lib/reconstructor.py:76-79). The reference also evaluates
+    torchvision's fc layer and discards the result; it is omitted here (no observable effect)."""
+    feat = resnet18_features(sd, torch.cat([x1, x2], dim=1), training=training)
+    logits = F.linear(feat, sd['path_indices.weight'], sd['path_indices.bias'])
+    mag = F.linear(feat, sd['shift_magnitudes.weight'], sd['shift_magnitudes.bias']).squeeze()
+    return logits, mag
+
+
+def reconstructor_lenet(sd, x1, x2, training=True):
+    """Reconstructor.forward, LeNet branch (lib/reconstructor.py:18-49,72-75)."""
+    h = torch.cat([x1, x2], dim=1)
+    for i in (0, 4, 8):
+        h = F.conv2d(h, sd['feature_extractor.%d.weight' % i], sd['feature_extractor.%d.bias' % i])
+        h = F.relu(_bn(sd, 'feature_extractor.%d' % (i + 1), h, training))
+        if i != 8:
+            h = F.max_pool2d(h, 2, 2)
+    feat = h.mean(dim=[-1, -2]).view(x1.shape[0], -1)
+    outs = []
+    for head in ('path_indices', 'shift_magnitudes'):
+        t = F.linear(feat, sd[head + '.0.weight'], sd[head + '.0.bias'])
+        t = F.relu(_bn(sd, head + '.1', t, training))
+        outs.append(F.linear(t, sd[head + '.3.weight'], sd[head + '.3.bias']))
+    return outs[0], outs[1].squeeze()
+
+
+def training_loss(logits, mag_pred, target_idx, target_mag, lambda_cls=1.0, lambda_reg=0.25):
+    """lib/trainer.py:245-249 (+ accuracy :257-258)."""
+    ce = F.cross_entropy(logits, target_idx)
+    l1 = torch.mean(torch.abs(mag_pred - target_mag))
+    acc = torch.mean((torch.argmax(logits, dim=1) == target_idx).to(torch.float32))
+    return lambda_cls * ce + lambda_reg * l1, ce, l1, acc
+
+
+def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (lib/trainer.py:153-156), single tensor, in place."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)

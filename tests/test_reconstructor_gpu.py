@@ -1,0 +1,119 @@
+"""GPU: HIP Reconstructor (ResNet-18) forward/backward, loss and Adam kernels vs the CPU oracle."""
+import copy
+
+import pytest
+import torch
+
+from oracle import wgs_oracle as O
+from tests import golden_inputs as GI
+from tests.util import rel_err
+from warpedganspace_amd import _lib as L
+from warpedganspace_amd.reconstructor import Reconstructor
+
+pytestmark = pytest.mark.gpu
+
+
+def seeded_resnet(K, seed):
+    torch.manual_seed(seed)
+    R = Reconstructor('ResNet', K, channels=3)
+    sd = R.state_dict()
+    # non-trivial BN affine parameters / running stats
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in sd:
+        if k.endswith('bn1.weight') or k.endswith('bn2.weight') or k.endswith('downsample.1.weight'):
+            sd[k] = 1.0 + 0.2 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith('bn1.bias') or k.endswith('bn2.bias') or k.endswith('downsample.1.bias'):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    R.load_state_dict(sd)
+    return R
+
+
+@pytest.mark.parametrize('B,K,S', [(4, 16, 64), (3, 128, 96)])
+def test_resnet_forward_backward_vs_oracle(dev, B, K, S):
+    R = seeded_resnet(K, 3)
+    sd = {k: v.detach().clone().contiguous() for k, v in R.state_dict().items()}
+    for k in list(sd):
+        if sd[k].is_floating_point() and not (k.endswith('running_mean') or k.endswith('running_var')):
+            sd[k].requires_grad_(True)
+    x1 = GI.rt(50, B, 3, S, S)
+    x2 = GI.rt(51, B, 3, S, S).requires_grad_(True)
+    tgt = torch.randint(0, K, (B,), generator=torch.Generator().manual_seed(9))
+    tmag = GI.rt(52, B) * 0.3
+    lo, mo = O.reconstructor_resnet(sd, x1, x2, training=True)
+    loss_o, ce_o, l1_o, acc_o = O.training_loss(lo, mo, tgt, tmag)
+    loss_o.backward()
+
+    R = R.to(dev).train()
+    x2d = x2.detach().to(dev).requires_grad_(True)
+    lg, mg = R(x1.to(dev), x2d)
+    assert rel_err(lg, lo.detach()) < 1e-4
+    assert rel_err(mg, mo.detach()) < 1e-4
+    assert torch.equal(torch.argmax(lg, 1).cpu(), torch.argmax(lo, 1))       # path-index argmax bit-exact
+    loss, ce, l1, acc = O.training_loss(lg, mg, tgt.to(dev), tmag.to(dev))   # torch ops on the HIP outputs
+    loss.backward()
+    assert rel_err(x2d.grad, x2.grad) < 1e-3
+    worst = 0.0
+    for name, p in R.named_parameters():
+        if name.startswith('features_extractor.fc'):
+            assert p.grad is None
+            continue
+        e = rel_err(p.grad, sd[name].grad)
+        worst = max(worst, e)
+        assert e < 2e-3, (name, e)
+    print('worst parameter-gradient rel err', worst)
+    # running statistics were updated like nn.BatchNorm (momentum 0.1, unbiased variance)
+    for name, b in R.named_buffers():
+        if name.endswith('running_mean') or name.endswith('running_var'):
+            assert rel_err(b, sd[name]) < 1e-4, name
+        if name.endswith('num_batches_tracked'):
+            assert int(b) == 1
+
+
+def test_resnet_eval_mode_uses_running_stats(dev):
+    R = seeded_resnet(8, 4)
+    sd = {k: v.detach().clone() for k, v in R.state_dict().items()}
+    x1, x2 = GI.rt(60, 2, 3, 64, 64), GI.rt(61, 2, 3, 64, 64)
+    lo, mo = O.reconstructor_resnet(sd, x1, x2, training=False)
+    R = R.to(dev).eval()
+    with torch.no_grad():
+        lg, mg = R(x1.to(dev), x2.to(dev))
+    assert rel_err(lg, lo) < 1e-4 and rel_err(mg, mo) < 1e-4
+
+
+def test_loss_kernel_vs_oracle(dev):
+    import ctypes
+    B, K = 32, 128
+    logits = GI.rt(70, B, K) * 3
+    logits[3, 7] = logits[3, 90] = 50.0          # tie: argmax must be the lowest index
+    tgt = torch.randint(0, K, (B,), generator=torch.Generator().manual_seed(1))
+    mp, mt = GI.rt(71, B), GI.rt(72, B)
+    mp[5] = mt[5]                                # |.|' at 0 is 0
+    lg = logits.clone().requires_grad_(True)
+    mpg = mp.clone().requires_grad_(True)
+    total, ce, l1, acc = O.training_loss(lg, mpg, tgt, mt, 1.0, 0.25)
+    total.backward()
+    d = lambda t, dt=torch.float32: t.to(dev)
+    dl, dm = torch.empty(B, K, device=dev), torch.empty(B, device=dev)
+    stats, am, ws = torch.empty(4, device=dev), torch.empty(B, dtype=torch.int64, device=dev), torch.empty(2 * B, device=dev)
+    L.check(L.lib().wgs_ce_l1_loss(L.ptr(d(logits)), L.ptr(d(tgt), torch.int64), L.ptr(d(mp)), L.ptr(d(mt)), L.c_float(1.0),
+                                   L.c_float(0.25), L.ptr(dl), L.ptr(dm), L.ptr(stats), L.ptr(am, torch.int64), L.ptr(ws),
+                                   B, K, L.stream()))
+    assert torch.equal(am.cpu(), torch.argmax(logits, 1)) and int(am[3]) == 7
+    assert rel_err(stats, torch.stack([ce, l1, total, acc]).detach()) < 1e-6
+    assert rel_err(dl, lg.grad) < 1e-5 and rel_err(dm, mpg.grad) < 1e-6
+
+
+def test_adam_kernel_vs_torch(dev):
+    n = 100003
+    p0, g = GI.rt(80, n), GI.rt(81, n) * 0.01
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=1e-4)
+    pd, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gs = g * step
+        p.grad = gs.clone()
+        opt.step()
+        L.check(L.lib().wgs_adam_step(L.ptr(pd), L.ptr(gs.to(dev)), L.ptr(m), L.ptr(v), L.c_int64(n), L.c_float(1e-4),
+                                      L.c_float(0.9), L.c_float(0.999), L.c_float(1e-8), step, L.c_float(1.0), L.stream()))
+    assert (pd.cpu() - p.detach()).abs().max().item() < 2e-7 * p0.abs().max().item() + 1e-9
+    assert rel_err(pd.cpu() - p0, p.detach() - p0) < 1e-4

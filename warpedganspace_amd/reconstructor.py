@@ -1,0 +1,284 @@
+"""Reconstructor R — host-side mirror of lib/reconstructor.py:10-79 on the HIP kernels.
+
+Same constructor (`Reconstructor(reconstructor_type, dim, channels=3)`), same `forward(x1, x2) ->
+(logits [B,dim], magnitudes [B])`, same state_dict keys/shapes, so
+`reconstructor.pt` / `checkpoint.pt` files are interchangeable with the reference.
+
+ResNet branch: the reference uses torchvision's `resnet18` (un-vendored third-party dependency,
+absent here); this module restates its public definition — conv7x7/2 -> BN -> ReLU -> maxpool3/2 ->
+4 stages x 2 BasicBlocks (64,128,256,512) -> global avg-pool — with the first conv widened to 6 input
+channels (lib/reconstructor.py:56-60).  torchvision's `fc` (512->1000) is kept as a parameter for
+checkpoint compatibility but never executed: the reference runs it and discards the result
+(lib/reconstructor.py:77), so neither outputs nor gradients depend on it.
+
+Execution is an explicit kernel schedule on NHWC activations: implicit-GEMM MFMA convs (fwd / dgrad /
+wgrad), fused train-mode BatchNorm(+residual)(+ReLU), max/avg pooling, small dense heads.
+"""
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import conv as C
+
+BN_EPS, BN_MOM = 1e-5, 0.1
+
+
+def _conv(ci, co, k, stride, pad):
+    m = nn.Conv2d(ci, co, k, stride=stride, padding=pad, bias=False)
+    nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+    return m
+
+
+class _BasicBlock(nn.Module):
+    """Parameter container with torchvision BasicBlock's names (conv1, bn1, conv2, bn2, downsample.{0,1})."""
+
+    def __init__(self, ci, co, stride):
+        super().__init__()
+        self.conv1 = _conv(ci, co, 3, stride, 1)
+        self.bn1 = nn.BatchNorm2d(co)
+        self.conv2 = _conv(co, co, 3, 1, 1)
+        self.bn2 = nn.BatchNorm2d(co)
+        self.stride = stride
+        if stride != 1 or ci != co:
+            self.downsample = nn.Sequential(_conv(ci, co, 1, stride, 0), nn.BatchNorm2d(co))
+        else:
+            self.downsample = None
+
+
+class _ResNet18(nn.Module):
+    """Parameter container with torchvision resnet18's names."""
+
+    def __init__(self, in_channels=6):
+        super().__init__()
+        self.conv1 = _conv(in_channels, 64, 7, 2, 3)
+        self.bn1 = nn.BatchNorm2d(64)
+        chans = [64, 128, 256, 512]
+        ci = 64
+        for i, co in enumerate(chans):
+            stride = 1 if i == 0 else 2
+            setattr(self, 'layer%d' % (i + 1), nn.Sequential(_BasicBlock(ci, co, stride), _BasicBlock(co, co, 1)))
+            ci = co
+        self.fc = nn.Linear(512, 1000)   # present in the reference's state_dict; never executed (see module doc)
+
+    def blocks(self):
+        return [b for i in range(1, 5) for b in getattr(self, 'layer%d' % i)]
+
+
+def _packed(conv):
+    """[Co, T, Ci] view of a conv weight whose memory is channels_last (re-laid out once if it is not)."""
+    w = conv.weight
+    Co, Ci, kh, kw = w.shape
+    if not w.permute(0, 2, 3, 1).is_contiguous():
+        w.data = w.data.contiguous(memory_format=torch.channels_last)
+        if not w.permute(0, 2, 3, 1).is_contiguous():   # 1x1 / degenerate strides: force an explicit copy
+            w.data = w.data.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return w.detach().permute(0, 2, 3, 1).reshape(Co, kh * kw, Ci)
+
+
+def _grad_like(conv, dw_packed):
+    """Logical [Co,Ci,kh,kw] (channels_last strided) view of a packed [Co,T,Ci] gradient."""
+    Co, Ci, kh, kw = conv.weight.shape
+    return dw_packed.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
+
+
+class _BN:
+    """One fused BatchNorm launch pair + what its backward needs."""
+
+    @staticmethod
+    def fwd(bn, x, ws, residual=None, relu=True, train=True):
+        N, Cn = x.numel() // x.shape[-1], x.shape[-1]
+        y = torch.empty_like(x)
+        mean = torch.empty(Cn, device=x.device)
+        invstd = torch.empty(Cn, device=x.device)
+        L.check(L.lib().wgs_bn_fwd(L.ptr(x), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(residual), L.ptr(y), L.ptr(mean),
+                                   L.ptr(invstd), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                   L.ptr(bn.num_batches_tracked, torch.int64), L.rawptr(ws), L.c_int64(N), Cn,
+                                   L.c_float(bn.eps), L.c_float(bn.momentum if bn.momentum is not None else 0.1),
+                                   int(relu), int(train), L.stream()), 'wgs_bn_fwd')
+        return y, (mean, invstd)
+
+    @staticmethod
+    def bwd(bn, x, stats, dyA, dyB, out, ws, want_res=False, train=True):
+        N, Cn = x.numel() // x.shape[-1], x.shape[-1]
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_res else None
+        dg = torch.empty(Cn, device=x.device)
+        db = torch.empty(Cn, device=x.device)
+        L.check(L.lib().wgs_bn_bwd(L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr(out), L.ptr(stats[0]), L.ptr(stats[1]),
+                                   L.ptr(bn.weight), L.ptr(dx), L.ptr(dres), L.ptr(dg), L.ptr(db), L.rawptr(ws),
+                                   L.c_int64(N), Cn, int(train), L.stream()), 'wgs_bn_bwd')
+        return dx, dres, dg, db
+
+
+class _RFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, x1, x2, *params):
+        logits, mag, saved = R._forward_impl(x1, x2, save=any(ctx.needs_input_grad))
+        ctx.R, ctx.saved = R, saved
+        ctx.need_x = (ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return logits, mag
+
+    @staticmethod
+    def backward(ctx, dlogits, dmag):
+        R = ctx.R
+        grads, d1, d2 = R._backward_impl(ctx.saved, dlogits.contiguous(), dmag.contiguous(), ctx.need_x)
+        plist = [grads.get(id(p)) if p.requires_grad else None for p in R._param_list()]
+        return (None, d1, d2) + tuple(plist)
+
+
+class Reconstructor(nn.Module):
+    def __init__(self, reconstructor_type, dim, channels=3):
+        super().__init__()
+        self.reconstructor_type = reconstructor_type
+        self.dim = dim
+        self.channels = channels
+        if reconstructor_type == 'ResNet':
+            self.features_extractor = _ResNet18(in_channels=2 * channels)
+            self.path_indices = nn.Linear(512, dim)          # lib/reconstructor.py:66
+            self.shift_magnitudes = nn.Linear(512, 1)        # :69
+        elif reconstructor_type == 'LeNet':
+            from .lenet import build_lenet
+            build_lenet(self)
+        else:
+            raise ValueError("reconstructor_type must be 'ResNet' or 'LeNet', got %r" % (reconstructor_type,))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def _param_list(self):
+        return list(self.parameters())
+
+    # -- reference signature ---------------------------------------------------------------------------
+    def forward(self, x1, x2):
+        if not x1.is_cuda:
+            raise L.WgsError("Reconstructor runs on the HIP kernels only: inputs must be GPU tensors (no CPU fallback)")
+        if self.reconstructor_type == 'LeNet':
+            from .lenet import lenet_forward
+            return lenet_forward(self, x1, x2)
+        return _RFunction.apply(self, x1, x2, *self._param_list())
+
+    # -- explicit schedule -------------------------------------------------------------------------------
+    def _forward_impl(self, x1, x2, save=True):
+        fe = self.features_extractor
+        train = self.training
+        lib, st = L.lib(), L.stream()
+        dev = x1.device
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, c, H, W = x1.shape
+        ws = torch.empty(2 * 512, dtype=torch.float64, device=dev)
+        Cp = 8
+        x = torch.empty(B, H, W, Cp, device=dev)
+        L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
+        # stem: conv1 weights padded from 2c to Cp input channels
+        w1 = _packed(fe.conv1)
+        w1p = torch.zeros(64, 49, Cp, device=dev)
+        w1p[:, :, :2 * c] = w1
+        c1 = C.conv2d(x, w1p, 7, stride=2, pad=3)
+        a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
+        Hp = (a1.shape[1] + 2 - 3) // 2 + 1
+        p1 = torch.empty(B, Hp, Hp, 64, device=dev)
+        idx = torch.empty(B, Hp, Hp, 64, dtype=torch.uint8, device=dev)
+        L.check(lib.wgs_maxpool_fwd(L.ptr(a1), L.ptr(p1), L.rawptr(idx), B, a1.shape[1], a1.shape[2], 64, 3, 2, 1, st),
+                'maxpool')
+        saved_blocks = []
+        h = p1
+        for blk in fe.blocks():
+            xin = h
+            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1)
+            aa, sa = _BN.fwd(blk.bn1, ca, ws, relu=True, train=train)
+            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1)
+            if blk.downsample is not None:
+                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0)
+                ad, sd = _BN.fwd(blk.downsample[1], cd, ws, relu=False, train=train)
+                ident = ad
+            else:
+                cd, sd, ident = None, None, xin
+            o, sb = _BN.fwd(blk.bn2, cb, ws, residual=ident, relu=True, train=train)
+            saved_blocks.append((xin, ca, aa, sa, cb, sb, cd, sd, o))
+            h = o
+        P = h.shape[1] * h.shape[2]
+        feat = torch.empty(B, 512, device=dev)
+        L.check(lib.wgs_avgpool_fwd(L.ptr(h), L.ptr(feat), B, P, 512, st), 'avgpool')
+        K = self.dim
+        logits = torch.empty(B, K, device=dev)
+        mag = torch.empty(B, 1, device=dev)
+        for lin, out, n in ((self.path_indices, logits, K), (self.shift_magnitudes, mag, 1)):
+            L.check(lib.wgs_linear_fwd(L.ptr(feat), L.ptr(lin.weight), L.ptr(lin.bias), L.ptr(out), B, n, 512, 512, n,
+                                       L.c_float(1.0), L.c_float(1.0), 0, 0, L.c_float(0.0), L.c_float(1.0), st), 'head')
+        saved = dict(x=x, c1=c1, a1=a1, st1=st1, idx=idx, p1shape=p1.shape, blocks=saved_blocks, feat=feat, hshape=h.shape,
+                     B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws) if save else None
+        return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
+
+    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True)):
+        """Returns ({id(param): grad}, d_x1 or None, d_x2 or None)."""
+        fe = self.features_extractor
+        lib, st = L.lib(), L.stream()
+        B, train, ws = S['B'], S['train'], S['ws']
+        dev = dlogits.device
+        K = self.dim
+        grads = {}
+        feat = S['feat']
+        dmag = dmag.reshape(B, 1)
+        dfeat = torch.empty(B, 512, device=dev)
+        for i, (lin, g, n) in enumerate(((self.path_indices, dlogits, K), (self.shift_magnitudes, dmag, 1))):
+            L.check(lib.wgs_linear_dgrad(L.ptr(g), L.ptr(lin.weight), None, L.ptr(dfeat), B, n, 512, n, 512, L.c_float(1.0),
+                                         L.c_float(1.0), L.c_float(1.0), i, st), 'head_dgrad')
+            dw, db = torch.empty_like(lin.weight), torch.empty_like(lin.bias)
+            L.check(lib.wgs_linear_wgrad(L.ptr(g), L.ptr(feat), L.ptr(dw), L.ptr(db), B, n, 512, st), 'head_wgrad')
+            grads[id(lin.weight)], grads[id(lin.bias)] = dw, db
+        hs = S['hshape']
+        dh = torch.empty(hs, device=dev)
+        L.check(lib.wgs_avgpool_bwd(L.ptr(dfeat), L.ptr(dh), B, hs[1] * hs[2], 512, st), 'avgpool_bwd')
+        dyA, dyB = dh, None
+        blocks = fe.blocks()
+        for blk, (xin, ca, aa, sa, cb, sb, cd, sd, o) in zip(reversed(blocks), reversed(S['blocks'])):
+            # o = relu(bn2(cb) + identity)
+            dcb, dres, dg, db_ = _BN.bwd(blk.bn2, cb, sb, dyA, dyB, o, ws, want_res=True, train=train)
+            grads[id(blk.bn2.weight)], grads[id(blk.bn2.bias)] = dg, db_
+            w2 = _packed(blk.conv2)
+            Co, T, Ci = w2.shape
+            dw2 = torch.zeros_like(w2)
+            C.conv2d_wgrad(aa, dcb, dw2, 3, stride=1, pad=1)
+            grads[id(blk.conv2.weight)] = _grad_like(blk.conv2, dw2)
+            daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1)
+            dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train)
+            grads[id(blk.bn1.weight)], grads[id(blk.bn1.bias)] = dg, db_
+            w1 = _packed(blk.conv1)
+            Co, T, Ci = w1.shape
+            dw1 = torch.zeros_like(w1)
+            C.conv2d_wgrad(xin, dca, dw1, 3, stride=blk.stride, pad=1)
+            grads[id(blk.conv1.weight)] = _grad_like(blk.conv1, dw1)
+            dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1)
+            if blk.downsample is not None:
+                dcd, _, dg, db_ = _BN.bwd(blk.downsample[1], cd, sd, dres, None, None, ws, train=train)
+                grads[id(blk.downsample[1].weight)], grads[id(blk.downsample[1].bias)] = dg, db_
+                wd = _packed(blk.downsample[0])
+                Co, T, Ci = wd.shape
+                dwd = torch.zeros_like(wd)
+                C.conv2d_wgrad(xin, dcd, dwd, 1, stride=blk.stride, pad=0)
+                grads[id(blk.downsample[0].weight)] = _grad_like(blk.downsample[0], dwd)
+                dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0)
+            else:
+                dside = dres
+            dyA, dyB = dmain, dside
+        # stem
+        dp1 = dyA + dyB
+        a1 = S['a1']
+        da1 = torch.empty_like(a1)
+        L.check(lib.wgs_maxpool_bwd(L.ptr(dp1), L.rawptr(S['idx']), L.ptr(da1), B, a1.shape[1], a1.shape[2], 64, 3, 2, 1, st),
+                'maxpool_bwd')
+        dc1, _, dg, db_ = _BN.bwd(fe.bn1, S['c1'], S['st1'], da1, None, a1, ws, train=train)
+        grads[id(fe.bn1.weight)], grads[id(fe.bn1.bias)] = dg, db_
+        c, Cp = S['c'], S['Cp']
+        dw1p = torch.zeros(64, 49, Cp, device=dev)
+        C.conv2d_wgrad(S['x'], dc1, dw1p, 7, stride=2, pad=3)
+        grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, dw1p[:, :, :2 * c].contiguous())
+        d1 = d2 = None
+        if need_x[0] or need_x[1]:
+            w1p = torch.zeros(64, 49, Cp, device=dev)
+            w1p[:, :, :2 * c] = _packed(fe.conv1)
+            dx = C.conv2d_dgrad(dc1, C.repack_w_t(w1p, 64, 49, Cp), (S['H'], S['W']), 7, stride=2, pad=3)
+            d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
+            d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
+            L.check(lib.wgs_unpack_pair_grad(L.ptr(dx), L.ptr(d1), L.ptr(d2), B, c, S['H'] * S['W'], Cp, st), 'unpack_pair')
+        return grads, d1, d2
