@@ -52,7 +52,8 @@ def test_maxpool_fwd_bwd(dev, B, Cc, H, k, s, p):
     idx = torch.empty(B, Ho, Ho, Cc, dtype=torch.uint8, device=dev)
     L.check(L.lib().wgs_maxpool_fwd(L.ptr(xd), L.ptr(yd), L.rawptr(idx), B, H, H, Cc, k, s, p, L.stream()))
     dx = torch.empty_like(xd)
-    L.check(L.lib().wgs_maxpool_bwd(L.ptr(nhwc(g).to(dev)), L.rawptr(idx), L.ptr(dx), B, H, H, Cc, k, s, p, L.stream()))
+    gd = nhwc(g).to(dev)
+    L.check(L.lib().wgs_maxpool_bwd(L.ptr(gd), L.rawptr(idx), L.ptr(dx), B, H, H, Cc, k, s, p, L.stream()))
     assert torch.equal(nchw(yd).cpu(), y.detach())
     assert rel_err(nchw(dx), x.grad) < 1e-6          # includes torch's first-maximum tie-breaking
 
@@ -60,15 +61,17 @@ def test_maxpool_fwd_bwd(dev, B, Cc, H, k, s, p):
 def test_avgpool_pack_colsum(dev):
     B, P, Cc = 5, 64, 512
     x = torch.randn(B, P, Cc)
+    xd = x.to(dev)
     y = torch.empty(B, Cc, device=dev)
-    L.check(L.lib().wgs_avgpool_fwd(L.ptr(x.to(dev)), L.ptr(y), B, P, Cc, L.stream()))
+    L.check(L.lib().wgs_avgpool_fwd(L.ptr(xd), L.ptr(y), B, P, Cc, L.stream()))
     assert rel_err(y, x.mean(1)) < 1e-6
     dx = torch.empty(B, P, Cc, device=dev)
     L.check(L.lib().wgs_avgpool_bwd(L.ptr(y), L.ptr(dx), B, P, Cc, L.stream()))
     assert rel_err(dx, (y.cpu() / P)[:, None, :].expand(B, P, Cc)) < 1e-6
     a, b = torch.randn(3, 3, 7, 9), torch.randn(3, 3, 7, 9)
     out = torch.empty(3, 7, 9, 8, device=dev)
-    L.check(L.lib().wgs_pack_pair_nhwc(L.ptr(a.to(dev)), L.ptr(b.to(dev)), L.ptr(out), 3, 3, 63, 8, L.stream()))
+    ad, bd = a.to(dev), b.to(dev)
+    L.check(L.lib().wgs_pack_pair_nhwc(L.ptr(ad), L.ptr(bd), L.ptr(out), 3, 3, 63, 8, L.stream()))
     ref = torch.cat([a, b, torch.zeros(3, 2, 7, 9)], 1).permute(0, 2, 3, 1)
     assert torch.equal(out.cpu(), ref)
     d1, d2 = torch.empty(3, 3, 7, 9, device=dev), torch.empty(3, 3, 7, 9, device=dev)
@@ -77,5 +80,6 @@ def test_avgpool_pack_colsum(dev):
     xs = torch.randn(1000, 64)
     cs = torch.empty(64, device=dev)
     ws = torch.empty(128, dtype=torch.float64, device=dev)
-    L.check(L.lib().wgs_colsum(L.ptr(xs.to(dev)), L.ptr(cs), L.rawptr(ws), L.c_int64(1000), 64, L.stream()))
+    xsd = xs.to(dev)
+    L.check(L.lib().wgs_colsum(L.ptr(xsd), L.ptr(cs), L.rawptr(ws), L.c_int64(1000), 64, L.stream()))
     assert rel_err(cs, xs.double().sum(0)) < 1e-6

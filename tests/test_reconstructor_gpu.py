@@ -114,10 +114,10 @@ def test_loss_kernel_vs_oracle(dev):
     mpg = mp.clone().requires_grad_(True)
     total, ce, l1, acc = O.training_loss(lg, mpg, tgt, mt, 1.0, 0.25)
     total.backward()
-    d = lambda t, dt=torch.float32: t.to(dev)
+    lgd, tgd, mpd, mtd = logits.to(dev), tgt.to(dev), mp.to(dev), mt.to(dev)    # keep the device copies alive
     dl, dm = torch.empty(B, K, device=dev), torch.empty(B, device=dev)
     stats, am, ws = torch.empty(4, device=dev), torch.empty(B, dtype=torch.int64, device=dev), torch.empty(2 * B, device=dev)
-    L.check(L.lib().wgs_ce_l1_loss(L.ptr(d(logits)), L.ptr(d(tgt), torch.int64), L.ptr(d(mp)), L.ptr(d(mt)), L.c_float(1.0),
+    L.check(L.lib().wgs_ce_l1_loss(L.ptr(lgd), L.ptr(tgd, torch.int64), L.ptr(mpd), L.ptr(mtd), L.c_float(1.0),
                                    L.c_float(0.25), L.ptr(dl), L.ptr(dm), L.ptr(stats), L.ptr(am, torch.int64), L.ptr(ws),
                                    B, K, L.stream()))
     assert torch.equal(am.cpu(), torch.argmax(logits, 1)) and int(am[3]) == 7
@@ -135,7 +135,8 @@ def test_adam_kernel_vs_torch(dev):
         gs = g * step
         p.grad = gs.clone()
         opt.step()
-        L.check(L.lib().wgs_adam_step(L.ptr(pd), L.ptr(gs.to(dev)), L.ptr(m), L.ptr(v), L.c_int64(n), L.c_float(1e-4),
+        gsd = gs.to(dev)
+        L.check(L.lib().wgs_adam_step(L.ptr(pd), L.ptr(gsd), L.ptr(m), L.ptr(v), L.c_int64(n), L.c_float(1e-4),
                                       L.c_float(0.9), L.c_float(0.999), L.c_float(1e-8), step, L.c_float(1.0), L.stream()))
     assert (pd.cpu() - p.detach()).abs().max().item() < 2e-7 * p0.abs().max().item() + 1e-9
-    assert rel_err(pd.cpu() - p0, p.detach() - p0) < 1e-4
+    assert rel_err(pd.cpu() - p0, p.detach() - p0) < 1e-3     # the update itself (~3e-4 of |p|), fp32-rounded

@@ -18,8 +18,10 @@ def fused_bias_act(x, bias=None, ref=None, act=3, grad=0, alpha=0.2, scale=2 ** 
         step_b *= s
     has_b = bias is not None and bias.numel() > 0
     has_r = ref is not None and ref.numel() > 0
-    L.check(L.lib().wgs_bias_act(L.ptr(x), L.ptr(bias.contiguous() if has_b else None),
-                                 L.ptr(ref.contiguous() if has_r else None), L.ptr(y), act, grad,
+    # hold every (possibly re-laid-out) operand in a local until the launch has been issued
+    bias_c = bias.contiguous() if has_b else None
+    ref_c = ref.contiguous() if has_r else None
+    L.check(L.lib().wgs_bias_act(L.ptr(x), L.ptr(bias_c), L.ptr(ref_c), L.ptr(y), act, grad,
                                  L.c_float(alpha), L.c_float(scale), L.c_int64(x.numel()), step_b,
                                  bias.numel() if has_b else 1, L.stream()), 'wgs_bias_act')
     return y
@@ -67,7 +69,8 @@ def upfirdn2d_mhwc(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0
     out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
     out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
     y = torch.empty(major, out_h, out_w, minor, dtype=x.dtype, device=x.device)
-    L.check(L.lib().wgs_upfirdn2d(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(y), major, in_h, in_w, minor, kh, kw,
+    kernel_c = kernel.contiguous()
+    L.check(L.lib().wgs_upfirdn2d(L.ptr(x), L.ptr(kernel_c), L.ptr(y), major, in_h, in_w, minor, kh, kw,
                                   up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, L.stream()),
             'wgs_upfirdn2d')
     return y

@@ -49,8 +49,9 @@ class _RbfField(torch.autograd.Function):
         dlg = torch.zeros(K, dtype=torch.float32, device=z.device) if (need_lg and use_loggamma) else None
         dz = torch.zeros_like(z) if need_z else None
         lg = loggamma.reshape(-1) if use_loggamma else None
+        gout = gout.contiguous()
         L.check(L.lib().wgs_rbf_bwd(L.ptr(table), L.ptr(alphas), L.ptr(lg), L.c_float(gamma), L.ptr(idx, torch.int64),
-                                    L.ptr(z), L.ptr(scale if has_scale else None), L.ptr(gout.contiguous()),
+                                    L.ptr(z), L.ptr(scale if has_scale else None), L.ptr(gout),
                                     L.ptr(ws), L.ptr(dtable), L.ptr(dlg), L.ptr(dalphas), L.ptr(dz),
                                     B, K, n2, d, L.stream()), 'wgs_rbf_bwd')
         return (dtable if need_table else None, dalphas, dlg.view_as(loggamma) if dlg is not None else None, dz,
@@ -110,8 +111,9 @@ class SupportSets(nn.Module):
         path = torch.empty(n, K, 2 * steps + 1, d, device=codes.device)
         shift = torch.empty_like(path)
         lg = self.LOGGAMMA.reshape(-1) if self.learn_gammas else None
+        codes = codes.contiguous()
         L.check(L.lib().wgs_rbf_traverse(L.ptr(self.SUPPORT_SETS), L.ptr(self.ALPHAS), L.ptr(lg),
-                                         L.c_float(float(self.gamma)), L.ptr(codes.contiguous()), L.c_float(eps),
+                                         L.c_float(float(self.gamma)), L.ptr(codes), L.c_float(eps),
                                          steps, L.ptr(path), L.ptr(shift), n, K, n2, d, L.stream()),
                 'wgs_rbf_traverse')
         return path, shift
