@@ -348,3 +348,58 @@ def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
     v.mul_(b2).addcmul_(g, g, value=1 - b2)
     bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
     p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+# =================================================================================================
+# One training step as written in the reference — lib/trainer.py:190-254
+# =================================================================================================
+class ReferenceStep:
+    """Holds leaf copies of the G / S / R state dicts and replays the reference's loop body with plain
+    torch autograd: G(z) WITH a graph, warp, G(z + shift), R, CE + lambda*L1, loss.backward() (which also
+    builds the generator's never-used weight gradients, exactly like the reference), two Adam steps."""
+
+    def __init__(self, sd_g, sd_s, sd_r, size, learn_gammas=True, gamma=None, lambda_cls=1.0, lambda_reg=0.25,
+                 lr_s=1e-4, lr_r=1e-4, shift_in_w_space=False, g_requires_grad=True, reconstructor='ResNet'):
+        self.size, self.learn_gammas, self.gamma = size, learn_gammas, gamma
+        self.lc, self.lr_, self.w_space, self.rtype = lambda_cls, lambda_reg, shift_in_w_space, reconstructor
+        self.g = {k: v.detach().clone().requires_grad_(g_requires_grad and v.is_floating_point() and
+                                                        not k.startswith('noises.') and not k.endswith('kernel'))
+                  for k, v in sd_g.items()}
+        self.s = {k: v.detach().clone() for k, v in sd_s.items()}
+        self.s['SUPPORT_SETS'].requires_grad_(True)
+        if learn_gammas:
+            self.s['LOGGAMMA'].requires_grad_(True)
+        self.r = {}
+        for k, v in sd_r.items():
+            v = v.detach().clone().contiguous()
+            trainable = v.is_floating_point() and not (k.endswith('running_mean') or k.endswith('running_var'))
+            self.r[k] = v.requires_grad_(True) if trainable else v
+        self.opt = {'s': {}, 'r': {}}
+        self.t = 0
+        self.lrs = {'s': lr_s, 'r': lr_r}
+
+    def step(self, z, idx, mag):
+        K = self.s['ALPHAS'].shape[0]
+        for d in (self.g, self.s, self.r):
+            for v in d.values():
+                if v.is_floating_point() and v.requires_grad:
+                    v.grad = None
+        img = sg2_generate(self.g, z, self.size)                                              # :200
+        mask = torch.zeros(z.shape[0], K)
+        mask[torch.arange(z.shape[0]), idx] = 1.0                                            # :227-231
+        code = sg2_mapping(self.g, z) if self.w_space else z
+        shift = mag.reshape(-1, 1) * support_sets_forward(self.s, mask, code, self.learn_gammas, self.gamma)   # :235
+        img_shifted = sg2_generate(self.g, z, self.size, shift, shift_in_w_space=self.w_space)   # :239
+        fn = reconstructor_resnet if self.rtype == 'ResNet' else reconstructor_lenet
+        logits, mag_hat = fn(self.r, img, img_shifted, training=True)                        # :242
+        loss, ce, l1, acc = training_loss(logits, mag_hat, idx, mag, self.lc, self.lr_)      # :245-249
+        loss.backward()                                                                      # :250
+        self.t += 1
+        for grp, d in (('s', self.s), ('r', self.r)):                                        # :253-254
+            for k, v in d.items():
+                if v.is_floating_point() and v.requires_grad and v.grad is not None:
+                    stt = self.opt[grp].setdefault(k, (torch.zeros_like(v), torch.zeros_like(v)))
+                    with torch.no_grad():
+                        adam_step(v, v.grad, stt[0], stt[1], self.t, lr=self.lrs[grp])
+        return dict(loss=loss.item(), ce=ce.item(), l1=l1.item(), acc=acc.item(), argmax=torch.argmax(logits, 1),
+                    logits=logits.detach(), img=img.detach(), img_shifted=img_shifted.detach(), shift=shift.detach())

@@ -1,0 +1,89 @@
+"""GPU: the full training step (warp -> G -> R -> loss -> backward -> Adam x2) vs the oracle's replay of
+lib/trainer.py:190-254 on identical (z, idx, magnitudes) and identical initial weights."""
+import types
+
+import pytest
+import torch
+
+from oracle import wgs_oracle as O
+from tests import golden_inputs as GI
+from tests.util import rel_err
+from warpedganspace_amd.gan_load import StyleGAN2Wrapper
+from warpedganspace_amd.reconstructor import Reconstructor
+from warpedganspace_amd.stylegan2 import Generator
+from warpedganspace_amd.support_sets import SupportSets
+from warpedganspace_amd.trainer import TrainStep
+
+pytestmark = pytest.mark.gpu
+
+
+def make(dev, size, K, N, B, w_space=False):
+    torch.manual_seed(0)
+    G = Generator(size, 512, 8)
+    sd_g = GI.fill_state_dict(G.state_dict(), 900 + size)
+    # keep the (random) mapping network well conditioned: scale its weights up so that w is O(1)
+    for k in sd_g:
+        if k.startswith('style.') and k.endswith('weight'):
+            sd_g[k] = sd_g[k] * 100.0
+    G.load_state_dict(sd_g)
+    c = GI.support_sets_case(K, N, 512, B, 31, learn_gammas=True)
+    S = SupportSets(K, N, 512, learn_gammas=True, gamma=c['gamma'])
+    S.load_state_dict(c['sd'])
+    R = Reconstructor('ResNet', K)
+    sd_r = {k: v.detach().clone().contiguous() for k, v in R.state_dict().items()}
+    params = types.SimpleNamespace(reconstructor_lr=1e-4, support_set_lr=1e-4, min_shift_magnitude=0.25,
+                                   max_shift_magnitude=0.45, lambda_cls=1.0, lambda_reg=0.25, z_truncation=None,
+                                   shift_in_w_space=w_space)
+    ref = O.ReferenceStep(sd_g, c['sd'], sd_r, size, learn_gammas=True, gamma=c['gamma'], shift_in_w_space=w_space,
+                          g_requires_grad=False)
+    wrap = StyleGAN2Wrapper(G, w_space).to(dev).eval()
+    eng = TrainStep(wrap, S.to(dev).train(), R.to(dev).train(), params, B, dev, seed=1)
+    return eng, ref, c
+
+
+@pytest.mark.parametrize('w_space', [False, True])
+def test_two_steps_vs_reference_replay(dev, w_space):
+    size, K, N, B = 32, 16, 4, 4
+    eng, ref, c = make(dev, size, K, N, B, w_space)
+    g = torch.Generator().manual_seed(7)
+    for it in range(2):
+        z = torch.randn(B, 512, generator=g)
+        idx = torch.randint(0, K, (B,), generator=g)
+        mag = (torch.rand(B, generator=g) * 0.2 + 0.25) * torch.where(torch.rand(B, generator=g) > 0.3, 1.0, -1.0)
+        o = ref.step(z, idx, mag)
+        stats = eng.step(z.to(dev), idx.to(dev), mag.to(dev)).tolist()
+        assert abs(stats[0] - o['ce']) < 1e-4 * max(1.0, abs(o['ce']))
+        assert abs(stats[1] - o['l1']) < 1e-4 * max(1.0, abs(o['l1']))
+        assert abs(stats[2] - o['loss']) < 1e-4 * max(1.0, abs(o['loss']))
+        assert abs(stats[3] - o['acc']) < 1e-6
+        assert torch.equal(eng.argmax.cpu(), o['argmax'])                       # path-index argmax bit-exact
+        # post-step parameters: Adam's first steps move every touched weight by ~lr, so compare the UPDATE
+        sd_s = eng.S.state_dict()
+        rows = torch.unique(idx)
+        upd_ref = ref.s['SUPPORT_SETS'].detach()[rows] - c['sd']['SUPPORT_SETS'][rows]
+        upd = sd_s['SUPPORT_SETS'].cpu()[rows] - c['sd']['SUPPORT_SETS'][rows]
+        assert rel_err(upd, upd_ref) < 5e-2, it
+        assert rel_err(sd_s['SUPPORT_SETS'].cpu(), ref.s['SUPPORT_SETS'].detach()) < 1e-6
+        assert rel_err(sd_s['LOGGAMMA'].cpu(), ref.s['LOGGAMMA'].detach()) < 1e-5
+        sd_r = eng.R.state_dict()
+        for k, v in ref.r.items():
+            if k.startswith('features_extractor.fc') or k.endswith('num_batches_tracked'):
+                continue
+            assert rel_err(sd_r[k].cpu(), v.detach()) < 2e-4, (it, k)
+    st = eng.pop_stats()
+    assert set(st) == {'accuracy', 'classification_loss', 'regression_loss', 'total_loss'}
+
+
+def test_sampler_distribution_matches_reference_quirk(dev):
+    """lib/trainer.py:212-221: weights = arange(2B) without replacement => ~71 % positive magnitudes and
+    index 0 (the first negative one) is never drawn; |mag| in [min, max]."""
+    eng, _, _ = make(dev, 32, 16, 4, 64)
+    pos = tot = 0
+    for _ in range(50):
+        z, idx, mag = eng.sample()
+        assert z.shape == (64, 512) and idx.min() >= 0 and idx.max() < 16
+        a = mag.abs()
+        assert float(a.min()) >= 0.25 - 1e-6 and float(a.max()) <= 0.45 + 1e-6
+        pos += int((mag > 0).sum())
+        tot += 64
+    assert 0.64 < pos / tot < 0.78

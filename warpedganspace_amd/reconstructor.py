@@ -98,12 +98,12 @@ class _BN:
         return y, (mean, invstd)
 
     @staticmethod
-    def bwd(bn, x, stats, dyA, dyB, out, ws, want_res=False, train=True):
+    def bwd(bn, x, stats, dyA, dyB, out, ws, want_res=False, train=True, gbuf=None):
         N, Cn = x.numel() // x.shape[-1], x.shape[-1]
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_res else None
-        dg = torch.empty(Cn, device=x.device)
-        db = torch.empty(Cn, device=x.device)
+        dg = gbuf[id(bn.weight)] if gbuf is not None else torch.empty(Cn, device=x.device)
+        db = gbuf[id(bn.bias)] if gbuf is not None else torch.empty(Cn, device=x.device)
         L.check(L.lib().wgs_bn_bwd(L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr(out), L.ptr(stats[0]), L.ptr(stats[1]),
                                    L.ptr(bn.weight), L.ptr(dx), L.ptr(dres), L.ptr(dg), L.ptr(db), L.rawptr(ws),
                                    L.c_int64(N), Cn, int(train), L.stream()), 'wgs_bn_bwd')
@@ -209,8 +209,10 @@ class Reconstructor(nn.Module):
                      B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws) if save else None
         return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
 
-    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True)):
-        """Returns ({id(param): grad}, d_x1 or None, d_x2 or None)."""
+    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None):
+        """Returns ({id(param): grad}, d_x1 or None, d_x2 or None).  With `gbuf` ({id(param): zero-initialised
+        buffer in the parameter's MEMORY layout, conv weights packed [Co,T,Ci]}) gradients are written /
+        accumulated straight into those buffers (the trainer's flat gradient bucket)."""
         fe = self.features_extractor
         lib, st = L.lib(), L.stream()
         B, train, ws = S['B'], S['train'], S['ws']
@@ -223,7 +225,10 @@ class Reconstructor(nn.Module):
         for i, (lin, g, n) in enumerate(((self.path_indices, dlogits, K), (self.shift_magnitudes, dmag, 1))):
             L.check(lib.wgs_linear_dgrad(L.ptr(g), L.ptr(lin.weight), None, L.ptr(dfeat), B, n, 512, n, 512, L.c_float(1.0),
                                          L.c_float(1.0), L.c_float(1.0), i, st), 'head_dgrad')
-            dw, db = torch.empty_like(lin.weight), torch.empty_like(lin.bias)
+            if gbuf is not None:
+                dw, db = gbuf[id(lin.weight)], gbuf[id(lin.bias)]
+            else:
+                dw, db = torch.empty_like(lin.weight), torch.empty_like(lin.bias)
             L.check(lib.wgs_linear_wgrad(L.ptr(g), L.ptr(feat), L.ptr(dw), L.ptr(db), B, n, 512, st), 'head_wgrad')
             grads[id(lin.weight)], grads[id(lin.bias)] = dw, db
         hs = S['hshape']
@@ -233,28 +238,28 @@ class Reconstructor(nn.Module):
         blocks = fe.blocks()
         for blk, (xin, ca, aa, sa, cb, sb, cd, sd, o) in zip(reversed(blocks), reversed(S['blocks'])):
             # o = relu(bn2(cb) + identity)
-            dcb, dres, dg, db_ = _BN.bwd(blk.bn2, cb, sb, dyA, dyB, o, ws, want_res=True, train=train)
+            dcb, dres, dg, db_ = _BN.bwd(blk.bn2, cb, sb, dyA, dyB, o, ws, want_res=True, train=train, gbuf=gbuf)
             grads[id(blk.bn2.weight)], grads[id(blk.bn2.bias)] = dg, db_
             w2 = _packed(blk.conv2)
             Co, T, Ci = w2.shape
-            dw2 = torch.zeros_like(w2)
+            dw2 = gbuf[id(blk.conv2.weight)] if gbuf is not None else torch.zeros_like(w2)
             C.conv2d_wgrad(aa, dcb, dw2, 3, stride=1, pad=1)
             grads[id(blk.conv2.weight)] = _grad_like(blk.conv2, dw2)
             daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1)
-            dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train)
+            dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train, gbuf=gbuf)
             grads[id(blk.bn1.weight)], grads[id(blk.bn1.bias)] = dg, db_
             w1 = _packed(blk.conv1)
             Co, T, Ci = w1.shape
-            dw1 = torch.zeros_like(w1)
+            dw1 = gbuf[id(blk.conv1.weight)] if gbuf is not None else torch.zeros_like(w1)
             C.conv2d_wgrad(xin, dca, dw1, 3, stride=blk.stride, pad=1)
             grads[id(blk.conv1.weight)] = _grad_like(blk.conv1, dw1)
             dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1)
             if blk.downsample is not None:
-                dcd, _, dg, db_ = _BN.bwd(blk.downsample[1], cd, sd, dres, None, None, ws, train=train)
+                dcd, _, dg, db_ = _BN.bwd(blk.downsample[1], cd, sd, dres, None, None, ws, train=train, gbuf=gbuf)
                 grads[id(blk.downsample[1].weight)], grads[id(blk.downsample[1].bias)] = dg, db_
                 wd = _packed(blk.downsample[0])
                 Co, T, Ci = wd.shape
-                dwd = torch.zeros_like(wd)
+                dwd = gbuf[id(blk.downsample[0].weight)] if gbuf is not None else torch.zeros_like(wd)
                 C.conv2d_wgrad(xin, dcd, dwd, 1, stride=blk.stride, pad=0)
                 grads[id(blk.downsample[0].weight)] = _grad_like(blk.downsample[0], dwd)
                 dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0)
@@ -267,11 +272,13 @@ class Reconstructor(nn.Module):
         da1 = torch.empty_like(a1)
         L.check(lib.wgs_maxpool_bwd(L.ptr(dp1), L.rawptr(S['idx']), L.ptr(da1), B, a1.shape[1], a1.shape[2], 64, 3, 2, 1, st),
                 'maxpool_bwd')
-        dc1, _, dg, db_ = _BN.bwd(fe.bn1, S['c1'], S['st1'], da1, None, a1, ws, train=train)
+        dc1, _, dg, db_ = _BN.bwd(fe.bn1, S['c1'], S['st1'], da1, None, a1, ws, train=train, gbuf=gbuf)
         grads[id(fe.bn1.weight)], grads[id(fe.bn1.bias)] = dg, db_
         c, Cp = S['c'], S['Cp']
         dw1p = torch.zeros(64, 49, Cp, device=dev)
         C.conv2d_wgrad(S['x'], dc1, dw1p, 7, stride=2, pad=3)
+        if gbuf is not None:
+            gbuf[id(fe.conv1.weight)].copy_(dw1p[:, :, :2 * c])
         grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, dw1p[:, :, :2 * c].contiguous())
         d1 = d2 = None
         if need_x[0] or need_x[1]:

@@ -1,0 +1,297 @@
+"""Training driver — mirror of the reference's lib/trainer.py (`Trainer(params, exp_dir, use_cuda,
+multi_gpu).train(generator, support_sets, reconstructor)`) around an MI355X-native step.
+
+`TrainStep` is the hot loop body (lib/trainer.py:190-261) re-scheduled for one process per GPU:
+  * z, path indices and shift magnitudes are sampled in HBM (same distributions, incl. the reference's
+    arange-weighted draw without replacement, :212-221) — no host round trips, no per-sample mask loop;
+  * the un-shifted branch G(z) runs without saving anything (it has no trainable ancestor); only the
+    shifted branch is differentiated, and only w.r.t. its input (the reference also builds G's weight
+    gradients and throws them away);
+  * R's and S's gradients land in ONE flat fp32 bucket [R | S] that is all-reduced (RCCL, sum) once
+    per step when world_size > 1 and consumed by two fused Adam launches (grad_scale = 1/world);
+  * loss, its gradient, argmax and accuracy come from one kernel; statistics stay on the device
+    until a log boundary.
+Data-parallel semantics follow SURVEY.md §5.8: `--batch-size` is GLOBAL (local = global/world), the loss
+is a mean over the global batch, BatchNorm statistics stay per rank, rank 0 writes checkpoints.
+"""
+import json
+import os
+import os.path as osp
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .aux import TrainingStatTracker, sample_z, sec2dhms, update_progress, update_stdout
+from .support_sets import rbf_workspace
+
+
+class FlatBucket:
+    """Re-homes parameters into one flat fp32 buffer (memory order preserved) with a matching flat gradient
+    and Adam moment buffers.  `gview[id(p)]` is the gradient region of p in p's MEMORY layout (conv weights:
+    packed [Co, kh*kw, Ci])."""
+
+    def __init__(self, groups, device):
+        # groups: list of (lr, [params])
+        self.segments, self.gview, self.groups = [], {}, []
+        total = 0
+        for lr, params in groups:
+            start = total
+            for p in params:
+                n = (p.numel() + 3) & ~3
+                self.segments.append((p, total, p.numel()))
+                total += n
+            self.groups.append((lr, start, total))
+        self.flat = torch.zeros(total, device=device)
+        self.grad = torch.zeros(total, device=device)
+        self.exp_avg = torch.zeros(total, device=device)
+        self.exp_avg_sq = torch.zeros(total, device=device)
+        self.step_count = 0
+        with torch.no_grad():
+            for p, off, n in self.segments:
+                seg, gseg = self.flat[off:off + n], self.grad[off:off + n]
+                if p.dim() == 4:
+                    Co, Ci, kh, kw = p.shape
+                    seg.view(Co, kh, kw, Ci).copy_(p.data.permute(0, 2, 3, 1))
+                    p.data = seg.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
+                    self.gview[id(p)] = gseg.view(Co, kh * kw, Ci)
+                    p.grad = gseg.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
+                else:
+                    seg.view(p.shape).copy_(p.data)
+                    p.data = seg.view(p.shape)
+                    self.gview[id(p)] = gseg.view(p.shape)
+                    p.grad = gseg.view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def adam_step(self, world=1, betas=(0.9, 0.999), eps=1e-8):
+        self.step_count += 1
+        for lr, a, b in self.groups:
+            if b > a:
+                L.check(L.lib().wgs_adam_step(L.rawptr(self.flat[a:]), L.rawptr(self.grad[a:]), L.rawptr(self.exp_avg[a:]),
+                                              L.rawptr(self.exp_avg_sq[a:]), L.c_int64(b - a), L.c_float(lr),
+                                              L.c_float(betas[0]), L.c_float(betas[1]), L.c_float(eps), self.step_count,
+                                              L.c_float(1.0 / world), L.stream()), 'wgs_adam_step')
+
+
+class TrainStep:
+    """One optimisation step of lib/trainer.py:190-261 on this rank's share of the batch."""
+
+    def __init__(self, generator, support_sets, reconstructor, params, local_batch, device, world=1, seed=None):
+        self.G, self.S, self.R, self.p = generator, support_sets, reconstructor, params
+        self.B, self.dev, self.world = local_batch, device, world
+        self.gen = torch.Generator(device=device)
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        r_params = [p for n, p in reconstructor.named_parameters()
+                    if p.requires_grad and not n.startswith('features_extractor.fc')]
+        s_params = [p for p in support_sets.parameters() if p.requires_grad]
+        self.bucket = FlatBucket([(params.reconstructor_lr, r_params), (params.support_set_lr, s_params)], device)
+        K, n2 = support_sets.ALPHAS.shape
+        self.K, self.n2, self.d = K, n2, support_sets.support_vectors_dim
+        self.rbf_ws = rbf_workspace(local_batch, n2, self.d, device)
+        self.stats = torch.zeros(4, device=device)        # (ce, l1, total, accuracy) of the last step
+        self.stats_sum = torch.zeros(4, device=device)
+        self.stats_n = 0
+        self.dlogits = torch.empty(local_batch, K, device=device)
+        self.dmag = torch.empty(local_batch, device=device)
+        self.argmax = torch.empty(local_batch, dtype=torch.int64, device=device)
+        self.loss_ws = torch.empty(2 * local_batch, device=device)
+        self.w_space = bool(getattr(params, 'shift_in_w_space', False))
+
+    # -- sampling (lib/trainer.py:195-221), on the device ---------------------------------------------
+    def sample(self):
+        p, B = self.p, self.B
+        z = sample_z(B, self.G.dim_z, truncation=getattr(p, 'z_truncation', None), device=self.dev, generator=self.gen)
+        idx = torch.randint(0, self.K, (B,), device=self.dev, generator=self.gen)
+        lo, hi = p.min_shift_magnitude, p.max_shift_magnitude
+        pos = (lo - hi) * torch.rand(B, device=self.dev, generator=self.gen) + hi
+        neg = (lo - hi) * torch.rand(B, device=self.dev, generator=self.gen) - lo
+        pool = torch.cat((neg, pos))
+        ids = torch.arange(2 * B, dtype=torch.float, device=self.dev)          # weights 0..2B-1, :218
+        mag = pool[torch.multinomial(ids, B, replacement=False, generator=self.gen)]
+        return z, idx, mag
+
+    def step(self, z=None, idx=None, mag=None):
+        G, S, R, p, B = self.G, self.S, self.R, self.p, self.B
+        lib, st = L.lib(), L.stream()
+        if z is None:
+            z, idx, mag = self.sample()
+        self.bucket.zero_grad()
+        with torch.no_grad():
+            img = G(z)                                                        # :200, nothing saved
+            code = G.get_w(z) if self.w_space else z                          # :236
+        # shift = mag * S(mask, code)   (:235) — fused scale
+        lg = S.LOGGAMMA.reshape(-1) if S.learn_gammas else None
+        shift = torch.empty(B, self.d, device=self.dev)
+        L.check(lib.wgs_rbf_fwd(L.ptr(S.SUPPORT_SETS), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
+                                L.ptr(idx, torch.int64), L.ptr(code), L.ptr(mag), L.ptr(shift), L.ptr(self.rbf_ws),
+                                B, self.K, self.n2, self.d, st), 'wgs_rbf_fwd')
+        shift.requires_grad_(True)
+        img_shifted = G(z, shift)                                             # :239, input-gradient only
+        logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True)   # :242
+        L.check(lib.wgs_ce_l1_loss(L.ptr(logits), L.ptr(idx, torch.int64), L.ptr(mag_hat.reshape(B)), L.ptr(mag),
+                                   L.c_float(p.lambda_cls), L.c_float(p.lambda_reg), L.ptr(self.dlogits), L.ptr(self.dmag),
+                                   L.ptr(self.stats), L.ptr(self.argmax, torch.int64), L.ptr(self.loss_ws), B, self.K, st),
+                'wgs_ce_l1_loss')                                             # :245-249,257-258
+        gb = self.bucket.gview
+        _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb)
+        del saved
+        img_shifted.backward(d_img)                                           # G: d image -> d shift
+        dtable = gb[id(S.SUPPORT_SETS)]
+        dlg = gb[id(S.LOGGAMMA)].reshape(-1) if (S.learn_gammas and id(S.LOGGAMMA) in gb) else None
+        dal = gb[id(S.ALPHAS)] if (S.learn_alphas and id(S.ALPHAS) in gb) else None
+        gshift = shift.grad.contiguous()
+        L.check(lib.wgs_rbf_bwd(L.ptr(S.SUPPORT_SETS), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
+                                L.ptr(idx, torch.int64), L.ptr(code), L.ptr(mag), L.ptr(gshift), L.ptr(self.rbf_ws),
+                                L.ptr(dtable), L.ptr(dlg), L.ptr(dal), None, B, self.K, self.n2, self.d, st), 'wgs_rbf_bwd')
+        if self.world > 1:
+            dist.all_reduce(self.bucket.grad)                                 # RCCL sum; Adam divides by world
+        self.bucket.adam_step(world=self.world)                               # :253-254
+        self.stats_sum += self.stats
+        self.stats_n += 1
+        return self.stats
+
+    def pop_stats(self):
+        """Mean (accuracy, classification_loss, regression_loss, total_loss) since the last call (one sync)."""
+        s = self.stats_sum.clone()
+        if self.world > 1:
+            dist.all_reduce(s)
+            s /= self.world
+        v = (s / max(self.stats_n, 1)).tolist()
+        self.stats_sum.zero_()
+        self.stats_n = 0
+        return {'accuracy': v[3], 'classification_loss': v[0], 'regression_loss': v[1], 'total_loss': v[2]}
+
+
+class Trainer(object):
+    def __init__(self, params=None, exp_dir=None, use_cuda=False, multi_gpu=False, root="experiments"):
+        if params is None:
+            raise ValueError("Cannot build a Trainer instance with empty params: params={}".format(params))
+        self.params = params
+        self.use_cuda = use_cuda
+        self.multi_gpu = multi_gpu
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.tensorboard = getattr(params, 'tensorboard', False)
+        self.wip_dir = osp.join(root, "wip", exp_dir)
+        self.complete_dir = osp.join(root, "complete", exp_dir)
+        self.stats_json = osp.join(self.wip_dir, 'stats.json')
+        self.models_dir = osp.join(self.wip_dir, 'models')
+        self.checkpoint = osp.join(self.models_dir, 'checkpoint.pt')
+        if self.rank == 0:
+            os.makedirs(self.models_dir, exist_ok=True)
+            if not osp.isfile(self.stats_json):
+                with open(self.stats_json, 'w') as out:
+                    json.dump({}, out)
+        self.tb_writer = None
+        if self.tensorboard and self.rank == 0:
+            try:   # optional dependency (absent in this image); the reference imports it unconditionally
+                from torch.utils.tensorboard import SummaryWriter
+                self.tb_dir = osp.join(self.wip_dir, 'tensorboard')
+                os.makedirs(self.tb_dir, exist_ok=True)
+                self.tb_writer = SummaryWriter(log_dir=self.tb_dir)
+            except Exception as e:  # noqa: BLE001
+                print("#. TensorBoard unavailable ({}); continuing without it".format(e))
+        self.iter_times = np.array([])
+        self.stat_tracker = TrainingStatTracker()
+
+    @staticmethod
+    def _plain(sd):
+        return {k: v.detach().clone(memory_format=torch.contiguous_format) for k, v in sd.items()}
+
+    def get_starting_iteration(self, support_sets, reconstructor):
+        """Resume from models/checkpoint.pt if present (lib/trainer.py:74-89): {'iter','support_sets','reconstructor'}."""
+        starting_iter = 1
+        if osp.isfile(self.checkpoint):
+            ck = torch.load(self.checkpoint, map_location='cpu')
+            starting_iter = ck['iter']
+            support_sets.load_state_dict(ck['support_sets'])
+            reconstructor.load_state_dict(ck['reconstructor'])
+        return starting_iter
+
+    def log_progress(self, iteration, mean_iter_time, elapsed_time, eta, stats):
+        with open(self.stats_json) as f:
+            stats_dict = json.load(f)
+        stats_dict.update({iteration: stats})
+        with open(self.stats_json, 'w') as out:
+            json.dump(stats_dict, out)
+        update_progress("  \\__.Training [bs: {}] [iter: {:06d}/{:06d}] ".format(
+            self.params.batch_size, iteration, self.params.max_iter), self.params.max_iter, iteration + 1)
+        if iteration < self.params.max_iter - 1:
+            print()
+        print("      \\__Batch accuracy      : {:.03f}".format(stats['accuracy']))
+        print("      \\__Classification loss : {:.08f}".format(stats['classification_loss']))
+        print("      \\__Regression loss     : {:.08f}".format(stats['regression_loss']))
+        print("      \\__Total loss          : {:.08f}".format(stats['total_loss']))
+        print("         ===================================================================")
+        print("      \\__Mean iter time      : {:.3f} sec".format(mean_iter_time))
+        print("      \\__Elapsed time        : {}".format(sec2dhms(elapsed_time)))
+        print("      \\__ETA                 : {}".format(sec2dhms(eta)))
+        print("         ===================================================================")
+        if sys.stdout.isatty():
+            update_stdout(10)
+
+    def train(self, generator, support_sets, reconstructor):
+        p = self.params
+        if not (self.use_cuda and torch.cuda.is_available()):
+            raise L.WgsError("this Trainer drives the HIP kernels: a GPU is required (the reference's CPU path is "
+                             "restated only in oracle/, for checking)")
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if self.rank == 0:
+            torch.save(self._plain(support_sets.state_dict()), osp.join(self.models_dir, 'support_sets_init.pt'))
+        generator.to(dev).eval()
+        support_sets.to(dev).train()
+        reconstructor.to(dev).train()
+        starting_iter = self.get_starting_iteration(support_sets, reconstructor)
+        if self.world > 1:   # identical replicas on every rank
+            for t in list(support_sets.parameters()) + list(reconstructor.parameters()) + list(reconstructor.buffers()):
+                dist.broadcast(t.data, 0)
+        if starting_iter == p.max_iter:
+            print("#. This experiment has already been completed and can be found @ {}".format(self.wip_dir))
+            if self.rank == 0:
+                try:
+                    shutil.copytree(src=self.wip_dir, dst=self.complete_dir, ignore=shutil.ignore_patterns('checkpoint.pt'))
+                except IOError as e:
+                    print("  \\__Already exists -- {}".format(e))
+            sys.exit()
+        if p.batch_size % self.world:
+            raise ValueError("--batch-size ({}) is the GLOBAL batch and must divide by the world size ({})".format(
+                p.batch_size, self.world))
+        engine = TrainStep(generator, support_sets, reconstructor, p, p.batch_size // self.world, dev, world=self.world,
+                           seed=getattr(p, 'seed', None))
+        if self.rank == 0:
+            print("#. Start training from iteration {}".format(starting_iter))
+        t0 = time.time()
+        for iteration in range(starting_iter, p.max_iter + 1):
+            iter_t0 = time.time()
+            engine.step()
+            if self.tb_writer is not None or iteration % p.log_freq == 0:
+                stats = engine.pop_stats()
+                if self.tb_writer is not None:
+                    for key, value in stats.items():
+                        self.tb_writer.add_scalar(key, value, iteration)
+            iter_t = time.time()
+            self.iter_times = np.append(self.iter_times, iter_t - iter_t0)
+            elapsed_time = iter_t - t0
+            eta = elapsed_time * ((p.max_iter - iteration) / (iteration - starting_iter + 1))
+            if iteration % p.log_freq == 0 and self.rank == 0:
+                self.log_progress(iteration, self.iter_times.mean(), elapsed_time, eta, stats)
+            if iteration % p.ckp_freq == 0 and self.rank == 0:
+                torch.save({'iter': iteration, 'support_sets': self._plain(support_sets.state_dict()),
+                            'reconstructor': self._plain(reconstructor.state_dict())}, self.checkpoint)
+        elapsed_time = time.time() - t0
+        if self.rank == 0:
+            torch.save(self._plain(support_sets.state_dict()), osp.join(self.models_dir, 'support_sets.pt'))
+            torch.save(self._plain(reconstructor.state_dict()), osp.join(self.models_dir, 'reconstructor.pt'))
+            print("#.Training completed -- Total elapsed time: {}.".format(sec2dhms(elapsed_time)))
+            try:
+                shutil.copytree(src=self.wip_dir, dst=self.complete_dir, ignore=shutil.ignore_patterns('checkpoint.pt'))
+            except IOError as e:
+                print("  \\__Already exists -- {}".format(e))
+        return engine
