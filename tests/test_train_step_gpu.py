@@ -57,19 +57,35 @@ def test_two_steps_vs_reference_replay(dev, w_space):
         assert abs(stats[2] - o['loss']) < 1e-4 * max(1.0, abs(o['loss']))
         assert abs(stats[3] - o['acc']) < 1e-6
         assert torch.equal(eng.argmax.cpu(), o['argmax'])                       # path-index argmax bit-exact
-        # post-step parameters: Adam's first steps move every touched weight by ~lr, so compare the UPDATE
+        # gradients (read back from the flat bucket before they are reused) — well-posed comparison
+        gb = eng.bucket.gview
+        assert rel_err(gb[id(eng.S.SUPPORT_SETS)], ref.s['SUPPORT_SETS'].grad) < 2e-3, it
+        assert rel_err(gb[id(eng.S.LOGGAMMA)], ref.s['LOGGAMMA'].grad) < 2e-3, it
+        worst = 0.0
+        for name, prm in eng.R.named_parameters():
+            if name.startswith('features_extractor.fc'):
+                continue
+            gref = ref.r[name].grad
+            gm = prm.grad
+            worst = max(worst, rel_err(gm, gref))
+        assert worst < 2e-3, (it, worst)
+        # post-step parameters.  Adam's first steps move every weight by ~lr*sign(g): entries whose gradient
+        # is numerically zero may legitimately go either way, so compare in the mean and by sign agreement.
         sd_s = eng.S.state_dict()
         rows = torch.unique(idx)
         upd_ref = ref.s['SUPPORT_SETS'].detach()[rows] - c['sd']['SUPPORT_SETS'][rows]
         upd = sd_s['SUPPORT_SETS'].cpu()[rows] - c['sd']['SUPPORT_SETS'][rows]
-        assert rel_err(upd, upd_ref) < 5e-2, it
-        assert rel_err(sd_s['SUPPORT_SETS'].cpu(), ref.s['SUPPORT_SETS'].detach()) < 1e-6
-        assert rel_err(sd_s['LOGGAMMA'].cpu(), ref.s['LOGGAMMA'].detach()) < 1e-5
+        assert float((torch.sign(upd) == torch.sign(upd_ref)).float().mean()) > 0.995
+        assert float((upd - upd_ref).abs().mean()) < 0.02 * 1e-4 * (it + 1)
+        untouched = [k for k in range(K) if k not in set(idx.tolist()) and (it == 0)]
+        if untouched:   # dense Adam: rows never selected so far have zero gradient and zero moments -> unchanged
+            assert torch.equal(sd_s['SUPPORT_SETS'].cpu()[untouched], c['sd']['SUPPORT_SETS'][untouched])
         sd_r = eng.R.state_dict()
         for k, v in ref.r.items():
             if k.startswith('features_extractor.fc') or k.endswith('num_batches_tracked'):
                 continue
-            assert rel_err(sd_r[k].cpu(), v.detach()) < 2e-4, (it, k)
+            d = (sd_r[k].cpu() - v.detach()).abs()
+            assert float(d.mean()) < 0.03 * 1e-4 * (it + 1) + 1e-7 * float(v.abs().mean()), (it, k, float(d.mean()))
     st = eng.pop_stats()
     assert set(st) == {'accuracy', 'classification_loss', 'regression_loss', 'total_loss'}
 
