@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py — training-step images/sec (warp -> G -> R -> loss -> backward -> Adam) on MI355X.
+
+Workload (BASELINE.json `metric`, configs[2]): StyleGAN2-FFHQ-256 architecture (random-init weights drawn
+exactly as the reference constructors do; no checkpoints offline), K=128 warping functions x N=32 dipoles,
+ResNet-18 reconstructor, batch 32 per GPU, Z-space shifts, --learn-gammas, synthetic z ~ N(0, I).
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); gradients of R and S are
+all-reduced over RCCL once per step; per-GPU batch is fixed (weak scaling).
+
+Prints ONE JSON line on rank 0: metric/value (whole-job images/sec), ms_per_step, `roofline` for the dominant
+kernel family (implicit-GEMM MFMA conv: algorithmic FLOPs of its launches / their HIP-event durations,
+against the fp32-MFMA peak) and `cpu_baseline` (the oracle's replay of the reference step, as written,
+on this box's host cores — a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+GFLOP_PER_IMG = 285.8          # G fwd x2 + G dgrad + R fwd + R bwd, StyleGAN2-256 / ResNet-18
+FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build(dev, size, K, N, B, seed, w_space=False):
+    from warpedganspace_amd.gan_load import build_stylegan2
+    from warpedganspace_amd.reconstructor import Reconstructor
+    from warpedganspace_amd.support_sets import SupportSets
+    from warpedganspace_amd.trainer import TrainStep
+    torch.manual_seed(seed)
+    G = build_stylegan2(None, resolution=size, shift_in_w_space=w_space)
+    S = SupportSets(K, N, G.dim_z, learn_alphas=False, learn_gammas=True, gamma=1.0 / G.dim_z)
+    R = Reconstructor('ResNet', K, channels=3)
+    params = types.SimpleNamespace(reconstructor_lr=1e-4, support_set_lr=1e-4, min_shift_magnitude=0.25,
+                                   max_shift_magnitude=0.45, lambda_cls=1.0, lambda_reg=0.25, z_truncation=None,
+                                   shift_in_w_space=w_space)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    eng = TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), params, B, dev, world=world, seed=seed)
+    return eng
+
+
+def cpu_baseline(size, K, N, b, steps, threads):
+    """The reference step AS WRITTEN (incl. the generator's unused weight gradients) replayed by the oracle
+    with plain PyTorch-CPU ops on this box's host cores.  Bounded sample."""
+    from oracle import wgs_oracle as O
+    from warpedganspace_amd.reconstructor import Reconstructor
+    from warpedganspace_amd.stylegan2 import Generator
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    sd_g = {k: v.detach().clone() for k, v in Generator(size, 512, 8).state_dict().items()}
+    sd_s = O.support_sets_init(K, N, 512, 1.0 / 512)
+    sd_r = {k: v.detach().clone().contiguous() for k, v in Reconstructor('ResNet', K).state_dict().items()}
+    ref = O.ReferenceStep(sd_g, sd_s, sd_r, size, learn_gammas=True, gamma=1.0 / 512, g_requires_grad=True)
+    g = torch.Generator().manual_seed(1)
+    times = []
+    for it in range(steps + 1):
+        z = torch.randn(b, 512, generator=g)
+        idx = torch.randint(0, K, (b,), generator=g)
+        mag = (torch.rand(b, generator=g) * 0.2 + 0.25)
+        t0 = time.time()
+        ref.step(z, idx, mag)
+        if it > 0:
+            times.append(time.time() - t0)
+    dt = sum(times) / len(times)
+    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d step(s) of batch %d after 1 warm-up, StyleGAN2-%d K=%d N=%d ResNet-18, reference step as written "
+                      "(lib/trainer.py:190-254) replayed by oracle/wgs_oracle.py on PyTorch-CPU" % (steps, b, size, K, N)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('-K', type=int, default=128)
+    ap.add_argument('-N', type=int, default=32)
+    ap.add_argument('--w-space', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=1)
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    from warpedganspace_amd import conv as C
+    eng = build(dev, args.size, args.K, args.N, args.batch, seed=rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = eng.pop_stats()
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    roofline = None
+    if not args.no_roofline:
+        # HIP events around every implicit-GEMM launch (torch's current stream IS the launch stream)
+        C.PROFILE = []
+        nprof = 2
+        for _ in range(nprof):
+            eng.step()
+        torch.cuda.synchronize()
+        recs, C.PROFILE = C.PROFILE, None
+        fl = sum(r[1] for r in recs)
+        ms = sum(r[2].elapsed_time(r[3]) for r in recs)
+        by_kind = {}
+        for r in recs:
+            k = by_kind.setdefault(r[0], [0.0, 0.0, 0])
+            k[0] += r[1]; k[1] += r[2].elapsed_time(r[3]); k[2] += 1
+        roofline = {"bound": "mfma", "kernel": "igemm_nt_kernel / igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(fl / ms / 1e9, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                    "launches_per_step": len(recs) // nprof, "avg_launch_ms": round(ms / len(recs), 4),
+                    "conv_ms_per_step": round(ms / nprof, 3), "conv_gflop_per_step": round(fl / nprof / 1e9, 1),
+                    "by_kind": {k: {"TFLOP/s": round(v[0] / v[1] / 1e9, 2), "ms_per_step": round(v[1] / nprof, 3),
+                                    "launches": v[2] // nprof} for k, v in by_kind.items()},
+                    "step_achieved_TFLOPs": round(value / world * GFLOP_PER_IMG / 1e3, 2),
+                    "step_frac": round(value / world * GFLOP_PER_IMG / 1e3 / FP32_MFMA_PEAK_TF, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args.size, args.K, args.N, args.cpu_batch, args.cpu_steps, os.cpu_count() or 1)
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": repr(e)}
+
+    if rank == 0:
+        out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-256 K=128", "value": round(value, 2),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "fp32 (f32-input MFMA, f32 accumulate)", "data": "synthetic (random-init weights, z ~ N(0,I))",
+               "config": {"workload": "StyleGAN2-FFHQ-%d arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
+                                      % (args.size, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "algorithmic_gflop_per_image": GFLOP_PER_IMG},
+               "last_stats": stats, "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

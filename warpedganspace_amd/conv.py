@@ -29,8 +29,24 @@ class WgradDesc(ctypes.Structure):
                 ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
 
 
+# bench.py sets this to a list to collect (kind, algorithmic FLOPs, start event, end event) per launch;
+# the events are recorded on torch's current stream, which is the stream the kernels are launched on.
+PROFILE = None
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+def _timed(kind, flops, fn):
+    if PROFILE is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    PROFILE.append((kind, flops, s, e))
+    return r
 
 
 def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
@@ -53,7 +69,8 @@ def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None,
     d.act_slope, d.gain = act_slope, gain
     for i, (ty, tx, ti) in enumerate(taps):
         d.dy[i], d.dx[i], d.wt[i] = ty, tx, ti
-    L.check(L.lib().wgs_conv_igemm(ctypes.byref(d), L.stream()), 'wgs_conv_igemm')
+    flops = 2.0 * d.B * Hg * Wg * d.Co * d.Ci * len(taps)
+    _timed('igemm_nt', flops, lambda: L.check(L.lib().wgs_conv_igemm(ctypes.byref(d), L.stream()), 'wgs_conv_igemm'))
     return y
 
 
@@ -137,7 +154,8 @@ def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0):
         for kx in range(k):
             d.dy_t[i], d.dx_t[i], d.wt[i] = ky - pad, kx - pad, i
             i += 1
-    L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad')
+    flops = 2.0 * B * Ho * Wo * Co * Ci * k * k
+    _timed('igemm_wgrad', flops, lambda: L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad'))
     return dw_packed
 
 
