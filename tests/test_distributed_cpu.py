@@ -1,0 +1,96 @@
+"""CPU, world_size 2 over gloo: the data-parallel contract of the step.
+
+The gradient bucket logic is device-agnostic plumbing (flat buffer + one all-reduce + 1/world scaling);
+here it is driven with gradients produced by the oracle on each rank's shard and checked against the
+single-process gradient of the concatenated global batch (what nn.DataParallel computes in the reference,
+lib/trainer.py:162-166,245-250).  BatchNorm-free sub-problem (S only + a linear head) so that per-rank
+statistics do not enter; the BN-per-rank semantics are documented in DESIGN.md §5."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wgs_oracle as O
+from tests import golden_inputs as GI
+from warpedganspace_amd.trainer import FlatBucket
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _loss(sd, head, z, idx, mag, gamma, K):
+    mask = GI.one_hot(idx, K)
+    shift = mag.reshape(-1, 1) * O.support_sets_forward(sd, mask, z, True, gamma)
+    logits = (z + shift) @ head
+    return O.training_loss(logits, shift.norm(dim=1), idx, mag)[0]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    K, N, d, Bg = 8, 2, 16, 8
+    c = GI.support_sets_case(K, N, d, Bg, 77, learn_gammas=True)
+    head = GI.rt(78, d, K)
+    # this rank's replica of the trainable parameters, re-homed into a flat bucket
+    table = torch.nn.Parameter(c['sd']['SUPPORT_SETS'].clone())
+    lg = torch.nn.Parameter(c['sd']['LOGGAMMA'].clone())
+    bucket = FlatBucket([(1e-4, [table, lg])], torch.device('cpu'))
+    sl = slice(rank * Bg // world, (rank + 1) * Bg // world)          # shard the global batch by sample
+    sd = {'SUPPORT_SETS': table, 'ALPHAS': c['sd']['ALPHAS'], 'LOGGAMMA': lg}
+    loss = _loss(sd, head, c['z'][sl], c['idx'][sl], c['gout'][sl, 0] * 0.3, c['gamma'], K)
+    g_table, g_lg = torch.autograd.grad(loss, [table, lg])
+    bucket.zero_grad()
+    bucket.gview[id(table)].copy_(g_table)
+    bucket.gview[id(lg)].copy_(g_lg)
+    dist.all_reduce(bucket.grad)                                       # the step's single collective (sum)
+    avg = bucket.grad / world                                          # Adam's grad_scale = 1/world
+    if rank == 0:
+        q.put((avg.clone(), table.data_ptr() == bucket.flat.data_ptr()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_allreduced_bucket_equals_global_batch_gradient():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    avg, aliased = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert aliased                                                      # parameters are views of the flat buffer
+    K, N, d, Bg = 8, 2, 16, 8
+    c = GI.support_sets_case(K, N, d, Bg, 77, learn_gammas=True)
+    head = GI.rt(78, d, K)
+    table = c['sd']['SUPPORT_SETS'].clone().requires_grad_(True)
+    lg = c['sd']['LOGGAMMA'].clone().requires_grad_(True)
+    sd = {'SUPPORT_SETS': table, 'ALPHAS': c['sd']['ALPHAS'], 'LOGGAMMA': lg}
+    loss = _loss(sd, head, c['z'], c['idx'], c['gout'][:, 0] * 0.3, c['gamma'], K)   # mean over the GLOBAL batch
+    g_table, g_lg = torch.autograd.grad(loss, [table, lg])
+    ref = torch.cat([g_table.reshape(-1), g_lg.reshape(-1)])
+    assert (avg[:ref.numel()] - ref).abs().max().item() < 1e-5 * ref.abs().max().item() + 1e-9
+
+
+def test_flat_bucket_keeps_conv_memory_layout():
+    conv = torch.nn.Conv2d(6, 4, 3, bias=False)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    w0 = conv.weight.detach().clone()
+    lin = torch.nn.Linear(5, 3)
+    b = FlatBucket([(1e-3, [conv.weight, lin.weight, lin.bias])], torch.device('cpu'))
+    assert torch.equal(conv.weight.detach(), w0)
+    assert conv.weight.permute(0, 2, 3, 1).is_contiguous()               # still [Co,kh,kw,Ci] in memory (packed)
+    assert b.gview[id(conv.weight)].shape == (4, 9, 6)
+    b.gview[id(conv.weight)].fill_(1.0)
+    assert float(conv.weight.grad.sum()) == conv.weight.numel()
+    assert all(off % 4 == 0 for _, off, _ in b.segments)                 # 16-byte aligned segments
