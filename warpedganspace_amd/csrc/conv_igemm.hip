@@ -78,7 +78,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
         a_b[pa] = b;
     }
 
-    float4 ra[PA], rb[PB];
+    // Staging registers.  Loads are issued UNCONDITIONALLY from clamped (always valid) addresses and the
+    // padding / tail predicate is applied when the chunk is written to LDS: no branches and no s_waitcnt
+    // between the 8..12 global loads of a chunk, so they are all in flight while the MFMAs of the previous
+    // chunk run (the style multiply also waits until store time).
+    float4 ra[PA], rb[PB], rs[ASCALE ? PA : 1];
+    unsigned amask = 0, bmask = 0;
     const int cpt = p.Ci / BK;  // K-chunks per tap
     const int nk = p.ntaps * cpt;
 
@@ -86,27 +91,24 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
         const int t = kt / cpt;
         const int ci0 = (kt - t * cpt) * BK + q * 4;
         const int dy = p.dy[t], dx = p.dx[t];
+        amask = 0;
 #pragma unroll
         for (int pa = 0; pa < PA; ++pa) {
             const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
             const bool v = (r0 + pa * RPP < BM) && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v) {
-                val = *reinterpret_cast<const float4*>(p.x + ((size_t)(a_pix[pa] + iy * p.Wi + ix)) * p.Ci + ci0);
-                if (ASCALE) {
-                    const float4 s = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
-                    val.x *= s.x; val.y *= s.y; val.z *= s.z; val.w *= s.w;
-                }
-            }
-            ra[pa] = val;
+            const size_t off = v ? ((size_t)(a_pix[pa] + iy * p.Wi + ix)) * p.Ci + ci0 : (size_t)ci0;
+            ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
+            if (ASCALE) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
+            amask |= (v ? 1u : 0u) << pa;
         }
         const float* wt = p.w + (size_t)p.wt[t] * p.w_tap_stride + ci0;
+        bmask = 0;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             const int n = r0 + pb * RPP;
             const bool v = (n < BN) && (n0 + n < p.Co);
-            rb[pb] = v ? *reinterpret_cast<const float4*>(wt + (size_t)(n0 + n) * p.w_row_stride)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[pb] = *reinterpret_cast<const float4*>(wt + (size_t)(v ? n0 + n : 0) * p.w_row_stride);
+            bmask |= (v ? 1u : 0u) << pb;
         }
     };
     auto store_tile = [&](int buf) {
@@ -116,16 +118,20 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
         for (int pa = 0; pa < PA; ++pa) {
             const int row = r0 + pa * RPP;
             if (row < BM) {
+                float4 v = ra[pa];
+                if (ASCALE) { v.x *= rs[pa].x; v.y *= rs[pa].y; v.z *= rs[pa].z; v.w *= rs[pa].w; }
+                const bool ok = (amask >> pa) & 1u;
                 float* d = a + row * LD + q * 4;
-                d[0] = ra[pa].x; d[1] = ra[pa].y; d[2] = ra[pa].z; d[3] = ra[pa].w;
+                d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
             }
         }
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
             const int row = r0 + pb * RPP;
             if (row < BN) {
+                const bool ok = (bmask >> pb) & 1u;
                 float* d = b + row * LD + q * 4;
-                d[0] = rb[pb].x; d[1] = rb[pb].y; d[2] = rb[pb].z; d[3] = rb[pb].w;
+                d[0] = ok ? rb[pb].x : 0.f; d[1] = ok ? rb[pb].y : 0.f; d[2] = ok ? rb[pb].z : 0.f; d[3] = ok ? rb[pb].w : 0.f;
             }
         }
     };
@@ -165,30 +171,41 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: per-row output addressing staged once in LDS (tile buffers are free now) ----
+    // ---- epilogue: per-row output addressing (and the noise term) staged once in LDS ------------------
     int* r_pix = reinterpret_cast<int*>(smem);   // output pixel index (b*Ho+oy)*Wo+ox, or -1
     int* r_b = r_pix + BM;                       // sample index
-    int* r_hw = r_b + BM;                        // oy*Wo+ox (noise index)
+    float* r_nz = reinterpret_cast<float*>(r_b + BM);   // noise_w * noise[oy*Wo+ox]
     if (tid < BM) {
         const int m = m0 + tid;
-        int pix = -1, bb = 0, hw = 0;
+        int pix = -1, bb = 0;
+        float nz = 0.f;
         if (m < p.M) {
             const int gx = m % p.Wg;
             const int t = m / p.Wg;
             const int gy = t % p.Hg;
             bb = t / p.Hg;
-            hw = (gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
+            const int hw = (gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
             pix = bb * p.Ho * p.Wo + hw;
+            if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
         }
-        r_pix[tid] = pix; r_b[tid] = bb; r_hw[tid] = hw;
+        r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz;
     }
     __syncthreads();
-    const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+    // demodulation factors: a tile usually covers one or two samples -> two registers per column
+    const int b_lo = r_b[0];
+    const int m_last = min(m0 + BM, p.M) - 1;
+    const int b_hi = (m_last / p.Wg) / p.Hg;
+    const bool cs_fast = p.col_scale && (b_hi - b_lo <= 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
         const bool nok = n < p.Co;
         const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        float cs0 = 1.f, cs1 = 1.f;
+        if (cs_fast && nok) {
+            cs0 = p.col_scale[(size_t)b_lo * p.col_ld + n];
+            cs1 = p.col_scale[(size_t)b_hi * p.col_ld + n];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -197,9 +214,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
                 const int pix = r_pix[row];
                 if (pix >= 0 && nok) {
                     float v = acc[i][j][r];
-                    if (p.col_scale) v *= p.col_scale[(size_t)r_b[row] * p.col_ld + n];
-                    if (p.noise) v = fmaf(nw, p.noise[r_hw[row]], v);
-                    v += bias;
+                    if (p.col_scale) v *= cs_fast ? (r_b[row] == b_lo ? cs0 : cs1) : p.col_scale[(size_t)r_b[row] * p.col_ld + n];
+                    v += r_nz[row] + bias;
                     v = (v > 0.f ? v : v * p.act_slope) * p.gain;
                     p.y[(size_t)pix * p.Co + n] = v;
                 }
