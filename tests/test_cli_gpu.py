@@ -1,0 +1,67 @@
+"""GPU: train.py -> checkpoint2model.py -> traverse_latent_space.py end to end on a tiny synthetic setup,
+checking the reference's directory / file contract."""
+import json
+import os
+import os.path as osp
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = osp.dirname(osp.dirname(osp.abspath(__file__)))
+
+
+def run(cmd, cwd):
+    env = dict(os.environ, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable] + cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_train_checkpoint_traverse_roundtrip(tmp_path):
+    cwd = str(tmp_path)
+    run([osp.join(REPO, 'train.py'), '--gan-type', 'StyleGAN2', '--stylegan2-resolution', '256', '-K', '4', '-D', '2',
+         '--learn-gammas', '--max-iter', '4', '--batch-size', '2', '--log-freq', '2', '--ckp-freq', '2',
+         '--random-init-generator', '--seed', '0'], cwd)
+    exp = 'StyleGAN2-256-Z-ResNet-K4-D2-LearnGammas-eps0.25_0.45'
+    wip = osp.join(cwd, 'experiments', 'wip', exp)
+    done = osp.join(cwd, 'experiments', 'complete', exp)
+    a = json.load(open(osp.join(wip, 'args.json')))
+    assert a['gan_type'] == 'StyleGAN2' and a['num_support_sets'] == 4 and a['batch_size'] == 2 and 'seed' not in a
+    assert set(a) == {'gan_type', 'z_truncation', 'biggan_target_classes', 'stylegan2_resolution', 'shift_in_w_space',
+                      'num_support_sets', 'num_support_dipoles', 'learn_alphas', 'learn_gammas', 'gamma', 'support_set_lr',
+                      'reconstructor_type', 'min_shift_magnitude', 'max_shift_magnitude', 'reconstructor_lr', 'max_iter',
+                      'batch_size', 'lambda_cls', 'lambda_reg', 'log_freq', 'ckp_freq', 'tensorboard', 'cuda'}
+    stats = json.load(open(osp.join(wip, 'stats.json')))
+    assert set(stats) == {'2', '4'} and set(stats['2']) == {'accuracy', 'classification_loss', 'regression_loss', 'total_loss'}
+    for f in ('support_sets_init.pt', 'support_sets.pt', 'reconstructor.pt', 'checkpoint.pt'):
+        assert osp.isfile(osp.join(wip, 'models', f)), f
+    assert osp.isfile(osp.join(done, 'models', 'support_sets.pt')) and not osp.exists(osp.join(done, 'models', 'checkpoint.pt'))
+    ck = torch.load(osp.join(wip, 'models', 'checkpoint.pt'))
+    assert set(ck) == {'iter', 'support_sets', 'reconstructor'} and ck['iter'] == 4
+    ss = ck['support_sets']
+    assert ss['SUPPORT_SETS'].shape == (4, 2 * 2 * 512) and ss['ALPHAS'].shape == (4, 4) and ss['LOGGAMMA'].shape == (4, 1)
+    r = ck['reconstructor']
+    assert r['features_extractor.conv1.weight'].shape == (64, 6, 7, 7) and r['features_extractor.conv1.weight'].is_contiguous()
+    assert r['features_extractor.fc.weight'].shape == (1000, 512) and r['path_indices.weight'].shape == (4, 512)
+    init = torch.load(osp.join(wip, 'models', 'support_sets_init.pt'))
+    assert not torch.equal(init['SUPPORT_SETS'], ss['SUPPORT_SETS'])            # training moved the support sets
+    run([osp.join(REPO, 'checkpoint2model.py'), '--exp', wip], cwd)
+    assert osp.isfile(osp.join(wip, 'models', 'support_sets-4.pt')) and osp.isfile(osp.join(wip, 'models', 'reconstructor-4.pt'))
+    # latent-code pool in the reference's layout: experiments/latent_codes/<gan>/<pool>/<hash>/latent_code.pt
+    for j, h in enumerate(('aaaa', 'bbbb')):
+        d = osp.join(cwd, 'experiments', 'latent_codes', 'StyleGAN2', 'pool2', h)
+        os.makedirs(d)
+        torch.save(torch.randn(1, 512, generator=torch.Generator().manual_seed(j)), osp.join(d, 'latent_code.pt'))
+    run([osp.join(REPO, 'traverse_latent_space.py'), '--exp', done, '--pool', 'pool2', '--shift-steps', '4', '--eps', '0.2',
+         '--shift-leap', '2', '--img-size', '64', '--random-init-generator'], cwd)
+    out = osp.join(done, 'results', 'pool2', '8_0.2_1.6')
+    for h in ('aaaa', 'bbbb'):
+        plc = torch.load(osp.join(out, h, 'paths_latent_codes.pt'))
+        assert plc.shape == (4, 5, 512)                                        # [K, 2*steps/leap + 1, d]
+        assert osp.isfile(osp.join(out, h, 'original_image.jpg'))
+        assert sorted(os.listdir(osp.join(out, h, 'paths_images', 'path_003'))) == ['%06d.jpg' % t for t in range(5)]
+    z0 = torch.load(osp.join(cwd, 'experiments', 'latent_codes', 'StyleGAN2', 'pool2', 'aaaa', 'latent_code.pt'))
+    assert torch.allclose(plc.new_tensor(torch.load(osp.join(out, 'aaaa', 'paths_latent_codes.pt'))[0, 2]), z0[0], atol=1e-6)

@@ -41,3 +41,27 @@ def build_stylegan2(pretrained_gan_weights=None, resolution=1024, shift_in_w_spa
     if pretrained_gan_weights is not None:
         G.load_state_dict(torch.load(pretrained_gan_weights, map_location='cpu')['g_ema'], strict=False)
     return StyleGAN2Wrapper(G, shift_in_w_space=shift_in_w_space)
+
+
+def build_gan(gan_type, target_classes=None, stylegan2_resolution=1024, shift_in_w_space=False, weights=None,
+              random_init=False):
+    """Dispatcher used by train.py / traverse_latent_space.py (traverse_latent_space.py:43-69).
+    `weights` = path of the pre-trained generator file (lib/config.py GAN_WEIGHTS); with `random_init` the
+    generator keeps its constructor initialisation (no checkpoints are available offline)."""
+    import os
+    if weights is not None and not random_init and not os.path.isfile(weights):
+        raise FileNotFoundError("pre-trained generator weights not found: {} (use --random-init-generator for a "
+                                "synthetic run)".format(weights))
+    w = None if random_init else weights
+    if gan_type == 'StyleGAN2':
+        return build_stylegan2(w, resolution=stylegan2_resolution, shift_in_w_space=shift_in_w_space)
+    if gan_type == 'ProgGAN':
+        from .proggan import build_proggan
+        return build_proggan(w)
+    if gan_type in ('SNGAN_MNIST', 'SNGAN_AnimeFaces'):
+        from .sngan import build_sngan
+        return build_sngan(w, gan_type)
+    if gan_type == 'BigGAN':
+        from .biggan import build_biggan
+        return build_biggan(w, target_classes)
+    raise ValueError("unknown gan_type {!r}".format(gan_type))
