@@ -39,14 +39,14 @@ def test_train_checkpoint_traverse_roundtrip(tmp_path):
     for f in ('support_sets_init.pt', 'support_sets.pt', 'reconstructor.pt', 'checkpoint.pt'):
         assert osp.isfile(osp.join(wip, 'models', f)), f
     assert osp.isfile(osp.join(done, 'models', 'support_sets.pt')) and not osp.exists(osp.join(done, 'models', 'checkpoint.pt'))
-    ck = torch.load(osp.join(wip, 'models', 'checkpoint.pt'))
+    ck = torch.load(osp.join(wip, 'models', 'checkpoint.pt'), map_location='cpu')
     assert set(ck) == {'iter', 'support_sets', 'reconstructor'} and ck['iter'] == 4
     ss = ck['support_sets']
     assert ss['SUPPORT_SETS'].shape == (4, 2 * 2 * 512) and ss['ALPHAS'].shape == (4, 4) and ss['LOGGAMMA'].shape == (4, 1)
     r = ck['reconstructor']
     assert r['features_extractor.conv1.weight'].shape == (64, 6, 7, 7) and r['features_extractor.conv1.weight'].is_contiguous()
     assert r['features_extractor.fc.weight'].shape == (1000, 512) and r['path_indices.weight'].shape == (4, 512)
-    init = torch.load(osp.join(wip, 'models', 'support_sets_init.pt'))
+    init = torch.load(osp.join(wip, 'models', 'support_sets_init.pt'), map_location='cpu')
     assert not torch.equal(init['SUPPORT_SETS'], ss['SUPPORT_SETS'])            # training moved the support sets
     run([osp.join(REPO, 'checkpoint2model.py'), '--exp', wip], cwd)
     assert osp.isfile(osp.join(wip, 'models', 'support_sets-4.pt')) and osp.isfile(osp.join(wip, 'models', 'reconstructor-4.pt'))
