@@ -79,27 +79,38 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
-// gx[m,k] += wscale * sum_{n in this split} g'[m,n] w[n,k],  g' = gy * (gate ? (gate[m,n] > 0 ? gain : gain*slope) : 1)
-// grid = (K/256, M, n-splits); fp64 partial per thread (these reductions run over up to ~6000 terms — all
-// modulation layers — and feed the ill-conditioned mapping-network Jacobian), one fp32 atomic per output
-// and split.  The caller-visible output is zeroed first unless `accumulate`.
+// gx[m,k] (+)= wscale * sum_n g'[m,n] w[n,k],  g' = gy * (gate ? (gate[m,n] > 0 ? gain : gain*slope) : 1)
+// Block = 16 k-columns x 16 n-groups; every thread accumulates its n-stripe in fp64 and the 16 stripes are
+// combined in fp64 through LDS (these reductions run over up to ~6000 terms — all modulation layers — and
+// feed the ill-conditioned mapping-network Jacobian: partial sums must not be rounded to fp32).
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                            const float* __restrict__ gate, float* __restrict__ gx,
                                                            int M, int N, int K, int ldg, int ldx, float wscale,
-                                                           float slope, float gain, int nper) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
+                                                           float slope, float gain, int accumulate) {
+    __shared__ double red[16][17];
+    const int kl = threadIdx.x & 15, ng = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + kl;
     const int m = blockIdx.y;
-    if (k >= K) return;
-    const int n0 = blockIdx.z * nper, n1 = min(N, n0 + nper);
     const float* g = gy + (size_t)m * ldg;
     const float* gt = gate ? gate + (size_t)m * ldg : nullptr;
     double acc = 0.0;
-    for (int n = n0; n < n1; ++n) {
-        float gv = g[n];
-        if (gt) gv *= (gt[n] > 0.f ? gain : gain * slope);
-        acc = fma((double)gv, (double)w[(size_t)n * K + k], acc);
+    if (k < K) {
+        for (int n = ng; n < N; n += 16) {
+            float gv = g[n];
+            if (gt) gv *= (gt[n] > 0.f ? gain : gain * slope);
+            acc = fma((double)gv, (double)w[(size_t)n * K + k], acc);
+        }
     }
-    unsafeAtomicAdd(gx + (size_t)m * ldx + k, (float)(acc * (double)wscale));
+    red[ng][kl] = acc;
+    __syncthreads();
+    if (ng == 0 && k < K) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][kl];
+        float* o = gx + (size_t)m * ldx + k;
+        const float r = (float)(t * (double)wscale);
+        *o = accumulate ? (*o + r) : r;
+    }
 }
 
 // dW[n,k] = sum_m gy[m,n] x[m,k] ; db[n] = sum_m gy[m,n]   (Reconstructor heads; M = batch)
@@ -397,14 +408,8 @@ int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
 int wgs_linear_dgrad(const float* gy, const float* w, const float* gate_y, float* gx, int M, int N, int K, int ldg,
                      int ldx, float wscale, float gate_slope, float gate_gain, int accumulate, wgs_stream_t stream) {
     WGS_CHECK_ARG(gy && w && gx && M > 0 && N > 0 && K > 0, "wgs_linear_dgrad: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (!accumulate) (void)hipMemset2DAsync(gx, (size_t)ldx * sizeof(float), 0, (size_t)K * sizeof(float), M, st);
-    int splits = wgs_cdiv(1024, wgs_cdiv(K, 256) * M);       // aim at ~1024 workgroups
-    if (splits > wgs_cdiv(N, 32)) splits = wgs_cdiv(N, 32);   // >= 32 terms per split
-    if (splits < 1) splits = 1;
-    const int nper = wgs_cdiv(N, splits);
-    hipLaunchKernelGGL(linear_dgrad_kernel, dim3(wgs_cdiv(K, 256), M, wgs_cdiv(N, nper)), dim3(256), 0, st, gy, w, gate_y,
-                       gx, M, N, K, ldg, ldx, wscale, gate_slope, gate_gain, nper);
+    hipLaunchKernelGGL(linear_dgrad_kernel, dim3(wgs_cdiv(K, 16), M), dim3(256), 0, (hipStream_t)stream, gy, w, gate_y,
+                       gx, M, N, K, ldg, ldx, wscale, gate_slope, gate_gain, accumulate);
     WGS_CHECK_LAUNCH("linear_dgrad_kernel");
     return WGS_OK;
 }
