@@ -152,10 +152,21 @@ def fused_bias_act(x, bias=None, ref=None, act=3, grad=0, alpha=0.2, scale=2 ** 
     return y * scale
 
 
+# Test hook: when set to an iterator of boolean masks, successive fused_leaky_relu calls take their gate
+# (v > 0) from it instead of from their own pre-activation.  Lets a test differentiate the oracle through
+# exactly the piecewise-linear branch another fp32 evaluation took (a few of ~1e7 pre-activations round
+# to the other side of zero between any two implementations).
+GATE_OVERRIDE = None
+
+
 def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
     """FusedLeakyReLUFunction.forward, op/fused_act.py:51-59 (autograd of these torch ops is the
     same function the reference's hand-written backward computes, :19-48)."""
-    return F.leaky_relu(x + bias.view(1, -1, *([1] * (x.ndim - 2))), negative_slope) * scale
+    v = x + bias.view(1, -1, *([1] * (x.ndim - 2)))
+    if GATE_OVERRIDE is not None:
+        gate = next(GATE_OVERRIDE).to(v.device)
+        return torch.where(gate, v, v * negative_slope) * scale
+    return F.leaky_relu(v, negative_slope) * scale
 
 
 def upfirdn2d_mhwc(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):

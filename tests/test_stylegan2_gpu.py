@@ -101,6 +101,38 @@ def test_generator_vs_oracle_64_batch5(dev):
         assert e_mine < 3 * e_ref + 2e-4, (what, e_mine, e_ref)
 
 
+@pytest.mark.parametrize('size,B', [(32, 3), (128, 2)])
+def test_backward_exact_with_shared_gates(dev, size, B):
+    """The hand-derived backward against autograd of the oracle in float64, with the oracle forced through
+    the SAME leaky-relu gates the HIP forward took: every remaining difference is fp32 round-off."""
+    G, sd = build(size, 31 + size, dev)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    z = GI.rt(32 + size, B, 512)
+    probe = None
+    for w_space in (False, True):
+        G.debug_keep = {}
+        sh = (GI.rt(33 + size, B, 512) * 0.1).to(dev).requires_grad_(True)
+        img = StyleGAN2Wrapper(G, w_space)(z.to(dev), sh)
+        probe = GI.rt(34 + size, *img.shape)
+        (img * probe.to(dev)).sum().backward()
+        gates = ([] if w_space else [g.cpu() for g in G.debug_keep['mapping']]) + [g.cpu() for g in G.debug_keep['synthesis']]
+        G.debug_keep = None
+        sho = (GI.rt(33 + size, B, 512) * 0.1).double().requires_grad_(True)
+        if w_space:
+            w = O.sg2_mapping(sd64, z.double()).detach()
+            O.GATE_OVERRIDE = iter(gates)
+            img_o = O.sg2_synthesis(sd64, w + sho, size)
+        else:
+            O.GATE_OVERRIDE = iter(gates)
+            img_o = O.sg2_generate(sd64, z.double(), size, sho)
+        O.GATE_OVERRIDE = None
+        (img_o * probe.double()).sum().backward()
+        e = rel_err(sh.grad, sho.grad)
+        print('%s-space size %d: shared-gate gradient rel err %.3e' % ('W' if w_space else 'Z', size, e))
+        assert rel_err(img, img_o.detach()) < 1e-4
+        assert e < (2e-4 if w_space else 2e-3), e      # Z adds the ill-conditioned random mapping net
+
+
 def test_no_grad_forward_saves_nothing(dev):
     G, _ = build(32, 5, dev)
     with torch.no_grad():

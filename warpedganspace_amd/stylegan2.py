@@ -111,6 +111,8 @@ class _Mapping(torch.autograd.Function):
     def forward(ctx, G, z):
         w, saved = G._mapping_fwd(z, save=ctx.needs_input_grad[1])
         ctx.G, ctx.saved = G, saved
+        if G.debug_keep is not None and saved is not None:
+            G.debug_keep['mapping'] = [a > 0 for a in saved[1][1:]]
         return w
 
     @staticmethod
@@ -123,6 +125,8 @@ class _Synthesis(torch.autograd.Function):
     def forward(ctx, G, w):
         img, saved = G._synthesis_fwd(w, save=ctx.needs_input_grad[1])
         ctx.G, ctx.saved = G, saved
+        if G.debug_keep is not None and saved is not None:   # leaky-relu gates of every StyledConv, NCHW (tests)
+            G.debug_keep['synthesis'] = [(o > 0).permute(0, 3, 1, 2) for o in saved[1]]
         return img
 
     @staticmethod
@@ -168,6 +172,7 @@ class Generator(nn.Module):
         for p in self.parameters():       # G is frozen on this path (lib/trainer.py:143-150 puts it in eval)
             p.requires_grad_(False)
         self._prep = None
+        self.debug_keep = None   # tests set this to {} to read back the activation gates of a forward
 
     # -- derived, device-resident packed weights (rebuilt after load_state_dict / .to()) -----------
     def _apply(self, fn, *a, **k):
