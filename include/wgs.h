@@ -107,8 +107,9 @@ int wgs_upfirdn2d(const float* x, const float* kernel, float* y, int major, int 
  * One launch computes, for every GEMM pixel m = (b, gy, gx) of a Hg x Wg grid and every n < Co:
  *   acc = sum_{t < ntaps} sum_{k < Ci} A(b, gy*isy + dy[t], gx*isx + dx[t], k) * w[wt[t]*w_tap_stride + n*w_row_stride + k]
  *   A(b,iy,ix,k) = x[b,iy,ix,k] * (a_scale ? a_scale[b*a_ld + k] : 1)   (0 outside the image)
- *   v   = acc * (col_scale ? col_scale[b*col_ld + n] : 1) + (noise ? noise_w[0]*noise[oy*Wo+ox] : 0) + (bias ? bias[n] : 0)
- *   y[b, oy, ox, n] = (v > 0 ? v : v*act_slope) * gain,   oy = gy*osy + oy0, ox = gx*osx + ox0
+ *   v   = alpha * acc * (col_scale ? col_scale[b*col_ld + n] : 1) + (noise ? noise_w[0]*noise[oy*Wo+ox] : 0) + (bias ? bias[n] : 0)
+ *         + (addend ? addend[b, oy>>add_ups, ox>>add_ups, n] : 0)
+ *   y[b, oy, ox, n] = act ? tanh(v) : (v > 0 ? v : v*act_slope) * gain,   oy = gy*osy + oy0, ox = gx*osx + ox0
  * Plain conv: Hg=Ho, isy=stride, osy=1.  Stride-2 transposed conv / dgrad of strided conv: one launch
  * per output parity phase (osy=2, oy0=phase) with that phase's tap subset.
  * Requirements: Ci % 8 == 0, 16-B aligned rows, ntaps <= 64.
@@ -124,6 +125,11 @@ typedef struct wgs_conv_desc {
     const float* noise_w;    /* device scalar (NoiseInjection.weight) or NULL */
     int32_t B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps;
     int32_t a_ld, col_ld;    /* row strides of a_scale / col_scale (0 = Ci / Co) */
+    int32_t ups;             /* nearest-neighbour upsampling of the INPUT by 2^ups, folded into the gather: tap
+                                coordinates live on the (Hi<<ups)x(Wi<<ups) grid (ProgGAN / SNGAN / BigGAN blocks) */
+    int32_t add_ups, act;    /* addend is [B, Ho>>add_ups, Wo>>add_ups, Co]; act: 0 leaky (act_slope, gain), 1 tanh */
+    float alpha;             /* accumulator scale (0 = 1): ProgGAN WScale, BigGAN 1/sigma */
+    const float* addend;     /* optional tensor added before the activation (residual / bypass), or NULL */
     int64_t w_tap_stride, w_row_stride;
     float act_slope, gain;   /* identity: 1,1;  relu: 0,1;  fused lrelu: 0.2,sqrt(2) */
     int8_t dy[64], dx[64];
@@ -231,6 +237,9 @@ int wgs_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B,
 /* AdaptiveAvgPool2d(1) / features.mean([-1,-2]) (lib/reconstructor.py:74,78): [B,P,C] -> [B,C]. */
 int wgs_avgpool_fwd(const float* x, float* y, int B, int P, int C, wgs_stream_t stream);
 int wgs_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, wgs_stream_t stream);
+/* Backward of nn.Upsample(scale_factor=2, nearest) on NHWC: dx[b,y,x,:] = sum of dy[b,2y..2y+1,2x..2x+1,:]
+ * (models/ProgGAN/model.py:53, models/SNGAN/sn_gen_resnet.py:37,45, BigGAN GBlock). dy [B,2H,2W,C] -> dx [B,H,W,C]. */
+int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wgs_stream_t stream);
 /* out[c] = sum over rows of x[N,C] (conv bias gradient); ws = 2*C doubles. */
 int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_stream_t stream);
 

@@ -414,3 +414,30 @@ class ReferenceStep:
                         adam_step(v, v.grad, stt[0], stt[1], self.t, lr=self.lrs[grp])
         return dict(loss=loss.item(), ce=ce.item(), l1=l1.item(), acc=acc.item(), argmax=torch.argmax(logits, 1),
                     logits=logits.detach(), img=img.detach(), img_shifted=img_shifted.detach(), shift=shift.detach())
+
+
+# =================================================================================================
+# ProgGAN generator — models/ProgGAN/model.py:12-95, functional over the reference state_dict
+# =================================================================================================
+PROGGAN_UP = [False, False, True, False, True, False, True, False, True, False, True, False, True, False, True, False, True, False]
+PROGGAN_PAD = [3] + [1] * 17
+
+
+def proggan_pixel_norm(x):
+    """PixelNormLayer.forward, model.py:17-18."""
+    return x / torch.sqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def proggan_generate(sd, z, shift=None, num_blocks=18):
+    """ProgGANWrapper.forward (models/gan_load.py:115-120) + Generator.forward (model.py:92-95)."""
+    x = (z if shift is None else z + shift).reshape(z.shape[0], z.shape[1], 1, 1)
+    for i in range(num_blocks):
+        x = proggan_pixel_norm(x)                                                   # NormConvBlock / NormUpscaleConvBlock
+        if PROGGAN_UP[i]:
+            x = F.interpolate(x, scale_factor=2, mode='nearest')                    # :53
+        x = F.conv2d(x, sd['features.%d.conv.weight' % i], padding=PROGGAN_PAD[i])
+        x = x * sd['features.%d.wscale.scale' % i] + sd['features.%d.wscale.b' % i].view(1, -1, 1, 1)   # WScaleLayer :28-32
+        x = F.leaky_relu(x, negative_slope=0.2)
+    x = proggan_pixel_norm(x)
+    x = F.conv2d(x, sd['output.conv.weight'])
+    return x * sd['output.wscale.scale'] + sd['output.wscale.b'].view(1, -1, 1, 1)

@@ -138,3 +138,20 @@ def test_modulated_conv_oracle_vs_reference(golden, name, cin, cout, ks, up, dem
     assert rel_err(y, g['modconv_%s_y' % name]) < 1e-5
     assert rel_err(x.grad, g['modconv_%s_dx' % name]) < 1e-5
     assert rel_err(s.grad, g['modconv_%s_ds' % name]) < 1e-5
+
+
+def _proggan_sd(seed, num_blocks=18):
+    from warpedganspace_amd.proggan import Generator
+    return GI.fill_state_dict(Generator(num_blocks).state_dict(), seed)
+
+
+def test_proggan_oracle_vs_reference(golden):
+    g = golden('generators')
+    sd = _proggan_sd(500)
+    z = GI.rt(501, 2, 512)
+    sh = (GI.rt(502, 2, 512) * 0.1).requires_grad_(True)
+    img = O.proggan_generate(sd, z, sh)
+    (torch.nn.functional.avg_pool2d(img, 32) * GI.rt(503, 2, 3, 32, 32)).sum().backward()
+    assert rel_err(torch.nn.functional.avg_pool2d(img.detach(), 32), g['proggan_img_pool32']) < 1e-5
+    assert rel_err(img.detach()[:, :, 500:516, 300:316], g['proggan_img_crop']) < 1e-5
+    assert rel_err(sh.grad, g['proggan_dshift']) < 1e-4

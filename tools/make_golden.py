@@ -215,6 +215,28 @@ def gen_stylegan2(tmp):
     print('stylegan2.npz', len(out), 'arrays')
 
 
+def gen_generators(tmp):
+    """ProgGAN (models/ProgGAN/model.py) — full 1024^2 network, B=2: pooled image, 8-block prefix, d/dz."""
+    from models.ProgGAN.model import Generator as PG
+    out = {}
+    G = PG()
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 500))
+    G.eval()
+    z = GI.rt(501, 2, 512)
+    sh = (GI.rt(502, 2, 512) * 0.1).requires_grad_(True)
+    x = (z + sh).reshape(2, 512, 1, 1)
+    feat8 = G.features[:8](x)
+    out['proggan_feat8_sub'] = feat8.detach()[:, ::8, ::2, ::2].numpy()    # [2,64,16,16] sub-sample of [2,512,32,32]
+    img = G.output(G.features[8:](feat8))
+    probe = GI.rt(503, 2, 3, 32, 32)
+    (F.avg_pool2d(img, 32) * probe).sum().backward()
+    out['proggan_img_pool32'] = F.avg_pool2d(img.detach(), 32).numpy()
+    out['proggan_img_crop'] = img.detach()[:, :, 500:516, 300:316].numpy()
+    out['proggan_dshift'] = sh.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'generators.npz'), **out)
+    print('generators.npz', len(out), 'arrays')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')

@@ -15,8 +15,10 @@ class ConvDesc(ctypes.Structure):
                 ('a_scale', ctypes.c_void_p), ('col_scale', ctypes.c_void_p), ('bias', ctypes.c_void_p),
                 ('noise', ctypes.c_void_p), ('noise_w', ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ('B', 'Hi', 'Wi', 'Ci', 'Hg', 'Wg', 'isy', 'isx', 'Ho', 'Wo', 'Co',
-                                              'osy', 'osx', 'oy0', 'ox0', 'ntaps', 'a_ld', 'col_ld')] + \
-               [('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
+                                              'osy', 'osx', 'oy0', 'ox0', 'ntaps', 'a_ld', 'col_ld', 'ups', 'add_ups',
+                                              'act')] + \
+               [('alpha', ctypes.c_float), ('addend', ctypes.c_void_p),
+                ('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
                 ('act_slope', ctypes.c_float), ('gain', ctypes.c_float),
                 ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
 
@@ -51,7 +53,7 @@ def _timed(kind, flops, fn):
 
 def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
            a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
-           a_ld=0, col_ld=0):
+           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0):
     """taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
         raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
@@ -65,6 +67,7 @@ def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None,
     d.osy, d.osx, d.oy0, d.ox0 = osy, osy, oy0, ox0
     d.ntaps = len(taps)
     d.a_ld, d.col_ld = a_ld, col_ld
+    d.ups, d.add_ups, d.act, d.alpha, d.addend = ups, add_ups, act, alpha, _p(addend)
     d.w_tap_stride, d.w_row_stride = w_tap_stride, w_row_stride
     d.act_slope, d.gain = act_slope, gain
     for i, (ty, tx, ti) in enumerate(taps):

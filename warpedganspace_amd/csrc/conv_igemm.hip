@@ -34,9 +34,10 @@ struct ConvArgs {
     const float* bias;
     const float* noise;
     const float* noise_w;
-    int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M, a_ld, col_ld;
+    const float* addend;
+    int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M, a_ld, col_ld, ups, add_ups, act;
     long w_tap_stride, w_row_stride;
-    float act_slope, gain;
+    float act_slope, gain, alpha;
     signed char dy[64], dx[64];
     short wt[64];
 };
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
 #pragma unroll
         for (int pa = 0; pa < PA; ++pa) {
             const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
-            const bool v = (r0 + pa * RPP < BM) && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-            const size_t off = v ? ((size_t)(a_pix[pa] + iy * p.Wi + ix)) * p.Ci + ci0 : (size_t)ci0;
+            const bool v = (r0 + pa * RPP < BM) && iy >= 0 && iy < (p.Hi << p.ups) && ix >= 0 && ix < (p.Wi << p.ups);
+            const size_t off = v ? ((size_t)(a_pix[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups))) * p.Ci + ci0 : (size_t)ci0;
             ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
             if (ASCALE) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
             amask |= (v ? 1u : 0u) << pa;
@@ -175,9 +176,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
     int* r_pix = reinterpret_cast<int*>(smem);   // output pixel index (b*Ho+oy)*Wo+ox, or -1
     int* r_b = r_pix + BM;                       // sample index
     float* r_nz = reinterpret_cast<float*>(r_b + BM);   // noise_w * noise[oy*Wo+ox]
+    int* r_add = reinterpret_cast<int*>(r_nz + BM);     // pixel index into the (possibly lower-resolution) addend
     if (tid < BM) {
         const int m = m0 + tid;
-        int pix = -1, bb = 0;
+        int pix = -1, bb = 0, ap = 0;
         float nz = 0.f;
         if (m < p.M) {
             const int gx = m % p.Wg;
@@ -187,8 +189,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
             const int hw = (gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
             pix = bb * p.Ho * p.Wo + hw;
             if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
+            const int oy = gy * p.osy + p.oy0, ox = gx * p.osx + p.ox0;
+            ap = (bb * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
         }
-        r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz;
+        r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
     }
     __syncthreads();
     // demodulation factors: a tile usually covers one or two samples -> two registers per column
@@ -213,10 +217,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
                 const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int pix = r_pix[row];
                 if (pix >= 0 && nok) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * p.alpha;
                     if (p.col_scale) v *= cs_fast ? (r_b[row] == b_lo ? cs0 : cs1) : p.col_scale[(size_t)r_b[row] * p.col_ld + n];
                     v += r_nz[row] + bias;
-                    v = (v > 0.f ? v : v * p.act_slope) * p.gain;
+                    if (p.addend) v += p.addend[(size_t)r_add[row] * p.Co + n];
+                    v = (p.act == 1) ? tanhf(v) : (v > 0.f ? v : v * p.act_slope) * p.gain;
                     p.y[(size_t)pix * p.Co + n] = v;
                 }
             }
@@ -363,7 +368,7 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 int launch_nt(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
     const size_t smem = (size_t)2 * (BM + BN) * (BK + 1) * sizeof(float);
-    const size_t smem_epi = (size_t)3 * BM * sizeof(int);
+    const size_t smem_epi = (size_t)4 * BM * sizeof(int);
     const size_t sm = smem > smem_epi ? smem : smem_epi;
     dim3 grid((unsigned)(ntm * ntn)), block(256);
     if (a.a_scale) {
@@ -427,6 +432,9 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     a.col_ld = d->col_ld > 0 ? d->col_ld : d->Co;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
     a.act_slope = d->act_slope; a.gain = d->gain;
+    a.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+    a.addend = d->addend; a.ups = d->ups; a.add_ups = d->add_ups; a.act = d->act;
+    WGS_CHECK_ARG(d->ups >= 0 && d->ups <= 3 && d->add_ups >= 0 && d->add_ups <= 3, "wgs_conv_igemm: bad upsample shift");
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
     hipStream_t st = (hipStream_t)stream;
     const bool k32 = (d->Ci % 32 == 0);

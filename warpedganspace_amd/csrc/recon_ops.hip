@@ -302,6 +302,25 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
+// ---- backward of a nearest-neighbour 2x upsample: dx[b,y,x,c] = sum of the 2x2 block of dy ------------------
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H,
+                                                             int W, int C) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)B * H * W * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t r = e;
+        const int c = (int)(r % c4n) * 4; r /= c4n;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const float* p0 = dy + (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+        const float4 a = *reinterpret_cast<const float4*>(p0), bb = *reinterpret_cast<const float4*>(p0 + C);
+        const float4 cc = *reinterpret_cast<const float4*>(p0 + (size_t)2 * W * C), d = *reinterpret_cast<const float4*>(p0 + (size_t)2 * W * C + C);
+        *reinterpret_cast<float4*>(dx + e * 4) = make_float4(a.x + bb.x + cc.x + d.x, a.y + bb.y + cc.y + d.y,
+                                                             a.z + bb.z + cc.z + d.z, a.w + bb.w + cc.w + d.w);
+    }
+}
+
 // ---- loss: CrossEntropy(mean) + L1(mean), their gradients, argmax / accuracy ----------------------------
 // one block (256 threads) per sample.
 __global__ __launch_bounds__(256) void loss_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
@@ -480,6 +499,13 @@ int wgs_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, wgs_stream_
     WGS_CHECK_ARG(dy && dx && B > 0 && P > 0 && C > 0, "wgs_avgpool_bwd: bad arguments");
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, P, C);
     WGS_CHECK_LAUNCH("avgpool_bwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wgs_stream_t stream) {
+    WGS_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "wgs_upsample2x_bwd: bad arguments (C %% 4)");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C);
+    WGS_CHECK_LAUNCH("upsample2x_bwd_kernel");
     return WGS_OK;
 }
 

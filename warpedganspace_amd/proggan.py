@@ -1,0 +1,193 @@
+"""ProgGAN generator on the HIP kernels — host-side mirror of models/ProgGAN/model.py:12-95 and
+ProgGANWrapper (models/gan_load.py:109-120).  Parameter names/shapes equal the reference's state_dict
+(`features.{i}.conv.weight`, `features.{i}.wscale.{scale,b}`, `output.conv.weight`, `output.wscale.*`).
+
+Block = PixelNorm -> (nearest 2x upsample) -> conv (no bias) -> WScale (x*scale + b) -> leaky-relu(0.2):
+the upsample is folded into the implicit-GEMM gather (descriptor `ups`), WScale + leaky-relu into its
+epilogue (`alpha`, `bias`, `act_slope`); PixelNorm is a row-wise kernel on the NHWC tensor.  Backward
+propagates only the input gradient (G is frozen).
+
+`num_blocks` < 18 truncates the network (e.g. 14 blocks = 256x256) for tests and for the 256^2 variant of
+BASELINE config 2; the default is the reference's fixed 1024^2 network.
+"""
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import conv as C
+
+# (in_channels, out_channels, kernel, padding, upsample) — models/ProgGAN/model.py:68-86
+BLOCKS = [(512, 512, 4, 3, False), (512, 512, 3, 1, False), (512, 512, 3, 1, True), (512, 512, 3, 1, False),
+          (512, 512, 3, 1, True), (512, 512, 3, 1, False), (512, 512, 3, 1, True), (512, 512, 3, 1, False),
+          (512, 256, 3, 1, True), (256, 256, 3, 1, False), (256, 128, 3, 1, True), (128, 128, 3, 1, False),
+          (128, 64, 3, 1, True), (64, 64, 3, 1, False), (64, 32, 3, 1, True), (32, 32, 3, 1, False),
+          (32, 16, 3, 1, True), (16, 16, 3, 1, False)]
+
+
+class _WScale(nn.Module):
+    def __init__(self, size):
+        super().__init__()
+        self.scale = nn.Parameter(torch.randn([1]))
+        self.b = nn.Parameter(torch.randn(size))
+
+
+class _Block(nn.Module):
+    def __init__(self, ci, co, k, pad):
+        super().__init__()
+        self.conv = nn.Conv2d(ci, co, k, 1, pad, bias=False)
+        self.wscale = _WScale(co)
+
+
+class _PG(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, G, z):
+        img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
+        ctx.G, ctx.saved = G, saved
+        return img
+
+    @staticmethod
+    def backward(ctx, gimg):
+        return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
+
+
+class Generator(nn.Module):
+    def __init__(self, num_blocks=18):
+        super().__init__()
+        self.num_blocks = num_blocks
+        self.features = nn.Sequential(*[_Block(ci, co, k, p) for (ci, co, k, p, _) in BLOCKS[:num_blocks]])
+        self.output = nn.Module()
+        self.output.conv = nn.Conv2d(BLOCKS[num_blocks - 1][1], 3, kernel_size=1, padding=0, bias=False)
+        self.output.wscale = _WScale(3)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self._prep = None
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def _prepare(self):
+        dev = self.output.conv.weight.device
+        if self._prep is not None and self._prep['dev'] == dev:
+            return self._prep
+        if dev.type != 'cuda':
+            raise L.WgsError("ProgGAN Generator runs on the HIP kernels only: move it to the GPU (no CPU fallback)")
+        P = {'dev': dev, 'layers': []}
+        with torch.no_grad():
+            for blk, (ci, co, k, pad, up) in zip(self.features, BLOCKS):
+                wp = C.pack_weight(blk.conv.weight.float())
+                P['layers'].append(dict(wp=wp, wt=C.repack_w_t(wp, co, k * k, ci), ci=ci, co=co, k=k, pad=pad, up=up,
+                                        scale=float(blk.wscale.scale.item()), b=blk.wscale.b.contiguous()))
+            co = self.output.conv.weight.shape[0]
+            ci = self.output.conv.weight.shape[1]
+            # 1x1 conv to 3 channels: output channels padded to 4 so rows stay float4-aligned
+            wp = torch.zeros(4, 1, ci, device=dev)
+            wp[:3] = C.pack_weight(self.output.conv.weight.float())
+            b = torch.zeros(4, device=dev)
+            b[:3] = self.output.wscale.b
+            P['out'] = dict(wp=wp, wt=C.repack_w_t(wp, 4, 1, ci), ci=ci, scale=float(self.output.wscale.scale.item()), b=b)
+        self._prep = P
+        return P
+
+    @staticmethod
+    def _pixelnorm(x, eps=1e-8):
+        y = torch.empty_like(x)
+        rows, d = x.numel() // x.shape[-1], x.shape[-1]
+        L.check(L.lib().wgs_pixelnorm_fwd(L.ptr(x), L.ptr(y), rows, d, L.c_float(eps), L.stream()), 'pixelnorm')
+        return y
+
+    @staticmethod
+    def _pixelnorm_bwd(x, gy, eps=1e-8):
+        gx = torch.empty_like(x)
+        rows, d = x.numel() // x.shape[-1], x.shape[-1]
+        L.check(L.lib().wgs_pixelnorm_bwd(L.ptr(x), L.ptr(gy), L.ptr(gx), rows, d, L.c_float(eps), L.stream()), 'pixelnorm_bwd')
+        return gx
+
+    def _fwd(self, z, save):
+        """z [B,512] (the wrapper reshapes to [B,512,1,1], models/gan_load.py:115-120)."""
+        P = self._prepare()
+        B = z.shape[0]
+        x = z.contiguous().reshape(B, 1, 1, 512)
+        saved = []
+        for ly in P['layers']:
+            xn = self._pixelnorm(x)
+            H = x.shape[1] << (1 if ly['up'] else 0)
+            Ho = H + 2 * ly['pad'] - ly['k'] + 1
+            y = torch.empty(B, Ho, Ho, ly['co'], device=z.device)
+            k, pad = ly['k'], ly['pad']
+            taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
+            C.launch(xn, ly['wp'], y, taps, Ho, Ho, w_tap_stride=ly['ci'], w_row_stride=k * k * ly['ci'], ups=1 if ly['up'] else 0,
+                     alpha=ly['scale'], bias=ly['b'], act_slope=0.2, gain=1.0)
+            if save:
+                saved.append((x, xn, y))
+            x = y
+        xn = self._pixelnorm(x)
+        o = P['out']
+        Hc = x.shape[1]
+        y4 = torch.empty(B, Hc, Hc, 4, device=z.device)
+        C.launch(xn, o['wp'], y4, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['scale'], bias=o['b'])
+        img = y4[..., :3].permute(0, 3, 1, 2).contiguous()
+        return img, ((saved, x, xn) if save else None)
+
+    def _bwd(self, saved_all, gimg):
+        P = self._prepare()
+        lib, st = L.lib(), L.stream()
+        saved, x_last, xn_last = saved_all
+        B = gimg.shape[0]
+        dev = gimg.device
+        Hc = gimg.shape[2]
+        g4 = torch.zeros(B, Hc, Hc, 4, device=dev)
+        g4[..., :3] = gimg.permute(0, 2, 3, 1)
+        o = P['out']
+        gxn = torch.empty(B, Hc, Hc, o['ci'], device=dev)
+        C.launch(g4, o['wt'], gxn, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'] * 4, w_row_stride=4, alpha=o['scale'])
+        g = self._pixelnorm_bwd(x_last, gxn)
+        for ly, (x, xn, y) in zip(reversed(P['layers']), reversed(saved)):
+            # y = lrelu(scale*conv + b): dpre = g * (y > 0 ? 1 : 0.2)
+            dpre = torch.empty_like(y)
+            L.check(lib.wgs_bias_act(L.ptr(g), None, L.ptr(y), L.ptr(dpre), 3, 1, L.c_float(0.2), L.c_float(1.0),
+                                     L.c_int64(y.numel()), 1, 1, st), 'lrelu_bwd')
+            k, pad = ly['k'], ly['pad']
+            Hup = x.shape[1] << (1 if ly['up'] else 0)
+            dup = torch.empty(B, Hup, Hup, ly['ci'], device=dev)
+            taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
+            C.launch(dpre, ly['wt'], dup, taps, Hup, Hup, w_tap_stride=ly['ci'] * ly['co'], w_row_stride=ly['co'], alpha=ly['scale'])
+            if ly['up']:
+                gxn = torch.empty_like(xn)
+                L.check(lib.wgs_upsample2x_bwd(L.ptr(dup), L.ptr(gxn), B, x.shape[1], x.shape[2], ly['ci'], st), 'upsample_bwd')
+            else:
+                gxn = dup
+            g = self._pixelnorm_bwd(x, gxn)
+        return g.reshape(B, 512)
+
+    def forward(self, x):
+        """x: [B,512,1,1] like the reference (or [B,512])."""
+        return _PG.apply(self, x.reshape(x.shape[0], -1))
+
+
+class ProgGANWrapper(nn.Module):
+    """models/gan_load.py:109-120."""
+
+    def __init__(self, G):
+        super().__init__()
+        self.G = G
+        self.dim_z = 512
+
+    @staticmethod
+    def _reshape(z):
+        return z.reshape(z.size()[0], z.size()[1], 1, 1)
+
+    def forward(self, z, shift=None):
+        return self.G(self._reshape(z) if shift is None else self._reshape(z + shift))
+
+
+def build_proggan(pretrained_gan_weights=None, num_blocks=18):
+    """models/gan_load.py:123-129 (plain state_dict file)."""
+    G = Generator(num_blocks)
+    if pretrained_gan_weights is not None:
+        G.load_state_dict(torch.load(pretrained_gan_weights, map_location='cpu'))
+    return ProgGANWrapper(G)
