@@ -84,12 +84,12 @@ class Generator(nn.Module):
                                         scale=float(blk.wscale.scale.item()), b=blk.wscale.b.contiguous()))
             co = self.output.conv.weight.shape[0]
             ci = self.output.conv.weight.shape[1]
-            # 1x1 conv to 3 channels: output channels padded to 4 so rows stay float4-aligned
-            wp = torch.zeros(4, 1, ci, device=dev)
+            # 1x1 conv to 3 channels: output channels padded to 8 (the dgrad contraction needs Ci % 8 == 0)
+            wp = torch.zeros(8, 1, ci, device=dev)
             wp[:3] = C.pack_weight(self.output.conv.weight.float())
-            b = torch.zeros(4, device=dev)
+            b = torch.zeros(8, device=dev)
             b[:3] = self.output.wscale.b
-            P['out'] = dict(wp=wp, wt=C.repack_w_t(wp, 4, 1, ci), ci=ci, scale=float(self.output.wscale.scale.item()), b=b)
+            P['out'] = dict(wp=wp, wt=C.repack_w_t(wp, 8, 1, ci), ci=ci, scale=float(self.output.wscale.scale.item()), b=b)
         self._prep = P
         return P
 
@@ -128,7 +128,7 @@ class Generator(nn.Module):
         xn = self._pixelnorm(x)
         o = P['out']
         Hc = x.shape[1]
-        y4 = torch.empty(B, Hc, Hc, 4, device=z.device)
+        y4 = torch.empty(B, Hc, Hc, 8, device=z.device)
         C.launch(xn, o['wp'], y4, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['scale'], bias=o['b'])
         img = y4[..., :3].permute(0, 3, 1, 2).contiguous()
         return img, ((saved, x, xn) if save else None)
@@ -140,11 +140,11 @@ class Generator(nn.Module):
         B = gimg.shape[0]
         dev = gimg.device
         Hc = gimg.shape[2]
-        g4 = torch.zeros(B, Hc, Hc, 4, device=dev)
+        g4 = torch.zeros(B, Hc, Hc, 8, device=dev)
         g4[..., :3] = gimg.permute(0, 2, 3, 1)
         o = P['out']
         gxn = torch.empty(B, Hc, Hc, o['ci'], device=dev)
-        C.launch(g4, o['wt'], gxn, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'] * 4, w_row_stride=4, alpha=o['scale'])
+        C.launch(g4, o['wt'], gxn, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'] * 8, w_row_stride=8, alpha=o['scale'])
         g = self._pixelnorm_bwd(x_last, gxn)
         for ly, (x, xn, y) in zip(reversed(P['layers']), reversed(saved)):
             # y = lrelu(scale*conv + b): dpre = g * (y > 0 ? 1 : 0.2)
