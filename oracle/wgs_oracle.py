@@ -423,6 +423,13 @@ PROGGAN_UP = [False, False, True, False, True, False, True, False, True, False, 
 PROGGAN_PAD = [3] + [1] * 17
 
 
+def _leaky_relu(v, slope):
+    """F.leaky_relu, or the GATE_OVERRIDE test hook (see fused_leaky_relu)."""
+    if GATE_OVERRIDE is not None:
+        return torch.where(next(GATE_OVERRIDE).to(v.device), v, v * slope)
+    return F.leaky_relu(v, negative_slope=slope)
+
+
 def proggan_pixel_norm(x):
     """PixelNormLayer.forward, model.py:17-18."""
     return x / torch.sqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)
@@ -437,7 +444,7 @@ def proggan_generate(sd, z, shift=None, num_blocks=18):
             x = F.interpolate(x, scale_factor=2, mode='nearest')                    # :53
         x = F.conv2d(x, sd['features.%d.conv.weight' % i], padding=PROGGAN_PAD[i])
         x = x * sd['features.%d.wscale.scale' % i] + sd['features.%d.wscale.b' % i].view(1, -1, 1, 1)   # WScaleLayer :28-32
-        x = F.leaky_relu(x, negative_slope=0.2)
+        x = _leaky_relu(x, 0.2)
     x = proggan_pixel_norm(x)
     x = F.conv2d(x, sd['output.conv.weight'])
     return x * sd['output.wscale.scale'] + sd['output.wscale.b'].view(1, -1, 1, 1)

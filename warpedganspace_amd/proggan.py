@@ -43,6 +43,8 @@ class _PG(torch.autograd.Function):
     def forward(ctx, G, z):
         img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
         ctx.G, ctx.saved = G, saved
+        if G.debug_keep is not None and saved is not None:     # leaky-relu gates, NCHW (tests)
+            G.debug_keep['gates'] = [(y > 0).permute(0, 3, 1, 2) for (_, _, y) in saved[0]]
         return img
 
     @staticmethod
@@ -61,6 +63,7 @@ class Generator(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         self._prep = None
+        self.debug_keep = None
 
     def _apply(self, fn, *a, **k):
         self._prep = None
