@@ -81,6 +81,7 @@ int wgs_rbf_traverse(const float* table, const float* alphas, const float* logga
  * fused_bias_act_kernel.cu:18-49).  y = act(x + b[(i/step_b) % size_b]) * scale, with the
  * reference's act*10+grad switch: act 1 linear, act 3 leaky-relu; grad 0 forward, grad 1 backward
  * gated on `ref` > 0, grad 2 -> 0.  bias / ref may be NULL (the reference passes empty tensors).
+ * Extension: act 9 = tanh (grad 0) and its backward x*(1-ref^2) (grad 1), for the SNGAN / BigGAN output layer.
  */
 int wgs_bias_act(const float* x, const float* bias, const float* ref, float* y, int act, int grad,
                  float alpha, float scale, int64_t size_x, int step_b, int size_b,

@@ -448,3 +448,36 @@ def proggan_generate(sd, z, shift=None, num_blocks=18):
     x = proggan_pixel_norm(x)
     x = F.conv2d(x, sd['output.conv.weight'])
     return x * sd['output.wscale.scale'] + sd['output.wscale.b'].view(1, -1, 1, 1)
+
+
+# =================================================================================================
+# SNGAN ResNet generator — models/SNGAN/sn_gen_resnet.py:24-112 (eval mode), over the GenWrapper state_dict
+# =================================================================================================
+def _relu(v):
+    if GATE_OVERRIDE is not None:
+        return torch.where(next(GATE_OVERRIDE).to(v.device), v, torch.zeros_like(v))
+    return F.relu(v)
+
+
+def sngan_generate(sd, z, shift=None, channels=(256, 256, 256, 256), seed_dim=4):
+    """SNGANWrapper.forward (models/gan_load.py:27-28) on make_resnet_generator's Sequential (:81-112)."""
+    def bn(prefix, x):
+        return F.batch_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'], sd[prefix + '.weight'],
+                            sd[prefix + '.bias'], training=False, eps=1e-5)
+    x = z if shift is None else z + shift
+    x = F.linear(x, sd['model.0.weight'], sd['model.0.bias']).view(-1, channels[0], seed_dim, seed_dim)
+    for i in range(len(channels) - 1):
+        p = 'model.%d.' % (2 + i)
+        h = _relu(bn(p + 'model.0', x))
+        h = F.interpolate(h, scale_factor=2)
+        h = F.conv2d(h, sd[p + 'conv1.weight'], sd[p + 'conv1.bias'], padding=1)
+        h = _relu(bn(p + 'model.4', h))
+        h = F.conv2d(h, sd[p + 'conv2.weight'], sd[p + 'conv2.bias'], padding=1)
+        byp = F.interpolate(x, scale_factor=2)
+        if (p + 'bypass.1.weight') in sd:
+            byp = F.conv2d(byp, sd[p + 'bypass.1.weight'], sd[p + 'bypass.1.bias'], padding=1)
+        x = h + byp                                                            # ResBlockGenerator.forward :53-54
+    n = 2 + len(channels) - 1
+    x = _relu(bn('model.%d' % n, x))
+    x = F.conv2d(x, sd['model.%d.weight' % (n + 2)], sd['model.%d.bias' % (n + 2)], padding=1)
+    return torch.tanh(x)

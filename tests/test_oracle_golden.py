@@ -155,3 +155,24 @@ def test_proggan_oracle_vs_reference(golden):
     assert rel_err(torch.nn.functional.avg_pool2d(img.detach(), 32), g['proggan_img_pool32']) < 1e-5
     assert rel_err(img.detach()[:, :, 500:516, 300:316], g['proggan_img_crop']) < 1e-5
     assert rel_err(sh.grad, g['proggan_dshift']) < 1e-4
+
+
+def _sngan(tag):
+    from warpedganspace_amd.sngan import SN_RES_GEN_CONFIGS, make_resnet_generator
+    cfgname, ch, size, seed = {'mnist': ('sn_resnet32', 1, 32, 520), 'anime': ('sn_resnet64', 3, 64, 530)}[tag]
+    G = make_resnet_generator(SN_RES_GEN_CONFIGS[cfgname], img_size=size, channels=ch, latent_dim=128)
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), seed))
+    return G, G.state_dict(), SN_RES_GEN_CONFIGS[cfgname].channels, size, seed
+
+
+@pytest.mark.parametrize('tag', ['mnist', 'anime'])
+def test_sngan_oracle_vs_reference(golden, tag):
+    g = golden('generators')
+    _, sd, channels, size, seed = _sngan(tag)
+    z = GI.rt(seed + 1, 3, 128)
+    sh = (GI.rt(seed + 2, 3, 128) * 0.1).requires_grad_(True)
+    img = O.sngan_generate(sd, z, sh, channels=channels)
+    (img * GI.rt(seed + 3, *img.shape)).sum().backward()
+    ref = g['sngan_%s_img' % tag]
+    assert rel_err(img.detach() if size == 32 else torch.nn.functional.avg_pool2d(img.detach(), 4), ref) < 1e-5
+    assert rel_err(sh.grad, g['sngan_%s_dshift' % tag]) < 1e-4

@@ -233,6 +233,20 @@ def gen_generators(tmp):
     out['proggan_img_pool32'] = F.avg_pool2d(img.detach(), 32).numpy()
     out['proggan_img_crop'] = img.detach()[:, :, 500:516, 300:316].numpy()
     out['proggan_dshift'] = sh.grad.numpy()
+    # SNGAN (models/SNGAN/sn_gen_resnet.py), eval mode, both configurations used by build_sngan
+    from models.SNGAN.sn_gen_resnet import SN_RES_GEN_CONFIGS, make_resnet_generator
+    from models.SNGAN.distribution import NormalDistribution
+    for tag, cfgname, ch, size, seed in (('mnist', 'sn_resnet32', 1, 32, 520), ('anime', 'sn_resnet64', 3, 64, 530)):
+        Gs = make_resnet_generator(SN_RES_GEN_CONFIGS[cfgname], img_size=size, channels=ch, distribution=NormalDistribution(128))
+        Gs.load_state_dict(GI.fill_state_dict(Gs.state_dict(), seed))
+        Gs.eval()
+        z = GI.rt(seed + 1, 3, 128)
+        sh = (GI.rt(seed + 2, 3, 128) * 0.1).requires_grad_(True)
+        img = Gs.model(z + sh)
+        probe = GI.rt(seed + 3, *img.shape)
+        (img * probe).sum().backward()
+        out['sngan_%s_img' % tag] = img.detach().numpy() if size == 32 else F.avg_pool2d(img.detach(), 4).numpy()
+        out['sngan_%s_dshift' % tag] = sh.grad.numpy()
     np.savez_compressed(os.path.join(GOLD, 'generators.npz'), **out)
     print('generators.npz', len(out), 'arrays')
 

@@ -18,6 +18,8 @@ __device__ __forceinline__ float bias_act_one(float x, float ref, int mode, floa
         case 12: case 32: y = 0.f; break;
         case 30: y = (x > 0.f) ? x : x * alpha; break;
         case 31: y = (ref > 0.f) ? x : x * alpha; break;
+        case 90: y = tanhf(x); break;                     // extension: tanh (SNGAN / BigGAN output)
+        case 91: y = x * (1.f - ref * ref); break;        // its backward, ref = saved tanh output
     }
     return y * scale;
 }
