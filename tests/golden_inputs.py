@@ -43,7 +43,7 @@ def one_hot(idx, K):
     return m
 
 
-def fill_state_dict(sd, seed, skip_suffixes=('kernel', 'num_batches_tracked')):
+def fill_state_dict(sd, seed, skip_suffixes=('kernel', 'num_batches_tracked'), fan_in=False):
     """Deterministically overwrite every float tensor of a state_dict (in key order) with seeded
     normal values of a magnitude that keeps activations O(1). Returns a new dict."""
     rng = np.random.default_rng(seed)
@@ -63,6 +63,10 @@ def fill_state_dict(sd, seed, skip_suffixes=('kernel', 'num_batches_tracked')):
             a = a * 0.1
         elif k.endswith('.scale'):
             a = np.abs(a) * 0.05 + 0.02
+        elif fan_in and k.endswith('weight') and v.dim() >= 2:      # keep activations O(1) (no tanh saturation)
+            a = a * (2.0 / float(np.prod(v.shape[1:]))) ** 0.5
+        elif fan_in and k.endswith('weight') and v.dim() == 1:      # BatchNorm gains around 1
+            a = 1.0 + 0.2 * a
         out[k] = torch.from_numpy(a).reshape(v.shape)
     return out
 

@@ -161,7 +161,7 @@ def _sngan(tag):
     from warpedganspace_amd.sngan import SN_RES_GEN_CONFIGS, make_resnet_generator
     cfgname, ch, size, seed = {'mnist': ('sn_resnet32', 1, 32, 520), 'anime': ('sn_resnet64', 3, 64, 530)}[tag]
     G = make_resnet_generator(SN_RES_GEN_CONFIGS[cfgname], img_size=size, channels=ch, latent_dim=128)
-    G.load_state_dict(GI.fill_state_dict(G.state_dict(), seed))
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), seed, fan_in=True))
     return G, G.state_dict(), SN_RES_GEN_CONFIGS[cfgname].channels, size, seed
 
 

@@ -238,7 +238,7 @@ def gen_generators(tmp):
     from models.SNGAN.distribution import NormalDistribution
     for tag, cfgname, ch, size, seed in (('mnist', 'sn_resnet32', 1, 32, 520), ('anime', 'sn_resnet64', 3, 64, 530)):
         Gs = make_resnet_generator(SN_RES_GEN_CONFIGS[cfgname], img_size=size, channels=ch, distribution=NormalDistribution(128))
-        Gs.load_state_dict(GI.fill_state_dict(Gs.state_dict(), seed))
+        Gs.load_state_dict(GI.fill_state_dict(Gs.state_dict(), seed, fan_in=True))
         Gs.eval()
         z = GI.rt(seed + 1, 3, 128)
         sh = (GI.rt(seed + 2, 3, 128) * 0.1).requires_grad_(True)
