@@ -251,6 +251,37 @@ def gen_generators(tmp):
     print('generators.npz', len(out), 'arrays')
 
 
+def gen_reconstructor(tmp):
+    """LeNet reconstructor (lib/reconstructor.py:18-49,72-75), train mode, cfg1 shape: outputs, every
+    parameter gradient, d/dx2 and the updated running statistics.  (torchvision is absent: a stub module only
+    satisfies `from torchvision.models import resnet18`; the ResNet branch cannot be pinned here.)"""
+    tv, tvm = types.ModuleType('torchvision'), types.ModuleType('torchvision.models')
+    tvm.resnet18 = lambda *a, **k: (_ for _ in ()).throw(RuntimeError('torchvision is not available'))
+    tv.models = tvm
+    sys.modules.setdefault('torchvision', tv)
+    sys.modules.setdefault('torchvision.models', tvm)
+    rec = load_module_from(os.path.join(tmp, 'lib', 'reconstructor.py'), 'ref_reconstructor')
+    out = {}
+    for tag, (K, c, B, S) in {'cfg1': (32, 1, 16, 32), 'rgb': (8, 3, 5, 64)}.items():
+        R = rec.Reconstructor('LeNet', K, channels=c)
+        R.load_state_dict(GI.fill_state_dict(R.state_dict(), 700 + K, fan_in=True))
+        R.train()
+        x1 = GI.rt(701 + K, B, c, S, S)
+        x2 = GI.rt(702 + K, B, c, S, S).requires_grad_(True)
+        logits, mag = R(x1, x2)
+        (logits * GI.rt(703 + K, B, K)).sum().add((mag * GI.rt(704 + K, B)).sum()).backward()
+        out['lenet_%s_logits' % tag] = logits.detach().numpy()
+        out['lenet_%s_mag' % tag] = mag.detach().numpy()
+        out['lenet_%s_dx2' % tag] = x2.grad.numpy() if tag == 'cfg1' else x2.grad[:, :, ::4, ::4].numpy()
+        for n, p in R.named_parameters():
+            out['lenet_%s_grad_%s' % (tag, n)] = p.grad.numpy()
+        for n, b in R.named_buffers():
+            if 'running' in n:
+                out['lenet_%s_buf_%s' % (tag, n)] = b.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'reconstructor.npz'), **out)
+    print('reconstructor.npz', len(out), 'arrays')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')

@@ -152,13 +152,13 @@ class Reconstructor(nn.Module):
     def forward(self, x1, x2):
         if not x1.is_cuda:
             raise L.WgsError("Reconstructor runs on the HIP kernels only: inputs must be GPU tensors (no CPU fallback)")
-        if self.reconstructor_type == 'LeNet':
-            from .lenet import lenet_forward
-            return lenet_forward(self, x1, x2)
         return _RFunction.apply(self, x1, x2, *self._param_list())
 
     # -- explicit schedule -------------------------------------------------------------------------------
     def _forward_impl(self, x1, x2, save=True):
+        if self.reconstructor_type == 'LeNet':
+            from . import lenet
+            return lenet.forward_impl(self, x1, x2, save)
         fe = self.features_extractor
         train = self.training
         lib, st = L.lib(), L.stream()
@@ -213,6 +213,9 @@ class Reconstructor(nn.Module):
         """Returns ({id(param): grad}, d_x1 or None, d_x2 or None).  With `gbuf` ({id(param): zero-initialised
         buffer in the parameter's MEMORY layout, conv weights packed [Co,T,Ci]}) gradients are written /
         accumulated straight into those buffers (the trainer's flat gradient bucket)."""
+        if self.reconstructor_type == 'LeNet':
+            from . import lenet
+            return lenet.backward_impl(self, S, dlogits, dmag, need_x, gbuf)
         fe = self.features_extractor
         lib, st = L.lib(), L.stream()
         B, train, ws = S['B'], S['train'], S['ws']
