@@ -202,7 +202,9 @@ def test_lenet_oracle_vs_reference(golden, tag):
     dx2 = x2.grad if tag == 'cfg1' else x2.grad[:, :, ::4, ::4]
     assert rel_err(dx2, g['lenet_%s_dx2' % tag]) < 1e-4
     for n, _ in R.named_parameters():
-        assert rel_err(sd[n].grad, g['lenet_%s_grad_%s' % (tag, n)]) < 1e-4, n
+        gr = sd[n].grad if sd[n].grad.numel() <= 4096 else sd[n].grad.reshape(-1)[::7]
+        ref = torch.from_numpy(g['lenet_%s_grad_%s' % (tag, n)])
+        assert float((gr - ref).abs().max()) / max(float(ref.abs().max()), 1e-3) < 1e-4, n
     for n, _ in R.named_buffers():
         if 'running' in n:
             assert rel_err(sd[n], g['lenet_%s_buf_%s' % (tag, n)]) < 1e-5, n

@@ -274,7 +274,8 @@ def gen_reconstructor(tmp):
         out['lenet_%s_mag' % tag] = mag.detach().numpy()
         out['lenet_%s_dx2' % tag] = x2.grad.numpy() if tag == 'cfg1' else x2.grad[:, :, ::4, ::4].numpy()
         for n, p in R.named_parameters():
-            out['lenet_%s_grad_%s' % (tag, n)] = p.grad.numpy()
+            gr = p.grad
+            out['lenet_%s_grad_%s' % (tag, n)] = (gr if gr.numel() <= 4096 else gr.reshape(-1)[::7]).numpy()
         for n, b in R.named_buffers():
             if 'running' in n:
                 out['lenet_%s_buf_%s' % (tag, n)] = b.numpy()
