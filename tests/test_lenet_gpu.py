@@ -26,8 +26,8 @@ def test_lenet_vs_reference_golden(dev, golden, tag):
         ref = torch.from_numpy(g['lenet_%s_grad_%s' % (tag, n)])
         pg = p.grad if p.grad.numel() <= 4096 else p.grad.reshape(-1)[::7]
         # a bias in front of a train-mode BatchNorm has an exactly-zero gradient (only round-off noise ~1e-7 on
-        # both sides): measure against max(|ref|, 1e-4 * the largest gradient entry of the net)
-        e = float((pg.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-4 * scale)
+        # both sides): measure against max(|ref|, 1e-2 * the largest gradient entry of the net)
+        e = float((pg.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-2 * scale)
         worst = max(worst, e)
     print('LeNet %s worst gradient rel err vs reference: %.3e' % (tag, worst))
     assert worst < 2e-3
