@@ -370,11 +370,15 @@ class ReferenceStep:
     builds the generator's never-used weight gradients, exactly like the reference), two Adam steps."""
 
     def __init__(self, sd_g, sd_s, sd_r, size, learn_gammas=True, gamma=None, lambda_cls=1.0, lambda_reg=0.25,
-                 lr_s=1e-4, lr_r=1e-4, shift_in_w_space=False, g_requires_grad=True, reconstructor='ResNet'):
+                 lr_s=1e-4, lr_r=1e-4, shift_in_w_space=False, g_requires_grad=True, reconstructor='ResNet',
+                 generator='StyleGAN2', gen_kwargs=None):
+        """generator: 'StyleGAN2' (size = resolution), 'SNGAN' (gen_kwargs: channels=...), 'ProgGAN' (num_blocks=...)."""
         self.size, self.learn_gammas, self.gamma = size, learn_gammas, gamma
         self.lc, self.lr_, self.w_space, self.rtype = lambda_cls, lambda_reg, shift_in_w_space, reconstructor
+        self.gtype, self.gkw = generator, (gen_kwargs or {})
         self.g = {k: v.detach().clone().requires_grad_(g_requires_grad and v.is_floating_point() and
-                                                        not k.startswith('noises.') and not k.endswith('kernel'))
+                                                        not k.startswith('noises.') and not k.endswith('kernel') and
+                                                        'running' not in k)
                   for k, v in sd_g.items()}
         self.s = {k: v.detach().clone() for k, v in sd_s.items()}
         self.s['SUPPORT_SETS'].requires_grad_(True)
@@ -389,18 +393,27 @@ class ReferenceStep:
         self.t = 0
         self.lrs = {'s': lr_s, 'r': lr_r}
 
+    def _gen(self, z, shift=None):
+        if self.gtype == 'StyleGAN2':
+            return sg2_generate(self.g, z, self.size, shift, shift_in_w_space=self.w_space)
+        if self.gtype == 'SNGAN':
+            return sngan_generate(self.g, z, shift, **self.gkw)
+        if self.gtype == 'ProgGAN':
+            return proggan_generate(self.g, z, shift, **self.gkw)
+        raise ValueError(self.gtype)
+
     def step(self, z, idx, mag):
         K = self.s['ALPHAS'].shape[0]
         for d in (self.g, self.s, self.r):
             for v in d.values():
                 if v.is_floating_point() and v.requires_grad:
                     v.grad = None
-        img = sg2_generate(self.g, z, self.size)                                              # :200
+        img = self._gen(z)                                                                    # :200
         mask = torch.zeros(z.shape[0], K)
         mask[torch.arange(z.shape[0]), idx] = 1.0                                            # :227-231
         code = sg2_mapping(self.g, z) if self.w_space else z
         shift = mag.reshape(-1, 1) * support_sets_forward(self.s, mask, code, self.learn_gammas, self.gamma)   # :235
-        img_shifted = sg2_generate(self.g, z, self.size, shift, shift_in_w_space=self.w_space)   # :239
+        img_shifted = self._gen(z, shift)                                                     # :239
         fn = reconstructor_resnet if self.rtype == 'ResNet' else reconstructor_lenet
         logits, mag_hat = fn(self.r, img, img_shifted, training=True)                        # :242
         loss, ce, l1, acc = training_loss(logits, mag_hat, idx, mag, self.lc, self.lr_)      # :245-249

@@ -283,6 +283,60 @@ def gen_reconstructor(tmp):
     print('reconstructor.npz', len(out), 'arrays')
 
 
+def gen_step(tmp):
+    """One optimisation step of BASELINE config 1 (SNGAN-MNIST 32x32, LeNet, K=32, N=8, B=16) driven through the
+    REFERENCE modules (SNGANWrapper-equivalent model, SupportSets, Reconstructor) with the loop body of
+    lib/trainer.py:190-254 restated (lib/trainer.py itself needs tensorboard) and torch.optim.Adam."""
+    tv, tvm = types.ModuleType('torchvision'), types.ModuleType('torchvision.models')
+    tvm.resnet18 = lambda *a, **k: None
+    tv.models = tvm
+    sys.modules.setdefault('torchvision', tv)
+    sys.modules.setdefault('torchvision.models', tvm)
+    rec = load_module_from(os.path.join(tmp, 'lib', 'reconstructor.py'), 'ref_reconstructor_step')
+    ss = load_module_from(os.path.join(tmp, 'lib', 'support_sets.py'), 'ref_support_sets2')
+    from models.SNGAN.sn_gen_resnet import SN_RES_GEN_CONFIGS, make_resnet_generator
+    from models.SNGAN.distribution import NormalDistribution
+    K, N, B, d = 32, 8, 16, 128
+    Gw = make_resnet_generator(SN_RES_GEN_CONFIGS['sn_resnet32'], img_size=32, channels=1, distribution=NormalDistribution(d))
+    Gw.load_state_dict(GI.fill_state_dict(Gw.state_dict(), 800, fan_in=True))
+    G = Gw.model
+    c = GI.support_sets_case(K, N, d, B, 801, learn_gammas=True)
+    S = ss.SupportSets(K, N, d, learn_alphas=False, learn_gammas=True, gamma=c['gamma'])
+    S.load_state_dict(c['sd'])
+    R = rec.Reconstructor('LeNet', K, channels=1)
+    R.load_state_dict(GI.fill_state_dict(R.state_dict(), 802, fan_in=True))
+    G.eval(); S.train(); R.train()
+    opt_s = torch.optim.Adam(S.parameters(), lr=1e-4)
+    opt_r = torch.optim.Adam(R.parameters(), lr=1e-4)
+    z, idx = c['z'], c['idx']
+    mag = GI.rt(803, B).abs() * 0.1 + 0.25
+    mag = mag * torch.where(GI.rt(804, B) > -0.5, 1.0, -1.0)
+    G.zero_grad(); S.zero_grad(); R.zero_grad()
+    img = G(z)
+    mask = torch.zeros(B, K)
+    for i, index in enumerate(idx):
+        mask[i][index] += 1.0
+    shift = mag.reshape(-1, 1) * S(mask, z)
+    img_shifted = G(z + shift)
+    logits, mag_hat = R(img, img_shifted)
+    ce = torch.nn.CrossEntropyLoss()(logits, idx)
+    l1 = torch.mean(torch.abs(mag_hat - mag))
+    loss = 1.0 * ce + 0.25 * l1
+    loss.backward()
+    out = {'step_loss': np.float32(loss.item()), 'step_ce': np.float32(ce.item()), 'step_l1': np.float32(l1.item()),
+           'step_acc': np.float32((logits.argmax(1) == idx).float().mean().item()), 'step_argmax': logits.argmax(1).numpy(),
+           'step_logits': logits.detach().numpy(), 'step_shift': shift.detach().numpy(),
+           'step_img_shifted': img_shifted.detach().numpy()[:4],
+           'step_dS_rows': S.SUPPORT_SETS.grad[torch.unique(idx)].numpy()[:, ::4], 'step_dloggamma': S.LOGGAMMA.grad.numpy()}
+    for n, p in R.named_parameters():
+        out['step_gradnorm_' + n] = np.float32(p.grad.norm().item())
+    opt_s.step(); opt_r.step()
+    out['step_post_loggamma'] = S.LOGGAMMA.detach().numpy()
+    out['step_post_S_absmean_update'] = np.float32((S.SUPPORT_SETS.detach() - c['sd']['SUPPORT_SETS']).abs().mean().item())
+    np.savez_compressed(os.path.join(GOLD, 'step_cfg1.npz'), **out)
+    print('step_cfg1.npz', len(out), 'arrays')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
