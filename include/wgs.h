@@ -257,6 +257,20 @@ int wgs_ce_l1_loss(const float* logits, const int64_t* target, const float* mag_
 int wgs_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, wgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * BigGAN generator glue (models/BigGAN/layers.py).
+ */
+/* Eval-mode (class-conditional) BatchNorm + ReLU (ccbn.forward :303-322, bn.forward :358-363, GBlock :393-405):
+ *   y[b,p,c] = relu?( x[b,p,c]*scale[b,c] + shift[b,c] ),  x NHWC [B,P,C];
+ * backward: g' = g*(y > 0), dx = g'*scale, dscale[b,c] += sum_p g'*x, dshift[b,c] += sum_p g' (caller zeroes both). */
+int wgs_affine_relu_fwd(const float* x, const float* scale, const float* shift, float* y, int B, int P, int C, int relu,
+                        wgs_stream_t stream);
+int wgs_affine_relu_bwd(const float* x, const float* y, const float* g, const float* scale, float* dx, float* dscale,
+                        float* dshift, int B, int P, int C, int relu, wgs_stream_t stream);
+/* Row softmax and its backward (Attention.forward :163: F.softmax(theta^T phi, -1)). */
+int wgs_softmax_rows_fwd(const float* x, float* y, int64_t rows, int n, wgs_stream_t stream);
+int wgs_softmax_rows_bwd(const float* y, const float* dy, float* dx, int64_t rows, int n, wgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

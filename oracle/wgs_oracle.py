@@ -494,3 +494,67 @@ def sngan_generate(sd, z, shift=None, channels=(256, 256, 256, 256), seed_dim=4)
     x = _relu(bn('model.%d' % n, x))
     x = F.conv2d(x, sd['model.%d.weight' % (n + 2)], sd['model.%d.bias' % (n + 2)], padding=1)
     return torch.tanh(x)
+
+
+# =================================================================================================
+# BigGAN generator — models/BigGAN/BigGAN.py:222-243 + layers.py, eval mode, over the reference state_dict
+# =================================================================================================
+def _sn_weight(sd, prefix, eps):
+    """SN.W_ with update=False (layers.py:84-96) using ONE power-iteration step on the stored u0 (:24-47)."""
+    W = sd[prefix + '.weight']
+    Wm = W.reshape(W.shape[0], -1)
+    with torch.no_grad():
+        v = F.normalize(sd[prefix + '.u0'] @ Wm, eps=eps)
+        u = F.normalize(v @ Wm.t(), eps=eps)
+    sv = torch.squeeze((v @ Wm.t()) @ u.t())
+    return W / sv
+
+
+def biggan_generate(sd, z, class_ids, shift=None, ch=96, resolution=128, shared_dim=128, attention_res=64, bn_eps=1e-5,
+                    sn_eps=1e-6, bottom_width=4):
+    """BigGANWrapper.forward (models/gan_load.py:79-81) + Generator.forward with hier=True, G_shared=True."""
+    arch = {128: ([16, 16, 8, 4, 2], [16, 8, 4, 2, 1], [8, 16, 32, 64, 128])}[resolution]
+    z = z if shift is None else z + shift
+    y = F.embedding(class_ids, sd['shared.weight'])
+    nslots = len(arch[0]) + 1
+    cs = z.shape[1] // nslots
+    zs = torch.split(z, cs, 1)
+    ys = [torch.cat([y, item], 1) for item in zs[1:]]
+    h = F.linear(zs[0], _sn_weight(sd, 'linear', sn_eps), sd['linear.bias'])
+    h = h.view(h.size(0), -1, bottom_width, bottom_width)
+
+    def ccbn(prefix, x, yb):
+        gain = (1 + F.linear(yb, _sn_weight(sd, prefix + '.gain', sn_eps))).view(yb.size(0), -1, 1, 1)
+        bias = F.linear(yb, _sn_weight(sd, prefix + '.bias', sn_eps)).view(yb.size(0), -1, 1, 1)
+        out = F.batch_norm(x, sd[prefix + '.stored_mean'], sd[prefix + '.stored_var'], None, None, False, 0.1, bn_eps)
+        return out * gain + bias
+
+    def conv(prefix, x, pad):
+        return F.conv2d(x, _sn_weight(sd, prefix, sn_eps), sd.get(prefix + '.bias'), padding=pad)
+
+    for i, res in enumerate(arch[2]):
+        p = 'blocks.%d.0.' % i
+        x = h
+        t = _relu(ccbn(p + 'bn1', x, ys[i]))                               # GBlock.forward, layers.py:393-405
+        t = F.interpolate(t, scale_factor=2)
+        x = F.interpolate(x, scale_factor=2)
+        t = conv(p + 'conv1', t, 1)
+        t = _relu(ccbn(p + 'bn2', t, ys[i]))
+        t = conv(p + 'conv2', t, 1)
+        h = t + conv(p + 'conv_sc', x, 0)
+        if res == attention_res:                                           # Attention.forward, layers.py:153-166
+            a = 'blocks.%d.1.' % i
+            c = h.shape[1]
+            theta = conv(a + 'theta', h, 0)
+            phi = F.max_pool2d(conv(a + 'phi', h, 0), [2, 2])
+            g = F.max_pool2d(conv(a + 'g', h, 0), [2, 2])
+            n = h.shape[2] * h.shape[3]
+            theta = theta.view(-1, c // 8, n)
+            phi = phi.view(-1, c // 8, n // 4)
+            g = g.view(-1, c // 2, n // 4)
+            beta = F.softmax(torch.bmm(theta.transpose(1, 2), phi), -1)
+            o = conv(a + 'o', torch.bmm(g, beta.transpose(1, 2)).view(-1, c // 2, h.shape[2], h.shape[3]), 0)
+            h = sd[a + 'gamma'] * o + h
+    h = F.batch_norm(h, sd['output_layer.0.stored_mean'], sd['output_layer.0.stored_var'], sd['output_layer.0.gain'],
+                     sd['output_layer.0.bias'], False, 0.1, bn_eps)
+    return torch.tanh(conv('output_layer.2', _relu(h), 1))

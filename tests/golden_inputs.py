@@ -43,19 +43,22 @@ def one_hot(idx, K):
     return m
 
 
-def fill_state_dict(sd, seed, skip_suffixes=('kernel', 'num_batches_tracked'), fan_in=False):
+def fill_state_dict(sd, seed, skip_suffixes=('kernel', 'num_batches_tracked'), fan_in=False, per_key=False):
     """Deterministically overwrite every float tensor of a state_dict (in key order) with seeded
     normal values of a magnitude that keeps activations O(1). Returns a new dict."""
+    import zlib
     rng = np.random.default_rng(seed)
     out = {}
     for k, v in sd.items():
         if any(k.endswith(s) for s in skip_suffixes) or not torch.is_floating_point(v):
             out[k] = v.clone()
             continue
+        if per_key:      # independent of the order in which the module registers its tensors
+            rng = np.random.default_rng([seed, zlib.crc32(k.encode())])
         a = rng.standard_normal(tuple(v.shape)).astype(np.float32)
-        if k.endswith('running_var'):
+        if k.endswith('running_var') or k.endswith('stored_var'):
             a = np.abs(a) + 0.5
-        elif k.endswith('bias') or k.endswith('.b') or k.endswith('running_mean'):
+        elif k.endswith('bias') or k.endswith('.b') or k.endswith('running_mean') or k.endswith('stored_mean'):
             a = a * 0.1
         elif 'modulation.bias' in k:
             a = 1.0 + a * 0.1

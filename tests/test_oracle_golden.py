@@ -241,3 +241,24 @@ def test_cfg1_training_step_oracle_vs_reference(golden):
     rows = torch.unique(c['idx'])
     assert rel_err(ref.s['SUPPORT_SETS'].grad[rows][:, ::4], g['step_dS_rows']) < 1e-3
     assert rel_err(ref.s['LOGGAMMA'].detach(), g['step_post_loggamma']) < 1e-6
+
+
+def _biggan():
+    from warpedganspace_amd.biggan import build_biggan
+    W = build_biggan(None, (239,))
+    W.G.load_state_dict(GI.fill_state_dict(W.G.state_dict(), 540, fan_in=True, per_key=True))
+    return W
+
+
+def test_biggan_manifest_and_oracle_vs_reference(golden):
+    g = golden('generators')
+    W = _biggan()
+    sd = W.G.state_dict()
+    assert sorted(sd.keys()) == list(g['biggan_keys'])                     # same state_dict manifest as the reference
+    z = GI.rt(541, 2, 120)
+    sh = (GI.rt(542, 2, 120) * 0.1).requires_grad_(True)
+    img = O.biggan_generate(sd, z, torch.tensor([239, 100]), sh)
+    (img * GI.rt(543, *img.shape)).sum().backward()
+    assert rel_err(torch.nn.functional.avg_pool2d(img.detach(), 4), g['biggan_img_pool4']) < 1e-5
+    assert rel_err(img.detach()[:, :, 40:56, 70:86], g['biggan_img_crop']) < 1e-5
+    assert rel_err(sh.grad, g['biggan_dshift']) < 1e-4

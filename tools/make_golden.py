@@ -247,6 +247,30 @@ def gen_generators(tmp):
         (img * probe).sum().backward()
         out['sngan_%s_img' % tag] = img.detach().numpy() if size == 32 else F.avg_pool2d(img.detach(), 4).numpy()
         out['sngan_%s_dshift' % tag] = sh.grad.numpy()
+    # BigGAN-128 reference architecture (models/BigGAN/BigGAN.py + generator_config.json), eval mode
+    import json
+    from models.BigGAN import BigGAN as BG, utils as BU
+    with open(os.path.join(tmp, 'models', 'BigGAN', 'generator_config.json')) as f:
+        config = json.load(f)
+    config['resolution'] = BU.imsize_dict[config['dataset']]
+    config['n_classes'] = BU.nclass_dict[config['dataset']]
+    config['G_activation'] = BU.activation_dict[config['G_nl']]
+    config['D_activation'] = BU.activation_dict[config['D_nl']]
+    config['skip_init'] = True
+    config['no_optim'] = True
+    Gb = BG.Generator(**config)
+    Gb.load_state_dict(GI.fill_state_dict(Gb.state_dict(), 540, fan_in=True, per_key=True))
+    Gb.eval()
+    out['biggan_keys'] = np.array(sorted(Gb.state_dict().keys()))
+    z = GI.rt(541, 2, Gb.dim_z)
+    sh = (GI.rt(542, 2, Gb.dim_z) * 0.1).requires_grad_(True)
+    yb = Gb.shared(torch.tensor([239, 100]))
+    img = Gb(z + sh, yb)
+    probe = GI.rt(543, *img.shape)
+    (img * probe).sum().backward()
+    out['biggan_img_pool4'] = F.avg_pool2d(img.detach(), 4).numpy()
+    out['biggan_img_crop'] = img.detach()[:, :, 40:56, 70:86].numpy()
+    out['biggan_dshift'] = sh.grad.numpy()
     np.savez_compressed(os.path.join(GOLD, 'generators.npz'), **out)
     print('generators.npz', len(out), 'arrays')
 
