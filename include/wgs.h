@@ -129,6 +129,10 @@ typedef struct wgs_conv_desc {
     int32_t ups;             /* nearest-neighbour upsampling of the INPUT by 2^ups, folded into the gather: tap
                                 coordinates live on the (Hi<<ups)x(Wi<<ups) grid (ProgGAN / SNGAN / BigGAN blocks) */
     int32_t add_ups, act;    /* addend is [B, Ho>>add_ups, Wo>>add_ups, Co]; act: 0 leaky (act_slope, gain), 1 tanh */
+    int32_t precision;       /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: split-bf16 — every fp32 operand is split
+                                into bf16 hi + lo while it is staged and each product block is 3 x v_mfma_f32_32x32x16_bf16
+                                (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-16 relative per product, 5.3x the fp32 MFMA rate.
+                                Shapes it does not cover (Ci % 32 != 0) silently use the exact kernel. */
     float alpha;             /* accumulator scale (0 = 1): ProgGAN WScale, BigGAN 1/sigma */
     const float* addend;     /* optional tensor added before the activation (residual / bypass), or NULL */
     int64_t w_tap_stride, w_row_stride;

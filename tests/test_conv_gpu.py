@@ -107,3 +107,40 @@ def test_conv_large_matches_blockwise(dev):
     assert rel_err(y3, 0.5 * y1 + y2) < 1e-5
     ref = F.conv2d(x1[:1].cpu().permute(0, 3, 1, 2), w, padding=1)
     assert rel_err(nchw(y1[:1]), ref) < 1e-5
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,k,s,p', [(2, 32, 64, 9, 3, 1, 1), (3, 64, 128, 8, 3, 1, 1), (2, 128, 160, 6, 3, 1, 1),
+                                             (2, 64, 128, 9, 3, 2, 1), (1, 512, 512, 4, 3, 1, 1), (2, 256, 24, 12, 1, 1, 0)])
+def test_conv_split_bf16_precision(dev, B, Ci, Co, H, k, s, p):
+    """precision=1 (3 x bf16 MFMA on hi/lo splits): fwd / dgrad within ~2e-5 of float64 — fp32-class, inside the 1e-3 gate."""
+    torch.manual_seed(Ci + Co)
+    x = torch.randn(B, Ci, H, H, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, k, k, dtype=torch.float64) / (Ci * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    xd = nhwc(x.detach().float()).to(dev)
+    wp = C.pack_weight(w.detach().float()).to(dev)
+    yd = C.conv2d(xd, wp, k, stride=s, pad=p, precision=1)
+    e1 = rel_err(nchw(yd), y.detach())
+    dx = C.conv2d_dgrad(nhwc(g.float()).to(dev), C.repack_w_t(wp, Co, k * k, Ci), (H, H), k, stride=s, pad=p, precision=1)
+    e2 = rel_err(nchw(dx), x.grad)
+    print('split-bf16 conv %s: fwd %.2e dgrad %.2e' % ((B, Ci, Co, H, k, s, p), e1, e2))
+    assert e1 < 1e-4 and e2 < 1e-4
+    yx = C.conv2d(xd, wp, k, stride=s, pad=p, precision=0)
+    assert rel_err(yd, yx) < 1e-4
+
+
+def test_conv_split_bf16_fused_epilogue(dev):
+    torch.manual_seed(6)
+    B, Ci, Co, H = 3, 64, 96, 8
+    x = torch.randn(B, Ci, H, H)
+    w = torch.randn(Co, Ci, 3, 3) / (Ci * 9) ** 0.5
+    s = torch.randn(B, Ci) + 1.0
+    dm = torch.rand(B, Co) + 0.5
+    bias, noise, nw = torch.randn(Co), torch.randn(H, H), torch.tensor([0.37])
+    ref = (F.conv2d(x * s[:, :, None, None], w, padding=1) * dm[:, :, None, None] + nw * noise[None, None] + bias[None, :, None, None])
+    ref = F.leaky_relu(ref, 0.2) * 2 ** 0.5
+    y = C.conv2d(nhwc(x).to(dev), C.pack_weight(w).to(dev), 3, pad=1, a_scale=s.to(dev), col_scale=dm.to(dev), bias=bias.to(dev),
+                 noise=noise.to(dev), noise_w=nw.to(dev), act_slope=0.2, gain=2 ** 0.5, precision=1)
+    assert rel_err(nchw(y), ref) < 1e-4

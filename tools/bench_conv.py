@@ -27,8 +27,9 @@ for ci, co, h in shapes:
     y = torch.empty(B, h, h, co, device=dev)
     ms = timeit(lambda: C.conv2d(x, w, 3, pad=1, out=y))
     ms2 = timeit(lambda: C.conv2d(x, w, 3, pad=1, out=y, a_scale=s, col_scale=s[:, :co].contiguous(), act_slope=0.2, gain=1.41))
+    ms3 = timeit(lambda: C.conv2d(x, w, 3, pad=1, out=y, a_scale=s, col_scale=s[:, :co].contiguous(), act_slope=0.2, gain=1.41, precision=1))
     fl = 2.0 * B * h * h * co * ci * 9
-    print('conv %4d->%4d @%3d  M=%8d  %8.3f ms  %6.1f TF | fused %8.3f ms %6.1f TF' % (ci, co, h, B * h * h, ms, fl / ms / 1e9, ms2, fl / ms2 / 1e9))
+    print('conv %4d->%4d @%3d  M=%8d  %8.3f ms  %6.1f TF | fused %8.3f ms %6.1f TF' % (ci, co, h, B * h * h, ms, fl / ms / 1e9, ms2, fl / ms2 / 1e9) + ' | split-bf16 %8.3f ms %6.1f TF' % (ms3, fl / ms3 / 1e9))
     if h <= 64:
         xt = torch.randn(B, h, h, ci, device=dev)
         ms = timeit(lambda: C.conv_transpose2d_s2(xt, w))

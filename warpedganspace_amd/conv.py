@@ -4,6 +4,7 @@ weights are "packed" as [Cout, T, Cin] (T = kh*kw taps; this is the memory of a 
 [Cout, Cin, kh, kw] tensor in channels_last format) or, for dgrad contractions, [T, Cin, Cout].
 """
 import ctypes
+import os
 
 import torch
 
@@ -16,7 +17,7 @@ class ConvDesc(ctypes.Structure):
                 ('noise', ctypes.c_void_p), ('noise_w', ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ('B', 'Hi', 'Wi', 'Ci', 'Hg', 'Wg', 'isy', 'isx', 'Ho', 'Wo', 'Co',
                                               'osy', 'osx', 'oy0', 'ox0', 'ntaps', 'a_ld', 'col_ld', 'ups', 'add_ups',
-                                              'act')] + \
+                                              'act', 'precision')] + \
                [('alpha', ctypes.c_float), ('addend', ctypes.c_void_p),
                 ('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
                 ('act_slope', ctypes.c_float), ('gain', ctypes.c_float),
@@ -30,6 +31,10 @@ class WgradDesc(ctypes.Structure):
                [('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
                 ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
 
+
+# Arithmetic of the implicit-GEMM launches: 0 = exact fp32 MFMA (default), 1 = split-bf16 x3 MFMA (see wgs.h).
+# Set through the environment (WGS_CONV_PRECISION=bf16x3) or by assigning conv.PRECISION.
+PRECISION = 1 if os.environ.get('WGS_CONV_PRECISION', 'fp32').lower() in ('bf16x3', '1') else 0
 
 # bench.py sets this to a list to collect (kind, algorithmic FLOPs, start event, end event) per launch;
 # the events are recorded on torch's current stream, which is the stream the kernels are launched on.
@@ -53,7 +58,7 @@ def _timed(kind, flops, fn):
 
 def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
            a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
-           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0):
+           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None):
     """taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
         raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
@@ -68,6 +73,7 @@ def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None,
     d.ntaps = len(taps)
     d.a_ld, d.col_ld = a_ld, col_ld
     d.ups, d.add_ups, d.act, d.alpha, d.addend = ups, add_ups, act, alpha, _p(addend)
+    d.precision = PRECISION if precision is None else precision
     d.w_tap_stride, d.w_row_stride = w_tap_stride, w_row_stride
     d.act_slope, d.gain = act_slope, gain
     for i, (ty, tx, ti) in enumerate(taps):

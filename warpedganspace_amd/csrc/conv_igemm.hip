@@ -19,28 +19,14 @@
 // before the MFMAs of the current one (one barrier per chunk).  LDS rows are padded to BK+1 floats:
 // the per-lane operand reads (lane -> row, fixed k) are then bank-conflict free.
 #include "wgs_common.h"
+#include "conv_args.h"
 #include "../../include/wgs.h"
+
+using wgsconv::ConvArgs;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
-
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    float* y;
-    const float* a_scale;
-    const float* col_scale;
-    const float* bias;
-    const float* noise;
-    const float* noise_w;
-    const float* addend;
-    int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M, a_ld, col_ld, ups, add_ups, act;
-    long w_tap_stride, w_row_stride;
-    float act_slope, gain, alpha;
-    signed char dy[64], dx[64];
-    short wt[64];
-};
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool ASCALE>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
@@ -438,6 +424,10 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
     hipStream_t st = (hipStream_t)stream;
     const bool k32 = (d->Ci % 32 == 0);
+    if (d->precision == 1 && wgsconv::launch_bf16x3(a, st) == 0) {
+        WGS_CHECK_LAUNCH("igemm_nt_bf16x3_kernel");
+        return WGS_OK;
+    }
     if (d->Co > 64) {
         if (k32) launch_nt<128, 128, 32, 2, 2>(a, st); else launch_nt<128, 128, 8, 2, 2>(a, st);
     } else if (d->Co > 32) {

@@ -1,0 +1,257 @@
+// Implicit-GEMM convolution on the bf16 matrix cores with fp32-class accuracy ("split-bf16 x3").
+//
+// Same GEMM view, descriptor, prologue (style scale) and epilogue (demod / noise / bias / addend / activation) as
+// conv_igemm.hip, but every fp32 operand value v is split while it is staged into LDS,
+//     hi = bf16_rn(v),  lo = bf16_rn(v - hi)            (v = hi + lo up to 2^-17 relative)
+// and each 32x32x16 product block is evaluated as  hi*hi + hi*lo + lo*hi  with three
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate; the dropped lo*lo term is <= 2^-16 relative).  The bf16 MFMA
+// issues in 8 cycles/CU against 64 for v_mfma_f32_32x32x2_f32 x 8 k-steps, so three of them cost 3/16 of the
+// exact fp32 path: a 5.3x higher matrix-core ceiling (833 TFLOP/s fp32-equivalent) at ~1e-5 relative error.
+//
+// LDS image per stage: A_hi, A_lo [BM][32] bf16 and B_hi, B_lo [BN][32] bf16, rows padded to 80 bytes so that the
+// 16-lane groups of ds_read_b128 (one lane = one row, 8 consecutive k) hit 16 distinct 4-bank slots.
+// 2 stages x 40 KiB = 80 KiB per workgroup -> two workgroups per CU.
+#include "wgs_common.h"
+#include "conv_args.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+using wgsconv::ConvArgs;
+
+constexpr int BK = 32;          // fp32 values per K-chunk
+constexpr int ROWB = 80;        // bytes per LDS row: 32 bf16 = 64 B + 16 B pad
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float x) {     // round-to-nearest-even, result in the low 16 bits
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// split 4 floats into packed bf16 hi (2 words) and lo (2 words)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+    const unsigned h0 = bf16_rn_bits(v.x), h1 = bf16_rn_bits(v.y), h2 = bf16_rn_bits(v.z), h3 = bf16_rn_bits(v.w);
+    const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h1 << 16);
+    const float r2 = v.z - __uint_as_float(h2 << 16), r3 = v.w - __uint_as_float(h3 << 16);
+    hi.x = h0 | (h1 << 16); hi.y = h2 | (h3 << 16);
+    lo.x = bf16_rn_bits(r0) | (bf16_rn_bits(r1) << 16); lo.y = bf16_rn_bits(r2) | (bf16_rn_bits(r3) << 16);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ASCALE>
+__global__ __launch_bounds__(256) void igemm_nt_bf16x3_kernel(const ConvArgs p) {
+    constexpr int CPR = BK / 4;       // float4 chunks per tile row (8)
+    constexpr int RPP = 256 / CPR;    // rows filled per pass (32)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;     // A_hi | A_lo | B_hi | B_lo
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = (p.Co + BN - 1) / BN;
+    const int bid = blockIdx.x;
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    const int q = tid % CPR, r0 = tid / CPR;
+
+    int a_iy0[PA], a_ix0[PA], a_pix[PA], a_b[PA];
+#pragma unroll
+    for (int pa = 0; pa < PA; ++pa) {
+        const int m = m0 + r0 + pa * RPP;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int gx = mm % p.Wg;
+        const int t = mm / p.Wg;
+        const int gy = t % p.Hg;
+        const int b = t / p.Hg;
+        a_iy0[pa] = ok ? gy * p.isy : -100000;
+        a_ix0[pa] = gx * p.isx;
+        a_pix[pa] = b * p.Hi * p.Wi;
+        a_b[pa] = b;
+    }
+
+    float4 ra[PA], rb[PB], rs[ASCALE ? PA : 1];
+    unsigned amask = 0, bmask = 0;
+    const int cpt = p.Ci / BK;
+    const int nk = p.ntaps * cpt;
+
+    auto load_tile = [&](int kt) {
+        const int t = kt / cpt;
+        const int ci0 = (kt - t * cpt) * BK + q * 4;
+        const int dy = p.dy[t], dx = p.dx[t];
+        amask = 0;
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
+            const bool v = iy >= 0 && iy < (p.Hi << p.ups) && ix >= 0 && ix < (p.Wi << p.ups);
+            const size_t off = v ? ((size_t)(a_pix[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups))) * p.Ci + ci0 : (size_t)ci0;
+            ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
+            if (ASCALE) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
+            amask |= (v ? 1u : 0u) << pa;
+        }
+        const float* wt = p.w + (size_t)p.wt[t] * p.w_tap_stride + ci0;
+        bmask = 0;
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            const int n = r0 + pb * RPP;
+            const bool v = (n0 + n < p.Co);
+            rb[pb] = *reinterpret_cast<const float4*>(wt + (size_t)(v ? n0 + n : 0) * p.w_row_stride);
+            bmask |= (v ? 1u : 0u) << pb;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* base = smem_b + buf * STAGE;
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            float4 v = ra[pa];
+            if (ASCALE) { v.x *= rs[pa].x; v.y *= rs[pa].y; v.z *= rs[pa].z; v.w *= rs[pa].w; }
+            if (!((amask >> pa) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            const int off = (r0 + pa * RPP) * ROWB + q * 8;
+            *reinterpret_cast<uint2*>(base + off) = hi;
+            *reinterpret_cast<uint2*>(base + A_BYTES + off) = lo;
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            float4 v = rb[pb];
+            if (!((bmask >> pb) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            const int off = (r0 + pb * RPP) * ROWB + q * 8;
+            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + off) = hi;
+            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + B_BYTES + off) = lo;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* base = smem_b + cur * STAGE;
+        const unsigned char* a_hi = base + (wm * WM + l31) * ROWB + lh * 16;
+        const unsigned char* b_hi = base + 2 * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + i * 32 * ROWB + ks * 32);
+                al[i] = *reinterpret_cast<const bf16x8*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + j * 32 * ROWB + ks * 32);
+                bl[j] = *reinterpret_cast<const bf16x8*>(b_hi + B_BYTES + j * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical contract to conv_igemm.hip) ---------------------------------------------------
+    int* r_pix = reinterpret_cast<int*>(smem_b);
+    int* r_b = r_pix + BM;
+    float* r_nz = reinterpret_cast<float*>(r_b + BM);
+    int* r_add = reinterpret_cast<int*>(r_nz + BM);
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, bb = 0, ap = 0;
+        float nz = 0.f;
+        if (m < p.M) {
+            const int gx = m % p.Wg;
+            const int t = m / p.Wg;
+            const int gy = t % p.Hg;
+            bb = t / p.Hg;
+            const int hw = (gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
+            pix = bb * p.Ho * p.Wo + hw;
+            if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
+            const int oy = gy * p.osy + p.oy0, ox = gx * p.osx + p.ox0;
+            ap = (bb * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
+        }
+        r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
+    }
+    __syncthreads();
+    const int b_lo = r_b[0];
+    const int m_last = min(m0 + BM, p.M) - 1;
+    const int b_hi2 = (m_last / p.Wg) / p.Hg;
+    const bool cs_fast = p.col_scale && (b_hi2 - b_lo <= 1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        const bool nok = n < p.Co;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        float cs0 = 1.f, cs1 = 1.f;
+        if (cs_fast && nok) {
+            cs0 = p.col_scale[(size_t)b_lo * p.col_ld + n];
+            cs1 = p.col_scale[(size_t)b_hi2 * p.col_ld + n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int pix = r_pix[row];
+                if (pix >= 0 && nok) {
+                    float v = acc[i][j][r] * p.alpha;
+                    if (p.col_scale) v *= cs_fast ? (r_b[row] == b_lo ? cs0 : cs1) : p.col_scale[(size_t)r_b[row] * p.col_ld + n];
+                    v += r_nz[row] + bias;
+                    if (p.addend) v += p.addend[(size_t)r_add[row] * p.Co + n];
+                    v = (p.act == 1) ? tanhf(v) : (v > 0.f ? v : v * p.act_slope) * p.gain;
+                    p.y[(size_t)pix * p.Co + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch(const ConvArgs& a, hipStream_t st) {
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
+    const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
+    dim3 grid((unsigned)(ntm * ntn)), block(256);
+    if (a.a_scale) {
+        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, true>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+    } else {
+        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+    }
+}
+
+}  // namespace
+
+namespace wgsconv {
+
+int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
+    if (a.Ci % 32 != 0) return 1;
+    if (a.Co > 64) launch<128, 128, 2, 2>(a, st);
+    else if (a.Co > 32) launch<128, 64, 2, 2>(a, st);
+    else launch<128, 32, 4, 1>(a, st);
+    return 0;
+}
+
+}  // namespace wgsconv
