@@ -24,22 +24,21 @@ using wgsconv::ConvArgs;
 constexpr int BK = 32;          // fp32 values per K-chunk
 constexpr int ROWB = 80;        // bytes per LDS row: 32 bf16 = 64 B + 16 B pad
 
-__device__ __forceinline__ unsigned bf16_rn_bits(float x) {     // round-to-nearest-even, result in the low 16 bits
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-// split 4 floats into packed bf16 hi (2 words) and lo (2 words)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// split 4 floats into packed bf16 hi (2 words) and lo (2 words); the casts lower to v_cvt_pk_bf16_f32 (RNE)
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-    const unsigned h0 = bf16_rn_bits(v.x), h1 = bf16_rn_bits(v.y), h2 = bf16_rn_bits(v.z), h3 = bf16_rn_bits(v.w);
-    const float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h1 << 16);
-    const float r2 = v.z - __uint_as_float(h2 << 16), r3 = v.w - __uint_as_float(h3 << 16);
-    hi.x = h0 | (h1 << 16); hi.y = h2 | (h3 << 16);
-    lo.x = bf16_rn_bits(r0) | (bf16_rn_bits(r1) << 16); lo.y = bf16_rn_bits(r2) | (bf16_rn_bits(r3) << 16);
+    const f32x4 f = {v.x, v.y, v.z, v.w};
+    const bf16x4 h = __builtin_convertvector(f, bf16x4);
+    const f32x4 r = f - __builtin_convertvector(h, f32x4);
+    const bf16x4 l = __builtin_convertvector(r, bf16x4);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool ASCALE>
-__global__ __launch_bounds__(256) void igemm_nt_bf16x3_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs p) {
     constexpr int CPR = BK / 4;       // float4 chunks per tile row (8)
     constexpr int RPP = 256 / CPR;    // rows filled per pass (32)
     constexpr int PA = BM / RPP, PB = BN / RPP;
@@ -71,24 +70,41 @@ __global__ __launch_bounds__(256) void igemm_nt_bf16x3_kernel(const ConvArgs p) 
         a_b[pa] = b;
     }
 
-    float4 ra[PA], rb[PB], rs[ASCALE ? PA : 1];
-    unsigned amask = 0, bmask = 0;
+    // Two staging register sets: chunk kt+2 is requested from HBM/L2 while chunk kt is multiplied and chunk kt+1
+    // (requested one iteration earlier) is split and written to LDS — the bf16 MFMA phase of one chunk (768
+    // cycles) is too short to cover a load round trip on its own.
+    // The style vectors (a_scale, a [B,Ci] table that lives in L1/L2) are fetched only one iteration ahead, in a
+    // single register set.
+    struct Stage {
+        float4 ra[PA];
+        unsigned amask;
+    };
+    Stage s0, s1;
+    float4 rs[ASCALE ? PA : 1], rb[PB];     // weights (L2-resident, shared by every tile) also one iteration ahead
+    unsigned bmask = 0;
     const int cpt = p.Ci / BK;
     const int nk = p.ntaps * cpt;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, Stage& S) {
         const int t = kt / cpt;
         const int ci0 = (kt - t * cpt) * BK + q * 4;
         const int dy = p.dy[t], dx = p.dx[t];
-        amask = 0;
+        S.amask = 0;
 #pragma unroll
         for (int pa = 0; pa < PA; ++pa) {
             const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
             const bool v = iy >= 0 && iy < (p.Hi << p.ups) && ix >= 0 && ix < (p.Wi << p.ups);
             const size_t off = v ? ((size_t)(a_pix[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups))) * p.Ci + ci0 : (size_t)ci0;
-            ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
-            if (ASCALE) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
-            amask |= (v ? 1u : 0u) << pa;
+            S.ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
+            S.amask |= (v ? 1u : 0u) << pa;
+        }
+    };
+    auto load_scale = [&](int kt) {      // style vectors + weight rows of chunk kt
+        const int t = kt / cpt;
+        const int ci0 = (kt - t * cpt) * BK + q * 4;
+        if (ASCALE) {
+#pragma unroll
+            for (int pa = 0; pa < PA; ++pa) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
         }
         const float* wt = p.w + (size_t)p.wt[t] * p.w_tap_stride + ci0;
         bmask = 0;
@@ -100,13 +116,13 @@ __global__ __launch_bounds__(256) void igemm_nt_bf16x3_kernel(const ConvArgs p) 
             bmask |= (v ? 1u : 0u) << pb;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const Stage& S) {
         unsigned char* base = smem_b + buf * STAGE;
 #pragma unroll
         for (int pa = 0; pa < PA; ++pa) {
-            float4 v = ra[pa];
+            float4 v = S.ra[pa];
             if (ASCALE) { v.x *= rs[pa].x; v.y *= rs[pa].y; v.z *= rs[pa].z; v.w *= rs[pa].w; }
-            if (!((amask >> pa) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!((S.amask >> pa) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4(v, hi, lo);
             const int off = (r0 + pa * RPP) * ROWB + q * 8;
@@ -133,14 +149,8 @@ __global__ __launch_bounds__(256) void igemm_nt_bf16x3_kernel(const ConvArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto mma_tile = [&](int cur) {
         const unsigned char* base = smem_b + cur * STAGE;
         const unsigned char* a_hi = base + (wm * WM + l31) * ROWB + lh * 16;
         const unsigned char* b_hi = base + 2 * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
@@ -166,7 +176,26 @@ __global__ __launch_bounds__(256) void igemm_nt_bf16x3_kernel(const ConvArgs p) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    };
+
+    load_tile(0, s0);
+    load_scale(0);
+    store_tile(0, s0);
+    if (nk > 1) load_tile(1, s1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: LDS[0] = chunk kt, s1 = chunk kt+1 (in flight)
+        if (kt + 2 < nk) load_tile(kt + 2, s0);
+        if (kt + 1 < nk) load_scale(kt + 1);
+        mma_tile(0);
+        if (kt + 1 < nk) store_tile(1, s1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: LDS[1] = chunk kt+1, s0 = chunk kt+2 (in flight)
+        if (kt + 3 < nk) load_tile(kt + 3, s1);
+        if (kt + 2 < nk) load_scale(kt + 2);
+        mma_tile(1);
+        if (kt + 2 < nk) store_tile(0, s0);
         __syncthreads();
     }
 
