@@ -30,6 +30,7 @@ import torch.distributed as dist
 
 GFLOP_PER_IMG = 285.8          # G fwd x2 + G dgrad + R fwd + R bwd, StyleGAN2-256 / ResNet-18
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 
 
 def build(dev, size, K, N, B, seed, w_space=False):
@@ -97,6 +98,8 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=1)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--precision', choices=('bf16x3', 'fp32'), default='bf16x3',
+                    help="arithmetic of the implicit-GEMM convs: split-bf16 x3 MFMA (fp32-class, ~1e-5) or exact fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -111,6 +114,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from warpedganspace_amd import conv as C
+    C.PRECISION = 1 if args.precision == 'bf16x3' else 0
     eng = build(dev, args.size, args.K, args.N, args.batch, seed=rank)
 
     def barrier():
@@ -149,15 +153,20 @@ def main():
         for r in recs:
             k = by_kind.setdefault(r[0], [0.0, 0.0, 0])
             k[0] += r[1]; k[1] += r[2].elapsed_time(r[3]); k[2] += 1
-        roofline = {"bound": "mfma", "kernel": "igemm_nt_kernel / igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(fl / ms / 1e9, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(fl / ms / 1e9 / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+        bf = args.precision == 'bf16x3'
+        peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
+        roofline = {"bound": "mfma",
+                    "kernel": ("igemm_nt_bf16x3_kernel (3 x v_mfma_f32_32x32x16_bf16 per product block) + igemm_wgrad_kernel (fp32)"
+                               if bf else "igemm_nt_kernel / igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)"),
+                    "achieved": round(fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(fl / ms / 1e9 / peak, 4), "traffic": None,
+                    "executed_mfma_frac": round((3.0 if bf else 1.0) * fl / ms / 1e9 / peak, 4),
                     "launches_per_step": len(recs) // nprof, "avg_launch_ms": round(ms / len(recs), 4),
                     "conv_ms_per_step": round(ms / nprof, 3), "conv_gflop_per_step": round(fl / nprof / 1e9, 1),
                     "by_kind": {k: {"TFLOP/s": round(v[0] / v[1] / 1e9, 2), "ms_per_step": round(v[1] / nprof, 3),
                                     "launches": v[2] // nprof} for k, v in by_kind.items()},
                     "step_achieved_TFLOPs": round(value / world * GFLOP_PER_IMG / 1e3, 2),
-                    "step_frac": round(value / world * GFLOP_PER_IMG / 1e3 / FP32_MFMA_PEAK_TF, 4)}
+                    "step_frac": round(value / world * GFLOP_PER_IMG / 1e3 / peak, 4)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -170,7 +179,8 @@ def main():
         out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-256 K=128", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "fp32 (f32-input MFMA, f32 accumulate)", "data": "synthetic (random-init weights, z ~ N(0,I))",
+               "dtype": ("bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; R weight-gradients fp32 MFMA)"
+                         if args.precision == 'bf16x3' else "fp32 (f32-input MFMA, f32 accumulate)"), "data": "synthetic (random-init weights, z ~ N(0,I))",
                "config": {"workload": "StyleGAN2-FFHQ-%d arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (args.size, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
