@@ -37,14 +37,13 @@ def test_stylegan2_256_forward_and_gradient(dev, golden, split_bf16):
     assert eg < 1e-2     # Z-space gradient through ~1e8 leaky-relu gates + random mapping net (see test_stylegan2_gpu)
 
 
-def test_resnet_reconstructor_logits_and_argmax(dev, split_bf16):
+def test_reconstructor_stays_exact_fp32(dev, split_bf16):
+    """The trained network R ignores the global arithmetic switch (its convs pass precision=0)."""
     from tests.test_reconstructor_gpu import _run_pair
     R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, 4, 128, 64)
-    assert rel_err(lg, lo.detach()) < 1e-3 and rel_err(mg, mo.detach()) < 1e-3
+    assert rel_err(lg, lo.detach()) < 1e-4 and rel_err(mg, mo.detach()) < 1e-4
     assert torch.equal(torch.argmax(lg, 1).cpu(), torch.argmax(lo, 1))
-    errs = sorted(rel_err(p.grad, sd[n].grad) for n, p in R.named_parameters() if p.grad is not None)
-    print('split-bf16 ResNet-18: median param-grad rel err %.2e, max %.2e' % (errs[len(errs) // 2], errs[-1]))
-    assert errs[len(errs) // 2] < 1e-3
+    assert max(rel_err(p.grad, sd[n].grad) for n, p in R.named_parameters() if p.grad is not None) < 1e-3
 
 
 def test_training_step_loss_and_argmax(dev, split_bf16):

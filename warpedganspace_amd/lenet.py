@@ -133,7 +133,7 @@ def forward_impl(R, x1, x2, save=True):
     for ci_idx, bi_idx, pool in ((0, 1, True), (4, 5, True), (8, 9, False)):
         conv, bn = fe[ci_idx], fe[bi_idx]
         wp, b, Co, Ci, Cop, Cip = _padded_conv(conv, dev)
-        cout = C.conv2d(h, wp, 5, stride=1, pad=0, bias=b)
+        cout = C.conv2d(h, wp, 5, stride=1, pad=0, bias=b, precision=0)
         pbn = _PadBN(bn, Cop, dev)
         a = pbn.fwd(cout, ws, train)
         if pool:
@@ -204,7 +204,7 @@ def backward_impl(R, S, dlogits, dmag, need_x=(False, True), gbuf=None):
         last = (i == len(S['stages']) - 1)
         if not last or need_x[0] or need_x[1]:
             wt = C.repack_w_t(sg['wp'], sg['Cop'], 25, sg['Cip'])
-            g = C.conv2d_dgrad(dc, wt, xin.shape[1:3], 5, stride=1, pad=0)
+            g = C.conv2d_dgrad(dc, wt, xin.shape[1:3], 5, stride=1, pad=0, precision=0)
     if need_x[0] or need_x[1]:
         c = S['c']
         d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
