@@ -10,7 +10,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwgs_hip.so")
+LIB_PATH = os.environ.get("WGS_LIB", os.path.join(_HERE, "libwgs_hip.so"))   # WGS_LIB: development override
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "wgs.h")
 
 _lib = None

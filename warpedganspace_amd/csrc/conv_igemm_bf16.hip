@@ -21,6 +21,10 @@ namespace {
 
 using wgsconv::ConvArgs;
 
+#ifndef WGS_ABL
+#define WGS_ABL 0   // development ablations: 1 no split arithmetic, 2 no LDS stores, 3 no MFMA, 4 no global loads
+#endif
+
 constexpr int BK = 32;          // fp32 values per K-chunk
 constexpr int ROWB = 80;        // bytes per LDS row: 32 bf16 = 64 B + 16 B pad
 
@@ -29,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // split 4 floats into packed bf16 hi (2 words) and lo (2 words); the casts lower to v_cvt_pk_bf16_f32 (RNE)
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+    if (WGS_ABL == 1) { hi = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); lo = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); return; }
     const f32x4 f = {v.x, v.y, v.z, v.w};
     const bf16x4 h = __builtin_convertvector(f, bf16x4);
     const f32x4 r = f - __builtin_convertvector(h, f32x4);
@@ -85,9 +90,11 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
     const int cpt = p.Ci / BK;
     const int nk = p.ntaps * cpt;
 
+    // K order: channel chunk OUTER, tap INNER — consecutive iterations re-read the same pixels' channel chunk shifted
+    // by one tap, so a tile's activation working set per chunk (~17 KB) stays in L1/L2 across the taps.
     auto load_tile = [&](int kt, Stage& S) {
-        const int t = kt / cpt;
-        const int ci0 = (kt - t * cpt) * BK + q * 4;
+        const int t = kt % p.ntaps;
+        const int ci0 = (kt / p.ntaps) * BK + q * 4;
         const int dy = p.dy[t], dx = p.dx[t];
         S.amask = 0;
 #pragma unroll
@@ -95,13 +102,13 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
             const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
             const bool v = iy >= 0 && iy < (p.Hi << p.ups) && ix >= 0 && ix < (p.Wi << p.ups);
             const size_t off = v ? ((size_t)(a_pix[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups))) * p.Ci + ci0 : (size_t)ci0;
-            S.ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
+            if (WGS_ABL != 4) S.ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
             S.amask |= (v ? 1u : 0u) << pa;
         }
     };
     auto load_scale = [&](int kt) {      // style vectors + weight rows of chunk kt
-        const int t = kt / cpt;
-        const int ci0 = (kt - t * cpt) * BK + q * 4;
+        const int t = kt % p.ntaps;
+        const int ci0 = (kt / p.ntaps) * BK + q * 4;
         if (ASCALE) {
 #pragma unroll
             for (int pa = 0; pa < PA; ++pa) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
         for (int pb = 0; pb < PB; ++pb) {
             const int n = r0 + pb * RPP;
             const bool v = (n0 + n < p.Co);
-            rb[pb] = *reinterpret_cast<const float4*>(wt + (size_t)(v ? n0 + n : 0) * p.w_row_stride);
+            if (WGS_ABL != 4) rb[pb] = *reinterpret_cast<const float4*>(wt + (size_t)(v ? n0 + n : 0) * p.w_row_stride);
             bmask |= (v ? 1u : 0u) << pb;
         }
     };
@@ -126,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
             uint2 hi, lo;
             split4(v, hi, lo);
             const int off = (r0 + pa * RPP) * ROWB + q * 8;
+            if (WGS_ABL == 2) { asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y)); continue; }
             *reinterpret_cast<uint2*>(base + off) = hi;
             *reinterpret_cast<uint2*>(base + A_BYTES + off) = lo;
         }
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
             uint2 hi, lo;
             split4(v, hi, lo);
             const int off = (r0 + pb * RPP) * ROWB + q * 8;
+            if (WGS_ABL == 2) { asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y)); continue; }
             *reinterpret_cast<uint2*>(base + 2 * A_BYTES + off) = hi;
             *reinterpret_cast<uint2*>(base + 2 * A_BYTES + B_BYTES + off) = lo;
         }
@@ -171,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    if (WGS_ABL == 3) { asm volatile("" :: "v"(al[i]), "v"(ah[i]), "v"(bh[j]), "v"(bl[j])); continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
