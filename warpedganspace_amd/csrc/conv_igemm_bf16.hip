@@ -42,7 +42,16 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
     lo = __builtin_bit_cast(uint2, l);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool ASCALE>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(const __amdgpu_buffer_rsrc_t r, int voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+constexpr int OOB = (int)0x80000000;     // a byte offset beyond any buffer this kernel accepts (< 2 GiB): the load returns 0
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool ASCALE, bool UPS>
 __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs p) {
     constexpr int CPR = BK / 4;       // float4 chunks per tile row (8)
     constexpr int RPP = 256 / CPR;    // rows filled per pass (32)
@@ -55,11 +64,26 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ntn = (p.Co + BN - 1) / BN;
-    const int bid = blockIdx.x;
+    // XCD-aware tile order: hardware sends workgroup b to XCD b % 8.  Give every XCD a contiguous range of the
+    // (m-tile major, n-tile minor) tile list, so the n-tiles of one m-tile and its neighbouring image rows run on the
+    // same XCD at the same time and share their activation rows in that XCD's L2 instead of each fetching them from HBM.
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, xcd = bid & 7, slot = bid >> 3;
+        const int qn = nb >> 3, rn = nb & 7;
+        bid = xcd * qn + min(xcd, rn) + slot;
+    }
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     const int q = tid % CPR, r0 = tid / CPR;
 
-    int a_iy0[PA], a_ix0[PA], a_pix[PA], a_b[PA];
+    // All three operand streams go through buffer descriptors: 32-bit byte offsets (one VGPR per address, uniform
+    // parts folded on the scalar unit) and hardware range checking — an out-of-image tap, a row past M or a column
+    // past Co gets the offset OOB and reads as zero, so the loads are unconditional and need no masks afterwards.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ASCALE ? p.a_scale : p.x), 0, ASCALE ? p.s_bytes : 0, 0x00020000);
+
+    int a_iy0[PA], a_ix0[PA], a_off[PA], s_off[ASCALE ? PA : 1];
 #pragma unroll
     for (int pa = 0; pa < PA; ++pa) {
         const int m = m0 + r0 + pa * RPP;
@@ -71,57 +95,65 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
         const int b = t / p.Hg;
         a_iy0[pa] = ok ? gy * p.isy : -100000;
         a_ix0[pa] = gx * p.isx;
-        a_pix[pa] = b * p.Hi * p.Wi;
-        a_b[pa] = b;
+        // UPS: pixel index of the image origin; otherwise byte offset of (b, iy0, ix0, q*4) — taps add a uniform delta
+        a_off[pa] = UPS ? b * p.Hi * p.Wi : ((b * p.Hi * p.Wi + gy * p.isy * p.Wi + gx * p.isx) * p.Ci + q * 4) * 4;
+        if (ASCALE) s_off[pa] = (b * p.a_ld + q * 4) * 4;
+    }
+    int b_off[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int n = n0 + r0 + pb * RPP;
+        b_off[pb] = n < p.Co ? (int)((long)n * p.w_row_stride + q * 4) * 4 : OOB;
     }
 
-    // Two staging register sets: chunk kt+2 is requested from HBM/L2 while chunk kt is multiplied and chunk kt+1
-    // (requested one iteration earlier) is split and written to LDS — the bf16 MFMA phase of one chunk (768
-    // cycles) is too short to cover a load round trip on its own.
-    // The style vectors (a_scale, a [B,Ci] table that lives in L1/L2) are fetched only one iteration ahead, in a
-    // single register set.
-    struct Stage {
-        float4 ra[PA];
-        unsigned amask;
-    };
+    // Two activation staging register sets: chunk kt+2 is requested from HBM/L2 while chunk kt is multiplied and chunk
+    // kt+1 (requested one iteration earlier) is split and written to LDS.  Weights and style vectors (L2/L1-resident,
+    // shared by every tile) are fetched one iteration ahead in a single set, and are issued BEFORE the far activation
+    // prefetch: vmcnt retires in order, so the wait in store_tile() leaves the chunk-(kt+2) loads in flight.
+    struct Stage { float4 ra[PA]; };
     Stage s0, s1;
-    float4 rs[ASCALE ? PA : 1], rb[PB];     // weights (L2-resident, shared by every tile) also one iteration ahead
-    unsigned bmask = 0;
+    float4 rs[ASCALE ? PA : 1], rb[PB];
     const int cpt = p.Ci / BK;
     const int nk = p.ntaps * cpt;
+    const int Hup = p.Hi << p.ups, Wup = p.Wi << p.ups;
 
     // K order: channel chunk OUTER, tap INNER — consecutive iterations re-read the same pixels' channel chunk shifted
-    // by one tap, so a tile's activation working set per chunk (~17 KB) stays in L1/L2 across the taps.
-    auto load_tile = [&](int kt, Stage& S) {
-        const int t = kt % p.ntaps;
-        const int ci0 = (kt / p.ntaps) * BK + q * 4;
-        const int dy = p.dy[t], dx = p.dx[t];
-        S.amask = 0;
+    // by one tap, so a tile's activation working set per chunk (~17 KB) stays in L1/L2 across the taps.  Each
+    // workgroup starts at a different chunk so that concurrently running workgroups spread over the L2 channels.
+    const int kofs = (int)(blockIdx.x >> 3) % cpt;
+    // The main loop issues its loads unconditionally (straight-line code lets the compiler count vmcnt exactly and
+    // keep the far prefetch in flight across the LDS store); past the last chunk the uniform offset becomes OOB.
+    int tA = 0, cA = kofs, tB = 0, cB = kofs;      // (tap, chunk) cursors of the activation and weight/style streams
+    int nA = 0, nB = 0;                             // chunks requested so far
+    auto load_tile = [&](Stage& S) {
+        const int yx = p.tap_yx[tA];
+        const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+        const int cbyte = nA < nk ? cA * (BK * 4) : OOB;
+        ++nA;
+        const int delta = UPS ? 0 : p.tap_a[tA] + cbyte;
 #pragma unroll
         for (int pa = 0; pa < PA; ++pa) {
             const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
-            const bool v = iy >= 0 && iy < (p.Hi << p.ups) && ix >= 0 && ix < (p.Wi << p.ups);
-            const size_t off = v ? ((size_t)(a_pix[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups))) * p.Ci + ci0 : (size_t)ci0;
-            if (WGS_ABL != 4) S.ra[pa] = *reinterpret_cast<const float4*>(p.x + off);
-            S.amask |= (v ? 1u : 0u) << pa;
+            const bool v = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
+            int off;
+            if (UPS) off = ((a_off[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups)) * p.Ci + q * 4) * 4 + cbyte;
+            else off = a_off[pa] + delta;
+            if (WGS_ABL != 4) S.ra[pa] = buf_load4(rx, v ? off : OOB);
         }
+        if (++tA == p.ntaps) { tA = 0; if (++cA == cpt) cA = 0; }
     };
-    auto load_scale = [&](int kt) {      // style vectors + weight rows of chunk kt
-        const int t = kt % p.ntaps;
-        const int ci0 = (kt / p.ntaps) * BK + q * 4;
+    auto load_scale = [&]() {      // style vectors + weight rows of the next chunk
+        const int cbyte = nB < nk ? cB * (BK * 4) : OOB;
+        ++nB;
         if (ASCALE) {
 #pragma unroll
-            for (int pa = 0; pa < PA; ++pa) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
+            for (int pa = 0; pa < PA; ++pa) rs[pa] = buf_load4(rsc, s_off[pa] + cbyte);
         }
-        const float* wt = p.w + (size_t)p.wt[t] * p.w_tap_stride + ci0;
-        bmask = 0;
+        const int wdelta = p.tap_w[tB] + cbyte;
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            const int n = r0 + pb * RPP;
-            const bool v = (n0 + n < p.Co);
-            if (WGS_ABL != 4) rb[pb] = *reinterpret_cast<const float4*>(wt + (size_t)(v ? n0 + n : 0) * p.w_row_stride);
-            bmask |= (v ? 1u : 0u) << pb;
-        }
+        for (int pb = 0; pb < PB; ++pb)
+            if (WGS_ABL != 4) rb[pb] = buf_load4(rw, b_off[pb] + wdelta);
+        if (++tB == p.ntaps) { tB = 0; if (++cB == cpt) cB = 0; }
     };
     auto store_tile = [&](int buf, const Stage& S) {
         unsigned char* base = smem_b + buf * STAGE;
@@ -129,22 +161,17 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
         for (int pa = 0; pa < PA; ++pa) {
             float4 v = S.ra[pa];
             if (ASCALE) { v.x *= rs[pa].x; v.y *= rs[pa].y; v.z *= rs[pa].z; v.w *= rs[pa].w; }
-            if (!((S.amask >> pa) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4(v, hi, lo);
             const int off = (r0 + pa * RPP) * ROWB + q * 8;
-            if (WGS_ABL == 2) { asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y)); continue; }
             *reinterpret_cast<uint2*>(base + off) = hi;
             *reinterpret_cast<uint2*>(base + A_BYTES + off) = lo;
         }
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            float4 v = rb[pb];
-            if (!((bmask >> pb) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
-            split4(v, hi, lo);
+            split4(rb[pb], hi, lo);
             const int off = (r0 + pb * RPP) * ROWB + q * 8;
-            if (WGS_ABL == 2) { asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y)); continue; }
             *reinterpret_cast<uint2*>(base + 2 * A_BYTES + off) = hi;
             *reinterpret_cast<uint2*>(base + 2 * A_BYTES + B_BYTES + off) = lo;
         }
@@ -188,24 +215,24 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
         }
     };
 
-    load_tile(0, s0);
-    load_scale(0);
+    load_tile(s0);
+    load_scale();
     store_tile(0, s0);
-    if (nk > 1) load_tile(1, s1);
+    load_tile(s1);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         // even step: LDS[0] = chunk kt, s1 = chunk kt+1 (in flight)
-        if (kt + 2 < nk) load_tile(kt + 2, s0);
-        if (kt + 1 < nk) load_scale(kt + 1);
+        load_scale();            // weights + styles of chunk kt+1
+        load_tile(s0);           // activations of chunk kt+2
         mma_tile(0);
-        if (kt + 1 < nk) store_tile(1, s1);
+        store_tile(1, s1);
         __syncthreads();
         if (kt + 1 >= nk) break;
         // odd step: LDS[1] = chunk kt+1, s0 = chunk kt+2 (in flight)
-        if (kt + 3 < nk) load_tile(kt + 3, s1);
-        if (kt + 2 < nk) load_scale(kt + 2);
+        load_scale();
+        load_tile(s1);
         mma_tile(1);
-        if (kt + 2 < nk) store_tile(0, s0);
+        store_tile(0, s0);
         __syncthreads();
     }
 
@@ -270,23 +297,34 @@ void launch(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
     dim3 grid((unsigned)(ntm * ntn)), block(256);
-    if (a.a_scale) {
-        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, true>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, grid, block, sm, st, a);
-    } else {
-        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, false>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+#define WGS_BF16_LAUNCH(AS, UP)                                                                             \
+    {                                                                                                       \
+        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, AS, UP>;                                  \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);     \
+        hipLaunchKernelGGL(k, grid, block, sm, st, a);                                                      \
     }
+    if (a.a_scale) { if (a.ups) WGS_BF16_LAUNCH(true, true) else WGS_BF16_LAUNCH(true, false) }
+    else { if (a.ups) WGS_BF16_LAUNCH(false, true) else WGS_BF16_LAUNCH(false, false) }
+#undef WGS_BF16_LAUNCH
 }
 
 }  // namespace
 
 namespace wgsconv {
 
-int launch_bf16x3(const ConvArgs& a, hipStream_t st) {
-    if (a.Ci % 32 != 0) return 1;
+int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
+    if (a0.Ci % 32 != 0) return 1;
+    ConvArgs a = a0;
+    // operand extents for the buffer descriptors; every stream must be addressable with a 31-bit byte offset
+    const long xb = (long)a.B * a.Hi * a.Wi * a.Ci * 4;
+    int wt_max = 0;
+    for (int t = 0; t < a.ntaps; ++t) wt_max = a.wt[t] > wt_max ? a.wt[t] : wt_max;
+    const long wb = ((long)wt_max * a.w_tap_stride + (long)(a.Co - 1) * a.w_row_stride + a.Ci) * 4;
+    const long sb = a.a_scale ? ((long)(a.B - 1) * a.a_ld + a.Ci) * 4 : 0;
+    const long lim = 0x7fffffffL;
+    if (xb > lim || wb > lim || sb > lim) return 1;
+    a.x_bytes = (int)xb; a.w_bytes = (int)wb; a.s_bytes = (int)sb;
+    fill_tap_tables(a);
     if (a.Co > 64) launch<128, 128, 2, 2>(a, st);
     else if (a.Co > 32) launch<128, 64, 2, 2>(a, st);
     else launch<128, 32, 4, 1>(a, st);
