@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
     auto load_tile = [&](int kt) {
         const int t = kt / cpt;
         const int ci0 = (kt - t * cpt) * BK + q * 4;
-        const int dy = p.dy[t], dx = p.dx[t];
+        const int yx = p.tap_yx[t];       // dword tables: scalar loads (see conv_args.h)
+        const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
         amask = 0;
 #pragma unroll
         for (int pa = 0; pa < PA; ++pa) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
             if (ASCALE) rs[pa] = *reinterpret_cast<const float4*>(p.a_scale + (size_t)a_b[pa] * p.a_ld + ci0);
             amask |= (v ? 1u : 0u) << pa;
         }
-        const float* wt = p.w + (size_t)p.wt[t] * p.w_tap_stride + ci0;
+        const float* wt = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w) + p.tap_w[t]) + ci0;
         bmask = 0;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
@@ -422,6 +423,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     a.addend = d->addend; a.ups = d->ups; a.add_ups = d->add_ups; a.act = d->act;
     WGS_CHECK_ARG(d->ups >= 0 && d->ups <= 3 && d->add_ups >= 0 && d->add_ups <= 3, "wgs_conv_igemm: bad upsample shift");
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
+    wgsconv::fill_tap_tables(a);
     hipStream_t st = (hipStream_t)stream;
     const bool k32 = (d->Ci % 32 == 0);
     if (d->precision == 1 && wgsconv::launch_bf16x3(a, st) == 0) {

@@ -22,7 +22,9 @@ namespace {
 using wgsconv::ConvArgs;
 
 #ifndef WGS_ABL
-#define WGS_ABL 0   // development ablations: 1 no split arithmetic, 2 no LDS stores, 3 no MFMA, 4 no global loads
+#define WGS_ABL 0   // development ablations: 1 no split arithmetic, 2 no LDS stores, 3 no MFMA, 4 no global loads,
+                    // 7 no style loads, 8 no weight loads, 9 no activation loads, 10 no LDS operand reads,
+                    // 11 no 256-row tiles, 12 LDS stores after (not between) the MFMAs
 #endif
 
 constexpr int BK = 32;          // fp32 values per K-chunk
@@ -51,11 +53,15 @@ __device__ __forceinline__ float4 buf_load4(const __amdgpu_buffer_rsrc_t r, int 
 
 constexpr int OOB = (int)0x80000000;     // a byte offset beyond any buffer this kernel accepts (< 2 GiB): the load returns 0
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool ASCALE, bool UPS>
-__global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs p) {
+// ASCALE: 0 no style, 1 one style vector per tile row (tiles that span several samples), 2 one per tile (every tile
+// lies inside one sample: Hg*Wg is a multiple of BM) — the common case, and three fewer vector loads per thread/chunk.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ASCALE, bool UPS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 2 : 1) void igemm_nt_bf16x3_kernel(const ConvArgs p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int CPR = BK / 4;       // float4 chunks per tile row (8)
-    constexpr int RPP = 256 / CPR;    // rows filled per pass (32)
+    constexpr int RPP = NT / CPR;     // rows filled per pass (32 or 64)
     constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int PS = ASCALE == 1 ? PA : 1;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;     // A_hi | A_lo | B_hi | B_lo
@@ -83,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ASCALE ? p.a_scale : p.x), 0, ASCALE ? p.s_bytes : 0, 0x00020000);
 
-    int a_iy0[PA], a_ix0[PA], a_off[PA], s_off[ASCALE ? PA : 1];
+    int a_iy0[PA], a_ix0[PA], a_off[PA], s_off[PS];
+    if (ASCALE == 2) s_off[0] = ((m0 / (p.Hg * p.Wg)) * p.a_ld + q * 4) * 4;
 #pragma unroll
     for (int pa = 0; pa < PA; ++pa) {
         const int m = m0 + r0 + pa * RPP;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
         a_ix0[pa] = gx * p.isx;
         // UPS: pixel index of the image origin; otherwise byte offset of (b, iy0, ix0, q*4) — taps add a uniform delta
         a_off[pa] = UPS ? b * p.Hi * p.Wi : ((b * p.Hi * p.Wi + gy * p.isy * p.Wi + gx * p.isx) * p.Ci + q * 4) * 4;
-        if (ASCALE) s_off[pa] = (b * p.a_ld + q * 4) * 4;
+        if (ASCALE == 1) s_off[pa] = (b * p.a_ld + q * 4) * 4;
     }
     int b_off[PB];
 #pragma unroll
@@ -111,8 +118,9 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
     // shared by every tile) are fetched one iteration ahead in a single set, and are issued BEFORE the far activation
     // prefetch: vmcnt retires in order, so the wait in store_tile() leaves the chunk-(kt+2) loads in flight.
     struct Stage { float4 ra[PA]; };
+    constexpr bool DEEP = (NT == 256);
     Stage s0, s1;
-    float4 rs[ASCALE ? PA : 1], rb[PB];
+    float4 rs[PS], rb[PB];
     const int cpt = p.Ci / BK;
     const int nk = p.ntaps * cpt;
     const int Hup = p.Hi << p.ups, Wup = p.Wi << p.ups;
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
             int off;
             if (UPS) off = ((a_off[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups)) * p.Ci + q * 4) * 4 + cbyte;
             else off = a_off[pa] + delta;
-            if (WGS_ABL != 4) S.ra[pa] = buf_load4(rx, v ? off : OOB);
+            if (WGS_ABL != 4 && WGS_ABL != 9) S.ra[pa] = buf_load4(rx, v ? off : OOB);
         }
         if (++tA == p.ntaps) { tA = 0; if (++cA == cpt) cA = 0; }
     };
@@ -147,34 +155,36 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
         ++nB;
         if (ASCALE) {
 #pragma unroll
-            for (int pa = 0; pa < PA; ++pa) rs[pa] = buf_load4(rsc, s_off[pa] + cbyte);
+            for (int ps = 0; ps < PS; ++ps) if (WGS_ABL != 7 && WGS_ABL != 4) rs[ps] = buf_load4(rsc, s_off[ps] + cbyte);
         }
         const int wdelta = p.tap_w[tB] + cbyte;
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb)
-            if (WGS_ABL != 4) rb[pb] = buf_load4(rw, b_off[pb] + wdelta);
+            if (WGS_ABL != 4 && WGS_ABL != 8) rb[pb] = buf_load4(rw, b_off[pb] + wdelta);
         if (++tB == p.ntaps) { tB = 0; if (++cB == cpt) cB = 0; }
     };
-    auto store_tile = [&](int buf, const Stage& S) {
+    // one staged float4 (activation pieces 0..PA-1, then weight pieces PA..PA+PB-1): style multiply, hi/lo split, LDS
+    auto store_piece = [&](int buf, const Stage& S, int idx) {
         unsigned char* base = smem_b + buf * STAGE;
-#pragma unroll
-        for (int pa = 0; pa < PA; ++pa) {
-            float4 v = S.ra[pa];
-            if (ASCALE) { v.x *= rs[pa].x; v.y *= rs[pa].y; v.z *= rs[pa].z; v.w *= rs[pa].w; }
-            uint2 hi, lo;
-            split4(v, hi, lo);
-            const int off = (r0 + pa * RPP) * ROWB + q * 8;
-            *reinterpret_cast<uint2*>(base + off) = hi;
-            *reinterpret_cast<uint2*>(base + A_BYTES + off) = lo;
+        float4 v;
+        int off;
+        if (idx < PA) {
+            v = S.ra[idx];
+            if (ASCALE) { const float4 sc = rs[ASCALE == 1 ? idx : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            off = (r0 + idx * RPP) * ROWB + q * 8;
+        } else {
+            v = rb[idx - PA];
+            off = 2 * A_BYTES + (r0 + (idx - PA) * RPP) * ROWB + q * 8;
         }
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        if (WGS_ABL == 2) { asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y)); return; }
+        *reinterpret_cast<uint2*>(base + off) = hi;
+        *reinterpret_cast<uint2*>(base + off + (idx < PA ? A_BYTES : B_BYTES)) = lo;
+    };
+    auto store_tile = [&](int buf, const Stage& S) {
 #pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            uint2 hi, lo;
-            split4(rb[pb], hi, lo);
-            const int off = (r0 + pb * RPP) * ROWB + q * 8;
-            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + off) = hi;
-            *reinterpret_cast<uint2*>(base + 2 * A_BYTES + B_BYTES + off) = lo;
-        }
+        for (int idx = 0; idx < PA + PB; ++idx) store_piece(buf, S, idx);
     };
 
     f32x16 acc[TM][TN];
@@ -186,54 +196,87 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_bf16x3_kernel(const ConvArgs 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    auto mma_tile = [&](int cur) {
+    // Multiply chunk `cur` and, interleaved with the MFMAs, split + store the staged chunk S into LDS buffer `st`
+    // (st < 0: nothing to store).  The VALU/LDS-store work of a piece issues in the shadow of the 6 or 12 MFMAs of a
+    // (k-step, row-tile) slot instead of in a separate phase after them; FIRST is the first slot that carries stores
+    // (the one-set 8-wave form starts in the second half of the chunk, when its loads have had time to land).
+    constexpr int SLOTS = (BK / 16) * TM;
+    constexpr int FIRST = DEEP ? 0 : SLOTS / 2;
+    constexpr int PPS = (PA + PB + (SLOTS - FIRST) - 1) / (SLOTS - FIRST);    // pieces per slot
+    auto mma_tile = [&](int cur, int st, const Stage& S) {
         const unsigned char* base = smem_b + cur * STAGE;
         const unsigned char* a_hi = base + (wm * WM + l31) * ROWB + lh * 16;
         const unsigned char* b_hi = base + 2 * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + i * 32 * ROWB + ks * 32);
-                al[i] = *reinterpret_cast<const bf16x8*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
-            }
+            bf16x8 bh[TN], bl[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+                if (WGS_ABL == 10) { asm volatile("" : "=v"(bh[j]), "=v"(bl[j])); continue; }
                 bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + j * 32 * ROWB + ks * 32);
                 bl[j] = *reinterpret_cast<const bf16x8*>(b_hi + B_BYTES + j * 32 * ROWB + ks * 32);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                bf16x8 ah, al;
+                if (WGS_ABL == 10) asm volatile("" : "=v"(ah), "=v"(al));
+                else {
+                    ah = *reinterpret_cast<const bf16x8*>(a_hi + i * 32 * ROWB + ks * 32);
+                    al = *reinterpret_cast<const bf16x8*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (WGS_ABL == 3) { asm volatile("" :: "v"(al[i]), "v"(ah[i]), "v"(bh[j]), "v"(bl[j])); continue; }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (WGS_ABL == 3) { asm volatile("" :: "v"(al), "v"(ah), "v"(bh[j]), "v"(bl[j])); continue; }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
+                const int slot = ks * TM + i;
+                if (WGS_ABL != 12 && slot >= FIRST && st >= 0) {
+#pragma unroll
+                    for (int u = 0; u < PPS; ++u) {
+                        const int idx = (slot - FIRST) * PPS + u;
+                        if (idx < PA + PB) store_piece(st, S, idx);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (WGS_ABL == 12 && st >= 0) store_tile(st, S);
     };
 
-    load_tile(s0);
-    load_scale();
-    store_tile(0, s0);
-    load_tile(s1);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        // even step: LDS[0] = chunk kt, s1 = chunk kt+1 (in flight)
-        load_scale();            // weights + styles of chunk kt+1
-        load_tile(s0);           // activations of chunk kt+2
-        mma_tile(0);
-        store_tile(1, s1);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        // odd step: LDS[1] = chunk kt+1, s0 = chunk kt+2 (in flight)
+    if (DEEP) {
+        load_tile(s0);
         load_scale();
+        store_tile(0, s0);
         load_tile(s1);
-        mma_tile(1);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even step: LDS[0] = chunk kt, s1 = chunk kt+1 (in flight)
+            load_scale();            // weights + styles of chunk kt+1
+            load_tile(s0);           // activations of chunk kt+2
+            mma_tile(0, 1, s1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // odd step: LDS[1] = chunk kt+1, s0 = chunk kt+2 (in flight)
+            load_scale();
+            load_tile(s1);
+            mma_tile(1, 0, s0);
+            __syncthreads();
+        }
+    } else {
+        // 8-wave tiles: 128 accumulator registers per lane leave room for one staging set (prefetch distance 1)
+        load_tile(s0);
+        load_scale();
         store_tile(0, s0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            load_scale();
+            load_tile(s0);
+            mma_tile(cur, cur ^ 1, s0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue (identical contract to conv_igemm.hip) ---------------------------------------------------
@@ -296,16 +339,37 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
-    dim3 grid((unsigned)(ntm * ntn)), block(256);
+    dim3 grid((unsigned)(ntm * ntn)), block(64 * WAVES_M * WAVES_N);
+    const int mode = !a.a_scale ? 0 : ((a.Hg * a.Wg) % BM == 0 ? 2 : 1);
 #define WGS_BF16_LAUNCH(AS, UP)                                                                             \
     {                                                                                                       \
         auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, AS, UP>;                                  \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);     \
         hipLaunchKernelGGL(k, grid, block, sm, st, a);                                                      \
     }
-    if (a.a_scale) { if (a.ups) WGS_BF16_LAUNCH(true, true) else WGS_BF16_LAUNCH(true, false) }
-    else { if (a.ups) WGS_BF16_LAUNCH(false, true) else WGS_BF16_LAUNCH(false, false) }
+    if (a.ups) {
+        if (mode == 0) WGS_BF16_LAUNCH(0, true) else if (mode == 1) WGS_BF16_LAUNCH(1, true) else WGS_BF16_LAUNCH(2, true)
+    } else {
+        if (mode == 0) WGS_BF16_LAUNCH(0, false) else if (mode == 1) WGS_BF16_LAUNCH(1, false) else WGS_BF16_LAUNCH(2, false)
+    }
 #undef WGS_BF16_LAUNCH
+}
+
+// 8-wave 256-row tiles (one workgroup per CU): only the non-upsampling forms are instantiated
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_big(const ConvArgs& a, hipStream_t st) {
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
+    const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
+    dim3 grid((unsigned)(ntm * ntn)), block(64 * WAVES_M * WAVES_N);
+    if (!a.a_scale) {
+        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, 0, false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+    } else {
+        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, 2, false>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+    }
 }
 
 }  // namespace
@@ -325,7 +389,12 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     if (xb > lim || wb > lim || sb > lim) return 1;
     a.x_bytes = (int)xb; a.w_bytes = (int)wb; a.s_bytes = (int)sb;
     fill_tap_tables(a);
-    if (a.Co > 64) launch<128, 128, 2, 2>(a, st);
+    // 256-row tiles quarter the vector-memory / LDS-store work per MFMA; used when they still fill the 256 CUs
+    const bool big_ok = !a.ups && (!a.a_scale || (a.Hg * a.Wg) % 256 == 0) && WGS_ABL != 11;
+    const int ntm256 = (a.M + 255) / 256;
+    if (big_ok && a.Co % 256 == 0 && ntm256 * (a.Co / 256) >= 200) launch_big<256, 256, 2, 4>(a, st);
+    else if (big_ok && a.Co % 128 == 0 && ntm256 * (a.Co / 128) >= 200) launch_big<256, 128, 4, 2>(a, st);
+    else if (a.Co > 64) launch<128, 128, 2, 2>(a, st);
     else if (a.Co > 32) launch<128, 64, 2, 2>(a, st);
     else launch<128, 32, 4, 1>(a, st);
     return 0;
