@@ -133,35 +133,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     // keep the far prefetch in flight across the LDS store); past the last chunk the uniform offset becomes OOB.
     int tA = 0, cA = kofs, tB = 0, cB = kofs;      // (tap, chunk) cursors of the activation and weight/style streams
     int nA = 0, nB = 0;                             // chunks requested so far
-    auto load_tile = [&](Stage& S) {
+    // Per-chunk uniform state of the two streams (scalar registers), then one vector load per "piece":
+    // pieces 0..PA-1 activation rows, PA..PA+PB-1 weight rows, PA+PB.. style vectors.
+    int u_dy = 0, u_dx = 0, u_cbyteA = 0, u_delta = 0, u_cbyteB = 0, u_wdelta = 0;
+    auto begin_tile = [&]() {
         const int yx = p.tap_yx[tA];
-        const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
-        const int cbyte = nA < nk ? cA * (BK * 4) : OOB;
+        u_dy = (int)(short)(yx & 0xffff); u_dx = yx >> 16;
+        u_cbyteA = nA < nk ? cA * (BK * 4) : OOB;
+        u_delta = UPS ? 0 : p.tap_a[tA] + u_cbyteA;
         ++nA;
-        const int delta = UPS ? 0 : p.tap_a[tA] + cbyte;
-#pragma unroll
-        for (int pa = 0; pa < PA; ++pa) {
-            const int iy = a_iy0[pa] + dy, ix = a_ix0[pa] + dx;
-            const bool v = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
-            int off;
-            if (UPS) off = ((a_off[pa] + (iy >> p.ups) * p.Wi + (ix >> p.ups)) * p.Ci + q * 4) * 4 + cbyte;
-            else off = a_off[pa] + delta;
-            if (WGS_ABL != 4 && WGS_ABL != 9) S.ra[pa] = buf_load4(rx, v ? off : OOB);
-        }
         if (++tA == p.ntaps) { tA = 0; if (++cA == cpt) cA = 0; }
     };
-    auto load_scale = [&]() {      // style vectors + weight rows of the next chunk
-        const int cbyte = nB < nk ? cB * (BK * 4) : OOB;
+    auto begin_scale = [&]() {
+        u_cbyteB = nB < nk ? cB * (BK * 4) : OOB;
+        u_wdelta = p.tap_w[tB] + u_cbyteB;
         ++nB;
-        if (ASCALE) {
-#pragma unroll
-            for (int ps = 0; ps < PS; ++ps) if (WGS_ABL != 7 && WGS_ABL != 4) rs[ps] = buf_load4(rsc, s_off[ps] + cbyte);
-        }
-        const int wdelta = p.tap_w[tB] + cbyte;
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb)
-            if (WGS_ABL != 4 && WGS_ABL != 8) rb[pb] = buf_load4(rw, b_off[pb] + wdelta);
         if (++tB == p.ntaps) { tB = 0; if (++cB == cpt) cB = 0; }
+    };
+    auto load_piece = [&](Stage& S, int idx) {
+        if (idx < PA) {
+            const int iy = a_iy0[idx] + u_dy, ix = a_ix0[idx] + u_dx;
+            const bool v = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
+            int off;
+            if (UPS) off = ((a_off[idx] + (iy >> p.ups) * p.Wi + (ix >> p.ups)) * p.Ci + q * 4) * 4 + u_cbyteA;
+            else off = a_off[idx] + u_delta;
+            if (WGS_ABL != 4 && WGS_ABL != 9) S.ra[idx] = buf_load4(rx, v ? off : OOB);
+        } else if (idx < PA + PB) {
+            if (WGS_ABL != 4 && WGS_ABL != 8) rb[idx - PA] = buf_load4(rw, b_off[idx - PA] + u_wdelta);
+        } else if (ASCALE && idx < PA + PB + PS) {
+            if (WGS_ABL != 4 && WGS_ABL != 7) rs[idx - PA - PB] = buf_load4(rsc, s_off[idx - PA - PB] + u_cbyteB);
+        }
+    };
+    constexpr int NLOADS = PA + PB + (ASCALE ? PS : 0);
+    auto load_tile = [&](Stage& S) {     // whole-chunk forms (prologue)
+        begin_tile();
+#pragma unroll
+        for (int idx = 0; idx < PA; ++idx) load_piece(S, idx);
+    };
+    auto load_scale = [&]() {
+        begin_scale();
+#pragma unroll
+        for (int idx = PA; idx < PA + PB + PS; ++idx) load_piece(s0, idx);
     };
     // one staged float4 (activation pieces 0..PA-1, then weight pieces PA..PA+PB-1): style multiply, hi/lo split, LDS
     auto store_piece = [&](int buf, const Stage& S, int idx) {
@@ -196,53 +208,74 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    // Multiply chunk `cur` and, interleaved with the MFMAs, split + store the staged chunk S into LDS buffer `st`
-    // (st < 0: nothing to store).  The VALU/LDS-store work of a piece issues in the shadow of the 6 or 12 MFMAs of a
-    // (k-step, row-tile) slot instead of in a separate phase after them; FIRST is the first slot that carries stores
-    // (the one-set 8-wave form starts in the second half of the chunk, when its loads have had time to land).
+    // One chunk of the main loop.  Multiplies LDS buffer `cur`; interleaved with the MFMAs of each (k-step, row-tile)
+    // slot it (1) issues the vector loads of a later chunk — weight/style pieces first, then the activation pieces
+    // into LD — and (2) splits + stores the already-landed staged chunk ST into LDS buffer `st`, so that neither the
+    // address/VMEM-issue work nor the VALU/LDS-store work forms a phase of its own in which the matrix cores idle.
+    // Loads go in the first half of the slots, stores in the second half (the weight/style registers are a single set,
+    // filled and consumed within the chunk).  DEEP (4-wave tiles, two activation sets): ST was requested one chunk
+    // earlier and LD is the other set; one-set 8-wave tiles: LD == ST.
+    // The operand fragments of slot s+1 are read from LDS before the MFMAs of slot s are issued.
     constexpr int SLOTS = (BK / 16) * TM;
-    constexpr int FIRST = DEEP ? 0 : SLOTS / 2;
-    constexpr int PPS = (PA + PB + (SLOTS - FIRST) - 1) / (SLOTS - FIRST);    // pieces per slot
-    auto mma_tile = [&](int cur, int st, const Stage& S) {
+    constexpr int LSLOTS = SLOTS / 2;                                // slots that carry loads: [0, LSLOTS)
+    constexpr int SFIRST = SLOTS / 2;                                // slots that carry stores: [SFIRST, SLOTS)
+    constexpr int LPS = (NLOADS + LSLOTS - 1) / LSLOTS;              // loads per slot
+    constexpr int PPS = (PA + PB + (SLOTS - SFIRST) - 1) / (SLOTS - SFIRST);    // store pieces per slot
+    // load order: weights, styles, then activations (see the vmcnt note at the staging registers)
+    auto load_order = [&](int n) { return n < PB + (ASCALE ? PS : 0) ? PA + n : n - PB - (ASCALE ? PS : 0); };
+    auto mma_tile = [&](int cur, int st, Stage& LD, const Stage& ST) {
         const unsigned char* base = smem_b + cur * STAGE;
         const unsigned char* a_hi = base + (wm * WM + l31) * ROWB + lh * 16;
         const unsigned char* b_hi = base + 2 * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 bh[TN], bl[TN];
+        auto read_a = [&](int slot, bf16x8& h, bf16x8& l) {
+            const int ks = slot / TM, i = slot % TM;
+            if (WGS_ABL == 10) { asm volatile("" : "=v"(h), "=v"(l)); return; }
+            h = *reinterpret_cast<const bf16x8*>(a_hi + i * 32 * ROWB + ks * 32);
+            l = *reinterpret_cast<const bf16x8*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
+        };
+        auto read_b = [&](int ks, bf16x8* h, bf16x8* l) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (WGS_ABL == 10) { asm volatile("" : "=v"(bh[j]), "=v"(bl[j])); continue; }
-                bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + j * 32 * ROWB + ks * 32);
-                bl[j] = *reinterpret_cast<const bf16x8*>(b_hi + B_BYTES + j * 32 * ROWB + ks * 32);
+                if (WGS_ABL == 10) { asm volatile("" : "=v"(h[j]), "=v"(l[j])); continue; }
+                h[j] = *reinterpret_cast<const bf16x8*>(b_hi + j * 32 * ROWB + ks * 32);
+                l[j] = *reinterpret_cast<const bf16x8*>(b_hi + B_BYTES + j * 32 * ROWB + ks * 32);
+            }
+        };
+        bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
+        read_b(0, bh[0], bl[0]);
+        read_a(0, ah[0], al[0]);
+        begin_scale();
+        begin_tile();
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; ++slot) {
+            const int ks = slot / TM, i = slot % TM;
+            if (slot + 1 < SLOTS) {
+                read_a(slot + 1, ah[(slot + 1) & 1], al[(slot + 1) & 1]);
+                if ((slot + 1) % TM == 0) read_b(ks + 1, bh[(ks + 1) & 1], bl[(ks + 1) & 1]);
+            }
+            if (slot < LSLOTS) {
+#pragma unroll
+                for (int u = 0; u < LPS; ++u) {
+                    const int n = slot * LPS + u;
+                    if (n < NLOADS) load_piece(LD, load_order(n));
+                }
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                bf16x8 ah, al;
-                if (WGS_ABL == 10) asm volatile("" : "=v"(ah), "=v"(al));
-                else {
-                    ah = *reinterpret_cast<const bf16x8*>(a_hi + i * 32 * ROWB + ks * 32);
-                    al = *reinterpret_cast<const bf16x8*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (WGS_ABL == 3) { asm volatile("" :: "v"(al), "v"(ah), "v"(bh[j]), "v"(bl[j])); continue; }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                }
-                const int slot = ks * TM + i;
-                if (WGS_ABL != 12 && slot >= FIRST && st >= 0) {
-#pragma unroll
-                    for (int u = 0; u < PPS; ++u) {
-                        const int idx = (slot - FIRST) * PPS + u;
-                        if (idx < PA + PB) store_piece(st, S, idx);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < TN; ++j) {
+                if (WGS_ABL == 3) { asm volatile("" :: "v"(al[slot & 1]), "v"(ah[slot & 1]), "v"(bh[ks & 1][j]), "v"(bl[ks & 1][j])); continue; }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bl[ks & 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
             }
+            if (slot >= SFIRST && st >= 0) {
+#pragma unroll
+                for (int u = 0; u < PPS; ++u) {
+                    const int idx = (slot - SFIRST) * PPS + u;
+                    if (idx < PA + PB) store_piece(st, ST, idx);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (WGS_ABL == 12 && st >= 0) store_tile(st, S);
     };
 
     if (DEEP) {
@@ -252,29 +285,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
         load_tile(s1);
         __syncthreads();
         for (int kt = 0; kt < nk; kt += 2) {
-            // even step: LDS[0] = chunk kt, s1 = chunk kt+1 (in flight)
-            load_scale();            // weights + styles of chunk kt+1
-            load_tile(s0);           // activations of chunk kt+2
-            mma_tile(0, 1, s1);
+            // even step: LDS[0] = chunk kt; s1 = activations of chunk kt+1 (in flight); request weights/styles of
+            // chunk kt+1 and activations of chunk kt+2 -> s0; store chunk kt+1 into LDS[1]
+            mma_tile(0, 1, s0, s1);
             __syncthreads();
             if (kt + 1 >= nk) break;
-            // odd step: LDS[1] = chunk kt+1, s0 = chunk kt+2 (in flight)
-            load_scale();
-            load_tile(s1);
-            mma_tile(1, 0, s0);
+            mma_tile(1, 0, s1, s0);
             __syncthreads();
         }
     } else {
-        // 8-wave tiles: 128 accumulator registers per lane leave room for one staging set (prefetch distance 1)
         load_tile(s0);
         load_scale();
         store_tile(0, s0);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            load_scale();
-            load_tile(s0);
-            mma_tile(cur, cur ^ 1, s0);
+            mma_tile(cur, cur ^ 1, s0, s0);
             __syncthreads();
         }
     }
