@@ -139,6 +139,11 @@ typedef struct wgs_conv_desc {
     float act_slope, gain;   /* identity: 1,1;  relu: 0,1;  fused lrelu: 0.2,sqrt(2) */
     int8_t dy[64], dx[64];
     int16_t wt[64];
+    float* ws;               /* optional split-K workspace (caller-owned, like every buffer) or NULL.  Launches whose */
+    int64_t ws_bytes;        /* 128x128 tile count cannot fill the 256 CUs (4x4..16x16 generator layers: M = B*Hg*Wg of
+                                512..2048) split the K = taps*Ci contraction over up to 16 workgroups per tile; the
+                                partial tiles go to ws[split][M][Co] (plain stores, deterministic) and a second kernel
+                                reduces them and applies the epilogue.  Needs 4*ksplit*M*Co bytes; too small => fewer splits. */
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
 

@@ -144,3 +144,48 @@ def test_conv_split_bf16_fused_epilogue(dev):
     y = C.conv2d(nhwc(x).to(dev), C.pack_weight(w).to(dev), 3, pad=1, a_scale=s.to(dev), col_scale=dm.to(dev), bias=bias.to(dev),
                  noise=noise.to(dev), noise_w=nw.to(dev), act_slope=0.2, gain=2 ** 0.5, precision=1)
     assert rel_err(nchw(y), ref) < 1e-4
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(2, 64, 128, 6), (4, 128, 256, 8), (1, 512, 512, 4)])
+def test_conv_transpose_s2_split_bf16(dev, B, Ci, Co, H):
+    """precision=1 on the sub-pixel phase launches of the 4x4..16x16 generator layers: few tiles, so the K contraction is
+    split over workgroups (wgs_conv_desc.ws) and finished by the reduction/epilogue kernel, with strided phase outputs."""
+    torch.manual_seed(H + Ci)
+    x = torch.randn(B, Ci, H, H, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Ci, Co, 3, 3, dtype=torch.float64) / (Ci * 9) ** 0.5
+    y = F.conv_transpose2d(x, w, stride=2, padding=0)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    wp = C.pack_weight(w.permute(1, 0, 2, 3).float()).to(dev)
+    s = (torch.randn(B, Ci) + 1.0)
+    yd = C.conv_transpose2d_s2(nhwc(x.detach().float()).to(dev), wp, precision=1)
+    assert rel_err(nchw(yd), y.detach()) < 1e-4
+    ys = C.conv_transpose2d_s2(nhwc(x.detach().float()).to(dev), wp, a_scale=s.to(dev), precision=1)
+    ref_s = F.conv_transpose2d(x.detach() * s.double()[:, :, None, None], w, stride=2, padding=0)
+    assert rel_err(nchw(ys), ref_s) < 1e-4
+    dx = C.conv_transpose2d_s2_dgrad(nhwc(g.float()).to(dev), C.repack_w_t(wp, Co, 9, Ci), precision=1)
+    assert rel_err(nchw(dx), x.grad) < 1e-4
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(4, 64, 256, 128), (8, 32, 128, 128), (2, 64, 512, 256)])
+def test_conv_split_bf16_256_row_tiles(dev, B, Ci, Co, H):
+    """Shapes that take the 8-wave 256x256 / 256x128 tiles (enough 256-row tiles to fill the chip), with the whole
+    StyleGAN2 epilogue; reference = the exact-fp32 kernel (itself checked against PyTorch above) plus one CPU sample."""
+    torch.manual_seed(Co)
+    x = torch.randn(B, H, H, Ci, device=dev)
+    w = torch.randn(Co, Ci, 3, 3) / (Ci * 9) ** 0.5
+    wp = C.pack_weight(w).to(dev)
+    s = torch.randn(B, Ci, device=dev) + 1.0
+    dm = torch.rand(B, Co, device=dev) + 0.5
+    bias, noise, nw = torch.randn(Co, device=dev), torch.randn(H, H, device=dev), torch.tensor([0.37], device=dev)
+    kw = dict(a_scale=s, col_scale=dm, bias=bias, noise=noise, noise_w=nw, act_slope=0.2, gain=2 ** 0.5)
+    y1 = C.conv2d(x, wp, 3, pad=1, precision=1, **kw)
+    y0 = C.conv2d(x, wp, 3, pad=1, precision=0, **kw)
+    assert rel_err(y1, y0) < 2e-5
+    xb = x[B - 1:].cpu().permute(0, 3, 1, 2).double() * s[B - 1:].cpu().double()[:, :, None, None]
+    ref = F.conv2d(xb, w.double(), padding=1) * dm[B - 1:].cpu().double()[:, :, None, None] + (nw.cpu() * noise.cpu()).double()[None, None] \
+        + bias.cpu().double()[None, :, None, None]
+    ref = F.leaky_relu(ref, 0.2) * 2 ** 0.5
+    assert rel_err(nchw(y1[B - 1:]), ref) < 2e-5
+    y2 = C.conv2d(x, wp, 3, pad=1, precision=1)            # no style: the ASCALE=0 instantiation
+    assert rel_err(y2, C.conv2d(x, wp, 3, pad=1, precision=0)) < 2e-5

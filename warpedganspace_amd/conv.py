@@ -21,7 +21,8 @@ class ConvDesc(ctypes.Structure):
                [('alpha', ctypes.c_float), ('addend', ctypes.c_void_p),
                 ('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
                 ('act_slope', ctypes.c_float), ('gain', ctypes.c_float),
-                ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
+                ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
+                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -43,6 +44,18 @@ PROFILE = None
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+# split-K workspace (wgs_conv_desc.ws): one caller-owned buffer per device, reused by every launch on the stream
+WS_BYTES = 64 << 20
+_WS = {}
+
+
+def _workspace(device):
+    ws = _WS.get(device)
+    if ws is None:
+        ws = _WS[device] = torch.empty(WS_BYTES // 4, device=device, dtype=torch.float32)
+    return ws
 
 
 def _timed(kind, flops, fn):
@@ -76,6 +89,8 @@ def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None,
     d.precision = PRECISION if precision is None else precision
     d.w_tap_stride, d.w_row_stride = w_tap_stride, w_row_stride
     d.act_slope, d.gain = act_slope, gain
+    ws = _workspace(x.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     for i, (ty, tx, ti) in enumerate(taps):
         d.dy[i], d.dx[i], d.wt[i] = ty, tx, ti
     flops = 2.0 * d.B * Hg * Wg * d.Co * d.Ci * len(taps)

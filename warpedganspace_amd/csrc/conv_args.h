@@ -18,6 +18,9 @@ struct ConvArgs {
     int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M, a_ld, col_ld, ups, add_ups, act;
     long w_tap_stride, w_row_stride;
     float act_slope, gain, alpha;
+    float* ws;          // split-K workspace or null
+    long ws_bytes;
+    int ksplit;         // K splits of this launch (1 = none); set by launch_bf16x3
     int x_bytes, w_bytes, s_bytes;      // operand extents (bytes), filled in by launch_bf16x3 for its buffer descriptors
     signed char dy[64], dx[64];
     short wt[64];

@@ -423,6 +423,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     a.addend = d->addend; a.ups = d->ups; a.add_ups = d->add_ups; a.act = d->act;
     WGS_CHECK_ARG(d->ups >= 0 && d->ups <= 3 && d->add_ups >= 0 && d->add_ups <= 3, "wgs_conv_igemm: bad upsample shift");
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
+    a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
     wgsconv::fill_tap_tables(a);
     hipStream_t st = (hipStream_t)stream;
     const bool k32 = (d->Ci % 32 == 0);

@@ -24,7 +24,7 @@ using wgsconv::ConvArgs;
 #ifndef WGS_ABL
 #define WGS_ABL 0   // development ablations: 1 no split arithmetic, 2 no LDS stores, 3 no MFMA, 4 no global loads,
                     // 7 no style loads, 8 no weight loads, 9 no activation loads, 10 no LDS operand reads,
-                    // 11 no 256-row tiles, 12 LDS stores after (not between) the MFMAs
+                    // 11 no 256-row tiles, 13 no split-K
 #endif
 
 constexpr int BK = 32;          // fp32 values per K-chunk
@@ -122,7 +122,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     Stage s0, s1;
     float4 rs[PS], rb[PB];
     const int cpt = p.Ci / BK;
-    const int nk = p.ntaps * cpt;
+    // split-K: workgroup (tile, blockIdx.y) contracts chunks [kbeg, kbeg + nk) of the ntaps*cpt chunk sequence
+    const int nk_all = p.ntaps * cpt;
+    const int kper = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int kbeg = (int)blockIdx.y * kper;
+    const int nk = min(kper, nk_all - kbeg);
     const int Hup = p.Hi << p.ups, Wup = p.Wi << p.ups;
 
     // K order: channel chunk OUTER, tap INNER — consecutive iterations re-read the same pixels' channel chunk shifted
@@ -131,7 +135,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     const int kofs = (int)(blockIdx.x >> 3) % cpt;
     // The main loop issues its loads unconditionally (straight-line code lets the compiler count vmcnt exactly and
     // keep the far prefetch in flight across the LDS store); past the last chunk the uniform offset becomes OOB.
-    int tA = 0, cA = kofs, tB = 0, cB = kofs;      // (tap, chunk) cursors of the activation and weight/style streams
+    int tA = kbeg % p.ntaps, cA = (kbeg / p.ntaps + kofs) % cpt;      // (tap, chunk) cursors of the activation ...
+    int tB = tA, cB = cA;                                              // ... and weight/style streams
     int nA = 0, nB = 0;                             // chunks requested so far
     // Per-chunk uniform state of the two streams (scalar registers), then one vector load per "piece":
     // pieces 0..PA-1 activation rows, PA..PA+PB-1 weight rows, PA+PB.. style vectors.
@@ -305,6 +310,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
         }
     }
 
+    if (p.ksplit > 1) {
+        // split-K: raw partial tile -> ws[split][m][n]; conv_splitk_epilogue_kernel reduces and finishes
+        float* part = p.ws + (size_t)blockIdx.y * p.M * p.Co;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < p.M && n < p.Co) part[(size_t)m * p.Co + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue (identical contract to conv_igemm.hip) ---------------------------------------------------
     int* r_pix = reinterpret_cast<int*>(smem_b);
     int* r_b = r_pix + BM;
@@ -361,11 +382,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     }
 }
 
+// Second pass of a split-K launch: y[pix(m)][n] = epilogue(sum_s ws[s][m][n]) — the same epilogue as above
+// (alpha, demod, noise, bias, addend, activation).  One thread per 4 output channels.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArgs p) {
+    const int c4 = p.Co / 4;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)p.M * c4) return;
+    const int m = (int)(e / c4), n = (int)(e % c4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < p.ksplit; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)s * p.M + m) * p.Co + n);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const int gx = m % p.Wg;
+    const int t = m / p.Wg;
+    const int gy = t % p.Hg;
+    const int b = t / p.Hg;
+    const int oy = gy * p.osy + p.oy0, ox = gx * p.osx + p.ox0;
+    const int hw = oy * p.Wo + ox;
+    const float nz = (p.noise && p.noise_w) ? p.noise_w[0] * p.noise[hw] : 0.f;
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float u = o[k] * p.alpha;
+        if (p.col_scale) u *= p.col_scale[(size_t)b * p.col_ld + n + k];
+        u += nz + (p.bias ? p.bias[n + k] : 0.f);
+        if (p.addend) u += p.addend[((size_t)(b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups)) * p.Co + n + k];
+        o[k] = (p.act == 1) ? tanhf(u) : (u > 0.f ? u : u * p.act_slope) * p.gain;
+    }
+    *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + hw) * p.Co + n) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
-    dim3 grid((unsigned)(ntm * ntn)), block(64 * WAVES_M * WAVES_N);
+    dim3 grid((unsigned)(ntm * ntn), (unsigned)a.ksplit), block(64 * WAVES_M * WAVES_N);
     const int mode = !a.a_scale ? 0 : ((a.Hg * a.Wg) % BM == 0 ? 2 : 1);
 #define WGS_BF16_LAUNCH(AS, UP)                                                                             \
     {                                                                                                       \
@@ -420,7 +472,28 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     const int ntm256 = (a.M + 255) / 256;
     if (big_ok && a.Co % 256 == 0 && ntm256 * (a.Co / 256) >= 200) launch_big<256, 256, 2, 4>(a, st);
     else if (big_ok && a.Co % 128 == 0 && ntm256 * (a.Co / 128) >= 200) launch_big<256, 128, 4, 2>(a, st);
-    else if (a.Co > 64) launch<128, 128, 2, 2>(a, st);
+    else if (a.Co > 64) {
+        // too few 128x128 tiles for the 256 CUs: split K (needs the caller's workspace and 4-channel rows)
+        const int tiles = ((a.M + 127) / 128) * ((a.Co + 127) / 128);
+        const int nk = a.ntaps * (a.Ci / 32);
+        if (a.ws && tiles <= 128 && a.Co % 4 == 0 && WGS_ABL != 13) {
+            int ks = 256 / tiles;
+            if (ks > nk / 6) ks = nk / 6;                                   // >= 6 chunks per split
+            const long per = (long)a.M * a.Co * 4;
+            if ((long)ks * per > a.ws_bytes) ks = (int)(a.ws_bytes / per);
+            if (ks > 16) ks = 16;
+            if (ks >= 2) {
+                const int kper = (nk + ks - 1) / ks;
+                ks = (nk + kper - 1) / kper;                               // no empty splits
+                a.ksplit = ks;
+            }
+        }
+        launch<128, 128, 2, 2>(a, st);
+        if (a.ksplit > 1) {
+            const long work = (long)a.M * (a.Co / 4);
+            hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+        }
+    }
     else if (a.Co > 32) launch<128, 64, 2, 2>(a, st);
     else launch<128, 32, 4, 1>(a, st);
     return 0;
