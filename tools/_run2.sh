@@ -1,3 +1,2 @@
-timeout 300 python -m pytest tests -m gpu -q -x -k "bf16 or conv" 2>&1 | tail -3
-timeout 100 python tools/bench_small.py
-WGS_LIB=$PWD/tools/_bin/libwgs_abl13.so timeout 100 python tools/bench_small.py
+timeout 600 python -m pytest tests -m gpu -q -x -k "native or stylegan2 or seam or upfirdn or split" 2>&1 | tail -3
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | head -2

@@ -6,6 +6,7 @@
 // 2048 workgroups with a grid-stride loop.  The training hot path uses fused variants of these
 // (stylegan2_ops.hip); the entry points here keep the reference's generic operator contract.
 #include "wgs_common.h"
+#include "fir4.h"
 #include "../../include/wgs.h"
 
 namespace {
@@ -152,6 +153,13 @@ int wgs_upfirdn2d(const float* x, const float* kernel, float* y, int major, int 
     p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
     WGS_CHECK_ARG(p.out_h > 0 && p.out_w > 0, "wgs_upfirdn2d: empty output %dx%d", p.out_h, p.out_w);
     const bool v4 = (minor % 4 == 0);
+    if (v4 && kh == 4 && kw == 4 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1) {
+        // the StyleGAN2 blur and its gradient on wide NHWC tensors: sliding-window form (fir4.h)
+        wgsfir::launch_fir4<false>(x, kernel, y, major, in_h, in_w, p.out_h, p.out_w, minor, pad_y0, pad_x0, nullptr, nullptr,
+                                   nullptr, (hipStream_t)stream);
+        WGS_CHECK_LAUNCH("fir4_kernel");
+        return WGS_OK;
+    }
     const int64_t total = (int64_t)major * p.out_h * p.out_w * (v4 ? minor / 4 : minor);
     int grid = wgs_cdiv(total, 256);
     if (grid > 4096) grid = 4096;

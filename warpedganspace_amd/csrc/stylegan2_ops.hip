@@ -4,6 +4,7 @@
 // :270-282, and the hand-derived backward of the shifted branch (dgrad only; G is frozen).
 // All HBM-/latency-bound: float4 accesses over the channel (NHWC minor) axis, wave64 reductions.
 #include "wgs_common.h"
+#include "fir4.h"
 #include "../../include/wgs.h"
 
 namespace {
@@ -130,50 +131,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     if (db && k == 0) db[n] = accb;
 }
 
-// ---- Blur(4x4, pad (1,1)) + noise + bias + leaky-relu*sqrt(2) on NHWC ------------------------------
-// in [B, Hin, Win, C] (Hin = Ho+1), out [B, Ho, Wo, C].  The separable [1,3,3,1] kernel (outer product,
-// normalised, times up^2 = 4) is symmetric, so flipping is a no-op: k2[a][b] = k1[a]*k1[b]*4/64.
-__global__ __launch_bounds__(256) void blur_nba_kernel(const float* __restrict__ x, const float* __restrict__ kern,
-                                                       const float* __restrict__ noise, const float* __restrict__ noise_w,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                       int Ho, int Wo, int C) {
-    __shared__ float sk[16];
-    if (threadIdx.x < 16) sk[threadIdx.x] = kern[15 - threadIdx.x];  // flipped (upfirdn2d correlates with flip)
-    __syncthreads();
-    const int Hin = Ho + 1, Win = Wo + 1;
-    const int c4n = C >> 2;
-    const int64_t total = (int64_t)B * Ho * Wo * c4n;
-    const float nw = noise ? noise_w[0] : 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = e;
-        const int c = (int)(r % c4n) * 4; r /= c4n;
-        const int ox = (int)(r % Wo); r /= Wo;
-        const int oy = (int)(r % Ho);
-        const int b = (int)(r / Ho);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            const int iy = oy + ky - 1;
-            if (iy < 0 || iy >= Hin) continue;
-#pragma unroll
-            for (int kx = 0; kx < 4; ++kx) {
-                const int ix = ox + kx - 1;
-                if (ix < 0 || ix >= Win) continue;
-                const float wv = sk[ky * 4 + kx];
-                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * Hin + iy) * Win + ix) * C + c);
-                acc.x = fmaf(v.x, wv, acc.x); acc.y = fmaf(v.y, wv, acc.y);
-                acc.z = fmaf(v.z, wv, acc.z); acc.w = fmaf(v.w, wv, acc.w);
-            }
-        }
-        const float nz = noise ? nw * noise[oy * Wo + ox] : 0.f;
-        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
-        float4 o;
-        o.x = acc.x + nz + bv.x; o.y = acc.y + nz + bv.y; o.z = acc.z + nz + bv.z; o.w = acc.w + nz + bv.w;
-        o.x = (o.x > 0.f ? o.x : 0.2f * o.x) * SQRT2; o.y = (o.y > 0.f ? o.y : 0.2f * o.y) * SQRT2;
-        o.z = (o.z > 0.f ? o.z : 0.2f * o.z) * SQRT2; o.w = (o.w > 0.f ? o.w : 0.2f * o.w) * SQRT2;
-        *reinterpret_cast<float4*>(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c) = o;
-    }
-}
+// ---- Blur(4x4, pad (1,1)) + noise + bias + leaky-relu*sqrt(2) on NHWC: fir4.h (sliding-window FIR, EPI = true) ----
 
 // ---- ToRGB: 1x1 modulated conv to 3 channels, no demod, + bias + up-sampled skip -> NCHW image ------
 // img[b,o,p] = wscale * sum_c x[b,p,c] s[b,c] W[o,c] + bias[o] + skip[b,o,p]
@@ -426,11 +384,8 @@ int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const fl
     WGS_CHECK_ARG(x && kernel4x4 && bias && y, "wgs_sg2_blur_noise_bias_act: null pointer");
     WGS_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "wgs_sg2_blur_noise_bias_act: bad sizes (C %% 4)");
     WGS_CHECK_ARG(!noise || noise_w, "wgs_sg2_blur_noise_bias_act: noise needs noise_w");
-    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
-    int grid = wgs_cdiv(total, 256);
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(blur_nba_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, kernel4x4, noise, noise_w, bias, y, B, Ho, Wo, C);
-    WGS_CHECK_LAUNCH("blur_nba_kernel");
+    wgsfir::launch_fir4<true>(x, kernel4x4, y, B, Ho + 1, Wo + 1, Ho, Wo, C, 1, 1, noise, noise_w, bias, (hipStream_t)stream);
+    WGS_CHECK_LAUNCH("fir4_kernel<epilogue>");
     return WGS_OK;
 }
 
