@@ -40,6 +40,23 @@ inline void fill_tap_tables(ConvArgs& a) {
 }
 
 
+// Split-K policy shared by both kernels: `tiles` 128x128 output tiles, `nk` K-chunks.  Returns the number of splits
+// (1 = none): fill ~256 CUs, at least 6 chunks per split, at most 16, bounded by the caller's workspace.
+inline int choose_ksplit(const ConvArgs& a, int tiles, int nk) {
+    if (!a.ws || tiles > 128 || a.Co % 4 != 0) return 1;
+    int ks = 256 / tiles;
+    if (ks > nk / 6) ks = nk / 6;
+    const long per = (long)a.M * a.Co * 4;
+    if ((long)ks * per > a.ws_bytes) ks = (int)(a.ws_bytes / per);
+    if (ks > 16) ks = 16;
+    if (ks < 2) return 1;
+    const int kper = (nk + ks - 1) / ks;
+    return (nk + kper - 1) / kper;      // no empty splits
+}
+
+// second pass of a split-K launch: reduce ws[split][M][Co] and apply the epilogue (conv_igemm_bf16.hip)
+void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st);
+
 // split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per product block) variant; returns 0 when it handled the launch,
 // 1 when the shape is not supported (caller falls back to the exact fp32 kernel).
 int launch_bf16x3(const ConvArgs& a, hipStream_t st);

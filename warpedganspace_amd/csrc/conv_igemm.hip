@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
     float4 ra[PA], rb[PB], rs[ASCALE ? PA : 1];
     unsigned amask = 0, bmask = 0;
     const int cpt = p.Ci / BK;  // K-chunks per tap
-    const int nk = p.ntaps * cpt;
+    // split-K (see wgs_conv_desc.ws): workgroup (tile, blockIdx.y) contracts chunks [kbeg, kend)
+    const int nk_all = p.ntaps * cpt;
+    const int kper = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int kbeg = (int)blockIdx.y * kper;
+    const int kend = min(nk_all, kbeg + kper);
 
     auto load_tile = [&](int kt) {
         const int t = kt / cpt;
@@ -132,14 +136,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
+    load_tile(kbeg);
     store_tile(0);
     __syncthreads();
 
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt = kbeg; kt < kend; ++kt) {
+        const int cur = (kt - kbeg) & 1;
+        if (kt + 1 < kend) load_tile(kt + 1);
         const float* a = As + cur * BM * LD + (wm * WM + l31) * LD + lh;
         const float* b = Bs + cur * BN * LD + (wn * WN + l31) * LD + lh;
 #pragma unroll
@@ -155,10 +159,26 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (kt + 1 < kend) store_tile(cur ^ 1);
         __syncthreads();
     }
 
+    if (p.ksplit > 1) {
+        // raw partial tile -> ws[split][m][n]; wgsconv::launch_splitk_epilogue reduces and finishes
+        float* part = p.ws + (size_t)blockIdx.y * p.M * p.Co;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < p.M && n < p.Co) part[(size_t)m * p.Co + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue: per-row output addressing (and the noise term) staged once in LDS ------------------
     int* r_pix = reinterpret_cast<int*>(smem);   // output pixel index (b*Ho+oy)*Wo+ox, or -1
     int* r_b = r_pix + BM;                       // sample index
@@ -357,7 +377,7 @@ int launch_nt(const ConvArgs& a, hipStream_t st) {
     const size_t smem = (size_t)2 * (BM + BN) * (BK + 1) * sizeof(float);
     const size_t smem_epi = (size_t)4 * BM * sizeof(int);
     const size_t sm = smem > smem_epi ? smem : smem_epi;
-    dim3 grid((unsigned)(ntm * ntn)), block(256);
+    dim3 grid((unsigned)(ntm * ntn), (unsigned)a.ksplit), block(256);
     if (a.a_scale) {
         auto k = igemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>;
         if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -432,7 +452,12 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         return WGS_OK;
     }
     if (d->Co > 64) {
+        // too few tiles for the 256 CUs (ResNet layer3/4 at 16x16 / 8x8): split K over the caller's workspace
+        const int tiles = ((a.M + 127) / 128) * ((a.Co + 127) / 128);
+        const int nk = a.ntaps * (a.Ci / (k32 ? 32 : 8));
+        a.ksplit = wgsconv::choose_ksplit(a, tiles, nk);
         if (k32) launch_nt<128, 128, 32, 2, 2>(a, st); else launch_nt<128, 128, 8, 2, 2>(a, st);
+        if (a.ksplit > 1) wgsconv::launch_splitk_epilogue(a, st);
     } else if (d->Co > 32) {
         if (k32) launch_nt<128, 64, 32, 2, 2>(a, st); else launch_nt<128, 64, 8, 2, 2>(a, st);
     } else {

@@ -454,6 +454,11 @@ void launch_big(const ConvArgs& a, hipStream_t st) {
 
 namespace wgsconv {
 
+void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st) {
+    const long work = (long)a.M * (a.Co / 4);
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+}
+
 int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     if (a0.Ci % 32 != 0) return 1;
     ConvArgs a = a0;
@@ -475,24 +480,9 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     else if (a.Co > 64) {
         // too few 128x128 tiles for the 256 CUs: split K (needs the caller's workspace and 4-channel rows)
         const int tiles = ((a.M + 127) / 128) * ((a.Co + 127) / 128);
-        const int nk = a.ntaps * (a.Ci / 32);
-        if (a.ws && tiles <= 128 && a.Co % 4 == 0 && WGS_ABL != 13) {
-            int ks = 256 / tiles;
-            if (ks > nk / 6) ks = nk / 6;                                   // >= 6 chunks per split
-            const long per = (long)a.M * a.Co * 4;
-            if ((long)ks * per > a.ws_bytes) ks = (int)(a.ws_bytes / per);
-            if (ks > 16) ks = 16;
-            if (ks >= 2) {
-                const int kper = (nk + ks - 1) / ks;
-                ks = (nk + kper - 1) / kper;                               // no empty splits
-                a.ksplit = ks;
-            }
-        }
+        a.ksplit = WGS_ABL == 13 ? 1 : choose_ksplit(a, tiles, a.ntaps * (a.Ci / 32));
         launch<128, 128, 2, 2>(a, st);
-        if (a.ksplit > 1) {
-            const long work = (long)a.M * (a.Co / 4);
-            hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
-        }
+        if (a.ksplit > 1) launch_splitk_epilogue(a, st);
     }
     else if (a.Co > 32) launch<128, 64, 2, 2>(a, st);
     else launch<128, 32, 4, 1>(a, st);

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
             is = *reinterpret_cast<const float4*>(invstd + c);
         }
         if (active) {
-            for (int64_t r = r_begin + sub; r < r_end; r += rpi) {
+            // rows r, r+rpi, r+2rpi, r+3rpi per trip: four independent load groups in flight per thread
+            auto accum = [&](int64_t r) {
                 const size_t off = (size_t)r * C + c;
                 if (MODE == 0) {
                     const float4 v = *reinterpret_cast<const float4*>(x + off);
@@ -91,7 +92,12 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
                     a2.x = fmaf(g.x, (v.x - mu.x) * is.x, a2.x); a2.y = fmaf(g.y, (v.y - mu.y) * is.y, a2.y);
                     a2.z = fmaf(g.z, (v.z - mu.z) * is.z, a2.z); a2.w = fmaf(g.w, (v.w - mu.w) * is.w, a2.w);
                 }
+            };
+            int64_t r = r_begin + sub;
+            for (; r + 3 * (int64_t)rpi < r_end; r += 4 * (int64_t)rpi) {
+                accum(r); accum(r + rpi); accum(r + 2 * (int64_t)rpi); accum(r + 3 * (int64_t)rpi);
             }
+            for (; r < r_end; r += rpi) accum(r);
         }
         __syncthreads();
         red[0][threadIdx.x][0] = a1.x; red[0][threadIdx.x][1] = a1.y; red[0][threadIdx.x][2] = a1.z; red[0][threadIdx.x][3] = a1.w;
@@ -423,7 +429,7 @@ static int reduce_rows_per_block(int64_t N, int C) {
     const int c4n = C >> 2;
     const int tpr = c4n < 256 ? c4n : 256;
     const int rpi = 256 / tpr;
-    int64_t rpb = (N + 2047) / 2048;
+    int64_t rpb = (N + 767) / 768;     // ~3 workgroups per CU: enough loads in flight, few same-address fp64 atomics
     if (rpb < rpi * 4) rpb = rpi * 4;
     return (int)rpb;
 }

@@ -58,24 +58,30 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         wr[t] = (k < K) ? *reinterpret_cast<const float4*>(w + (size_t)n * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float b = bias ? bias[n] * bscale : 0.f;
-    for (int m = 0; m < M; ++m) {
-        float acc = 0.f;
+    // four batch rows per trip: their loads and shuffle reductions are independent, so the latencies overlap
+    for (int m0 = 0; m0 < M; m0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int k = 4 * lane + 256 * t;
-            if (k < K) {
-                float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k);
-                if (in_square) { xv.x *= xv.x; xv.y *= xv.y; xv.z *= xv.z; xv.w *= xv.w; }
-                acc = fmaf(xv.x, wr[t].x, acc); acc = fmaf(xv.y, wr[t].y, acc);
-                acc = fmaf(xv.z, wr[t].z, acc); acc = fmaf(xv.w, wr[t].w, acc);
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + u < M ? m0 + u : M - 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int k = 4 * lane + 256 * t;
+                if (k < K) {
+                    float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k);
+                    if (in_square) { xv.x *= xv.x; xv.y *= xv.y; xv.z *= xv.z; xv.w *= xv.w; }
+                    acc[u] = fmaf(xv.x, wr[t].x, acc[u]); acc[u] = fmaf(xv.y, wr[t].y, acc[u]);
+                    acc[u] = fmaf(xv.z, wr[t].z, acc[u]); acc[u] = fmaf(xv.w, wr[t].w, acc[u]);
+                }
             }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            float v = fmaf(acc, wscale, b);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane < 4 && m0 + lane < M) {
+            float v = fmaf(lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3], wscale, b);
             if (epi == 1) v = (v > 0.f ? v : 0.2f * v) * SQRT2;
             else if (epi == 2) v = rsqrtf(v + eps);
-            y[(size_t)m * ldy + n] = v * out_gain;
+            y[(size_t)(m0 + lane) * ldy + n] = v * out_gain;
         }
     }
 }
@@ -308,17 +314,30 @@ __global__ __launch_bounds__(256) void sg2_style_grad_kernel(const float* __rest
                                                              const float* __restrict__ wsq, float scale2,
                                                              float* __restrict__ dstyle, int Co, int Ci, int lds_,
                                                              int ldo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // block = 64 input channels x 4 partitions of the output-channel sum (fp64, combined through LDS)
+    __shared__ double red[4][64];
+    const int il = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
     const int b = blockIdx.y;
-    if (i >= Ci) return;
-    double acc = 0.0;
-    if (demod) {
-        for (int o = 0; o < Co; ++o) {
-            const double dm = demod[(size_t)b * Co + o];
-            acc = fma((double)num[(size_t)b * Co + o] * dm * dm, (double)wsq[(size_t)o * Ci + i], acc);
+    double acc0 = 0.0, acc1 = 0.0;
+    if (demod && i < Ci) {
+        int o = part;
+        for (; o + 4 < Co; o += 8) {
+            const double d0 = demod[(size_t)b * Co + o], d1 = demod[(size_t)b * Co + o + 4];
+            acc0 = fma((double)num[(size_t)b * Co + o] * d0 * d0, (double)wsq[(size_t)o * Ci + i], acc0);
+            acc1 = fma((double)num[(size_t)b * Co + o + 4] * d1 * d1, (double)wsq[(size_t)(o + 4) * Ci + i], acc1);
+        }
+        for (; o < Co; o += 4) {
+            const double d0 = demod[(size_t)b * Co + o];
+            acc0 = fma((double)num[(size_t)b * Co + o] * d0 * d0, (double)wsq[(size_t)o * Ci + i], acc0);
         }
     }
-    dstyle[(size_t)b * ldo + i] = (float)((double)dsdir[(size_t)b * Ci + i] - (double)s[(size_t)b * lds_ + i] * scale2 * acc);
+    red[part][il] = acc0 + acc1;
+    __syncthreads();
+    if (part == 0 && i < Ci) {
+        const double acc = red[0][il] + red[1][il] + red[2][il] + red[3][il];
+        dstyle[(size_t)b * ldo + i] = (float)((double)dsdir[(size_t)b * Ci + i] - (double)s[(size_t)b * lds_ + i] * scale2 * acc);
+    }
 }
 
 // wsq[o,i] = sum_t w[o,t,i]^2   (w packed [Co,T,Ci]; one-off for the frozen generator)
@@ -430,7 +449,7 @@ int wgs_sg2_style_grad(const float* num, const float* demod, const float* s, con
                        float scale2, float* dstyle, int B, int Co, int Ci, int ld_s, int ld_out, wgs_stream_t stream) {
     WGS_CHECK_ARG(s && dsdir && dstyle && B > 0 && Co > 0 && Ci > 0, "wgs_sg2_style_grad: bad arguments");
     WGS_CHECK_ARG(!demod || (num && wsq), "wgs_sg2_style_grad: demod needs num and wsq");
-    hipLaunchKernelGGL(sg2_style_grad_kernel, dim3(wgs_cdiv(Ci, 256), B), dim3(256), 0, (hipStream_t)stream, num, demod, s,
+    hipLaunchKernelGGL(sg2_style_grad_kernel, dim3(wgs_cdiv(Ci, 64), B), dim3(256), 0, (hipStream_t)stream, num, demod, s,
                        dsdir, wsq, scale2, dstyle, Co, Ci, ld_s, ld_out);
     WGS_CHECK_LAUNCH("sg2_style_grad_kernel");
     return WGS_OK;
