@@ -1,2 +1,3 @@
-timeout 600 python -m pytest tests -m gpu -q -x -k "native or stylegan2 or seam or upfirdn or split" 2>&1 | tail -3
+timeout 600 python -m pytest tests -m gpu -q -x -k "bf16 or conv or stylegan2" 2>&1 | tail -3
+timeout 100 python tools/bench_small.py
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | head -2

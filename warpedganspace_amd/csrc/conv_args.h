@@ -18,6 +18,7 @@ struct ConvArgs {
     int B, Hi, Wi, Ci, Hg, Wg, isy, isx, Ho, Wo, Co, osy, osx, oy0, ox0, ntaps, M, a_ld, col_ld, ups, add_ups, act;
     long w_tap_stride, w_row_stride;
     float act_slope, gain, alpha;
+    int HW, Mimg;       // Hg*Wg, and GEMM rows per sample (>= HW; M = B*Mimg).  Mimg == HW except in launch_bf16x3
     float* ws;          // split-K workspace or null
     long ws_bytes;
     int ksplit;         // K splits of this launch (1 = none); set by launch_bf16x3

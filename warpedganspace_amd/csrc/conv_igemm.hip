@@ -435,6 +435,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     a.isy = d->isy; a.isx = d->isx; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.osy = d->osy; a.osx = d->osx; a.oy0 = d->oy0; a.ox0 = d->ox0; a.ntaps = d->ntaps;
     a.M = d->B * d->Hg * d->Wg;
+    a.HW = d->Hg * d->Wg; a.Mimg = a.HW;
     a.a_ld = d->a_ld > 0 ? d->a_ld : d->Ci;
     a.col_ld = d->col_ld > 0 ? d->col_ld : d->Co;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;

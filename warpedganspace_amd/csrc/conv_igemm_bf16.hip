@@ -90,16 +90,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ASCALE ? p.a_scale : p.x), 0, ASCALE ? p.s_bytes : 0, 0x00020000);
 
     int a_iy0[PA], a_ix0[PA], a_off[PA], s_off[PS];
-    if (ASCALE == 2) s_off[0] = ((m0 / (p.Hg * p.Wg)) * p.a_ld + q * 4) * 4;
+    if (ASCALE == 2) s_off[0] = ((m0 / p.Mimg) * p.a_ld + q * 4) * 4;
 #pragma unroll
     for (int pa = 0; pa < PA; ++pa) {
         const int m = m0 + r0 + pa * RPP;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int gx = mm % p.Wg;
-        const int t = mm / p.Wg;
-        const int gy = t % p.Hg;
-        const int b = t / p.Hg;
+        // GEMM row m -> (sample b, pixel pix of the Hg x Wg grid); a sample owns Mimg >= Hg*Wg consecutive rows
+        // (Mimg is rounded up to the tile height when that keeps every tile inside one sample, see launch_bf16x3)
+        const int bq = m / p.Mimg, pq = m - bq * p.Mimg;
+        const bool ok = m < p.M && pq < p.HW;
+        const int b = ok ? bq : 0, pix = ok ? pq : 0;
+        const int gy = pix / p.Wg, gx = pix - gy * p.Wg;
         a_iy0[pa] = ok ? gy * p.isy : -100000;
         a_ix0[pa] = gx * p.isx;
         // UPS: pixel index of the image origin; otherwise byte offset of (b, iy0, ix0, q*4) — taps add a uniform delta
@@ -335,11 +335,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
         const int m = m0 + tid;
         int pix = -1, bb = 0, ap = 0;
         float nz = 0.f;
-        if (m < p.M) {
-            const int gx = m % p.Wg;
-            const int t = m / p.Wg;
-            const int gy = t % p.Hg;
-            bb = t / p.Hg;
+        const int bq = m / p.Mimg, pq = m - bq * p.Mimg;
+        if (m < p.M && pq < p.HW) {
+            const int gy = pq / p.Wg, gx = pq - gy * p.Wg;
+            bb = bq;
             const int hw = (gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
             pix = bb * p.Ho * p.Wo + hw;
             if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     __syncthreads();
     const int b_lo = r_b[0];
     const int m_last = min(m0 + BM, p.M) - 1;
-    const int b_hi2 = (m_last / p.Wg) / p.Hg;
+    const int b_hi2 = m_last / p.Mimg;
     const bool cs_fast = p.col_scale && (b_hi2 - b_lo <= 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -394,10 +393,9 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArg
         const float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)s * p.M + m) * p.Co + n);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
-    const int gx = m % p.Wg;
-    const int t = m / p.Wg;
-    const int gy = t % p.Hg;
-    const int b = t / p.Hg;
+    const int b = m / p.Mimg, pq = m - b * p.Mimg;
+    if (pq >= p.HW) return;            // padding row of a sample (see launch_bf16x3)
+    const int gy = pq / p.Wg, gx = pq - gy * p.Wg;
     const int oy = gy * p.osy + p.oy0, ox = gx * p.osx + p.ox0;
     const int hw = oy * p.Wo + ox;
     const float nz = (p.noise && p.noise_w) ? p.noise_w[0] * p.noise[hw] : 0.f;
@@ -418,7 +416,7 @@ void launch(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a.ksplit), block(64 * WAVES_M * WAVES_N);
-    const int mode = !a.a_scale ? 0 : ((a.Hg * a.Wg) % BM == 0 ? 2 : 1);
+    const int mode = !a.a_scale ? 0 : (a.Mimg % BM == 0 ? 2 : 1);
 #define WGS_BF16_LAUNCH(AS, UP)                                                                             \
     {                                                                                                       \
         auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, AS, UP>;                                  \
@@ -472,12 +470,18 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     if (xb > lim || wb > lim || sb > lim) return 1;
     a.x_bytes = (int)xb; a.w_bytes = (int)wb; a.s_bytes = (int)sb;
     fill_tap_tables(a);
-    // 256-row tiles quarter the vector-memory / LDS-store work per MFMA; used when they still fill the 256 CUs
-    const bool big_ok = !a.ups && (!a.a_scale || (a.Hg * a.Wg) % 256 == 0) && WGS_ABL != 11;
-    const int ntm256 = (a.M + 255) / 256;
-    if (big_ok && a.Co % 256 == 0 && ntm256 * (a.Co / 256) >= 200) launch_big<256, 256, 2, 4>(a, st);
-    else if (big_ok && a.Co % 128 == 0 && ntm256 * (a.Co / 128) >= 200) launch_big<256, 128, 4, 2>(a, st);
-    else if (a.Co > 64) {
+    // Styled launches want every tile inside one sample (one style vector per tile, and the only form the 8-wave
+    // tiles support).  When Hg*Wg is not a multiple of the tile height (the sub-pixel phases of the up-convs: 65x65,
+    // 129x129 ...) each sample's row range is padded up to it, if that costs < 13 % extra rows.
+    auto padded = [&](int bm) { const int mp = (a.HW + bm - 1) / bm * bm; return (!a.a_scale || mp * 100L <= a.HW * 113L) ? mp : 0; };
+    auto use_rows = [&](int mimg) { a.Mimg = mimg; a.M = a.B * mimg; };
+    const int mp256 = a.a_scale ? padded(256) : a.HW, mp128 = a.a_scale ? padded(128) : a.HW;
+    const int ntm256 = mp256 ? (a.B * mp256 + 255) / 256 : 0;
+    const bool big_ok = !a.ups && mp256 && WGS_ABL != 11;
+    if (big_ok && a.Co % 256 == 0 && ntm256 * (a.Co / 256) >= 200) { use_rows(mp256); launch_big<256, 256, 2, 4>(a, st); return 0; }
+    if (big_ok && a.Co % 128 == 0 && ntm256 * (a.Co / 128) >= 200) { use_rows(mp256); launch_big<256, 128, 4, 2>(a, st); return 0; }
+    if (mp128) use_rows(mp128);
+    if (a.Co > 64) {
         // too few 128x128 tiles for the 256 CUs: split K (needs the caller's workspace and 4-channel rows)
         const int tiles = ((a.M + 127) / 128) * ((a.Co + 127) / 128);
         a.ksplit = WGS_ABL == 13 ? 1 : choose_ksplit(a, tiles, a.ntaps * (a.Ci / 32));
