@@ -130,9 +130,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     const int Hup = p.Hi << p.ups, Wup = p.Wi << p.ups;
 
     // K order: channel chunk OUTER, tap INNER — consecutive iterations re-read the same pixels' channel chunk shifted
-    // by one tap, so a tile's activation working set per chunk (~17 KB) stays in L1/L2 across the taps.  Each
-    // workgroup starts at a different chunk so that concurrently running workgroups spread over the L2 channels.
-    const int kofs = (int)(blockIdx.x >> 3) % cpt;
+    // by one tap, so a tile's activation working set per chunk (~17 KB) stays in L1/L2 across the taps, and the
+    // workgroups of an XCD walk the chunks roughly in step, sharing each weight chunk in that XCD's L2.  (Starting
+    // every workgroup at a different chunk — WGS_ABL 5 — spreads L2 channels but makes the weights thrash: measured slower.)
+    const int kofs = WGS_ABL == 5 ? (int)(blockIdx.x >> 3) % cpt : 0;
     // The main loop issues its loads unconditionally (straight-line code lets the compiler count vmcnt exactly and
     // keep the far prefetch in flight across the LDS store); past the last chunk the uniform offset becomes OOB.
     int tA = kbeg % p.ntaps, cA = (kbeg / p.ntaps + kofs) % cpt;      // (tap, chunk) cursors of the activation ...
