@@ -1,4 +1,2 @@
-timeout 100 python tools/bench_abl.py
-WGS_LIB=$PWD/tools/_bin/libwgs_abl5.so timeout 100 python tools/bench_abl.py 2>&1 | grep TF
-export TMPDIR=/tmp
-WGS_LIB=$PWD/tools/_bin/libwgs_abl5.so timeout 150 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc3/hit5 -o p -- python tools/pmc_conv.py > gpurun_out/pmc3/hit5.log 2>&1
+timeout 600 python -m pytest tests -m gpu -q -x -k "conv or reconstructor or lenet or step" 2>&1 | tail -3
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | head -2

@@ -252,7 +252,9 @@ struct WgradArgs {
     short wt[64];
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// FLAT (few input channels, e.g. ResNet conv1 with Ci = 8): the GEMM columns are the flattened (tap, ci) pairs, so one
+// launch reads dy once for all taps instead of once per tap; grid.y = 1.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool FLAT = false>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
     constexpr int BK = 32;                 // pixels per chunk
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
@@ -264,10 +266,16 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int ntn = (p.Ci + BN - 1) / BN;
+    const int ntn = ((FLAT ? p.ntaps * p.Ci : p.Ci) + BN - 1) / BN;
     const int co0 = (blockIdx.x / ntn) * BM, ci0 = (blockIdx.x % ntn) * BN;
     const int t = blockIdx.y;
     const int dyt = p.dy_[t], dxt = p.dx_[t];
+    __shared__ int tap_yx[64];
+    if (FLAT) {
+        if (tid < p.ntaps) tap_yx[tid] = ((int)p.dy_[tid] & 0xffff) | ((int)p.dx_[tid] << 16);
+        __syncthreads();
+    }
+    const int ncol = FLAT ? p.ntaps * p.Ci : p.Ci;
     const int nchunks = (p.M + BK - 1) / BK;
     const int per = (nchunks + p.ksplit - 1) / p.ksplit;
     const int c_begin = blockIdx.z * per, c_end = min(nchunks, c_begin + per);
@@ -292,14 +300,21 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
             const int m = mbase + k;
             const int ci = ci0 + c4 * 4;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((e < BK * CB) && (m < p.M) && (ci < p.Ci)) {
+            if ((e < BK * CB) && (m < p.M) && (ci < ncol)) {
                 const int ox = m % p.Wo;
                 const int tt = m / p.Wo;
                 const int oy = tt % p.Ho;
                 const int b = tt / p.Ho;
-                const int iy = oy * p.isy + dyt, ix = ox * p.isx + dxt;
+                int dyc = dyt, dxc = dxt, cic = ci;
+                if (FLAT) {
+                    const int tc = ci / p.Ci;
+                    cic = ci - tc * p.Ci;
+                    const int yx = tap_yx[tc];
+                    dyc = (int)(short)(yx & 0xffff); dxc = yx >> 16;
+                }
+                const int iy = oy * p.isy + dyc, ix = ox * p.isx + dxc;
                 if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                    val = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci);
+                    val = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + cic);
             }
             rb[pb] = val;
         }
@@ -353,17 +368,20 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
         __syncthreads();
     }
     if (wave >= NW) return;
-    float* out = p.dw + (size_t)p.wt[t] * p.w_tap_stride;
+    float* out = p.dw + (FLAT ? (size_t)0 : (size_t)p.wt[t] * p.w_tap_stride);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int ci = ci0 + wn * WN + j * 32 + l31;
+        int ci = ci0 + wn * WN + j * 32 + l31;
+        const bool cok = ci < ncol;
+        size_t coff = ci;
+        if (FLAT && cok) { const int tc = ci / p.Ci; coff = (size_t)p.wt[tc] * p.w_tap_stride + (ci - tc * p.Ci); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < p.Co && ci < p.Ci) {
-                    float* d = out + (size_t)co * p.w_row_stride + ci;
+                if (co < p.Co && cok) {
+                    float* d = out + (size_t)co * p.w_row_stride + coff;
                     unsafeAtomicAdd(d, acc[i][j][r]);
                 }
             }
@@ -480,6 +498,19 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
     a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
+    hipStream_t st = (hipStream_t)stream;
+    if (d->Ci < 32 && d->ntaps * d->Ci >= 64) {
+        // few input channels: flatten (tap, ci) into the GEMM columns — one pass over dy instead of one per tap
+        const int ncol = d->ntaps * d->Ci;
+        const int tiles = ((d->Co + 63) / 64) * ((ncol + 127) / 128);
+        const int nchunks = (a.M + 31) / 32;
+        int ks = d->ksplit;
+        if (ks <= 0) { ks = (1024 + tiles - 1) / tiles; if (ks > nchunks / 4) ks = nchunks / 4; if (ks < 1) ks = 1; }
+        a.ksplit = ks;
+        hipLaunchKernelGGL((igemm_wgrad_kernel<64, 128, 2, 2, true>), dim3((unsigned)tiles, 1, (unsigned)ks), dim3(256), 0, st, a);
+        WGS_CHECK_LAUNCH("igemm_wgrad_kernel<flat>");
+        return WGS_OK;
+    }
     const int BM = d->Co >= 128 ? 128 : 64;
     const int BN = d->Ci >= 128 ? 128 : (d->Ci >= 64 ? 64 : 32);
     const int tiles = ((d->Co + BM - 1) / BM) * ((d->Ci + BN - 1) / BN);
@@ -491,7 +522,6 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
         if (ks < 1) ks = 1;
     }
     a.ksplit = ks;
-    hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)d->ntaps, (unsigned)ks), block(256);
     if (BM == 128 && BN == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, block, 0, st, a);
     else if (BM == 128 && BN == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, block, 0, st, a);
