@@ -146,6 +146,10 @@ typedef struct wgs_conv_desc {
                                 reduces them and applies the epilogue.  Needs 4*ksplit*M*Co bytes; too small => fewer splits. */
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
+/* n launches that share every operand and differ only in (Hg, Wg, oy0, ox0, taps) — the 4 sub-pixel phases of a
+ * stride-2 transposed conv (models/StyleGAN2/model.py:201-212).  Same results as n wgs_conv_igemm calls; when the
+ * split-bf16 8-wave kernel covers the shape they run as ONE launch (short-K phases fill the chip together). */
+int wgs_conv_igemm_multi(const wgs_conv_desc* descs, int n, wgs_stream_t stream);
 
 /* Weight gradient of a (strided) conv:  dw[co*w_row_stride + wt[t]*w_tap_stride + ci] +=
  *   sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*isy + dy[t], ox*isx + dx[t], ci]

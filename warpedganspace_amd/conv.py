@@ -69,13 +69,13 @@ def _timed(kind, flops, fn):
     return r
 
 
-def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
-           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
-           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None):
-    """taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
+def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
+          a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
+          a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None):
+    """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
         raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
-    d = ConvDesc()
+    d = ConvDesc() if into is None else into
     d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     d.a_scale, d.col_scale, d.bias = _p(a_scale), _p(col_scale), _p(bias)
     d.noise, d.noise_w = _p(noise), _p(noise_w)
@@ -93,8 +93,24 @@ def launch(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None,
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     for i, (ty, tx, ti) in enumerate(taps):
         d.dy[i], d.dx[i], d.wt[i] = ty, tx, ti
-    flops = 2.0 * d.B * Hg * Wg * d.Co * d.Ci * len(taps)
+    return d, 2.0 * d.B * Hg * Wg * d.Co * d.Ci * len(taps)
+
+
+def launch(x, w, y, taps, Hg, Wg, **kw):
+    """One implicit-GEMM launch (wgs_conv_igemm)."""
+    d, flops = _desc(x, w, y, taps, Hg, Wg, **kw)
     _timed('igemm_nt', flops, lambda: L.check(L.lib().wgs_conv_igemm(ctypes.byref(d), L.stream()), 'wgs_conv_igemm'))
+    return y
+
+
+def launch_multi(x, w, y, phases, **kw):
+    """Launches that differ only in (taps, Hg, Wg, oy0, ox0) — the sub-pixel phases of a transposed conv — through
+    wgs_conv_igemm_multi (one merged launch where the library supports it).  phases: list of (taps, Hg, Wg, oy0, ox0)."""
+    descs = (ConvDesc * len(phases))()
+    flops = 0.0
+    for i, (taps, Hg, Wg, oy0, ox0) in enumerate(phases):
+        flops += _desc(x, w, y, taps, Hg, Wg, oy0=oy0, ox0=ox0, into=descs[i], **kw)[1]
+    _timed('igemm_nt', flops, lambda: L.check(L.lib().wgs_conv_igemm_multi(descs, len(phases), L.stream()), 'wgs_conv_igemm_multi'))
     return y
 
 
@@ -144,14 +160,13 @@ def conv_transpose2d_s2(x, w_packed, k=3, out=None, **epi):
     Co = w_packed.shape[0]
     Ho, Wo = 2 * (Hi - 1) + k, 2 * (Wi - 1) + k
     y = out if out is not None else torch.empty(B, Ho, Wo, Co, device=x.device, dtype=x.dtype)
+    phases = []
     for py in range(2):
         for px in range(2):
             taps = [((py - ky) // 2, (px - kx) // 2, ky * k + kx)
                     for ky in range(k) if (py - ky) % 2 == 0 for kx in range(k) if (px - kx) % 2 == 0]
-            Hg, Wg = (Ho - py + 1) // 2, (Wo - px + 1) // 2
-            launch(x, w_packed, y, taps, Hg, Wg, osy=2, oy0=py, ox0=px, w_tap_stride=Ci, w_row_stride=k * k * Ci,
-                   **epi)
-    return y
+            phases.append((taps, (Ho - py + 1) // 2, (Wo - px + 1) // 2, py, px))
+    return launch_multi(x, w_packed, y, phases, osy=2, w_tap_stride=Ci, w_row_stride=k * k * Ci, **epi)
 
 
 def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):

@@ -5,6 +5,14 @@
 
 namespace wgsconv {
 
+// One output "phase" of a launch: the GEMM-row geometry and tap tables that differ between the sub-pixel phases of a
+// stride-2 transposed conv.  The split-bf16 kernel always reads phase-dependent values from ph[] (ph[0] for an
+// ordinary conv), so that the four phases of an up-conv can run as ONE launch (wgs_conv_igemm_multi).
+struct PhaseArgs {
+    int Wg, oy0, ox0, ntaps, HW, Mimg, M, tiles, cnt8;   // merged launches: (m,n) tiles of this phase, and ceil(tiles/8) per XCD
+    int tap_yx[16], tap_a[16], tap_w[16];
+};
+
 struct ConvArgs {
     const float* x;
     const float* w;
@@ -30,6 +38,8 @@ struct ConvArgs {
     int tap_yx[64];     // (dy & 0xffff) | (dx << 16)
     int tap_a[64];      // byte offset of the tap inside x for the non-upsampling case: ((dy*Wi + dx) * Ci) * 4
     int tap_w[64];      // byte offset of the tap's weight slab: wt * w_tap_stride * 4
+    int nphase;
+    PhaseArgs ph[4];
 };
 
 inline void fill_tap_tables(ConvArgs& a) {
@@ -61,5 +71,7 @@ void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st);
 // split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per product block) variant; returns 0 when it handled the launch,
 // 1 when the shape is not supported (caller falls back to the exact fp32 kernel).
 int launch_bf16x3(const ConvArgs& a, hipStream_t st);
+// the same for n <= 4 launches that differ only in (Hg, Wg, oy0, ox0, taps); 0 = handled as one merged launch
+int launch_bf16x3_multi(const ConvArgs* a, int n, hipStream_t st);
 
 }  // namespace wgsconv

@@ -437,7 +437,7 @@ int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stre
     return WGS_OK;
 }
 
-int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
+static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     WGS_CHECK_ARG(d && d->x && d->w && d->y, "wgs_conv_igemm: null pointer");
     WGS_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hg > 0 && d->Wg > 0 && d->Ho > 0 && d->Wo > 0,
                   "wgs_conv_igemm: bad spatial sizes");
@@ -446,7 +446,6 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     WGS_CHECK_ARG(d->ntaps > 0 && d->ntaps <= 64, "wgs_conv_igemm: ntaps=%d out of range (1..64)", d->ntaps);
     WGS_CHECK_ARG((long)d->B * d->Hg * d->Wg < (1L << 31) && (long)d->B * d->Ho * d->Wo < (1L << 31),
                   "wgs_conv_igemm: pixel count overflows int32");
-    ConvArgs a;
     a.x = d->x; a.w = d->w; a.y = d->y; a.a_scale = d->a_scale; a.col_scale = d->col_scale;
     a.bias = d->bias; a.noise = d->noise; a.noise_w = d->noise_w;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Hg = d->Hg; a.Wg = d->Wg;
@@ -464,6 +463,13 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
     wgsconv::fill_tap_tables(a);
+    return WGS_OK;
+}
+
+int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
+    ConvArgs a;
+    const int rc = build_conv_args(d, a);
+    if (rc != WGS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bool k32 = (d->Ci % 32 == 0);
     if (d->precision == 1 && wgsconv::launch_bf16x3(a, st) == 0) {
@@ -483,6 +489,24 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         if (k32) launch_nt<128, 32, 32, 4, 1>(a, st); else launch_nt<128, 32, 8, 4, 1>(a, st);
     }
     WGS_CHECK_LAUNCH("igemm_nt_kernel");
+    return WGS_OK;
+}
+
+int wgs_conv_igemm_multi(const wgs_conv_desc* descs, int n, wgs_stream_t stream) {
+    WGS_CHECK_ARG(descs && n > 0, "wgs_conv_igemm_multi: bad arguments");
+    if (n >= 2 && n <= 4 && descs[0].precision == 1) {
+        ConvArgs as[4];
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) ok = descs[i].precision == 1 && build_conv_args(&descs[i], as[i]) == WGS_OK;
+        if (ok && wgsconv::launch_bf16x3_multi(as, n, (hipStream_t)stream) == 0) {
+            WGS_CHECK_LAUNCH("igemm_nt_bf16x3_kernel<multi>");
+            return WGS_OK;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = wgs_conv_igemm(&descs[i], stream);
+        if (rc != WGS_OK) return rc;
+    }
     return WGS_OK;
 }
 

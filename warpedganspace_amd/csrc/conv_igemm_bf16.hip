@@ -20,6 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 using wgsconv::ConvArgs;
+using wgsconv::PhaseArgs;
 
 #ifndef WGS_ABL
 #define WGS_ABL 0   // development ablations: 1 no split arithmetic, 2 no LDS stores, 3 no MFMA, 4 no global loads,
@@ -73,13 +74,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     // XCD-aware tile order: hardware sends workgroup b to XCD b % 8.  Give every XCD a contiguous range of the
     // (m-tile major, n-tile minor) tile list, so the n-tiles of one m-tile and its neighbouring image rows run on the
     // same XCD at the same time and share their activation rows in that XCD's L2 instead of each fetching them from HBM.
-    int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x, xcd = bid & 7, slot = bid >> 3;
+    int phase = 0, tm, n0;
+    if (p.nphase == 1) {
+        const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int qn = nb >> 3, rn = nb & 7;
-        bid = xcd * qn + min(xcd, rn) + slot;
+        const int bid = xcd * qn + min(xcd, rn) + slot;
+        tm = bid / ntn;
+        n0 = (bid % ntn) * BN;
+    } else {
+        // merged phases: every XCD gets an equal slice of EVERY phase's tile list (the phases differ in work per tile —
+        // 4, 2, 2 and 1 taps — so slicing the concatenated list would leave some XCDs with only the heavy phase);
+        // each phase's tile count is padded to a multiple of 8 and the padding workgroups exit here.
+        const int xcd = blockIdx.x & 7;
+        int slot = blockIdx.x >> 3, t = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < p.nphase && t < 0) {
+                const int c = p.ph[i].cnt8;
+                if (slot < c) { t = xcd * c + slot; phase = i; } else slot -= c;
+            }
+        }
+        if (t < 0 || t >= p.ph[phase].tiles) return;
+        tm = t / ntn;
+        n0 = (t % ntn) * BN;
     }
-    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    const PhaseArgs& P = p.ph[phase];
+    const int m0 = tm * BM;
     const int q = tid % CPR, r0 = tid / CPR;
 
     // All three operand streams go through buffer descriptors: 32-bit byte offsets (one VGPR per address, uniform
@@ -90,16 +110,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ASCALE ? p.a_scale : p.x), 0, ASCALE ? p.s_bytes : 0, 0x00020000);
 
     int a_iy0[PA], a_ix0[PA], a_off[PA], s_off[PS];
-    if (ASCALE == 2) s_off[0] = ((m0 / p.Mimg) * p.a_ld + q * 4) * 4;
+    if (ASCALE == 2) s_off[0] = ((m0 / P.Mimg) * p.a_ld + q * 4) * 4;
 #pragma unroll
     for (int pa = 0; pa < PA; ++pa) {
         const int m = m0 + r0 + pa * RPP;
         // GEMM row m -> (sample b, pixel pix of the Hg x Wg grid); a sample owns Mimg >= Hg*Wg consecutive rows
         // (Mimg is rounded up to the tile height when that keeps every tile inside one sample, see launch_bf16x3)
-        const int bq = m / p.Mimg, pq = m - bq * p.Mimg;
-        const bool ok = m < p.M && pq < p.HW;
+        const int bq = m / P.Mimg, pq = m - bq * P.Mimg;
+        const bool ok = m < P.M && pq < P.HW;
         const int b = ok ? bq : 0, pix = ok ? pq : 0;
-        const int gy = pix / p.Wg, gx = pix - gy * p.Wg;
+        const int gy = pix / P.Wg, gx = pix - gy * P.Wg;
         a_iy0[pa] = ok ? gy * p.isy : -100000;
         a_ix0[pa] = gx * p.isx;
         // UPS: pixel index of the image origin; otherwise byte offset of (b, iy0, ix0, q*4) — taps add a uniform delta
@@ -123,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     float4 rs[PS], rb[PB];
     const int cpt = p.Ci / BK;
     // split-K: workgroup (tile, blockIdx.y) contracts chunks [kbeg, kbeg + nk) of the ntaps*cpt chunk sequence
-    const int nk_all = p.ntaps * cpt;
+    const int nk_all = P.ntaps * cpt;
     const int kper = (nk_all + p.ksplit - 1) / p.ksplit;
     const int kbeg = (int)blockIdx.y * kper;
     const int nk = min(kper, nk_all - kbeg);
@@ -136,25 +156,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     const int kofs = WGS_ABL == 5 ? (int)(blockIdx.x >> 3) % cpt : 0;
     // The main loop issues its loads unconditionally (straight-line code lets the compiler count vmcnt exactly and
     // keep the far prefetch in flight across the LDS store); past the last chunk the uniform offset becomes OOB.
-    int tA = kbeg % p.ntaps, cA = (kbeg / p.ntaps + kofs) % cpt;      // (tap, chunk) cursors of the activation ...
+    int tA = kbeg % P.ntaps, cA = (kbeg / P.ntaps + kofs) % cpt;      // (tap, chunk) cursors of the activation ...
     int tB = tA, cB = cA;                                              // ... and weight/style streams
     int nA = 0, nB = 0;                             // chunks requested so far
     // Per-chunk uniform state of the two streams (scalar registers), then one vector load per "piece":
     // pieces 0..PA-1 activation rows, PA..PA+PB-1 weight rows, PA+PB.. style vectors.
     int u_dy = 0, u_dx = 0, u_cbyteA = 0, u_delta = 0, u_cbyteB = 0, u_wdelta = 0;
     auto begin_tile = [&]() {
-        const int yx = p.tap_yx[tA];
+        const int yx = P.tap_yx[tA];
         u_dy = (int)(short)(yx & 0xffff); u_dx = yx >> 16;
         u_cbyteA = nA < nk ? cA * (BK * 4) : OOB;
-        u_delta = UPS ? 0 : p.tap_a[tA] + u_cbyteA;
+        u_delta = UPS ? 0 : P.tap_a[tA] + u_cbyteA;
         ++nA;
-        if (++tA == p.ntaps) { tA = 0; if (++cA == cpt) cA = 0; }
+        if (++tA == P.ntaps) { tA = 0; if (++cA == cpt) cA = 0; }
     };
     auto begin_scale = [&]() {
         u_cbyteB = nB < nk ? cB * (BK * 4) : OOB;
-        u_wdelta = p.tap_w[tB] + u_cbyteB;
+        u_wdelta = P.tap_w[tB] + u_cbyteB;
         ++nB;
-        if (++tB == p.ntaps) { tB = 0; if (++cB == cpt) cB = 0; }
+        if (++tB == P.ntaps) { tB = 0; if (++cB == cpt) cB = 0; }
     };
     auto load_piece = [&](Stage& S, int idx) {
         if (idx < PA) {
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
 
     if (p.ksplit > 1) {
         // split-K: raw partial tile -> ws[split][m][n]; conv_splitk_epilogue_kernel reduces and finishes
-        float* part = p.ws + (size_t)blockIdx.y * p.M * p.Co;
+        float* part = p.ws + (size_t)blockIdx.y * P.M * p.Co;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * WN + j * 32 + l31;
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < p.M && n < p.Co) part[(size_t)m * p.Co + n] = acc[i][j][r];
+                    if (m < P.M && n < p.Co) part[(size_t)m * p.Co + n] = acc[i][j][r];
                 }
         }
         return;
@@ -336,22 +356,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
         const int m = m0 + tid;
         int pix = -1, bb = 0, ap = 0;
         float nz = 0.f;
-        const int bq = m / p.Mimg, pq = m - bq * p.Mimg;
-        if (m < p.M && pq < p.HW) {
-            const int gy = pq / p.Wg, gx = pq - gy * p.Wg;
+        const int bq = m / P.Mimg, pq = m - bq * P.Mimg;
+        if (m < P.M && pq < P.HW) {
+            const int gy = pq / P.Wg, gx = pq - gy * P.Wg;
             bb = bq;
-            const int hw = (gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
+            const int hw = (gy * p.osy + P.oy0) * p.Wo + gx * p.osx + P.ox0;
             pix = bb * p.Ho * p.Wo + hw;
             if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
-            const int oy = gy * p.osy + p.oy0, ox = gx * p.osx + p.ox0;
+            const int oy = gy * p.osy + P.oy0, ox = gx * p.osx + P.ox0;
             ap = (bb * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
         }
         r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
     }
     __syncthreads();
     const int b_lo = r_b[0];
-    const int m_last = min(m0 + BM, p.M) - 1;
-    const int b_hi2 = m_last / p.Mimg;
+    const int m_last = min(m0 + BM, P.M) - 1;
+    const int b_hi2 = m_last / P.Mimg;
     const bool cs_fast = p.col_scale && (b_hi2 - b_lo <= 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -412,8 +432,17 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArg
     *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + hw) * p.Co + n) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// fill ph[0] of a single-phase launch from the main fields (after the row padding decision)
+void single_phase(ConvArgs& a) {
+    a.nphase = 1;
+    PhaseArgs& P = a.ph[0];
+    P.Wg = a.Wg; P.oy0 = a.oy0; P.ox0 = a.ox0; P.ntaps = a.ntaps; P.HW = a.HW; P.Mimg = a.Mimg; P.M = a.M; P.tiles = 0; P.cnt8 = 0;
+    for (int t = 0; t < a.ntaps; ++t) { P.tap_yx[t] = a.tap_yx[t]; P.tap_a[t] = a.tap_a[t]; P.tap_w[t] = a.tap_w[t]; }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch(const ConvArgs& a, hipStream_t st) {
+void launch(ConvArgs& a, hipStream_t st) {
+    single_phase(a);
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a.ksplit), block(64 * WAVES_M * WAVES_N);
@@ -434,10 +463,11 @@ void launch(const ConvArgs& a, hipStream_t st) {
 
 // 8-wave 256-row tiles (one workgroup per CU): only the non-upsampling forms are instantiated
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_big(const ConvArgs& a, hipStream_t st) {
+void launch_big(ConvArgs& a, hipStream_t st, int nblocks = 0) {
+    if (!nblocks) single_phase(a);
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
-    dim3 grid((unsigned)(ntm * ntn)), block(64 * WAVES_M * WAVES_N);
+    dim3 grid((unsigned)(nblocks ? nblocks : ntm * ntn)), block(64 * WAVES_M * WAVES_N);
     if (!a.a_scale) {
         auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, 0, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -458,18 +488,67 @@ void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
 }
 
-int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
-    if (a0.Ci % 32 != 0) return 1;
-    ConvArgs a = a0;
-    // operand extents for the buffer descriptors; every stream must be addressable with a 31-bit byte offset
+// operand extents for the buffer descriptors; every stream must be addressable with a 31-bit byte offset
+static bool set_extents(ConvArgs& a, int wt_max) {
     const long xb = (long)a.B * a.Hi * a.Wi * a.Ci * 4;
-    int wt_max = 0;
-    for (int t = 0; t < a.ntaps; ++t) wt_max = a.wt[t] > wt_max ? a.wt[t] : wt_max;
     const long wb = ((long)wt_max * a.w_tap_stride + (long)(a.Co - 1) * a.w_row_stride + a.Ci) * 4;
     const long sb = a.a_scale ? ((long)(a.B - 1) * a.a_ld + a.Ci) * 4 : 0;
     const long lim = 0x7fffffffL;
-    if (xb > lim || wb > lim || sb > lim) return 1;
+    if (xb > lim || wb > lim || sb > lim) return false;
     a.x_bytes = (int)xb; a.w_bytes = (int)wb; a.s_bytes = (int)sb;
+    return true;
+}
+
+// The four sub-pixel phases of an up-conv (or any launches that differ only in grid geometry and taps) as ONE launch
+// of the 8-wave kernel: 4x the workgroups per launch (short K loops: 1, 2, 2 and 4 taps) and one tail instead of four.
+int launch_bf16x3_multi(const ConvArgs* as, int n, hipStream_t st) {
+    if (n < 2 || n > 4) return 1;
+    ConvArgs a = as[0];
+    if (a.Ci % 32 != 0 || a.ups || a.Co % 128 != 0) return 1;
+    int wt_max = 0, ntm_all = 0;
+    for (int i = 0; i < n; ++i) {
+        const ConvArgs& b = as[i];
+        if (b.ntaps > 16) return 1;
+        if (b.x != a.x || b.w != a.w || b.y != a.y || b.a_scale != a.a_scale || b.col_scale != a.col_scale || b.bias != a.bias ||
+            b.noise != a.noise || b.noise_w != a.noise_w || b.addend != a.addend || b.B != a.B || b.Hi != a.Hi || b.Wi != a.Wi ||
+            b.Ci != a.Ci || b.Ho != a.Ho || b.Wo != a.Wo || b.Co != a.Co || b.isy != a.isy || b.isx != a.isx || b.osy != a.osy ||
+            b.osx != a.osx || b.ups != a.ups || b.add_ups != a.add_ups || b.act != a.act || b.alpha != a.alpha ||
+            b.act_slope != a.act_slope || b.gain != a.gain || b.a_ld != a.a_ld || b.col_ld != a.col_ld ||
+            b.w_tap_stride != a.w_tap_stride || b.w_row_stride != a.w_row_stride)
+            return 1;
+        for (int t = 0; t < b.ntaps; ++t) wt_max = b.wt[t] > wt_max ? b.wt[t] : wt_max;
+        ConvArgs c = b;
+        fill_tap_tables(c);
+        PhaseArgs& P = a.ph[i];
+        const int hw = c.Hg * c.Wg;
+        const int mp = (hw + 255) / 256 * 256;
+        if (a.a_scale && mp * 100L > hw * 113L) return 1;          // padding a sample's rows to 256 would cost > 13 %
+        P.Wg = c.Wg; P.oy0 = c.oy0; P.ox0 = c.ox0; P.ntaps = c.ntaps; P.HW = hw;
+        P.Mimg = a.a_scale ? mp : hw; P.M = c.B * P.Mimg;
+        for (int t = 0; t < c.ntaps; ++t) { P.tap_yx[t] = c.tap_yx[t]; P.tap_a[t] = c.tap_a[t]; P.tap_w[t] = c.tap_w[t]; }
+        ntm_all += (P.M + 255) / 256;
+    }
+    const int bn = a.Co % 256 == 0 ? 256 : 128, ntn = a.Co / bn;
+    int blocks8 = 0;
+    for (int i = 0; i < n; ++i) {
+        a.ph[i].tiles = ((a.ph[i].M + 255) / 256) * ntn;
+        a.ph[i].cnt8 = (a.ph[i].tiles + 7) / 8;
+        blocks8 += a.ph[i].cnt8;
+    }
+    if (!set_extents(a, wt_max)) return 1;
+    a.nphase = n; a.ksplit = 1;
+    if (ntm_all * ntn < 200) return 1;
+    if (bn == 256) launch_big<256, 256, 2, 4>(a, st, blocks8 * 8);
+    else launch_big<256, 128, 4, 2>(a, st, blocks8 * 8);
+    return 0;
+}
+
+int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
+    if (a0.Ci % 32 != 0 || a0.ntaps > 16) return 1;
+    ConvArgs a = a0;
+    int wt_max = 0;
+    for (int t = 0; t < a.ntaps; ++t) wt_max = a.wt[t] > wt_max ? a.wt[t] : wt_max;
+    if (!set_extents(a, wt_max)) return 1;
     fill_tap_tables(a);
     // Styled launches want every tile inside one sample (one style vector per tile, and the only form the 8-wave
     // tiles support).  When Hg*Wg is not a multiple of the tile height (the sub-pixel phases of the up-convs: 65x65,
