@@ -139,6 +139,11 @@ typedef struct wgs_conv_desc {
     float act_slope, gain;   /* identity: 1,1;  relu: 0,1;  fused lrelu: 0.2,sqrt(2) */
     int8_t dy[64], dx[64];
     int16_t wt[64];
+    const uint16_t* w_hi;    /* optional pre-split weights: bf16 planes hi = bf16(w), lo = bf16(w - hi) in the layout of w  */
+    const uint16_t* w_lo;    /* (wgs_split_bf16).  With them and a workspace of 4 bytes per INPUT element, precision = 1
+                                launches that take the 8-wave tiles use the LDS-DMA kernel: activations are style-modulated and
+                                split into the workspace by a pre-pass, and both operands are copied global -> LDS without
+                                staging registers (conv_igemm_dma.hip).  Results are bit-identical to the register-staged form. */
     float* ws;               /* optional split-K workspace (caller-owned, like every buffer) or NULL.  Launches whose */
     int64_t ws_bytes;        /* 128x128 tile count cannot fill the 256 CUs (4x4..16x16 generator layers: M = B*Hg*Wg of
                                 512..2048) split the K = taps*Ci contraction over up to 16 workgroups per tile; the
@@ -166,6 +171,9 @@ typedef struct wgs_wgrad_desc {
     int16_t wt[64];
 } wgs_wgrad_desc;
 int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
+
+/* hi[i] = bf16_rn(x[i]), lo[i] = bf16_rn(x[i] - hi[i]) (raw bf16 bit patterns), n % 4 == 0: the split used by precision = 1. */
+int wgs_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_stream_t stream);
 
 /* dst[t][ci][co] = src[co][t][ci]  (pack [Cout,T,Cin] weights for the dgrad contraction). */
 int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream);

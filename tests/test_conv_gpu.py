@@ -189,3 +189,50 @@ def test_conv_split_bf16_256_row_tiles(dev, B, Ci, Co, H):
     assert rel_err(nchw(y1[B - 1:]), ref) < 2e-5
     y2 = C.conv2d(x, wp, 3, pad=1, precision=1)            # no style: the ASCALE=0 instantiation
     assert rel_err(y2, C.conv2d(x, wp, 3, pad=1, precision=0)) < 2e-5
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(4, 64, 256, 128), (8, 32, 128, 128)])
+def test_conv_split_bf16_lds_dma_path(dev, B, Ci, Co, H):
+    """Pre-split weights (wgs_split_bf16) + workspace => the LDS-DMA kernel: same split values, same product order as the
+    register-staged kernel, so the results must be identical; also against the exact-fp32 kernel."""
+    torch.manual_seed(Co + 1)
+    x = torch.randn(B, H, H, Ci, device=dev)
+    wp = C.pack_weight(torch.randn(Co, Ci, 3, 3) / (Ci * 9) ** 0.5).to(dev)
+    ws = C.split_weight(wp)
+    hi = ws[0].view(torch.bfloat16).float()
+    assert torch.equal(hi, wp.to(torch.bfloat16).float())                       # round-to-nearest-even split
+    assert torch.equal(ws[1].view(torch.bfloat16).float(), (wp - hi).to(torch.bfloat16).float())
+    s = torch.randn(B, Ci, device=dev) + 1.0
+    dm = torch.rand(B, Co, device=dev) + 0.5
+    bias, noise, nw = torch.randn(Co, device=dev), torch.randn(H, H, device=dev), torch.tensor([0.37], device=dev)
+    kw = dict(a_scale=s, col_scale=dm, bias=bias, noise=noise, noise_w=nw, act_slope=0.2, gain=2 ** 0.5)
+    y_dma = C.conv2d(x, wp, 3, pad=1, precision=1, w_split=ws, **kw)
+    y_reg = C.conv2d(x, wp, 3, pad=1, precision=1, **kw)
+    assert torch.equal(y_dma, y_reg)
+    assert rel_err(y_dma, C.conv2d(x, wp, 3, pad=1, precision=0, **kw)) < 2e-5
+    y2 = C.conv2d(x, wp, 3, pad=1, precision=1, w_split=ws)                     # no style
+    assert torch.equal(y2, C.conv2d(x, wp, 3, pad=1, precision=1))
+    # dgrad form (weights packed [T, Ci, Co]) with a row scale
+    wt = C.repack_w_t(wp, Co, 9, Ci)
+    g = torch.randn(B, H, H, Co, device=dev)
+    d1 = C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=1, w_split=C.split_weight(wt)) if Ci % 128 == 0 else None
+    if d1 is not None:
+        assert torch.equal(d1, C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=1))
+
+
+def test_conv_transpose_s2_merged_phases_lds_dma(dev):
+    """Up-conv large enough for the merged 4-phase launch, with and without pre-split weights, vs the exact-fp32 phases."""
+    torch.manual_seed(11)
+    B, Ci, Co, H = 8, 64, 128, 64
+    x = torch.randn(B, H, H, Ci, device=dev)
+    wp = C.pack_weight(torch.randn(Co, Ci, 3, 3) / (Ci * 9) ** 0.5).to(dev)
+    s = torch.randn(B, Ci, device=dev) + 1.0
+    dm = torch.rand(B, Co, device=dev) + 0.5
+    y0 = C.conv_transpose2d_s2(x, wp, a_scale=s, col_scale=dm, precision=0)
+    y1 = C.conv_transpose2d_s2(x, wp, a_scale=s, col_scale=dm, precision=1)
+    y2 = C.conv_transpose2d_s2(x, wp, a_scale=s, col_scale=dm, precision=1, w_split=C.split_weight(wp))
+    assert rel_err(y1, y0) < 2e-5
+    assert torch.equal(y1, y2)
+    ref = F.conv_transpose2d((x[:1].cpu().permute(0, 3, 1, 2) * s[:1].cpu()[:, :, None, None]).double(),
+                             wp.cpu().reshape(Co, 3, 3, Ci).permute(3, 0, 1, 2).double(), stride=2) * dm[:1].cpu().double()[:, :, None, None]
+    assert rel_err(nchw(y2[:1]), ref) < 2e-5

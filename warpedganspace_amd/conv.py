@@ -22,6 +22,7 @@ class ConvDesc(ctypes.Structure):
                 ('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
                 ('act_slope', ctypes.c_float), ('gain', ctypes.c_float),
                 ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
+                ('w_hi', ctypes.c_void_p), ('w_lo', ctypes.c_void_p),
                 ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64)]
 
 
@@ -46,16 +47,28 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-# split-K workspace (wgs_conv_desc.ws): one caller-owned buffer per device, reused by every launch on the stream
+# Workspace (wgs_conv_desc.ws): one caller-owned buffer per device, reused by every launch on the stream — split-K
+# partial tiles (<= 64 MiB) or, for launches with pre-split weights, the split activation planes (4 bytes per input element).
 WS_BYTES = 64 << 20
 _WS = {}
 
 
-def _workspace(device):
+def _workspace(device, nbytes=0):
     ws = _WS.get(device)
-    if ws is None:
-        ws = _WS[device] = torch.empty(WS_BYTES // 4, device=device, dtype=torch.float32)
+    need = max(WS_BYTES, nbytes)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _WS[device] = torch.empty(need // 4, device=device, dtype=torch.float32)
     return ws
+
+
+def split_weight(w):
+    """Pre-split a (frozen) packed fp32 weight into its bf16 hi / lo planes for the LDS-DMA conv path (wgs_split_bf16).
+    Returns (hi, lo) int16 tensors of w's shape; pass them as w_split= to the conv functions."""
+    if not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and w.numel() % 4 == 0):
+        raise L.WgsError("split_weight needs a contiguous fp32 GPU tensor with numel % 4 == 0")
+    hi, lo = torch.empty_like(w, dtype=torch.int16), torch.empty_like(w, dtype=torch.int16)
+    L.check(L.lib().wgs_split_bf16(L.ptr(w), L.ptr(hi, torch.int16), L.ptr(lo, torch.int16), ctypes.c_int64(w.numel()), L.stream()), 'wgs_split_bf16')
+    return hi, lo
 
 
 def _timed(kind, flops, fn):
@@ -71,7 +84,7 @@ def _timed(kind, flops, fn):
 
 def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
-          a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None):
+          a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None, w_split=None):
     """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
         raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
@@ -89,8 +102,10 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     d.precision = PRECISION if precision is None else precision
     d.w_tap_stride, d.w_row_stride = w_tap_stride, w_row_stride
     d.act_slope, d.gain = act_slope, gain
-    ws = _workspace(x.device)
+    ws = _workspace(x.device, x.numel() * 4 if w_split is not None else 0)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    if w_split is not None:
+        d.w_hi, d.w_lo = w_split[0].data_ptr(), w_split[1].data_ptr()
     for i, (ty, tx, ti) in enumerate(taps):
         d.dy[i], d.dx[i], d.wt[i] = ty, tx, ti
     return d, 2.0 * d.B * Hg * Wg * d.Co * d.Ci * len(taps)

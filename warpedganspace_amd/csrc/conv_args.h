@@ -27,6 +27,10 @@ struct ConvArgs {
     long w_tap_stride, w_row_stride;
     float act_slope, gain, alpha;
     int HW, Mimg;       // Hg*Wg, and GEMM rows per sample (>= HW; M = B*Mimg).  Mimg == HW except in launch_bf16x3
+    const unsigned short* w_hi;     // pre-split bf16 planes of w (same packed layout), or null
+    const unsigned short* w_lo;
+    const unsigned short* a_hi;     // split (and style-modulated) activation planes: set by launch_bf16x3 (LDS-DMA path)
+    const unsigned short* a_lo;
     float* ws;          // split-K workspace or null
     long ws_bytes;
     int ksplit;         // K splits of this launch (1 = none); set by launch_bf16x3
@@ -73,5 +77,10 @@ void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st);
 int launch_bf16x3(const ConvArgs& a, hipStream_t st);
 // the same for n <= 4 launches that differ only in (Hg, Wg, oy0, ox0, taps); 0 = handled as one merged launch
 int launch_bf16x3_multi(const ConvArgs* a, int n, hipStream_t st);
+
+// LDS-DMA form of the 8-wave kernels (conv_igemm_dma.hip)
+void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
+                int C, hipStream_t st);
+void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st);
 
 }  // namespace wgsconv

@@ -429,6 +429,13 @@ __global__ __launch_bounds__(256) void repack_w_t_kernel(const float* __restrict
 
 extern "C" {
 
+int wgs_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && hi && lo && n > 0 && n % 4 == 0, "wgs_split_bf16: bad arguments (n %% 4)");
+    wgsconv::split_bf16(x, nullptr, 0, hi, lo, 1, (long)n, 4, (hipStream_t)stream);
+    WGS_CHECK_LAUNCH("modsplit_kernel");
+    return WGS_OK;
+}
+
 int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream) {
     WGS_CHECK_ARG(src && dst && Co > 0 && T > 0 && Ci > 0, "wgs_repack_w_t: bad arguments");
     dim3 grid((Ci + 31) / 32, (Co + 31) / 32, T);
@@ -462,6 +469,7 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     WGS_CHECK_ARG(d->ups >= 0 && d->ups <= 3 && d->add_ups >= 0 && d->add_ups <= 3, "wgs_conv_igemm: bad upsample shift");
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
+    a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = nullptr; a.a_lo = nullptr;
     wgsconv::fill_tap_tables(a);
     return WGS_OK;
 }

@@ -13,8 +13,9 @@
 // 2 stages x 40 KiB = 80 KiB per workgroup -> two workgroups per CU.
 #include "wgs_common.h"
 #include "conv_args.h"
+#include "conv_epilogue.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef wgsconv::epi_f32x16 f32x16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
@@ -25,7 +26,7 @@ using wgsconv::PhaseArgs;
 #ifndef WGS_ABL
 #define WGS_ABL 0   // development ablations: 1 no split arithmetic, 2 no LDS stores, 3 no MFMA, 4 no global loads,
                     // 7 no style loads, 8 no weight loads, 9 no activation loads, 10 no LDS operand reads,
-                    // 11 no 256-row tiles, 13 no split-K
+                    // 11 no 256-row tiles, 13 no split-K, 15 no LDS-DMA path
 #endif
 
 constexpr int BK = 32;          // fp32 values per K-chunk
@@ -74,30 +75,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     // XCD-aware tile order: hardware sends workgroup b to XCD b % 8.  Give every XCD a contiguous range of the
     // (m-tile major, n-tile minor) tile list, so the n-tiles of one m-tile and its neighbouring image rows run on the
     // same XCD at the same time and share their activation rows in that XCD's L2 instead of each fetching them from HBM.
-    int phase = 0, tm, n0;
-    if (p.nphase == 1) {
-        const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int qn = nb >> 3, rn = nb & 7;
-        const int bid = xcd * qn + min(xcd, rn) + slot;
-        tm = bid / ntn;
-        n0 = (bid % ntn) * BN;
-    } else {
-        // merged phases: every XCD gets an equal slice of EVERY phase's tile list (the phases differ in work per tile —
-        // 4, 2, 2 and 1 taps — so slicing the concatenated list would leave some XCDs with only the heavy phase);
-        // each phase's tile count is padded to a multiple of 8 and the padding workgroups exit here.
-        const int xcd = blockIdx.x & 7;
-        int slot = blockIdx.x >> 3, t = -1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < p.nphase && t < 0) {
-                const int c = p.ph[i].cnt8;
-                if (slot < c) { t = xcd * c + slot; phase = i; } else slot -= c;
-            }
-        }
-        if (t < 0 || t >= p.ph[phase].tiles) return;
-        tm = t / ntn;
-        n0 = (t % ntn) * BN;
-    }
+    int phase, tm, n0;
+    if (!wgsconv::conv_tile_of_block(p, ntn, BN, phase, tm, n0)) return;
     const PhaseArgs& P = p.ph[phase];
     const int m0 = tm * BM;
     const int q = tid % CPR, r0 = tid / CPR;
@@ -166,13 +145,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
         const int yx = P.tap_yx[tA];
         u_dy = (int)(short)(yx & 0xffff); u_dx = yx >> 16;
         u_cbyteA = nA < nk ? cA * (BK * 4) : OOB;
-        u_delta = UPS ? 0 : P.tap_a[tA] + u_cbyteA;
+        u_delta = UPS ? 0 : (int)((unsigned)P.tap_a[tA] + (unsigned)u_cbyteA);
         ++nA;
         if (++tA == P.ntaps) { tA = 0; if (++cA == cpt) cA = 0; }
     };
     auto begin_scale = [&]() {
         u_cbyteB = nB < nk ? cB * (BK * 4) : OOB;
-        u_wdelta = P.tap_w[tB] + u_cbyteB;
+        u_wdelta = (int)((unsigned)P.tap_w[tB] + (unsigned)u_cbyteB);
         ++nB;
         if (++tB == P.ntaps) { tB = 0; if (++cB == cpt) cB = 0; }
     };
@@ -181,13 +160,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
             const int iy = a_iy0[idx] + u_dy, ix = a_ix0[idx] + u_dx;
             const bool v = (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
             int off;
-            if (UPS) off = ((a_off[idx] + (iy >> p.ups) * p.Wi + (ix >> p.ups)) * p.Ci + q * 4) * 4 + u_cbyteA;
-            else off = a_off[idx] + u_delta;
+            if (UPS) off = (int)((unsigned)(((a_off[idx] + (iy >> p.ups) * p.Wi + (ix >> p.ups)) * p.Ci + q * 4) * 4) + (unsigned)u_cbyteA);
+            else off = (int)((unsigned)a_off[idx] + (unsigned)u_delta);
             if (WGS_ABL != 4 && WGS_ABL != 9) S.ra[idx] = buf_load4(rx, v ? off : OOB);
         } else if (idx < PA + PB) {
-            if (WGS_ABL != 4 && WGS_ABL != 8) rb[idx - PA] = buf_load4(rw, b_off[idx - PA] + u_wdelta);
+            if (WGS_ABL != 4 && WGS_ABL != 8) rb[idx - PA] = buf_load4(rw, (int)((unsigned)b_off[idx - PA] + (unsigned)u_wdelta));
         } else if (ASCALE && idx < PA + PB + PS) {
-            if (WGS_ABL != 4 && WGS_ABL != 7) rs[idx - PA - PB] = buf_load4(rsc, s_off[idx - PA - PB] + u_cbyteB);
+            if (WGS_ABL != 4 && WGS_ABL != 7) rs[idx - PA - PB] = buf_load4(rsc, (int)((unsigned)s_off[idx - PA - PB] + (unsigned)u_cbyteB));
         }
     };
     constexpr int NLOADS = PA + PB + (ASCALE ? PS : 0);
@@ -208,7 +187,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
         int off;
         if (idx < PA) {
             v = S.ra[idx];
-            if (ASCALE) { const float4 sc = rs[ASCALE == 1 ? idx : 0]; v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            // rounded fp32 product (no fma contraction into the split's residual): the LDS-DMA path's pre-pass does the same,
+            // so the two forms stage identical bf16 pairs
+            if (ASCALE) {
+                const float4 sc = rs[ASCALE == 1 ? idx : 0];
+                v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (no fma into the residual)
+            }
             off = (r0 + idx * RPP) * ROWB + q * 8;
         } else {
             v = rb[idx - PA];
@@ -347,59 +332,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
         }
         return;
     }
-    // ---- epilogue (identical contract to conv_igemm.hip) ---------------------------------------------------
-    int* r_pix = reinterpret_cast<int*>(smem_b);
-    int* r_b = r_pix + BM;
-    float* r_nz = reinterpret_cast<float*>(r_b + BM);
-    int* r_add = reinterpret_cast<int*>(r_nz + BM);
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int pix = -1, bb = 0, ap = 0;
-        float nz = 0.f;
-        const int bq = m / P.Mimg, pq = m - bq * P.Mimg;
-        if (m < P.M && pq < P.HW) {
-            const int gy = pq / P.Wg, gx = pq - gy * P.Wg;
-            bb = bq;
-            const int hw = (gy * p.osy + P.oy0) * p.Wo + gx * p.osx + P.ox0;
-            pix = bb * p.Ho * p.Wo + hw;
-            if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
-            const int oy = gy * p.osy + P.oy0, ox = gx * p.osx + P.ox0;
-            ap = (bb * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
-        }
-        r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
-    }
-    __syncthreads();
-    const int b_lo = r_b[0];
-    const int m_last = min(m0 + BM, P.M) - 1;
-    const int b_hi2 = m_last / P.Mimg;
-    const bool cs_fast = p.col_scale && (b_hi2 - b_lo <= 1);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        const bool nok = n < p.Co;
-        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-        float cs0 = 1.f, cs1 = 1.f;
-        if (cs_fast && nok) {
-            cs0 = p.col_scale[(size_t)b_lo * p.col_ld + n];
-            cs1 = p.col_scale[(size_t)b_hi2 * p.col_ld + n];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int pix = r_pix[row];
-                if (pix >= 0 && nok) {
-                    float v = acc[i][j][r] * p.alpha;
-                    if (p.col_scale) v *= cs_fast ? (r_b[row] == b_lo ? cs0 : cs1) : p.col_scale[(size_t)r_b[row] * p.col_ld + n];
-                    v += r_nz[row] + bias;
-                    if (p.addend) v += p.addend[(size_t)r_add[row] * p.Co + n];
-                    v = (p.act == 1) ? tanhf(v) : (v > 0.f ? v : v * p.act_slope) * p.gain;
-                    p.y[(size_t)pix * p.Co + n] = v;
-                }
-            }
-        }
-    }
+    wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh);
 }
 
 // Second pass of a split-K launch: y[pix(m)][n] = epilogue(sum_s ws[s][m][n]) — the same epilogue as above
@@ -499,6 +432,20 @@ static bool set_extents(ConvArgs& a, int wt_max) {
     return true;
 }
 
+// LDS-DMA path (conv_igemm_dma.hip) for a launch that takes the 8-wave tiles: needs pre-split weights and a workspace for
+// the split activation planes (4 bytes per input element).  Runs the modulate+split pre-pass and the DMA kernel.
+static bool try_dma(ConvArgs& a, int bn, int nblocks, hipStream_t st) {
+    const long elems = (long)a.B * a.Hi * a.Wi * a.Ci;
+    if (!a.w_hi || !a.w_lo || !a.ws || a.ws_bytes < elems * 4 || WGS_ABL == 15) return false;
+    unsigned short* hi = reinterpret_cast<unsigned short*>(a.ws);
+    unsigned short* lo = hi + elems;
+    split_bf16(a.x, a.a_scale, a.a_ld, hi, lo, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, st);
+    a.a_hi = hi; a.a_lo = lo;
+    a.x_bytes /= 2; a.w_bytes /= 2;            // extents of the bf16 planes
+    launch_dma_bf16x3(a, bn, nblocks, st);
+    return true;
+}
+
 // The four sub-pixel phases of an up-conv (or any launches that differ only in grid geometry and taps) as ONE launch
 // of the 8-wave kernel: 4x the workgroups per launch (short K loops: 1, 2, 2 and 4 taps) and one tail instead of four.
 int launch_bf16x3_multi(const ConvArgs* as, int n, hipStream_t st) {
@@ -538,6 +485,7 @@ int launch_bf16x3_multi(const ConvArgs* as, int n, hipStream_t st) {
     if (!set_extents(a, wt_max)) return 1;
     a.nphase = n; a.ksplit = 1;
     if (ntm_all * ntn < 200) return 1;
+    if (try_dma(a, bn, blocks8 * 8, st)) return 0;
     if (bn == 256) launch_big<256, 256, 2, 4>(a, st, blocks8 * 8);
     else launch_big<256, 128, 4, 2>(a, st, blocks8 * 8);
     return 0;
@@ -558,8 +506,16 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     const int mp256 = a.a_scale ? padded(256) : a.HW, mp128 = a.a_scale ? padded(128) : a.HW;
     const int ntm256 = mp256 ? (a.B * mp256 + 255) / 256 : 0;
     const bool big_ok = !a.ups && mp256 && WGS_ABL != 11;
-    if (big_ok && a.Co % 256 == 0 && ntm256 * (a.Co / 256) >= 200) { use_rows(mp256); launch_big<256, 256, 2, 4>(a, st); return 0; }
-    if (big_ok && a.Co % 128 == 0 && ntm256 * (a.Co / 128) >= 200) { use_rows(mp256); launch_big<256, 128, 4, 2>(a, st); return 0; }
+    if (big_ok && a.Co % 128 == 0) {
+        const int bn = a.Co % 256 == 0 && ntm256 * (a.Co / 256) >= 200 ? 256 : 128;
+        if (ntm256 * (a.Co / bn) >= 200) {
+            use_rows(mp256);
+            single_phase(a);
+            if (try_dma(a, bn, ntm256 * (a.Co / bn), st)) return 0;
+            if (bn == 256) launch_big<256, 256, 2, 4>(a, st); else launch_big<256, 128, 4, 2>(a, st);
+            return 0;
+        }
+    }
     if (mp128) use_rows(mp128);
     if (a.Co > 64) {
         // too few 128x128 tiles for the 256 CUs: split K (needs the caller's workspace and 4-channel rows)

@@ -1,0 +1,211 @@
+// Split-bf16 implicit-GEMM convolution, LDS-DMA form: both operands arrive ALREADY split into bf16 hi / lo planes and are
+// copied HBM/L2 -> LDS by `buffer_load_dwordx4 ... lds` — no staging registers, no split arithmetic and no ds_write in the
+// main loop, which is then only {issue DMA of chunk k+1, ds_read fragments, 3 MFMAs per product block}.
+//
+//   * weights: split once for the frozen generator (wgs_split_bf16; wgs_conv_desc.w_hi / w_lo, same packed layout as w)
+//   * activations: split (and style-modulated: the style multiply must precede the split) by modsplit_kernel below into the
+//     caller's workspace — one extra read + write of the activation tensor per launch, paid for by the conv kernel
+//     (measured: register-staged split + ds_write cost 24-33 % of the conv time on the 8-wave tiles).
+//
+// LDS image per stage: A_hi | A_lo [BM][32 bf16 = 64 B], B_hi | B_lo [BN][64 B], rows UNPADDED because an LDS-DMA writes
+// wave-uniform base + lane*16: one instruction fills 16 rows x 64 B.  Bank conflicts of the per-lane ds_read_b128 (lane =
+// row) are avoided by an XOR swizzle of the four 16-B chunks of a row with (row >> 2) & 3, applied on the SOURCE address of
+// the DMA (lane -> row = lane/4, slot = lane%4 fetches logical chunk slot ^ swz) and on the ds_read address.
+#include "wgs_common.h"
+#include "conv_args.h"
+#include "conv_epilogue.h"
+
+typedef wgsconv::epi_f32x16 f32x16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+using wgsconv::ConvArgs;
+using wgsconv::PhaseArgs;
+
+constexpr int BK = 32;                 // K values per chunk
+constexpr int ROW = 64;                // bytes per LDS row and plane (32 bf16)
+constexpr int OOB = (int)0x80000000;   // byte offset beyond any buffer this kernel accepts: the DMA writes zeros
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_kernel(const ConvArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW;
+    constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+    constexpr int AI = BM / 16 / NW, BI = BN / 16 / NW;     // 16-row DMA instructions per wave and plane
+    static_assert(AI >= 1 && BI >= 1 && AI * 16 * NW == BM && BI * 16 * NW == BN, "tile / wave count mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = (p.Co + BN - 1) / BN;
+    int phase, tm, n0;
+    if (!wgsconv::conv_tile_of_block(p, ntn, BN, phase, tm, n0)) return;
+    const PhaseArgs& P = p.ph[phase];
+    const int m0 = tm * BM;
+
+    const __amdgpu_buffer_rsrc_t rah = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.a_hi), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ral = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.a_lo), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_lo), 0, p.w_bytes, 0x00020000);
+
+    // DMA source side: this lane feeds LDS row (16*instr + lane/4), slot lane%4 of every instruction of its wave
+    const int lrow = lane >> 2, slot = lane & 3;
+    int a_iy0[AI], a_ix0[AI], a_off[AI], b_off[BI];
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int row = (wave * AI + j) * 16 + lrow;
+        const int m = m0 + row;
+        const int bq = m / P.Mimg, pq = m - bq * P.Mimg;
+        const bool ok = m < P.M && pq < P.HW;
+        const int b = ok ? bq : 0, pix = ok ? pq : 0;
+        const int gy = pix / P.Wg, gx = pix - gy * P.Wg;
+        a_iy0[j] = ok ? gy * p.isy : -100000;
+        a_ix0[j] = gx * p.isx;
+        const int lc = slot ^ ((row >> 2) & 3);
+        a_off[j] = ((b * p.Hi * p.Wi + gy * p.isy * p.Wi + gx * p.isx) * p.Ci + lc * 8) * 2;      // bytes in a bf16 plane
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = (wave * BI + j) * 16 + lrow;
+        const int n = n0 + row;
+        const int lc = slot ^ ((row >> 2) & 3);
+        b_off[j] = n < p.Co ? (int)((long)n * p.w_row_stride + lc * 8) * 2 : OOB;
+    }
+
+    const int cpt = p.Ci / BK;
+    const int nk = P.ntaps * cpt;
+    // K order: channel chunk outer, tap inner (see conv_igemm_bf16.hip)
+    int tC = 0, cC = 0, nC = 0;
+    auto issue = [&](int buf) {       // DMA of the next chunk into stage `buf`; past the last chunk everything is OOB
+        const int yx = P.tap_yx[tC];
+        const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+        const int cbyte = nC < nk ? cC * (BK * 2) : OOB;
+        // tap_a / tap_w are byte offsets for fp32 elements; unsigned adds: the sums may carry the OOB marker
+        const unsigned adelta = (unsigned)(P.tap_a[tC] >> 1) + (unsigned)cbyte;
+        const unsigned bdelta = (unsigned)(P.tap_w[tC] >> 1) + (unsigned)cbyte;
+        ++nC;
+        if (++tC == P.ntaps) { tC = 0; if (++cC == cpt) cC = 0; }
+        lds_byte* st = (lds_byte*)(smem_b + buf * STAGE);
+#pragma unroll
+        for (int j = 0; j < AI; ++j) {
+            const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+            const bool v = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const int off = v ? (int)((unsigned)a_off[j] + adelta) : OOB;
+            lds_byte* d = st + (wave * AI + j) * 16 * ROW;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, d, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, d + A_BYTES, 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int off = (int)((unsigned)b_off[j] + bdelta);
+            lds_byte* d = st + 2 * A_BYTES + (wave * BI + j) * 16 * ROW;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, d, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbl, d + B_BYTES, 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+    const int kc0 = ((0 + lh) ^ swz) * 16, kc1 = ((2 + lh) ^ swz) * 16;       // byte offset of this lane's 8 k-values, k-step 0 / 1
+    const int a_rd = (wm * WM + l31) * ROW, b_rd = 2 * A_BYTES + (wn * WN + l31) * ROW;
+
+    auto mma_tile = [&](int cur) {
+        const unsigned char* base = smem_b + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int kc = ks ? kc1 : kc0;
+            bf16x8 bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * ROW + kc);
+                bl[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + B_BYTES + j * 32 * ROW + kc);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * ROW + kc);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + a_rd + A_BYTES + i * 32 * ROW + kc);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    issue(0);
+    __syncthreads();                  // drains the DMA (vmcnt(0)) and publishes stage 0
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        issue(cur ^ 1);               // chunk kt+1 lands while chunk kt is multiplied
+        mma_tile(cur);
+        __syncthreads();
+    }
+    wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh);
+}
+
+// hi = bf16_rn(v), lo = bf16_rn(v - hi) of v = x * style (style per sample and channel, or none)
+__global__ __launch_bounds__(256) void modsplit_kernel(const float* __restrict__ x, const float* __restrict__ s, int s_ld,
+                                                       unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                       long per_sample4, int c4n, long total4) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(x)[e];
+        if (s) {
+            const long b = e / per_sample4;
+            const int c = (int)(e % c4n) * 4;
+            const float4 sc = *reinterpret_cast<const float4*>(s + b * s_ld + c);
+            v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (no fma into the residual)
+        }
+        const f32x4 f = {v.x, v.y, v.z, v.w};
+        const bf16x4 h = __builtin_convertvector(f, bf16x4);
+        const f32x4 r = f - __builtin_convertvector(h, f32x4);
+        const bf16x4 l = __builtin_convertvector(r, bf16x4);
+        reinterpret_cast<uint2*>(hi)[e] = __builtin_bit_cast(uint2, h);
+        reinterpret_cast<uint2*>(lo)[e] = __builtin_bit_cast(uint2, l);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_dma(const ConvArgs& a, hipStream_t st, int nblocks) {
+    const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROW;
+    auto k = igemm_dma_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a);
+}
+
+}  // namespace
+
+namespace wgsconv {
+
+void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
+                int C, hipStream_t st) {
+    const long total4 = nsamples * per_sample / 4;
+    long grid = (total4 + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(modsplit_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4);
+}
+
+// a: fully prepared arguments (phases filled, a_hi/a_lo/w_hi/w_lo and extents set); bn = 256 or 128
+void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st) {
+    if (bn == 256) launch_dma<256, 256, 2, 4>(a, st, nblocks);
+    else launch_dma<256, 128, 4, 2>(a, st, nblocks);
+}
+
+}  // namespace wgsconv

@@ -201,10 +201,12 @@ class Generator(nn.Module):
                 m = sc.conv
                 wp = C.pack_weight(m.weight[0].float())             # [Co, 9, Ci]
                 wt = C.repack_w_t(wp, m.out_channel, 9, m.in_channel)
+                # frozen weights: bf16 hi/lo planes for the LDS-DMA form of the split-bf16 conv kernels
+                wp_s, wt_s = C.split_weight(wp), C.split_weight(wt)
                 wsq = torch.empty(m.out_channel, m.in_channel, device=dev)
                 L.check(L.lib().wgs_sg2_wsq(L.ptr(wp), L.ptr(wsq), m.out_channel, 9, m.in_channel, L.stream()), 'wsq')
                 P['layers'].append(dict(
-                    wp=wp, wt=wt, wsq=wsq, Ci=m.in_channel, Co=m.out_channel, up=m.upsample, scale=m.scale, off=off,
+                    wp=wp, wt=wt, wp_s=wp_s, wt_s=wt_s, wsq=wsq, Ci=m.in_channel, Co=m.out_channel, up=m.upsample, scale=m.scale, off=off,
                     noise=getattr(self.noises, 'noise_{}'.format(i)).reshape(-1).contiguous(),
                     noise_w=sc.noise.weight.contiguous(), bias=sc.activate.bias.contiguous(),
                     blur=(m.blur.kernel.contiguous() if m.upsample else None),
@@ -289,7 +291,7 @@ class Generator(nn.Module):
                                        L.c_float(ly['scale']), st), 'demod')
             H = x.shape[1]
             if ly['up']:
-                t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod)
+                t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'])
                 y = torch.empty(B, 2 * H, 2 * H, Co, device=dev)
                 L.check(lib.wgs_sg2_blur_noise_bias_act(L.ptr(t), L.ptr(ly['blur']), L.ptr(ly['noise']),
                                                         L.ptr(ly['noise_w']), L.ptr(ly['bias']), L.ptr(y), B, 2 * H, 2 * H,
@@ -297,7 +299,7 @@ class Generator(nn.Module):
                 del t
             else:
                 y = C.conv2d(x, ly['wp'], 3, pad=1, a_scale=s_view, a_ld=sumC, col_scale=demod, noise=ly['noise'],
-                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2)
+                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'])
             outs.append(y)
             demods.append(demod)
             x = y
@@ -362,10 +364,10 @@ class Generator(nn.Module):
             # input gradient of this layer (un-scaled by its own style: the producer applies it)
             if ly['up']:
                 dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)
-                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], a_scale=demods[i])
+                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], a_scale=demods[i], w_split=ly['wt_s'])
                 del dt
             else:
-                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, a_scale=demods[i])
+                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, a_scale=demods[i], w_split=ly['wt_s'])
             del dy
             sA_off, num_next = ly['off'], num
         # bottom layer: its input is the ConstantInput -> only the style gradient remains
