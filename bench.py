@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--r-precision', choices=['fp32', 'bf16x3'], default='fp32', help='arithmetic of the Reconstructor convs (default exact fp32)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--precision', choices=('bf16x3', 'fp32'), default='bf16x3',
                     help="arithmetic of the implicit-GEMM convs: split-bf16 x3 MFMA (fp32-class, ~1e-5) or exact fp32 MFMA")
@@ -115,6 +116,8 @@ def main():
 
     from warpedganspace_amd import conv as C
     C.PRECISION = 1 if args.precision == 'bf16x3' else 0
+    from warpedganspace_amd import reconstructor as RR
+    RR.R_PRECISION = 1 if args.r_precision == 'bf16x3' else 0
     eng = build(dev, args.size, args.K, args.N, args.batch, seed=rank)
 
     def barrier():
@@ -188,7 +191,7 @@ def main():
         out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-256 K=128", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: exact fp32 MFMA)"
+               "dtype": ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: %s)" % ("exact fp32 MFMA" if args.r_precision == 'fp32' else "split-bf16 x3 convs, fp32 wgrad")
                          if args.precision == 'bf16x3' else "fp32 (f32-input MFMA, f32 accumulate)"), "data": "synthetic (random-init weights, z ~ N(0,I))",
                "config": {"workload": "StyleGAN2-FFHQ-%d arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (args.size, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),

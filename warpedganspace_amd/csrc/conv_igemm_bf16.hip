@@ -11,6 +11,7 @@
 // LDS image per stage: A_hi, A_lo [BM][32] bf16 and B_hi, B_lo [BN][32] bf16, rows padded to 80 bytes so that the
 // 16-lane groups of ds_read_b128 (one lane = one row, 8 consecutive k) hit 16 distinct 4-bank slots.
 // 2 stages x 40 KiB = 80 KiB per workgroup -> two workgroups per CU.
+#include <cstdlib>
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
@@ -437,6 +438,9 @@ static bool set_extents(ConvArgs& a, int wt_max) {
 static bool try_dma(ConvArgs& a, int bn, int nblocks, hipStream_t st) {
     const long elems = (long)a.B * a.Hi * a.Wi * a.Ci;
     if (!a.w_hi || !a.w_lo || !a.ws || a.ws_bytes < elems * 4 || WGS_ABL == 15) return false;
+    // the pre-pass reads + writes 8 bytes per input element whatever Cout is; measured (B=32): Cout=512 +15 % net,
+    // Cout=256 / 128 -2 % net (the DMA kernel alone is 13-21 % faster) — take it only where it pays
+    if (a.Co < 512 && !getenv("WGS_DMA_ALWAYS")) return false;
     unsigned short* hi = reinterpret_cast<unsigned short*>(a.ws);
     unsigned short* lo = hi + elems;
     split_bf16(a.x, a.a_scale, a.a_ld, hi, lo, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, st);

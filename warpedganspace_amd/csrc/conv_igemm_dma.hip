@@ -83,32 +83,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
     const int nk = P.ntaps * cpt;
     // K order: channel chunk outer, tap inner (see conv_igemm_bf16.hip)
     int tC = 0, cC = 0, nC = 0;
-    auto issue = [&](int buf) {       // DMA of the next chunk into stage `buf`; past the last chunk everything is OOB
+    // DMA of the next chunk, as 2*(AI+BI) pieces (activation hi/lo per 16-row group, then weight hi/lo) so that the
+    // issue can be spread between the MFMA slots; past the last chunk everything is OOB (zeros, no memory traffic)
+    constexpr int NPIECE = 2 * (AI + BI);
+    int u_dy = 0, u_dx = 0;
+    unsigned u_adelta = 0, u_bdelta = 0;
+    auto begin_chunk = [&]() {
         const int yx = P.tap_yx[tC];
-        const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+        u_dy = (int)(short)(yx & 0xffff); u_dx = yx >> 16;
         const int cbyte = nC < nk ? cC * (BK * 2) : OOB;
         // tap_a / tap_w are byte offsets for fp32 elements; unsigned adds: the sums may carry the OOB marker
-        const unsigned adelta = (unsigned)(P.tap_a[tC] >> 1) + (unsigned)cbyte;
-        const unsigned bdelta = (unsigned)(P.tap_w[tC] >> 1) + (unsigned)cbyte;
+        u_adelta = (unsigned)(P.tap_a[tC] >> 1) + (unsigned)cbyte;
+        u_bdelta = (unsigned)(P.tap_w[tC] >> 1) + (unsigned)cbyte;
         ++nC;
         if (++tC == P.ntaps) { tC = 0; if (++cC == cpt) cC = 0; }
+    };
+    auto issue_piece = [&](int buf, int idx) {
         lds_byte* st = (lds_byte*)(smem_b + buf * STAGE);
-#pragma unroll
-        for (int j = 0; j < AI; ++j) {
-            const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+        if (idx < 2 * AI) {
+            const int j = idx >> 1;
+            const int iy = a_iy0[j] + u_dy, ix = a_ix0[j] + u_dx;
             const bool v = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const int off = v ? (int)((unsigned)a_off[j] + adelta) : OOB;
-            lds_byte* d = st + (wave * AI + j) * 16 * ROW;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, d, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, d + A_BYTES, 16, off, 0, 0, 0);
+            const int off = v ? (int)((unsigned)a_off[j] + u_adelta) : OOB;
+            lds_byte* d = st + (wave * AI + j) * 16 * ROW + (idx & 1) * A_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds((idx & 1) ? ral : rah, d, 16, off, 0, 0, 0);
+        } else {
+            const int j = (idx - 2 * AI) >> 1;
+            const int off = (int)((unsigned)b_off[j] + u_bdelta);
+            lds_byte* d = st + 2 * A_BYTES + (wave * BI + j) * 16 * ROW + (idx & 1) * B_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds((idx & 1) ? rbl : rbh, d, 16, off, 0, 0, 0);
         }
+    };
+    auto issue = [&](int buf) {
+        begin_chunk();
 #pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            const int off = (int)((unsigned)b_off[j] + bdelta);
-            lds_byte* d = st + 2 * A_BYTES + (wave * BI + j) * 16 * ROW;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, d, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbl, d + B_BYTES, 16, off, 0, 0, 0);
-        }
+        for (int idx = 0; idx < NPIECE; ++idx) issue_piece(buf, idx);
     };
 
     f32x16 acc[TM][TN];
@@ -124,28 +133,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
     const int kc0 = ((0 + lh) ^ swz) * 16, kc1 = ((2 + lh) ^ swz) * 16;       // byte offset of this lane's 8 k-values, k-step 0 / 1
     const int a_rd = (wm * WM + l31) * ROW, b_rd = 2 * A_BYTES + (wn * WN + l31) * ROW;
 
-    auto mma_tile = [&](int cur) {
+    // Multiply stage `cur` while the DMA of the next chunk is issued into stage `nxt` between the first MFMA slots; the
+    // operand fragments of slot s+1 are read from LDS before the MFMAs of slot s.
+    constexpr int SLOTS = (BK / 16) * TM;
+    constexpr int LSLOTS = SLOTS / 2;
+    constexpr int LPS = (NPIECE + LSLOTS - 1) / LSLOTS;
+    auto mma_tile = [&](int cur, int nxt) {
         const unsigned char* base = smem_b + cur * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        auto read_a = [&](int slot, bf16x8& h, bf16x8& l) {
+            const int i = slot % TM, kc = (slot / TM) ? kc1 : kc0;
+            h = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * ROW + kc);
+            l = *reinterpret_cast<const bf16x8*>(base + a_rd + A_BYTES + i * 32 * ROW + kc);
+        };
+        auto read_b = [&](int ks, bf16x8* h, bf16x8* l) {
             const int kc = ks ? kc1 : kc0;
-            bf16x8 bh[TN], bl[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * ROW + kc);
-                bl[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + B_BYTES + j * 32 * ROW + kc);
+                h[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * ROW + kc);
+                l[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + B_BYTES + j * 32 * ROW + kc);
+            }
+        };
+        bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
+        read_b(0, bh[0], bl[0]);
+        read_a(0, ah[0], al[0]);
+        begin_chunk();
+#pragma unroll
+        for (int slot = 0; slot < SLOTS; ++slot) {
+            const int ks = slot / TM, i = slot % TM;
+            if (slot + 1 < SLOTS) {
+                read_a(slot + 1, ah[(slot + 1) & 1], al[(slot + 1) & 1]);
+                if ((slot + 1) % TM == 0) read_b(ks + 1, bh[(ks + 1) & 1], bl[(ks + 1) & 1]);
+            }
+            if (slot < LSLOTS) {
+#pragma unroll
+                for (int u = 0; u < LPS; ++u)
+                    if (slot * LPS + u < NPIECE) issue_piece(nxt, slot * LPS + u);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * ROW + kc);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + a_rd + A_BYTES + i * 32 * ROW + kc);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                }
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bl[ks & 1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -153,8 +183,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
     __syncthreads();                  // drains the DMA (vmcnt(0)) and publishes stage 0
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        issue(cur ^ 1);               // chunk kt+1 lands while chunk kt is multiplied
-        mma_tile(cur);
+        mma_tile(cur, cur ^ 1);       // chunk kt+1 lands while chunk kt is multiplied
         __syncthreads();
     }
     wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh);

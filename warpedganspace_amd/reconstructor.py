@@ -13,9 +13,11 @@ checkpoint compatibility but never executed: the reference runs it and discards 
 
 Execution is an explicit kernel schedule on NHWC activations: implicit-GEMM MFMA convs (fwd / dgrad /
 wgrad), fused train-mode BatchNorm(+residual)(+ReLU), max/avg pooling, small dense heads.
-The trained network always uses the EXACT fp32 MFMA kernels (precision=0), whatever arithmetic the frozen
+The trained network always uses the EXACT fp32 MFMA kernels (precision=R_PRECISION), whatever arithmetic the frozen
 generator is run in: its gradients pass through train-mode BatchNorm, which amplifies operand rounding.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -23,6 +25,9 @@ from . import _lib as L
 from . import conv as C
 
 BN_EPS, BN_MOM = 1e-5, 0.1
+# Arithmetic of R's conv fwd/dgrad launches: 0 = exact fp32 MFMA (default, see the module docstring); 1 = split-bf16 x3
+# (experiments only: WGS_R_PRECISION=bf16x3 or bench.py --r-precision bf16x3).
+R_PRECISION = 1 if os.environ.get('WGS_R_PRECISION', 'fp32').lower() in ('bf16x3', '1') else 0
 
 
 def _conv(ci, co, k, stride, pad):
@@ -175,7 +180,7 @@ class Reconstructor(nn.Module):
         w1 = _packed(fe.conv1)
         w1p = torch.zeros(64, 49, Cp, device=dev)
         w1p[:, :, :2 * c] = w1
-        c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=0)
+        c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=R_PRECISION)
         a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
         Hp = (a1.shape[1] + 2 - 3) // 2 + 1
         p1 = torch.empty(B, Hp, Hp, 64, device=dev)
@@ -186,11 +191,11 @@ class Reconstructor(nn.Module):
         h = p1
         for blk in fe.blocks():
             xin = h
-            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=0)
+            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=R_PRECISION)
             aa, sa = _BN.fwd(blk.bn1, ca, ws, relu=True, train=train)
-            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=0)
+            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=R_PRECISION)
             if blk.downsample is not None:
-                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=0)
+                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=R_PRECISION)
                 ad, sd = _BN.fwd(blk.downsample[1], cd, ws, relu=False, train=train)
                 ident = ad
             else:
@@ -250,7 +255,7 @@ class Reconstructor(nn.Module):
             dw2 = gbuf[id(blk.conv2.weight)] if gbuf is not None else torch.zeros_like(w2)
             C.conv2d_wgrad(aa, dcb, dw2, 3, stride=1, pad=1)
             grads[id(blk.conv2.weight)] = _grad_like(blk.conv2, dw2)
-            daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=0)
+            daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=R_PRECISION)
             dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train, gbuf=gbuf)
             grads[id(blk.bn1.weight)], grads[id(blk.bn1.bias)] = dg, db_
             w1 = _packed(blk.conv1)
@@ -258,7 +263,7 @@ class Reconstructor(nn.Module):
             dw1 = gbuf[id(blk.conv1.weight)] if gbuf is not None else torch.zeros_like(w1)
             C.conv2d_wgrad(xin, dca, dw1, 3, stride=blk.stride, pad=1)
             grads[id(blk.conv1.weight)] = _grad_like(blk.conv1, dw1)
-            dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=0)
+            dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=R_PRECISION)
             if blk.downsample is not None:
                 dcd, _, dg, db_ = _BN.bwd(blk.downsample[1], cd, sd, dres, None, None, ws, train=train, gbuf=gbuf)
                 grads[id(blk.downsample[1].weight)], grads[id(blk.downsample[1].bias)] = dg, db_
@@ -267,7 +272,7 @@ class Reconstructor(nn.Module):
                 dwd = gbuf[id(blk.downsample[0].weight)] if gbuf is not None else torch.zeros_like(wd)
                 C.conv2d_wgrad(xin, dcd, dwd, 1, stride=blk.stride, pad=0)
                 grads[id(blk.downsample[0].weight)] = _grad_like(blk.downsample[0], dwd)
-                dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0, precision=0)
+                dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0, precision=R_PRECISION)
             else:
                 dside = dres
             dyA, dyB = dmain, dside
@@ -289,7 +294,7 @@ class Reconstructor(nn.Module):
         if need_x[0] or need_x[1]:
             w1p = torch.zeros(64, 49, Cp, device=dev)
             w1p[:, :, :2 * c] = _packed(fe.conv1)
-            dx = C.conv2d_dgrad(dc1, C.repack_w_t(w1p, 64, 49, Cp), (S['H'], S['W']), 7, stride=2, pad=3, precision=0)
+            dx = C.conv2d_dgrad(dc1, C.repack_w_t(w1p, 64, 49, Cp), (S['H'], S['W']), 7, stride=2, pad=3, precision=R_PRECISION)
             d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
             d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
             L.check(lib.wgs_unpack_pair_grad(L.ptr(dx), L.ptr(d1), L.ptr(d2), B, c, S['H'] * S['W'], Cp, st), 'unpack_pair')
