@@ -38,7 +38,7 @@ def build(dev, size, K, N, B, seed, w_space=False):
     from warpedganspace_amd.reconstructor import Reconstructor
     from warpedganspace_amd.support_sets import SupportSets
     from warpedganspace_amd.trainer import TrainStep
-    torch.manual_seed(seed)
+    torch.manual_seed(0)          # identical random-init G / S / R on every rank; `seed` only drives the per-rank sampling
     G = build_stylegan2(None, resolution=size, shift_in_w_space=w_space)
     S = SupportSets(K, N, G.dim_z, learn_alphas=False, learn_gammas=True, gamma=1.0 / G.dim_z)
     R = Reconstructor('ResNet', K, channels=3)

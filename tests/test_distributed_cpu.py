@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
     # this rank's replica of the trainable parameters, re-homed into a flat bucket
     table = torch.nn.Parameter(c['sd']['SUPPORT_SETS'].clone())
     lg = torch.nn.Parameter(c['sd']['LOGGAMMA'].clone())
-    bucket = FlatBucket([(1e-4, [table, lg])], torch.device('cpu'))
+    bucket = FlatBucket([(1e-4, [table]), (1e-4, [lg])], torch.device('cpu'))   # two groups, like [R | S] in TrainStep
     sl = slice(rank * Bg // world, (rank + 1) * Bg // world)          # shard the global batch by sample
     sd = {'SUPPORT_SETS': table, 'ALPHAS': c['sd']['ALPHAS'], 'LOGGAMMA': lg}
     loss = _loss(sd, head, c['z'][sl], c['idx'][sl], c['gout'][sl, 0] * 0.3, c['gamma'], K)
@@ -50,7 +50,11 @@ def _worker(rank, world, port, q):
     bucket.zero_grad()
     bucket.gview[id(table)].copy_(g_table)
     bucket.gview[id(lg)].copy_(g_lg)
-    dist.all_reduce(bucket.grad)                                       # the step's single collective (sum)
+    # the step's collectives exactly as TrainStep.step issues them: one async all-reduce (sum) per bucket group, on
+    # views of the flat gradient, waited for before Adam
+    pending = [dist.all_reduce(bucket.grad[a:b], async_op=True) for _, a, b in bucket.groups]
+    for w in pending:
+        w.wait()
     avg = bucket.grad / world                                          # Adam's grad_scale = 1/world
     if rank == 0:
         q.put((avg.clone(), table.data_ptr() == bucket.flat.data_ptr()))

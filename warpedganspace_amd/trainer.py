@@ -92,6 +92,12 @@ class TrainStep:
                     if p.requires_grad and not n.startswith('features_extractor.fc')]
         s_params = [p for p in support_sets.parameters() if p.requires_grad]
         self.bucket = FlatBucket([(params.reconstructor_lr, r_params), (params.support_set_lr, s_params)], device)
+        if world > 1:
+            # replicas start from rank 0's parameters and BN running statistics, whatever each rank's RNG produced
+            dist.broadcast(self.bucket.flat, 0)
+            for b in reconstructor.buffers():
+                if b.is_floating_point():
+                    dist.broadcast(b.data, 0)
         K, n2 = support_sets.ALPHAS.shape
         self.K, self.n2, self.d = K, n2, support_sets.support_vectors_dim
         self.rbf_ws = rbf_workspace(local_batch, n2, self.d, device)
@@ -142,6 +148,12 @@ class TrainStep:
         gb = self.bucket.gview
         _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb)
         del saved
+        pending = []
+        if self.world > 1:
+            # R's gradients (the first bucket group, 47 MB at cfg3) are final here: their all-reduce runs on RCCL's
+            # stream while the generator's backward (no trainable parameters) computes d shift
+            _, a, b = self.bucket.groups[0]
+            pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
         img_shifted.backward(d_img)                                           # G: d image -> d shift
         dtable = gb[id(S.SUPPORT_SETS)]
         dlg = gb[id(S.LOGGAMMA)].reshape(-1) if (S.learn_gammas and id(S.LOGGAMMA) in gb) else None
@@ -151,7 +163,10 @@ class TrainStep:
                                 L.ptr(idx, torch.int64), L.ptr(code), L.ptr(mag), L.ptr(gshift), L.ptr(self.rbf_ws),
                                 L.ptr(dtable), L.ptr(dlg), L.ptr(dal), None, B, self.K, self.n2, self.d, st), 'wgs_rbf_bwd')
         if self.world > 1:
-            dist.all_reduce(self.bucket.grad)                                 # RCCL sum; Adam divides by world
+            _, a, b = self.bucket.groups[1]                                   # S's gradients (RCCL sum; Adam divides by world)
+            pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
+            for w in pending:
+                w.wait()
         self.bucket.adam_step(world=self.world)                               # :253-254
         self.stats_sum += self.stats
         self.stats_n += 1
