@@ -389,6 +389,87 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Narrow implicit GEMM: Cout <= 8 and Ci == 64 (the image-gradient dgrad of ResNet conv1: 64 -> 6(+2) channels over
+// 2 M pixels).  A 128x32 MFMA tile wastes 3/4 of its columns; here a wave owns 16 consecutive GEMM rows: lane =
+// (row r = lane / 16 of a 4-row group, 4 input channels k4 = lane % 16), so one float4 load per lane fetches 4 rows x
+// 64 channels, the 8 weight rows of a tap (float4 per lane, L1-resident) are reused by the 4 row groups, and the
+// 16-lane partial sums are combined by one butterfly transpose-reduction at the end.  Exact fp32 (fmaf chains).
+__global__ __launch_bounds__(256) void igemm_narrow_kernel(const ConvArgs p) {
+    const int lane = threadIdx.x & 63, lr = lane >> 4, k4 = (lane & 15) * 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m_first = wave * 16;
+    if (m_first >= p.M) return;
+    int iy0[4], ix0[4], pixo[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int m = m_first + g * 4 + lr;
+        const int mm = m < p.M ? m : 0;
+        const int gx = mm % p.Wg;
+        const int t = mm / p.Wg;
+        const int gy = t % p.Hg;
+        const int b = t / p.Hg;
+        iy0[g] = m < p.M ? gy * p.isy : -100000;      // invalid rows fail every bounds test
+        ix0[g] = gx * p.isx;
+        pixo[g] = (b * p.Hi * p.Wi + gy * p.isy * p.Wi + gx * p.isx) * 64 + k4;      // element offset of (row, k4), tap (0,0)
+    }
+    float acc[32];                     // [row group g][column n]
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    for (int t = 0; t < p.ntaps; ++t) {
+        const int yx = p.tap_yx[t];
+        const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+        const int adelta = p.tap_a[t] >> 2;                                           // (dy*Wi + dx) * Ci elements
+        const float* wt = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w) + p.tap_w[t]) + k4;
+        // branch-free: every load is issued unconditionally from a clamped address, masked afterwards
+        float4 wv[8], av[4];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) wv[n] = *reinterpret_cast<const float4*>(wt + (size_t)(n < p.Co ? n : 0) * p.w_row_stride);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int iy = iy0[g] + dy, ix = ix0[g] + dx;
+            const bool v = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const float4 a = *reinterpret_cast<const float4*>(p.x + (v ? pixo[g] + adelta : k4));
+            av[g] = v ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                float s = acc[g * 8 + n];
+                s = fmaf(av[g].x, wv[n].x, s); s = fmaf(av[g].y, wv[n].y, s);
+                s = fmaf(av[g].z, wv[n].z, s); s = fmaf(av[g].w, wv[n].w, s);
+                acc[g * 8 + n] = s;
+            }
+    }
+    // butterfly transpose-reduction over the 16 lanes of a row: 32 values -> 2 per lane
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int half = 16 >> s, off = 8 >> s;
+        const bool upper = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float send = upper ? acc[i] : acc[i + half];
+            const float keep = upper ? acc[i + half] : acc[i];
+            acc[i] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+    // lane (lr, j = lane % 16) now holds value indices 2j and 2j+1 -> (g, n) = (idx / 8, idx % 8) of row g*4 + lr
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = (lane & 15) * 2 + u, g = idx >> 3, n = idx & 7;
+        const int m = m_first + g * 4 + lr;
+        if (m < p.M && n < p.Co) {
+            const int gx = m % p.Wg;
+            const int t = m / p.Wg;
+            const int gy = t % p.Hg;
+            const int b = t / p.Hg;
+            const size_t pix = (size_t)b * p.Ho * p.Wo + (size_t)(gy * p.osy + p.oy0) * p.Wo + gx * p.osx + p.ox0;
+            p.y[pix * p.Co + n] = acc[u] * p.alpha + (p.bias ? p.bias[n] : 0.f);
+        }
+    }
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 int launch_nt(const ConvArgs& a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
@@ -479,6 +560,13 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     const int rc = build_conv_args(d, a);
     if (rc != WGS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&
+        d->act == 0 && d->act_slope == 1.f && d->gain == 1.f) {
+        const long waves = ((long)a.M + 15) / 16;
+        hipLaunchKernelGGL(igemm_narrow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+        WGS_CHECK_LAUNCH("igemm_narrow_kernel");
+        return WGS_OK;
+    }
     const bool k32 = (d->Ci % 32 == 0);
     if (d->precision == 1 && wgsconv::launch_bf16x3(a, st) == 0) {
         WGS_CHECK_LAUNCH("igemm_nt_bf16x3_kernel");
