@@ -239,3 +239,33 @@ def test_conv_transpose_s2_merged_phases_lds_dma(dev, monkeypatch):
     ref = F.conv_transpose2d((x[:1].cpu().permute(0, 3, 1, 2) * s[:1].cpu()[:, :, None, None]).double(),
                              wp.cpu().reshape(Co, 3, 3, Ci).permute(3, 0, 1, 2).double(), stride=2) * dm[:1].cpu().double()[:, :, None, None]
     assert rel_err(nchw(y2[:1]), ref) < 2e-5
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(8, 128, 128, 64), (2, 64, 128, 256), (32, 32, 256, 32)])
+def test_conv_split_bf16_patch_form(dev, B, Ci, Co, H):
+    """Stride-1 3x3 convs with pre-split weights take the patch kernel (halo patch staged once per channel chunk, taps read
+    shifted rows): forward and dgrad, all tile geometries (2x128, 4x64, 8x32 pixels), identical to the register-staged
+    kernel and within 2e-5 of the exact one; plus one CPU sample."""
+    torch.manual_seed(H + Co)
+    x = torch.randn(B, H, H, Ci, device=dev)
+    w = torch.randn(Co, Ci, 3, 3) / (Ci * 9) ** 0.5
+    wp = C.pack_weight(w).to(dev)
+    ws = C.split_weight(wp)
+    s = torch.randn(B, Ci, device=dev) + 1.0
+    dm = torch.rand(B, Co, device=dev) + 0.5
+    bias, noise, nw = torch.randn(Co, device=dev), torch.randn(H, H, device=dev), torch.tensor([0.37], device=dev)
+    kw = dict(a_scale=s, col_scale=dm, bias=bias, noise=noise, noise_w=nw, act_slope=0.2, gain=2 ** 0.5)
+    y_p = C.conv2d(x, wp, 3, pad=1, precision=1, w_split=ws, **kw)
+    y_r = C.conv2d(x, wp, 3, pad=1, precision=1, **kw)
+    assert torch.equal(y_p, y_r)
+    assert rel_err(y_p, C.conv2d(x, wp, 3, pad=1, precision=0, **kw)) < 2e-5
+    xb = x[:1].cpu().permute(0, 3, 1, 2).double() * s[:1].cpu().double()[:, :, None, None]
+    ref = F.conv2d(xb, w.double(), padding=1) * dm[:1].cpu().double()[:, :, None, None] + (nw.cpu() * noise.cpu()).double()[None, None] \
+        + bias.cpu().double()[None, :, None, None]
+    assert rel_err(nchw(y_p[:1]), F.leaky_relu(ref, 0.2) * 2 ** 0.5) < 2e-5
+    if Ci % 128 == 0:
+        wt = C.repack_w_t(wp, Co, 9, Ci)
+        g = torch.randn(B, H, H, Co, device=dev)
+        d_p = C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=1, w_split=C.split_weight(wt))
+        assert torch.equal(d_p, C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=1))
+        assert rel_err(d_p, C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=0)) < 2e-5

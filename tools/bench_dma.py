@@ -18,4 +18,4 @@ for ci, co, h in [(512, 512, 64), (256, 256, 128), (128, 128, 256)]:
     fl = 2.0 * B * h * h * co * ci * 9
     m0 = timeit(lambda: C.conv2d(x, w, 3, pad=1, out=y, a_scale=s, precision=1))
     m1 = timeit(lambda: C.conv2d(x, w, 3, pad=1, out=y, a_scale=s, precision=1, w_split=ws))
-    print(ci, co, h, 'reg %.3f ms %.1f TF | dma(+prepass) %.3f ms %.1f TF' % (m0, fl / m0 / 1e9, m1, fl / m1 / 1e9))
+    print(ci, co, h, 'reg %.3f ms %.1f TF | with pre-split weights (patch form) %.3f ms %.1f TF' % (m0, fl / m0 / 1e9, m1, fl / m1 / 1e9))

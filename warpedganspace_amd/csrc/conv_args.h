@@ -83,4 +83,8 @@ void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, un
                 int C, hipStream_t st);
 void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st);
 
+// patch form for stride-1 convs (conv_igemm_patch.hip); 0 = launch taken.  Needs x_bytes / w_bytes (fp32 extents) and the
+// 64-entry tap tables filled.
+int launch_patch_bf16x3(const ConvArgs& a, hipStream_t st);
+
 }  // namespace wgsconv

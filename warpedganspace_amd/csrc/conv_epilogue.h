@@ -8,34 +8,17 @@ namespace wgsconv {
 
 typedef float epi_f32x16 __attribute__((ext_vector_type(16)));
 
+// second half: the staged row arrays (r_pix / r_b / r_nz / r_add in LDS, filled by the caller and published with a
+// barrier) -> every accumulator gets alpha, demodulation, noise, bias, addend, activation and is stored
 template <int BM, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs& P, epi_f32x16 (&acc)[TM][TN], unsigned char* smem_b,
-                                              int m0, int n0, int wm, int wn, int tid, int l31, int lh) {
-    int* r_pix = reinterpret_cast<int*>(smem_b);
-    int* r_b = r_pix + BM;
-    float* r_nz = reinterpret_cast<float*>(r_b + BM);
-    int* r_add = reinterpret_cast<int*>(r_nz + BM);
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int pix = -1, bb = 0, ap = 0;
-        float nz = 0.f;
-        const int bq = m / P.Mimg, pq = m - bq * P.Mimg;
-        if (m < P.M && pq < P.HW) {
-            const int gy = pq / P.Wg, gx = pq - gy * P.Wg;
-            bb = bq;
-            const int oy = gy * p.osy + P.oy0, ox = gx * p.osx + P.ox0;
-            const int hw = oy * p.Wo + ox;
-            pix = bb * p.Ho * p.Wo + hw;
-            if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
-            ap = (bb * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
-        }
-        r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
-    }
-    __syncthreads();
+__device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x16 (&acc)[TM][TN], const unsigned char* smem_b,
+                                                    int n0, int wm, int wn, int l31, int lh) {
+    const int* r_pix = reinterpret_cast<const int*>(smem_b);
+    const int* r_b = r_pix + BM;
+    const float* r_nz = reinterpret_cast<const float*>(r_b + BM);
+    const int* r_add = reinterpret_cast<const int*>(r_nz + BM);
     // demodulation factors: a tile usually covers one or two samples -> two registers per column
-    const int b_lo = r_b[0];
-    const int m_last = min(m0 + BM, P.M) - 1;
-    const int b_hi2 = m_last / P.Mimg;
+    const int b_lo = r_b[0], b_hi2 = r_b[BM - 1];
     const bool cs_fast = p.col_scale && (b_hi2 - b_lo <= 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -64,6 +47,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs
             }
         }
     }
+}
+
+template <int BM, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs& P, epi_f32x16 (&acc)[TM][TN], unsigned char* smem_b,
+                                              int m0, int n0, int wm, int wn, int tid, int l31, int lh) {
+    int* r_pix = reinterpret_cast<int*>(smem_b);
+    int* r_b = r_pix + BM;
+    float* r_nz = reinterpret_cast<float*>(r_b + BM);
+    int* r_add = reinterpret_cast<int*>(r_nz + BM);
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int pix = -1, bb = 0, ap = 0;
+        float nz = 0.f;
+        const int bq = m / P.Mimg, pq = m - bq * P.Mimg;
+        // rows past the end keep the sample index of the last valid row, so that r_b[BM-1] bounds the tile's samples
+        bb = m < P.M ? bq : (P.M - 1) / P.Mimg;
+        if (m < P.M && pq < P.HW) {
+            const int gy = pq / P.Wg, gx = pq - gy * P.Wg;
+            const int oy = gy * p.osy + P.oy0, ox = gx * p.osx + P.ox0;
+            const int hw = oy * p.Wo + ox;
+            pix = bb * p.Ho * p.Wo + hw;
+            if (p.noise && p.noise_w) nz = p.noise_w[0] * p.noise[hw];
+            ap = (bb * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
+        }
+        r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
+    }
+    __syncthreads();
+    conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh);
 }
 
 // workgroup -> (phase, m-tile, n-tile); false = padding workgroup of a merged launch (exits)

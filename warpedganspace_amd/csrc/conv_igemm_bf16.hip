@@ -27,7 +27,7 @@ using wgsconv::PhaseArgs;
 #ifndef WGS_ABL
 #define WGS_ABL 0   // development ablations: 1 no split arithmetic, 2 no LDS stores, 3 no MFMA, 4 no global loads,
                     // 7 no style loads, 8 no weight loads, 9 no activation loads, 10 no LDS operand reads,
-                    // 11 no 256-row tiles, 13 no split-K, 15 no LDS-DMA path
+                    // 11 no 256-row tiles, 13 no split-K, 15 no LDS-DMA path, 16 no patch form
 #endif
 
 constexpr int BK = 32;          // fp32 values per K-chunk
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     // shared by every tile) are fetched one iteration ahead in a single set, and are issued BEFORE the far activation
     // prefetch: vmcnt retires in order, so the wait in store_tile() leaves the chunk-(kt+2) loads in flight.
     struct Stage { float4 ra[PA]; };
-    constexpr bool DEEP = (NT == 256);
+    constexpr bool DEEP = (TM * TN <= 4);      // 64 accumulator registers: room for two activation staging sets
     Stage s0, s1;
     float4 rs[PS], rb[PB];
     const int cpt = p.Ci / BK;
@@ -502,6 +502,8 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     for (int t = 0; t < a.ntaps; ++t) wt_max = a.wt[t] > wt_max ? a.wt[t] : wt_max;
     if (!set_extents(a, wt_max)) return 1;
     fill_tap_tables(a);
+    // stride-1 3x3 convs with pre-split weights: the patch form stages the activation halo patch once per channel chunk
+    if (WGS_ABL != 16 && !getenv("WGS_NO_PATCH") && launch_patch_bf16x3(a, st) == 0) return 0;
     // Styled launches want every tile inside one sample (one style vector per tile, and the only form the 8-wave
     // tiles support).  When Hg*Wg is not a multiple of the tile height (the sub-pixel phases of the up-convs: 65x65,
     // 129x129 ...) each sample's row range is padded up to it, if that costs < 13 % extra rows.

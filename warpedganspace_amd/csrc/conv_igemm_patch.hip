@@ -1,0 +1,274 @@
+// Split-bf16 implicit-GEMM convolution, PATCH form, for stride-1 convs with a small tap neighbourhood (3x3): the
+// activation operand of a 256-pixel tile is staged ONCE per 32-channel chunk as the tile's input patch (tile + halo), and
+// all taps of the chunk read their rows from that patch with a shifted row index.
+//
+//   register-staged / DMA forms: A tile (256 rows x 32 ch) loaded + split + written to LDS for EVERY tap  (9x per chunk)
+//   patch form:                  (R+2) x (Wt+2) pixels loaded + split + written once per chunk            (2.0x .. 1.3x)
+//
+// i.e. 4.4x .. 6.8x less vector-memory, split-VALU and ds_write work on the activation side — which is what bounds the
+// Cout = 128 layers at 256x256 (20 % of the training step): with only 128 output columns to amortise an activation row
+// over, the register-staged kernel spent more time staging than multiplying (no-MFMA ablation: 1.87 of 2.3 ms).
+//
+// Tile = R x Wt output pixels of ONE sample (Wt = min(W, 128), R = 256 / Wt): every tile has one style vector.
+// Weights come pre-split (wgs_split_bf16) and are copied global -> LDS by DMA per (chunk, tap), double-buffered.
+// LDS: patch hi | lo (unpadded 64-B rows, XOR-swizzled 16-B chunks) single-buffered — the next chunk's patch waits in
+// registers during the 9 tap steps and is written between two barriers at the chunk boundary — plus two weight stages.
+#include "wgs_common.h"
+#include "conv_args.h"
+#include "conv_epilogue.h"
+
+typedef wgsconv::epi_f32x16 f32x16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+using wgsconv::ConvArgs;
+
+constexpr int BK = 32;
+constexpr int ROW = 64;                  // bytes per LDS row and plane (32 bf16)
+constexpr int BM = 256;                  // output pixels per tile
+constexpr int PMAX = 528;                // patch pixels the LDS image holds (4 x 130 = 520 is the largest used)
+constexpr int NT = 512;
+constexpr int NPL = (PMAX * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (9)
+constexpr int OOB = (int)0x80000000;
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+struct PatchGeom {       // uniform per launch
+    int Wt, R, PW, PH, tiles_x, tiles_per_img, dy_min, dx_min;
+};
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(NT, 1) void igemm_patch_bf16x3_kernel(const ConvArgs p, const PatchGeom g) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int P_BYTES = PMAX * ROW;                 // one patch plane
+    constexpr int B_BYTES = BN * ROW;                   // one weight plane of a stage
+    constexpr int B_STAGE = 2 * B_BYTES;
+    constexpr int BI = BN / 16 / 8;                     // 16-row DMA instructions per wave and plane
+    static_assert(WAVES_M * WAVES_N == 8 && BI >= 1, "8 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* patch = smem_b;                      // hi | lo
+    unsigned char* bst = smem_b + 2 * P_BYTES;          // two weight stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntn = p.Co / BN;
+    // XCD-aware order over the (tile-major, column-tile minor) list, as in the other kernels
+    int bid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int qn = nb >> 3, rn = nb & 7;
+        bid = xcd * qn + min(xcd, rn) + slot;
+    }
+    const int tile = bid / ntn, n0 = (bid % ntn) * BN;
+    const int b = tile / g.tiles_per_img;
+    const int trem = tile - b * g.tiles_per_img;
+    const int ty0 = (trem / g.tiles_x) * g.R, tx0 = (trem % g.tiles_x) * g.Wt;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_lo), 0, p.w_bytes, 0x00020000);
+
+    // ---- patch staging: element e = tid + j*NT -> patch pixel e / 8, float4 q = e % 8 (= tid % 8 for every j)
+    const int q = tid & 7;
+    const int npatch = g.PH * g.PW;
+    int p_goff[NPL];        // byte offset of (pixel, q) in x for chunk 0, or OOB
+    int p_loff[NPL];        // byte offset in the hi patch plane
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int pp = (tid + j * NT) >> 3;
+        const int pr = pp / g.PW, pc = pp - pr * g.PW;
+        const int iy = ty0 + g.dy_min + pr, ix = tx0 + g.dx_min + pc;
+        const bool v = pp < npatch && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        p_goff[j] = v ? (((b * p.Hi + iy) * p.Wi + ix) * p.Ci + q * 4) * 4 : OOB;
+        p_loff[j] = pp < PMAX ? pp * ROW + (((q >> 1) ^ ((pp >> 2) & 3)) << 4) + ((q & 1) << 3) : -1;
+    }
+    const float* sc_ptr = p.a_scale ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
+    float4 pr_[NPL];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    const int cpt = p.Ci / BK;
+    auto load_patch = [&](int c) {
+        const int cbyte = c < cpt ? c * (BK * 4) : OOB;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
+            pr_[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+        if (sc_ptr && c < cpt) sc = *reinterpret_cast<const float4*>(sc_ptr + c * BK);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            float4 v = pr_[j];
+            v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (no fma into the residual)
+            const f32x4 f = {v.x, v.y, v.z, v.w};
+            const bf16x4 h = __builtin_convertvector(f, bf16x4);
+            const f32x4 r = f - __builtin_convertvector(h, f32x4);
+            const bf16x4 l = __builtin_convertvector(r, bf16x4);
+            if (p_loff[j] >= 0) {
+                *reinterpret_cast<uint2*>(patch + p_loff[j]) = __builtin_bit_cast(uint2, h);
+                *reinterpret_cast<uint2*>(patch + P_BYTES + p_loff[j]) = __builtin_bit_cast(uint2, l);
+            }
+        }
+    };
+
+    // ---- weight DMA: this lane feeds LDS row 16*instr + lane/4, slot lane%4
+    const int lrow = lane >> 2, slot = lane & 3;
+    int b_off[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = (wave * BI + j) * 16 + lrow;
+        const int lc = slot ^ ((row >> 2) & 3);
+        b_off[j] = (int)((long)(n0 + row) * p.w_row_stride + lc * 8) * 2;
+    }
+    auto issue_b = [&](int stage, int c, int t) {        // weights of (chunk c, tap t) -> stage; past the end: zeros
+        const unsigned delta = c < cpt ? (unsigned)((p.tap_w[t] >> 1) + c * (BK * 2)) : (unsigned)OOB;
+        lds_byte* st = (lds_byte*)(bst + stage * B_STAGE);
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int off = (int)((unsigned)b_off[j] + delta);
+            lds_byte* d = st + (wave * BI + j) * 16 * ROW;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, d, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbl, d + B_BYTES, 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- operand fragment addressing
+    const int l31 = lane & 31, lh = lane >> 5;
+    int pp0[TM];             // patch pixel of this lane's row for tap offset 0
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31;
+        const int ty = r / g.Wt, tx = r - ty * g.Wt;
+        pp0[i] = ty * g.PW + tx;
+    }
+    const int bswz = (l31 >> 2) & 3;
+    const int b_rd = (wn * WN + l31) * ROW;
+    const int bk0 = ((0 + lh) ^ bswz) << 4, bk1 = ((2 + lh) ^ bswz) << 4;
+
+    auto mma_tap = [&](int stage, int tapoff) {
+        const unsigned char* bb = bst + stage * B_STAGE + b_rd;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = ks * 2 + lh;
+            bf16x8 bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * ROW + (ks ? bk1 : bk0));
+                bl[j] = *reinterpret_cast<const bf16x8*>(bb + B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int pp = pp0[i] + tapoff;
+                const unsigned char* pa = patch + pp * ROW + ((kc ^ ((pp >> 2) & 3)) << 4);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(pa + P_BYTES);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- main loop: chunk outer, tap inner
+    load_patch(0);
+    issue_b(0, 0, 0);
+    store_patch();
+    __syncthreads();
+    int stage = 0;
+    for (int c = 0; c < cpt; ++c) {
+        load_patch(c + 1);                       // waits in registers through the tap steps (OOB past the last chunk)
+        for (int t = 0; t < p.ntaps; ++t) {
+            const bool last = (t + 1 == p.ntaps);
+            issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + 1);
+            const int yx = p.tap_yx[t];
+            const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+            mma_tap(stage, (dy - g.dy_min) * g.PW + (dx - g.dx_min));
+            __syncthreads();                     // weight stage swap; after the last tap also: patch no longer read
+            stage ^= 1;
+        }
+        if (c + 1 < cpt) {
+            store_patch();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (contract of conv_igemm.hip; rows are the R x Wt tile pixels of sample b)
+    int* r_pix = reinterpret_cast<int*>(smem_b);
+    int* r_b = r_pix + BM;
+    float* r_nz = reinterpret_cast<float*>(r_b + BM);
+    int* r_add = reinterpret_cast<int*>(r_nz + BM);
+    if (tid < BM) {
+        const int ty = tid / g.Wt, tx = tid - ty * g.Wt;
+        const int oy = ty0 + ty, ox = tx0 + tx;
+        const int hw = oy * p.Wo + ox;
+        r_pix[tid] = b * p.Ho * p.Wo + hw;
+        r_b[tid] = b;
+        r_nz[tid] = (p.noise && p.noise_w) ? p.noise_w[0] * p.noise[hw] : 0.f;
+        r_add[tid] = (b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
+    }
+    __syncthreads();
+    wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh);
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+void launch_patch(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
+    const size_t sm = (size_t)2 * PMAX * ROW + (size_t)2 * 2 * BN * ROW;
+    auto k = igemm_patch_bf16x3_kernel<BN, WAVES_M, WAVES_N>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT), sm, st, a, g);
+}
+
+}  // namespace
+
+namespace wgsconv {
+
+// Returns 0 when the launch was taken: stride-1, same-size conv (Hg = Hi = Ho ...), pre-split weights, taps within a
+// neighbourhood whose patch fits, power-of-two width >= 32, Cout a multiple of 128, enough tiles for the chip.
+int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
+    const ConvArgs& a = a0;
+    if (!a.w_hi || !a.w_lo || a.ups || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 || a.oy0 || a.ox0) return 1;
+    if (a.Hg != a.Hi || a.Wg != a.Wi || a.Ho != a.Hi || a.Wo != a.Wi || a.Ci % 32 || a.Co % 128 || a.ntaps < 4 || a.ntaps > 16) return 1;
+    const int W = a.Wi, H = a.Hi;
+    if (W < 32 || (W & (W - 1))) return 1;
+    PatchGeom g;
+    g.Wt = W < 128 ? W : 128;
+    g.R = BM / g.Wt;
+    if (H % g.R) return 1;
+    int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
+    for (int t = 0; t < a.ntaps; ++t) {
+        dy0 = a.dy[t] < dy0 ? a.dy[t] : dy0; dy1 = a.dy[t] > dy1 ? a.dy[t] : dy1;
+        dx0 = a.dx[t] < dx0 ? a.dx[t] : dx0; dx1 = a.dx[t] > dx1 ? a.dx[t] : dx1;
+    }
+    g.dy_min = dy0; g.dx_min = dx0;
+    g.PH = g.R + dy1 - dy0; g.PW = g.Wt + dx1 - dx0;
+    if (g.PH * g.PW > PMAX) return 1;
+    g.tiles_x = W / g.Wt;
+    g.tiles_per_img = (H / g.R) * g.tiles_x;
+    const int bn = a.Co % 256 == 0 ? 256 : 128;
+    const int nblocks = a.B * g.tiles_per_img * (a.Co / bn);
+    if (nblocks < 200) return 1;
+    ConvArgs b = a;
+    b.w_bytes = a.w_bytes / 2;          // extents of the bf16 weight planes (x stays fp32)
+    if (bn == 256) launch_patch<256, 2, 4>(b, g, nblocks, st);
+    else launch_patch<128, 4, 2>(b, g, nblocks, st);
+    return 0;
+}
+
+}  // namespace wgsconv
