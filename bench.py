@@ -168,7 +168,7 @@ def main():
             traffic_note = ("GB per launch of %s, %s: FETCH_SIZE x2 (gfx950) + WRITE_SIZE from profiles/r1_conv_pmc.json; algorithmic %.3f GB"
                             % (rec['kernel'], rec['shape'], (rec['algorithmic_read_bytes'] + rec['algorithmic_write_bytes']) / 1e9))
         roofline = {"bound": "mfma",
-                    "kernel": ("igemm_nt_bf16x3_kernel (3 x v_mfma_f32_32x32x16_bf16 per product block) + igemm_wgrad_kernel (fp32)"
+                    "kernel": ("split-bf16 implicit-GEMM family: igemm_patch_bf16x3_kernel (dominant), igemm_nt_bf16x3_kernel, igemm_dma_bf16x3_kernel (3 x v_mfma_f32_32x32x16_bf16 per product block) + exact-fp32 igemm_nt / igemm_wgrad for the Reconstructor"
                                if bf else "igemm_nt_kernel / igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)"),
                     "achieved": round(fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(fl / ms / 1e9 / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
