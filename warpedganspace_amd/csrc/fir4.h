@@ -4,7 +4,8 @@
 //
 // where kf is the FLIPPED kernel (upfirdn2d correlates with the flipped kernel, upfirdn2d.py:176-178).  One thread
 // owns one (sample, 16-row strip, column, 4 channels) and walks down its strip keeping the last four input rows
-// (4x4 float4) in registers: 4.75 loads per output instead of 16, every load a fully coalesced row segment.
+// (4x5 float4: two adjacent output columns per thread) in registers: ~3 loads per output instead of 16, every load a
+// fully coalesced row segment.
 // EPI adds the StyleGAN2 noise + bias + leaky-relu*sqrt(2) epilogue (model.py:303-310, fused_act.py:91-99).
 #pragma once
 #include "wgs_common.h"
@@ -23,27 +24,29 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
     for (int i = 0; i < 16; ++i) kf[i] = kern[15 - i];
     const int c4n = C >> 2;
     const int strips = (Ho + TY - 1) / TY;
-    const long total = (long)B * strips * Wo * c4n;
+    const int wpairs = (Wo + 1) >> 1;                 // a thread owns TWO adjacent output columns: 5 loads per row for 2 outputs
+    const long total = (long)B * strips * wpairs * c4n;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     long r = e;
     const int c = (int)(r % c4n) * 4; r /= c4n;
-    const int ox = (int)(r % Wo); r /= Wo;
+    const int ox = (int)(r % wpairs) * 2; r /= wpairs;
     const int oy0 = (int)(r % strips) * TY;
     const int b = (int)(r / strips);
+    const bool two = ox + 1 < Wo;
     const float nw = (EPI && noise) ? noise_w[0] : 0.f;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI) bv = *reinterpret_cast<const float4*>(bias + c);
     const float* xb = x + (size_t)b * Hin * Win * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
     const int ix0 = ox - px0;
-    float4 win[4][4];
+    float4 win[4][5];
 #pragma unroll
     for (int rr = 0; rr < TY + 3; ++rr) {
         const int iy = oy0 - py0 + rr;
         const bool rowok = iy >= 0 && iy < Hin;
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
+        for (int kx = 0; kx < 5; ++kx) {
             const int ix = ix0 + kx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rowok && ix >= 0 && ix < Win) v = *reinterpret_cast<const float4*>(xb + ((size_t)iy * Win + ix) * C);
@@ -52,25 +55,29 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
         if (rr >= 3) {
             const int oy = oy0 + rr - 3;
             if (oy < Ho) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int ky = 0; ky < 4; ++ky)
+                for (int px = 0; px < 2; ++px) {
+                    if (px == 1 && !two) break;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) {
-                        const float wv = kf[ky * 4 + kx];
-                        const float4 v = win[(rr - 3 + ky) & 3][kx];
-                        acc.x = fmaf(v.x, wv, acc.x); acc.y = fmaf(v.y, wv, acc.y);
-                        acc.z = fmaf(v.z, wv, acc.z); acc.w = fmaf(v.w, wv, acc.w);
+                    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            const float wv = kf[ky * 4 + kx];
+                            const float4 v = win[(rr - 3 + ky) & 3][kx + px];
+                            acc.x = fmaf(v.x, wv, acc.x); acc.y = fmaf(v.y, wv, acc.y);
+                            acc.z = fmaf(v.z, wv, acc.z); acc.w = fmaf(v.w, wv, acc.w);
+                        }
+                    if (EPI) {
+                        const float nz = noise ? nw * noise[oy * Wo + ox + px] : 0.f;
+                        acc.x += nz + bv.x; acc.y += nz + bv.y; acc.z += nz + bv.z; acc.w += nz + bv.w;
+                        acc.x = (acc.x > 0.f ? acc.x : 0.2f * acc.x) * 1.4142135623730951f;
+                        acc.y = (acc.y > 0.f ? acc.y : 0.2f * acc.y) * 1.4142135623730951f;
+                        acc.z = (acc.z > 0.f ? acc.z : 0.2f * acc.z) * 1.4142135623730951f;
+                        acc.w = (acc.w > 0.f ? acc.w : 0.2f * acc.w) * 1.4142135623730951f;
                     }
-                if (EPI) {
-                    const float nz = noise ? nw * noise[oy * Wo + ox] : 0.f;
-                    acc.x += nz + bv.x; acc.y += nz + bv.y; acc.z += nz + bv.z; acc.w += nz + bv.w;
-                    acc.x = (acc.x > 0.f ? acc.x : 0.2f * acc.x) * 1.4142135623730951f;
-                    acc.y = (acc.y > 0.f ? acc.y : 0.2f * acc.y) * 1.4142135623730951f;
-                    acc.z = (acc.z > 0.f ? acc.z : 0.2f * acc.z) * 1.4142135623730951f;
-                    acc.w = (acc.w > 0.f ? acc.w : 0.2f * acc.w) * 1.4142135623730951f;
+                    *reinterpret_cast<float4*>(yb + ((size_t)oy * Wo + ox + px) * C) = acc;
                 }
-                *reinterpret_cast<float4*>(yb + ((size_t)oy * Wo + ox) * C) = acc;
             }
         }
     }
@@ -80,7 +87,7 @@ template <bool EPI>
 inline void launch_fir4(const float* x, const float* kern, float* y, int B, int Hin, int Win, int Ho, int Wo, int C, int py0,
                         int px0, const float* noise, const float* noise_w, const float* bias, hipStream_t st) {
     const int strips = (Ho + TY - 1) / TY;
-    const long total = (long)B * strips * Wo * (C / 4);
+    const long total = (long)B * strips * ((Wo + 1) / 2) * (C / 4);
     hipLaunchKernelGGL(fir4_kernel<EPI>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
                        C, py0, px0, noise, noise_w, bias);
 }

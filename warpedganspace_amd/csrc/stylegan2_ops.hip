@@ -146,12 +146,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ skip, float* __restrict__ img,
-                                                        int P, int C, float wscale) {
+                                                        int P, int C, float wscale, int ppb) {
+    // ppb = pixels per block (64, 128 or 256): small maps use small blocks so that the launch still fills the chip
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wm = sm;               // [3][C] modulated weights W[o,c]*s[b,c]*wscale
     float* res = sm + 3 * C;      // [3][256]
     const int b = blockIdx.y;
-    const int p0 = blockIdx.x * 256;
+    const int p0 = blockIdx.x * ppb;
+    const int ppwave = ppb >> 2;
     for (int i = threadIdx.x; i < 3 * C; i += 256) wm[i] = w[i] * s[(size_t)b * C + (i % C)] * wscale;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
     const int lpp = c4n < 64 ? c4n : 64;   // lanes per pixel (power of two: C in {32..512})
     const int ppw = 64 / lpp;              // pixels per wave iteration
     const int sub = lane / lpp, cl = lane % lpp;
-    for (int it = 0; it < 64; it += ppw) {
-        const int pl = wave * 64 + it + sub;
+    for (int it = 0; it < ppwave; it += ppw) {
+        const int pl = wave * ppwave + it + sub;
         const int p = p0 + pl;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         if (p < P) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
     }
     __syncthreads();
     const int p = p0 + threadIdx.x;
-    if (p < P) {
+    if (p < P && threadIdx.x < ppb) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const size_t off = ((size_t)b * 3 + o) * P + p;
@@ -413,7 +415,10 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
     WGS_CHECK_ARG(x && s && w && bias && img, "wgs_sg2_torgb_fwd: null pointer");
     WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && (C & (C - 1)) == 0, "wgs_sg2_torgb_fwd: C=%d must be a power of two >= 4", C);
     const size_t smem = (size_t)(3 * C + 3 * 256) * sizeof(float);
-    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, 256), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale);
+    int ppb = 256;
+    while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
+    if (C < 32) ppb = 256;                // a wave iteration covers 64 / (C/4) pixels: needs ppb/4 >= that
+    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale, ppb);
     WGS_CHECK_LAUNCH("torgb_fwd_kernel");
     return WGS_OK;
 }
