@@ -194,6 +194,19 @@ int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
                    wgs_stream_t stream);
 /* gx[m*ldx + k] (+)= wscale * sum_n gy[m*ldg + n] * gate(gate_y[m*ldg + n]) * w[n*K + k];
  * gate(v) = v > 0 ? gain : gain*slope when gate_y != NULL (backward of the fused leaky-relu), else 1. */
+/* Up to 16 independent bias-free layers y_i = epi(wscale_i * f(x_i) W_i^T) * out_gain_i in one launch (same M, f and epi
+ * as wgs_linear_fwd; K_i <= 512): the per-layer demodulation vectors of the StyleGAN2 synthesis network
+ * (model.py:196-199) are 13 such GEMVs per pass. */
+typedef struct wgs_linear_batch {
+    int32_t n, M, in_square, epilogue;
+    const float* x[16];
+    const float* w[16];
+    float* y[16];
+    int32_t N[16], K[16], ldx[16], ldy[16];
+    float wscale[16], eps[16], out_gain[16];
+} wgs_linear_batch;
+int wgs_linear_fwd_batch(const wgs_linear_batch* batch, wgs_stream_t stream);
+
 int wgs_linear_dgrad(const float* gy, const float* w, const float* gate_y, float* gx, int M, int N, int K, int ldg,
                      int ldx, float wscale, float gate_slope, float gate_gain, int accumulate, wgs_stream_t stream);
 /* dw[n*K+k] = sum_m gy[m*N+n] x[m*K+k];  db[n] = sum_m gy[m*N+n] (db may be NULL). */

@@ -86,6 +86,58 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
+// The same for up to 16 independent small layers in ONE launch (blockIdx.y = layer): the per-layer demodulation
+// vectors of the synthesis network are 13 such GEMVs per pass, each too small to fill the chip or hide its latency.
+struct LinearBatchArgs {
+    int n, M, in_square, epi;
+    const float* x[16];
+    const float* w[16];
+    float* y[16];
+    int N[16], K[16], ldx[16], ldy[16];
+    float wscale[16], eps[16], out_gain[16];
+};
+__global__ __launch_bounds__(256) void linear_fwd_batch_kernel(const LinearBatchArgs a) {
+    const int l = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    const int N = a.N[l], K = a.K[l];
+    if (n >= N) return;
+    const float* x = a.x[l];
+    const float* w = a.w[l];
+    const int ldx = a.ldx[l];
+    float4 wr[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int k = 4 * lane + 256 * t;
+        wr[t] = (k < K) ? *reinterpret_cast<const float4*>(w + (size_t)n * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int m0 = 0; m0 < a.M; m0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + u < a.M ? m0 + u : a.M - 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = 4 * lane + 256 * t;
+                if (k < K) {
+                    float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k);
+                    if (a.in_square) { xv.x *= xv.x; xv.y *= xv.y; xv.z *= xv.z; xv.w *= xv.w; }
+                    acc[u] = fmaf(xv.x, wr[t].x, acc[u]); acc[u] = fmaf(xv.y, wr[t].y, acc[u]);
+                    acc[u] = fmaf(xv.z, wr[t].z, acc[u]); acc[u] = fmaf(xv.w, wr[t].w, acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane < 4 && m0 + lane < a.M) {
+            float v = (lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) * a.wscale[l];
+            if (a.epi == 1) v = (v > 0.f ? v : 0.2f * v) * SQRT2;
+            else if (a.epi == 2) v = rsqrtf(v + a.eps[l]);
+            a.y[l][(size_t)(m0 + lane) * a.ldy[l] + n] = v * a.out_gain[l];
+        }
+    }
+}
+
 // gx[m,k] (+)= wscale * sum_n g'[m,n] w[n,k],  g' = gy * (gate ? (gate[m,n] > 0 ? gain : gain*slope) : 1)
 // Block = 16 k-columns x 16 n-groups; every thread accumulates its n-stripe in fp64 and the 16 stripes are
 // combined in fp64 through LDS (these reductions run over up to ~6000 terms — all modulation layers — and
@@ -381,6 +433,23 @@ int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
     if (K <= 256) WGS_LIN(1); else if (K <= 512) WGS_LIN(2); else if (K <= 1024) WGS_LIN(4); else WGS_LIN(8);
 #undef WGS_LIN
     WGS_CHECK_LAUNCH("linear_fwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_linear_fwd_batch(const wgs_linear_batch* b, wgs_stream_t stream) {
+    WGS_CHECK_ARG(b && b->n > 0 && b->n <= 16 && b->M > 0, "wgs_linear_fwd_batch: 1..16 layers");
+    LinearBatchArgs a;
+    a.n = b->n; a.M = b->M; a.in_square = b->in_square; a.epi = b->epilogue;
+    int nmax = 0;
+    for (int i = 0; i < b->n; ++i) {
+        WGS_CHECK_ARG(b->x[i] && b->w[i] && b->y[i] && b->N[i] > 0 && b->K[i] > 0 && b->K[i] % 4 == 0 && b->K[i] <= 512 && b->ldx[i] % 4 == 0,
+                      "wgs_linear_fwd_batch: layer %d needs K %% 4 == 0, K <= 512, ldx %% 4 == 0", i);
+        a.x[i] = b->x[i]; a.w[i] = b->w[i]; a.y[i] = b->y[i]; a.N[i] = b->N[i]; a.K[i] = b->K[i]; a.ldx[i] = b->ldx[i]; a.ldy[i] = b->ldy[i];
+        a.wscale[i] = b->wscale[i]; a.eps[i] = b->eps[i]; a.out_gain[i] = b->out_gain[i];
+        nmax = b->N[i] > nmax ? b->N[i] : nmax;
+    }
+    hipLaunchKernelGGL(linear_fwd_batch_kernel, dim3(wgs_cdiv(nmax, 4), b->n), dim3(256), 0, (hipStream_t)stream, a);
+    WGS_CHECK_LAUNCH("linear_fwd_batch_kernel");
     return WGS_OK;
 }
 

@@ -13,6 +13,7 @@ kernel schedule instead of nn.Module calls:
   * backward is hand-derived and propagates ONLY the input gradient (G is frozen, lib/trainer.py
     never uses its weight gradients): d image -> d latent -> (Z space) d z.
 """
+import ctypes
 import math
 
 import torch
@@ -21,6 +22,14 @@ from torch import nn
 from . import _lib as L
 from . import conv as C
 from . import ops
+
+
+class LinearBatch(ctypes.Structure):
+    """ctypes mirror of wgs_linear_batch (include/wgs.h)."""
+    _fields_ = [('n', ctypes.c_int32), ('M', ctypes.c_int32), ('in_square', ctypes.c_int32), ('epilogue', ctypes.c_int32),
+                ('x', ctypes.c_void_p * 16), ('w', ctypes.c_void_p * 16), ('y', ctypes.c_void_p * 16),
+                ('N', ctypes.c_int32 * 16), ('K', ctypes.c_int32 * 16), ('ldx', ctypes.c_int32 * 16), ('ldy', ctypes.c_int32 * 16),
+                ('wscale', ctypes.c_float * 16), ('eps', ctypes.c_float * 16), ('out_gain', ctypes.c_float * 16)]
 
 SQRT2 = 2 ** 0.5
 
@@ -280,15 +289,29 @@ class Generator(nn.Module):
                                    self.style_dim, sumC, L.c_float(P['mod_scale']), L.c_float(1.0), 0, 0,
                                    L.c_float(0.0), L.c_float(1.0), st), 'modulation')
         x = P['const'].unsqueeze(0).expand(B, -1, -1, -1).contiguous()
-        outs, demods = [], []
+        outs = []
         skip = None
+        # every layer's demodulation vector scale * rsqrt(scale^2 * sum_i s^2 wsq + 1e-8) in one batched launch
+        demods = [torch.empty(B, ly['Co'], device=dev) for ly in P['layers']]
+        nl = len(P['layers'])
+        if nl <= 16 and all(ly['Ci'] <= 512 for ly in P['layers']):
+            lb = LinearBatch()
+            lb.n, lb.M, lb.in_square, lb.epilogue = nl, B, 1, 2
+            for i, ly in enumerate(P['layers']):
+                lb.x[i] = S.data_ptr() + 4 * ly['off']
+                lb.w[i], lb.y[i] = ly['wsq'].data_ptr(), demods[i].data_ptr()
+                lb.N[i], lb.K[i], lb.ldx[i], lb.ldy[i] = ly['Co'], ly['Ci'], sumC, ly['Co']
+                lb.wscale[i], lb.eps[i], lb.out_gain[i] = ly['scale'] ** 2, 1e-8, ly['scale']
+            L.check(lib.wgs_linear_fwd_batch(ctypes.byref(lb), st), 'demod batch')
+        else:
+            for i, ly in enumerate(P['layers']):
+                L.check(lib.wgs_linear_fwd(L.rawptr(S[:, ly['off']:]), L.ptr(ly['wsq']), None, L.ptr(demods[i]), B, ly['Co'], ly['Ci'],
+                                           sumC, ly['Co'], L.c_float(ly['scale'] ** 2), L.c_float(0.0), 1, 2, L.c_float(1e-8),
+                                           L.c_float(ly['scale']), st), 'demod')
         for i, ly in enumerate(P['layers']):
             Ci, Co = ly['Ci'], ly['Co']
             s_view = S[:, ly['off']:]
-            demod = torch.empty(B, Co, device=dev)   # scale * rsqrt(scale^2 * sum_i s^2 wsq + 1e-8)
-            L.check(lib.wgs_linear_fwd(L.rawptr(s_view), L.ptr(ly['wsq']), None, L.ptr(demod), B, Co, Ci, sumC, Co,
-                                       L.c_float(ly['scale'] ** 2), L.c_float(0.0), 1, 2, L.c_float(1e-8),
-                                       L.c_float(ly['scale']), st), 'demod')
+            demod = demods[i]
             H = x.shape[1]
             if ly['up']:
                 t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'])
@@ -301,7 +324,6 @@ class Generator(nn.Module):
                 y = C.conv2d(x, ly['wp'], 3, pad=1, a_scale=s_view, a_ld=sumC, col_scale=demod, noise=ly['noise'],
                              noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'])
             outs.append(y)
-            demods.append(demod)
             x = y
             if i % 2 == 0:
                 r = P['rgbs'][i // 2]
