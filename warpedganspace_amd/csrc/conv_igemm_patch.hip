@@ -13,6 +13,7 @@
 // Weights come pre-split (wgs_split_bf16) and are copied global -> LDS by DMA per (chunk, tap), double-buffered.
 // LDS: patch hi | lo (unpadded 64-B rows, XOR-swizzled 16-B chunks) single-buffered — the next chunk's patch waits in
 // registers during the 9 tap steps and is written between two barriers at the chunk boundary — plus two weight stages.
+#include <cstdlib>
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
@@ -29,11 +30,9 @@ using wgsconv::ConvArgs;
 
 constexpr int BK = 32;
 constexpr int ROW = 64;                  // bytes per LDS row and plane (32 bf16)
-constexpr int BM = 256;                  // output pixels per tile
-constexpr int PMAX = 528;                // patch pixels the LDS image holds (4 x 130 = 520 is the largest used)
-constexpr int NT = 512;
-constexpr int NPL = (PMAX * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (9)
 constexpr int OOB = (int)0x80000000;
+// patch pixels the LDS image holds: 256-pixel tiles 4 x 130 = 520, 128-pixel tiles 4 x 66 = 264 (3x3 taps)
+constexpr int pmax_of(int bm) { return bm == 256 ? 528 : 272; }
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
@@ -41,14 +40,19 @@ struct PatchGeom {       // uniform per launch
     int Wt, R, PW, PH, tiles_x, tiles_per_img, dy_min, dx_min;
 };
 
-template <int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(NT, 1) void igemm_patch_bf16x3_kernel(const ConvArgs p, const PatchGeom g) {
+// BM = 256 (8 waves, one workgroup per CU) or 128 (4 waves, 100 KB less LDS: two workgroups per CU, whose barriers,
+// patch stores and epilogues overlap each other's MFMAs — the better shape when K is short, i.e. Cin = 128).
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void igemm_patch_bf16x3_kernel(const ConvArgs p, const PatchGeom g) {
+    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    constexpr int PMAX = pmax_of(BM);
+    constexpr int NPL = (PMAX * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (9)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int P_BYTES = PMAX * ROW;                 // one patch plane
     constexpr int B_BYTES = BN * ROW;                   // one weight plane of a stage
     constexpr int B_STAGE = 2 * B_BYTES;
-    constexpr int BI = BN / 16 / 8;                     // 16-row DMA instructions per wave and plane
-    static_assert(WAVES_M * WAVES_N == 8 && BI >= 1, "8 waves");
+    constexpr int BI = BN / 16 / NW;                    // 16-row DMA instructions per wave and plane
+    static_assert(BI >= 1 && BI * 16 * NW == BN, "tile / wave count mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* patch = smem_b;                      // hi | lo
     unsigned char* bst = smem_b + 2 * P_BYTES;          // two weight stages
@@ -227,12 +231,12 @@ __global__ __launch_bounds__(NT, 1) void igemm_patch_bf16x3_kernel(const ConvArg
     wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh);
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_patch(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
-    const size_t sm = (size_t)2 * PMAX * ROW + (size_t)2 * 2 * BN * ROW;
-    auto k = igemm_patch_bf16x3_kernel<BN, WAVES_M, WAVES_N>;
+    const size_t sm = (size_t)2 * pmax_of(BM) * ROW + (size_t)2 * 2 * BN * ROW;
+    auto k = igemm_patch_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT), sm, st, a, g);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
 }
 
 }  // namespace
@@ -247,9 +251,13 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     if (a.Hg != a.Hi || a.Wg != a.Wi || a.Ho != a.Hi || a.Wo != a.Wi || a.Ci % 32 || a.Co % 128 || a.ntaps < 4 || a.ntaps > 16) return 1;
     const int W = a.Wi, H = a.Hi;
     if (W < 32 || (W & (W - 1))) return 1;
+    // tile shape: 256 pixels (2x128 / 4x64 / 8x32) in general; 128 pixels (2x64 / 4x32) with two workgroups per CU
+    // when the K loop is short (Cin <= 128) and Cout = 128
+    const int bn = a.Co % 256 == 0 ? 256 : 128;
+    const int bm = (bn == 128 && a.Ci <= 128 && !getenv("WGS_PATCH_BM256")) ? 128 : 256;
     PatchGeom g;
-    g.Wt = W < 128 ? W : 128;
-    g.R = BM / g.Wt;
+    g.Wt = bm == 256 ? (W < 128 ? W : 128) : (W < 64 ? W : 64);
+    g.R = bm / g.Wt;
     if (H % g.R) return 1;
     int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
     for (int t = 0; t < a.ntaps; ++t) {
@@ -258,16 +266,16 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     }
     g.dy_min = dy0; g.dx_min = dx0;
     g.PH = g.R + dy1 - dy0; g.PW = g.Wt + dx1 - dx0;
-    if (g.PH * g.PW > PMAX) return 1;
+    if (g.PH * g.PW > pmax_of(bm)) return 1;
     g.tiles_x = W / g.Wt;
     g.tiles_per_img = (H / g.R) * g.tiles_x;
-    const int bn = a.Co % 256 == 0 ? 256 : 128;
     const int nblocks = a.B * g.tiles_per_img * (a.Co / bn);
     if (nblocks < 200) return 1;
     ConvArgs b = a;
     b.w_bytes = a.w_bytes / 2;          // extents of the bf16 weight planes (x stays fp32)
-    if (bn == 256) launch_patch<256, 2, 4>(b, g, nblocks, st);
-    else launch_patch<128, 4, 2>(b, g, nblocks, st);
+    if (bn == 256) launch_patch<256, 256, 2, 4>(b, g, nblocks, st);
+    else if (bm == 256) launch_patch<256, 128, 4, 2>(b, g, nblocks, st);
+    else launch_patch<128, 128, 2, 2>(b, g, nblocks, st);
     return 0;
 }
 
