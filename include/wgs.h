@@ -252,7 +252,9 @@ int wgs_unpack_pair_grad(const float* dy, float* d1, float* d2, int B, int c, in
  * BasicBlock:  y = relu?( (x - mean)*invstd*gamma + beta (+ residual) ).
  * train != 0: batch statistics (biased variance), running stats updated with `momentum` and the unbiased
  * variance, num_batches_tracked += 1 (all three may be NULL); else running statistics are used.
- * save_mean / save_invstd [C] are written for the backward; ws = 2*C doubles of scratch. C % 4 == 0. */
+ * save_mean / save_invstd [C] are written for the backward; ws = WGS_BN_WS_DOUBLES(C) doubles of scratch
+ * (32 replicas of the 2*C partial sums, so that the reduction's fp64 atomics do not all hit the same addresses). C % 4 == 0. */
+#define WGS_BN_WS_DOUBLES(C) (64 * (C))
 int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
                int64_t N, int C, float eps, float momentum, int relu, int train, wgs_stream_t stream);
@@ -275,7 +277,7 @@ int wgs_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, wgs_stream_
 /* Backward of nn.Upsample(scale_factor=2, nearest) on NHWC: dx[b,y,x,:] = sum of dy[b,2y..2y+1,2x..2x+1,:]
  * (models/ProgGAN/model.py:53, models/SNGAN/sn_gen_resnet.py:37,45, BigGAN GBlock). dy [B,2H,2W,C] -> dx [B,H,W,C]. */
 int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wgs_stream_t stream);
-/* out[c] = sum over rows of x[N,C] (conv bias gradient); ws = 2*C doubles. */
+/* out[c] = sum over rows of x[N,C] (conv bias gradient); ws = WGS_BN_WS_DOUBLES(C) doubles. */
 int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_stream_t stream);
 
 /* Loss of lib/trainer.py:245-249 and the statistics of :257-261:

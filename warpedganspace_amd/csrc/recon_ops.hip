@@ -43,7 +43,10 @@ __global__ __launch_bounds__(256) void unpack_pair_kernel(const float* __restric
 // MODE 0: s1 = sum x, s2 = sum x^2                                   (BN forward statistics)
 // MODE 1: g = (dyA + dyB) * (out > 0),  s1 = sum g, s2 = sum g*xhat    (BN backward statistics)
 // MODE 2: s1 = sum x                                                  (bias gradient)
-// ws: double[2*C], zeroed by the caller; accumulated with fp64 atomics.
+// ws: double[WS_REP][2*C], zeroed by the caller; workgroup b accumulates into replica b % WS_REP with fp64 atomics
+// (hundreds of workgroups adding to the same 2*C addresses serialise in the L2 atomic units: replicas cut that 32x);
+// ws_collapse_kernel then sums the replicas into replica 0, which the consumers read.
+constexpr int WS_REP = 32;
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dyA,
                                                           const float* __restrict__ dyB, const float* __restrict__ out,
@@ -110,11 +113,21 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
                 for (int q = 0; q < 4; ++q) { t1[q] += red[0][s * tpr + cl][q]; t2[q] += red[1][s * tpr + cl][q]; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                unsafeAtomicAdd(ws + c + q, t1[q]);
-                if (MODE != 2) unsafeAtomicAdd(ws + C + c + q, t2[q]);
+                double* wr = ws + (size_t)(blockIdx.x % WS_REP) * 2 * C;
+                unsafeAtomicAdd(wr + c + q, t1[q]);
+                if (MODE != 2) unsafeAtomicAdd(wr + C + c + q, t2[q]);
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ws_collapse_kernel(double* __restrict__ ws, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double t = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < WS_REP; ++r) t += ws[(size_t)r * n + i];
+    ws[i] = t;
 }
 
 // BN forward finalize (train mode): batch mean / biased var -> mean, invstd; running stats as nn.BatchNorm
@@ -442,10 +455,11 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
     WGS_CHECK_ARG(train || (running_mean && running_var), "wgs_bn_fwd: eval mode needs running stats");
     hipStream_t st = (hipStream_t)stream;
     if (train) {
-        (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
+        (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
         const int rpb = reduce_rows_per_block(N, C);
         hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                            nullptr, nullptr, ws, N, C, rpb);
+        hipLaunchKernelGGL(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(wgs_cdiv(C, 256)), dim3(256), 0, st, ws, save_mean, save_invstd,
                            running_mean, running_var, num_batches_tracked, N, C, eps, momentum);
     } else {
@@ -464,10 +478,11 @@ int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* 
     WGS_CHECK_ARG(x && dyA && save_mean && save_invstd && gamma && dx && ws, "wgs_bn_bwd: null pointer");
     WGS_CHECK_ARG(N > 0 && C >= 4 && C % 4 == 0, "wgs_bn_bwd: C=%d must be a multiple of 4", C);
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
+    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
     const int rpb = reduce_rows_per_block(N, C);
     hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
                        save_invstd, ws, N, C, rpb);
+    hipLaunchKernelGGL(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
                        save_invstd, gamma, ws, dx, dres, dgamma, dbeta, N, C, train);
     WGS_CHECK_LAUNCH("bn_bwd");
@@ -518,10 +533,11 @@ int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, w
 int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && out && ws && N > 0 && C >= 4 && C % 4 == 0, "wgs_colsum: bad arguments (C %% 4)");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
+    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
     const int rpb = reduce_rows_per_block(N, C);
     hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                        nullptr, ws, N, C, rpb);
+    hipLaunchKernelGGL(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
     // reuse the BN-backward epilogue's block-0 copy: dbeta = s1
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(1), dim3(256), 0, st, x, x, nullptr, nullptr, x, x, x, ws, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, out, (int64_t)0, C, 0);

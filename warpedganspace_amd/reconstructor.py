@@ -172,7 +172,7 @@ class Reconstructor(nn.Module):
         dev = x1.device
         x1, x2 = x1.contiguous(), x2.contiguous()
         B, c, H, W = x1.shape
-        ws = torch.empty(2 * 512, dtype=torch.float64, device=dev)
+        ws = torch.empty(64 * 512, dtype=torch.float64, device=dev)      # WGS_BN_WS_DOUBLES(512)
         Cp = 8
         x = torch.empty(B, H, W, Cp, device=dev)
         L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
