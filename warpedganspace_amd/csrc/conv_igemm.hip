@@ -396,6 +396,17 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
 // 64 channels, the 8 weight rows of a tap (float4 per lane, L1-resident) are reused by the 4 row groups, and the
 // 16-lane partial sums are combined by one butterfly transpose-reduction at the end.  Exact fp32 (fmaf chains).
 __global__ __launch_bounds__(256) void igemm_narrow_kernel(const ConvArgs p) {
+    // the launch's weights (<= 16 taps x 8 columns x 64 channels = 32 KB) live in LDS: every wave re-reads them for each of
+    // its row groups, and as 8 vector loads per tap they made the kernel texture-path bound
+    __shared__ __attribute__((aligned(16))) float wsm[16 * 8 * 64];
+    for (int e = threadIdx.x; e < p.ntaps * 8 * 16; e += 256) {
+        const int k4 = (e & 15) * 4, n = (e >> 4) & 7, t = e >> 7;
+        const float* wt = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w) + p.tap_w[t]);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.Co) v = *reinterpret_cast<const float4*>(wt + (size_t)n * p.w_row_stride + k4);
+        *reinterpret_cast<float4*>(&wsm[(t * 8 + n) * 64 + k4]) = v;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, lr = lane >> 4, k4 = (lane & 15) * 4;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int m_first = wave * 16;
@@ -420,11 +431,8 @@ __global__ __launch_bounds__(256) void igemm_narrow_kernel(const ConvArgs p) {
         const int yx = p.tap_yx[t];
         const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
         const int adelta = p.tap_a[t] >> 2;                                           // (dy*Wi + dx) * Ci elements
-        const float* wt = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.w) + p.tap_w[t]) + k4;
         // branch-free: every load is issued unconditionally from a clamped address, masked afterwards
         float4 wv[8], av[4];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) wv[n] = *reinterpret_cast<const float4*>(wt + (size_t)(n < p.Co ? n : 0) * p.w_row_stride);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int iy = iy0[g] + dy, ix = ix0[g] + dx;
@@ -432,6 +440,8 @@ __global__ __launch_bounds__(256) void igemm_narrow_kernel(const ConvArgs p) {
             const float4 a = *reinterpret_cast<const float4*>(p.x + (v ? pixo[g] + adelta : k4));
             av[g] = v ? a : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) wv[n] = *reinterpret_cast<const float4*>(&wsm[(t * 8 + n) * 64 + k4]);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -560,7 +570,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     const int rc = build_conv_args(d, a);
     if (rc != WGS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&
+    if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && d->ntaps <= 16 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&
         d->act == 0 && d->act_slope == 1.f && d->gain == 1.f) {
         const long waves = ((long)a.M + 15) / 16;
         hipLaunchKernelGGL(igemm_narrow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
