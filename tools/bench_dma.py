@@ -11,7 +11,7 @@ def timeit(fn, n=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 B = 32
-for ci, co, h in [(512, 512, 64), (256, 256, 128), (128, 128, 256)]:
+for ci, co, h in [(512, 512, 64), (256, 256, 128), (128, 128, 256), (512, 512, 32), (512, 512, 16)]:
     x = torch.randn(B, h, h, ci, device=dev); w = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
     s = torch.randn(B, ci, device=dev); y = torch.empty(B, h, h, co, device=dev)
     ws = C.split_weight(w)

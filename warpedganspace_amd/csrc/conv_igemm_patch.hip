@@ -250,30 +250,38 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     if (!a.w_hi || !a.w_lo || a.ups || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 || a.oy0 || a.ox0) return 1;
     if (a.Hg != a.Hi || a.Wg != a.Wi || a.Ho != a.Hi || a.Wo != a.Wi || a.Ci % 32 || a.Co % 128 || a.ntaps < 4 || a.ntaps > 16) return 1;
     const int W = a.Wi, H = a.Hi;
-    if (W < 32 || (W & (W - 1))) return 1;
-    // tile shape: 256 pixels (2x128 / 4x64 / 8x32) in general; 128 pixels (2x64 / 4x32) with two workgroups per CU
-    // when the K loop is short (Cin <= 128) and Cout = 128
-    const int bn = a.Co % 256 == 0 ? 256 : 128;
-    const int bm = (bn == 128 && a.Ci <= 128 && !getenv("WGS_PATCH_BM256")) ? 128 : 256;
-    PatchGeom g;
-    g.Wt = bm == 256 ? (W < 128 ? W : 128) : (W < 64 ? W : 64);
-    g.R = bm / g.Wt;
-    if (H % g.R) return 1;
+    if (W < 16 || (W & (W - 1))) return 1;
     int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
     for (int t = 0; t < a.ntaps; ++t) {
         dy0 = a.dy[t] < dy0 ? a.dy[t] : dy0; dy1 = a.dy[t] > dy1 ? a.dy[t] : dy1;
         dx0 = a.dx[t] < dx0 ? a.dx[t] : dx0; dx1 = a.dx[t] > dx1 ? a.dx[t] : dx1;
     }
-    g.dy_min = dy0; g.dx_min = dx0;
-    g.PH = g.R + dy1 - dy0; g.PW = g.Wt + dx1 - dx0;
-    if (g.PH * g.PW > pmax_of(bm)) return 1;
-    g.tiles_x = W / g.Wt;
-    g.tiles_per_img = (H / g.R) * g.tiles_x;
-    const int nblocks = a.B * g.tiles_per_img * (a.Co / bn);
-    if (nblocks < 200) return 1;
+    // tile shape: 256 pixels (2x128 / 4x64 / 8x32, 8 waves) x 256 or 128 columns in general; 128 pixels (2x64 / 4x32 /
+    // 8x16, 4 waves, two workgroups per CU) x 128 columns when the K loop is short (Cin <= 128 with Cout = 128) or when
+    // the larger tiles would leave CUs idle (16x16 .. 32x32 maps)
+    PatchGeom g;
+    int bm = 0, bn = 0, nblocks = 0;
+    auto try_shape = [&](int tbm, int tbn) {
+        if (bm || a.Co % tbn) return;
+        const int wt = tbm == 256 ? (W < 128 ? W : 128) : (W < 64 ? W : 64);
+        const int r = tbm / wt;
+        if (r < 1 || H % r) return;
+        const int ph = r + dy1 - dy0, pw = wt + dx1 - dx0;
+        if (ph * pw > pmax_of(tbm)) return;
+        const int nb = a.B * (H / r) * (W / wt) * (a.Co / tbn);
+        if (nb < 200) return;
+        bm = tbm; bn = tbn; nblocks = nb;
+        g.Wt = wt; g.R = r; g.PH = ph; g.PW = pw; g.dy_min = dy0; g.dx_min = dx0;
+        g.tiles_x = W / wt; g.tiles_per_img = (H / r) * g.tiles_x;
+    };
+    if (a.Co == 128 && a.Ci <= 128 && !getenv("WGS_PATCH_BM256")) try_shape(128, 128);
+    try_shape(256, 256);
+    try_shape(256, 128);
+    try_shape(128, 128);
+    if (!bm) return 1;
     ConvArgs b = a;
     b.w_bytes = a.w_bytes / 2;          // extents of the bf16 weight planes (x stays fp32)
-    if (bn == 256) launch_patch<256, 256, 2, 4>(b, g, nblocks, st);
+    if (bm == 256 && bn == 256) launch_patch<256, 256, 2, 4>(b, g, nblocks, st);
     else if (bm == 256) launch_patch<256, 128, 4, 2>(b, g, nblocks, st);
     else launch_patch<128, 128, 2, 2>(b, g, nblocks, st);
     return 0;
