@@ -454,6 +454,7 @@ static bool try_dma(ConvArgs& a, int bn, int nblocks, hipStream_t st) {
 // of the 8-wave kernel: 4x the workgroups per launch (short K loops: 1, 2, 2 and 4 taps) and one tail instead of four.
 int launch_bf16x3_multi(const ConvArgs* as, int n, hipStream_t st) {
     if (n < 2 || n > 4) return 1;
+    if (as[0].w_hi && getenv("WGS_PHASE_PATCH")) return 1;      // experiment: phases one by one through the patch form
     ConvArgs a = as[0];
     if (a.Ci % 32 != 0 || a.ups || a.Co % 128 != 0) return 1;
     int wt_max = 0, ntm_all = 0;

@@ -38,6 +38,10 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
 struct PatchGeom {       // uniform per launch
     int Wt, R, PW, PH, tiles_x, tiles_per_img, dy_min, dx_min;
+    // flat != 0: a tile is BM CONSECUTIVE pixels of the (Hg x Wg) output grid of one sample (any Wg, e.g. the 65 x 65 and
+    // 129 x 129 grids of the up-conv phases) and its patch is the full-width band of input rows those pixels touch;
+    // flat == 0: rectangular R x Wt tiles (the 256-wide maps, whose full-width band would not fit)
+    int flat, Wg, HW;
 };
 
 // BM = 256 (8 waves, one workgroup per CU) or 128 (4 waves, 100 KB less LDS: two workgroups per CU, whose barriers,
@@ -71,7 +75,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     const int tile = bid / ntn, n0 = (bid % ntn) * BN;
     const int b = tile / g.tiles_per_img;
     const int trem = tile - b * g.tiles_per_img;
-    const int ty0 = (trem / g.tiles_x) * g.R, tx0 = (trem % g.tiles_x) * g.Wt;
+    int ty0, tx0;                 // origin of the tile in the output grid (flat: first grid row, column 0)
+    const int tile_m0 = trem * BM;      // flat: first grid pixel of the tile
+    if (g.flat) { ty0 = tile_m0 / g.Wg; tx0 = 0; }
+    else { ty0 = (trem / g.tiles_x) * g.R; tx0 = (trem % g.tiles_x) * g.Wt; }
+    // tile row r -> grid pixel (gy, gx) relative to (ty0, tx0); false = past the sample's last pixel (flat tiles only)
+    auto row_of = [&](int r, int& ry, int& rx) {
+        if (g.flat) {
+            const int m = tile_m0 + r;
+            const int mm = m < g.HW ? m : g.HW - 1;
+            const int gy = mm / g.Wg;
+            ry = gy - ty0; rx = mm - gy * g.Wg;
+            return m < g.HW;
+        }
+        ry = r / g.Wt; rx = r - ry * g.Wt;
+        return true;
+    };
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_hi), 0, p.w_bytes, 0x00020000);
@@ -156,7 +175,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + l31;
-        const int ty = r / g.Wt, tx = r - ty * g.Wt;
+        int ty, tx;
+        row_of(r, ty, tx);
         pp0[i] = ty * g.PW + tx;
     }
     const int bswz = (l31 >> 2) & 3;
@@ -219,10 +239,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     float* r_nz = reinterpret_cast<float*>(r_b + BM);
     int* r_add = reinterpret_cast<int*>(r_nz + BM);
     if (tid < BM) {
-        const int ty = tid / g.Wt, tx = tid - ty * g.Wt;
-        const int oy = ty0 + ty, ox = tx0 + tx;
+        int ty, tx;
+        const bool ok = row_of(tid, ty, tx);
+        const int oy = (ty0 + ty) * p.osy + p.oy0, ox = (tx0 + tx) * p.osx + p.ox0;
         const int hw = oy * p.Wo + ox;
-        r_pix[tid] = b * p.Ho * p.Wo + hw;
+        r_pix[tid] = ok ? b * p.Ho * p.Wo + hw : -1;
         r_b[tid] = b;
         r_nz[tid] = (p.noise && p.noise_w) ? p.noise_w[0] * p.noise[hw] : 0.f;
         r_add[tid] = (b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
@@ -247,32 +268,41 @@ namespace wgsconv {
 // neighbourhood whose patch fits, power-of-two width >= 32, Cout a multiple of 128, enough tiles for the chip.
 int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     const ConvArgs& a = a0;
-    if (!a.w_hi || !a.w_lo || a.ups || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 || a.oy0 || a.ox0) return 1;
-    if (a.Hg != a.Hi || a.Wg != a.Wi || a.Ho != a.Hi || a.Wo != a.Wi || a.Ci % 32 || a.Co % 128 || a.ntaps < 4 || a.ntaps > 16) return 1;
-    const int W = a.Wi, H = a.Hi;
-    if (W < 16 || (W & (W - 1))) return 1;
+    if (!a.w_hi || !a.w_lo || a.ups || a.isy != 1 || a.isx != 1) return 1;
+    if (a.Ci % 32 || a.Co % 128 || a.ntaps < 2 || a.ntaps > 16) return 1;
     int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
     for (int t = 0; t < a.ntaps; ++t) {
         dy0 = a.dy[t] < dy0 ? a.dy[t] : dy0; dy1 = a.dy[t] > dy1 ? a.dy[t] : dy1;
         dx0 = a.dx[t] < dx0 ? a.dx[t] : dx0; dx1 = a.dx[t] > dx1 ? a.dx[t] : dx1;
     }
-    // tile shape: 256 pixels (2x128 / 4x64 / 8x32, 8 waves) x 256 or 128 columns in general; 128 pixels (2x64 / 4x32 /
-    // 8x16, 4 waves, two workgroups per CU) x 128 columns when the K loop is short (Cin <= 128 with Cout = 128) or when
-    // the larger tiles would leave CUs idle (16x16 .. 32x32 maps)
+    const int Wg = a.Wg, Hg = a.Hg, HW = a.Hg * a.Wg;
+    // tile shape: 256 pixels (8 waves) x 256 or 128 columns in general; 128 pixels (4 waves, two workgroups per CU) x 128
+    // columns when the K loop is short (Cin <= 128 with Cout = 128) or when the larger tiles would leave CUs idle.
+    // Geometry: consecutive grid pixels with a full-width patch band when that fits (grids up to ~130 wide, any size —
+    // the sub-pixel phases' 65 x 65 / 129 x 129 grids included), else rectangular tiles of a power-of-two-wide grid.
     PatchGeom g;
     int bm = 0, bn = 0, nblocks = 0;
     auto try_shape = [&](int tbm, int tbn) {
         if (bm || a.Co % tbn) return;
-        const int wt = tbm == 256 ? (W < 128 ? W : 128) : (W < 64 ? W : 64);
-        const int r = tbm / wt;
-        if (r < 1 || H % r) return;
-        const int ph = r + dy1 - dy0, pw = wt + dx1 - dx0;
-        if (ph * pw > pmax_of(tbm)) return;
-        const int nb = a.B * (H / r) * (W / wt) * (a.Co / tbn);
+        PatchGeom t;
+        t.dy_min = dy0; t.dx_min = dx0; t.Wg = Wg; t.HW = HW;
+        const int rows_max = (tbm + Wg - 2) / Wg + 1;            // grid rows a run of tbm consecutive pixels can touch
+        if ((rows_max + dy1 - dy0) * (Wg + dx1 - dx0) <= pmax_of(tbm)) {
+            t.flat = 1; t.Wt = Wg; t.R = rows_max; t.PH = rows_max + dy1 - dy0; t.PW = Wg + dx1 - dx0;
+            t.tiles_x = 1; t.tiles_per_img = (HW + tbm - 1) / tbm;
+            if ((long)t.tiles_per_img * tbm * 100 > (long)HW * 113) return;      // > 13 % of the rows would be padding
+        } else {
+            if (Wg < 16 || (Wg & (Wg - 1))) return;
+            const int wt = tbm == 256 ? (Wg < 128 ? Wg : 128) : (Wg < 64 ? Wg : 64);
+            const int r = tbm / wt;
+            if (r < 1 || Hg % r) return;
+            t.flat = 0; t.Wt = wt; t.R = r; t.PH = r + dy1 - dy0; t.PW = wt + dx1 - dx0;
+            if (t.PH * t.PW > pmax_of(tbm)) return;
+            t.tiles_x = Wg / wt; t.tiles_per_img = (Hg / r) * t.tiles_x;
+        }
+        const int nb = a.B * t.tiles_per_img * (a.Co / tbn);
         if (nb < 200) return;
-        bm = tbm; bn = tbn; nblocks = nb;
-        g.Wt = wt; g.R = r; g.PH = ph; g.PW = pw; g.dy_min = dy0; g.dx_min = dx0;
-        g.tiles_x = W / wt; g.tiles_per_img = (H / r) * g.tiles_x;
+        bm = tbm; bn = tbn; nblocks = nb; g = t;
     };
     if (a.Co == 128 && a.Ci <= 128 && !getenv("WGS_PATCH_BM256")) try_shape(128, 128);
     try_shape(256, 256);
