@@ -54,10 +54,12 @@ _WS = {}
 
 
 def _workspace(device, nbytes=0):
-    ws = _WS.get(device)
+    # one buffer per (device, stream): launches on different streams may run concurrently
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     need = max(WS_BYTES, nbytes)
     if ws is None or ws.numel() * 4 < need:
-        ws = _WS[device] = torch.empty(need // 4, device=device, dtype=torch.float32)
+        ws = _WS[key] = torch.empty(need // 4, device=device, dtype=torch.float32)
     return ws
 
 

@@ -86,6 +86,7 @@ class TrainStep:
         self.G, self.S, self.R, self.p = generator, support_sets, reconstructor, params
         self.B, self.dev, self.world = local_batch, device, world
         self.gen = torch.Generator(device=device)
+        self.side_stream = torch.cuda.Stream(device=device)
         if seed is not None:
             self.gen.manual_seed(seed)
         r_params = [p for n, p in reconstructor.named_parameters()
@@ -129,8 +130,17 @@ class TrainStep:
         if z is None:
             z, idx, mag = self.sample()
         self.bucket.zero_grad()
+        # The un-shifted pass G(z) (nothing saved, :200) runs on a side stream next to the shifted pass: both are the same
+        # network on independent inputs, and their 4x4 .. 16x16 layers each fill only part of the chip.
+        cur = torch.cuda.current_stream(self.dev)
+        side = self.side_stream if os.environ.get('WGS_TWO_STREAMS', '1') != '0' else None
+        if side is not None:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), torch.no_grad():
+                img = G(z)
         with torch.no_grad():
-            img = G(z)                                                        # :200, nothing saved
+            if side is None:
+                img = G(z)                                                    # :200, nothing saved
             code = G.get_w(z) if self.w_space else z                          # :236
         # shift = mag * S(mask, code)   (:235) — fused scale
         lg = S.LOGGAMMA.reshape(-1) if S.learn_gammas else None
@@ -140,6 +150,9 @@ class TrainStep:
                                 B, self.K, self.n2, self.d, st), 'wgs_rbf_fwd')
         shift.requires_grad_(True)
         img_shifted = G(z, shift)                                             # :239, input-gradient only
+        if side is not None:
+            cur.wait_stream(side)
+            img.record_stream(cur)
         logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True)   # :242
         L.check(lib.wgs_ce_l1_loss(L.ptr(logits), L.ptr(idx, torch.int64), L.ptr(mag_hat.reshape(B)), L.ptr(mag),
                                    L.c_float(p.lambda_cls), L.c_float(p.lambda_reg), L.ptr(self.dlogits), L.ptr(self.dmag),
