@@ -241,7 +241,8 @@ def test_conv_transpose_s2_merged_phases_lds_dma(dev, monkeypatch):
     assert rel_err(nchw(y2[:1]), ref) < 2e-5
 
 
-@pytest.mark.parametrize('B,Ci,Co,H', [(8, 128, 128, 64), (2, 64, 128, 256), (32, 32, 256, 32), (32, 128, 512, 16)])
+@pytest.mark.parametrize('B,Ci,Co,H', [(8, 128, 128, 64), (2, 64, 128, 256), (32, 32, 256, 32), (32, 128, 512, 16),
+                                       (16, 64, 128, 48), (32, 64, 256, 40)])    # last two: grids that are not powers of two
 def test_conv_split_bf16_patch_form(dev, B, Ci, Co, H):
     """Stride-1 3x3 convs with pre-split weights take the patch kernel (halo patch staged once per channel chunk, taps read
     shifted rows): forward and dgrad, all tile geometries (2x128, 4x64, 8x32 pixels), identical to the register-staged

@@ -139,3 +139,31 @@ def test_no_grad_forward_saves_nothing(dev):
     with torch.no_grad():
         img = StyleGAN2Wrapper(G, False)(torch.randn(3, 512, device=dev))
     assert img.shape == (3, 3, 32, 32) and not img.requires_grad
+
+
+def test_linear_fwd_batch_equals_per_layer(dev):
+    """wgs_linear_fwd_batch (all demodulation GEMVs of a pass in one launch) == one wgs_linear_fwd per layer, bit for bit."""
+    import ctypes
+    from warpedganspace_amd import _lib as L
+    from warpedganspace_amd.stylegan2 import LinearBatch
+    torch.manual_seed(3)
+    B, sumC = 5, 512 + 256 + 64
+    S = torch.randn(B, sumC, device=dev)
+    layers = [(512, 512, 0, 0.02), (256, 512, 0, 0.03), (128, 256, 512, 0.05), (64, 64, 768, 0.07)]     # (Co, Ci, offset, scale)
+    wsq = [torch.rand(co, ci, device=dev) for co, ci, _, _ in layers]
+    out_b = [torch.empty(B, co, device=dev) for co, _, _, _ in layers]
+    out_s = [torch.empty(B, co, device=dev) for co, _, _, _ in layers]
+    lb = LinearBatch()
+    lb.n, lb.M, lb.in_square, lb.epilogue = len(layers), B, 1, 2
+    for i, (co, ci, off, sc) in enumerate(layers):
+        lb.x[i] = S.data_ptr() + 4 * off
+        lb.w[i], lb.y[i] = wsq[i].data_ptr(), out_b[i].data_ptr()
+        lb.N[i], lb.K[i], lb.ldx[i], lb.ldy[i] = co, ci, sumC, co
+        lb.wscale[i], lb.eps[i], lb.out_gain[i] = sc ** 2, 1e-8, sc
+    L.check(L.lib().wgs_linear_fwd_batch(ctypes.byref(lb), L.stream()), 'batch')
+    for i, (co, ci, off, sc) in enumerate(layers):
+        L.check(L.lib().wgs_linear_fwd(L.rawptr(S[:, off:]), L.ptr(wsq[i]), None, L.ptr(out_s[i]), B, co, ci, sumC, co,
+                                       L.c_float(sc ** 2), L.c_float(0.0), 1, 2, L.c_float(1e-8), L.c_float(sc), L.stream()), 'single')
+        assert torch.equal(out_b[i], out_s[i])
+        ref = sc / torch.sqrt(sc ** 2 * (S[:, off:off + ci].double() ** 2 @ wsq[i].double().t()) + 1e-8)
+        assert (out_b[i].double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
