@@ -50,6 +50,70 @@ def build(dev, size, K, N, B, seed, w_space=False):
     return eng
 
 
+def hbm_subpaths(eng, dev, B):
+    """Achieved GB/s of the HBM-bound sub-kernels of the step on their cfg3-sized operands:
+    algorithmic bytes / HIP-event time of the standalone launch (on torch's current stream = the launch stream)."""
+    import ctypes
+    from warpedganspace_amd import _lib as L
+    lib, st = L.lib(), L.stream()
+
+    def timed(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e-3
+
+    out = {}
+    S = eng.S
+    K, n2 = S.ALPHAS.shape
+    d = S.support_vectors_dim
+    z = torch.randn(B, d, device=dev); idx = torch.randint(0, K, (B,), device=dev); mag = torch.rand(B, device=dev)
+    shift = torch.empty(B, d, device=dev)
+    lg = S.LOGGAMMA.reshape(-1)
+    t = timed(lambda: L.check(lib.wgs_rbf_fwd(L.ptr(S.SUPPORT_SETS), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
+                                              L.ptr(idx, torch.int64), L.ptr(z), L.ptr(mag), L.ptr(shift), L.ptr(eng.rbf_ws),
+                                              B, K, n2, d, st), 'rbf'))
+    by = B * ((n2 * d + n2 + 1 + d) * 4 + d * 4)
+    out['rbf_fwd'] = {"bytes": by, "us": round(t * 1e6, 1), "GB/s": round(by / t / 1e9, 1), "note": "latency-bound: 4.3 MB per launch"}
+    # Adam on the flat [R | S] bucket: 4 reads + 3 writes per element
+    bk = eng.bucket
+    n = bk.flat.numel()
+    sc = bk.step_count
+    t = timed(lambda: bk.adam_step(world=1))
+    bk.step_count = sc
+    out['adam'] = {"bytes": 7 * 4 * n, "us": round(t * 1e6, 1), "GB/s": round(7 * 4 * n / t / 1e9, 1)}
+    # blur + noise + bias + lrelu of the 256x256 up-conv: [B,257,257,128] -> [B,256,256,128]
+    C_, H = 128, 256
+    tin = torch.randn(B, H + 1, H + 1, C_, device=dev); y = torch.empty(B, H, H, C_, device=dev)
+    k4 = torch.ones(4, 4, device=dev) / 16; nz = torch.randn(H * H, device=dev); nw = torch.ones(1, device=dev); bias = torch.zeros(C_, device=dev)
+    t = timed(lambda: L.check(lib.wgs_sg2_blur_noise_bias_act(L.ptr(tin), L.ptr(k4), L.ptr(nz), L.ptr(nw), L.ptr(bias), L.ptr(y),
+                                                              B, H, H, C_, st), 'blur'))
+    by = (tin.numel() + y.numel()) * 4
+    out['blur_noise_bias_act_256'] = {"bytes": by, "us": round(t * 1e6, 1), "GB/s": round(by / t / 1e9, 1)}
+    # ToRGB at 256x256: reads [B,65536,128], writes [B,3,65536]
+    s_ = torch.randn(B, C_, device=dev); w_ = torch.randn(3, C_, device=dev); b3 = torch.zeros(3, device=dev)
+    img = torch.empty(B, 3, H * H, device=dev)
+    t = timed(lambda: L.check(lib.wgs_sg2_torgb_fwd(L.ptr(y), L.ptr(s_), L.ptr(w_), L.ptr(b3), None, L.ptr(img), B, H * H, C_,
+                                                    L.c_float(1.0), st), 'torgb'))
+    by = (y.numel() + img.numel()) * 4
+    out['torgb_256'] = {"bytes": by, "us": round(t * 1e6, 1), "GB/s": round(by / t / 1e9, 1)}
+    # train-mode BatchNorm forward (+ReLU) of ResNet conv1's output [B*128*128, 64]: stats pass + apply pass = 2 reads + 1 write
+    N_, Cb = B * 128 * 128, 64
+    xb = torch.randn(N_, Cb, device=dev); yb = torch.empty_like(xb)
+    g_, b_ = torch.ones(Cb, device=dev), torch.zeros(Cb, device=dev)
+    mean, invstd = torch.empty(Cb, device=dev), torch.empty(Cb, device=dev)
+    ws = torch.empty(64 * Cb, dtype=torch.float64, device=dev)
+    t = timed(lambda: L.check(lib.wgs_bn_fwd(L.ptr(xb), L.ptr(g_), L.ptr(b_), None, L.ptr(yb), L.ptr(mean), L.ptr(invstd), None, None,
+                                             None, L.rawptr(ws), L.c_int64(N_), Cb, L.c_float(1e-5), L.c_float(0.1), 1, 1, st), 'bn'))
+    by = 3 * xb.numel() * 4
+    out['bn_fwd_relu_conv1'] = {"bytes": by, "us": round(t * 1e6, 1), "GB/s": round(by / t / 1e9, 1)}
+    out['peak'] = {"GB/s": 8000.0, "achievable_GB/s": 6300.0, "source": "MI355X_MICROARCH.md"}
+    return out
+
+
 def cpu_baseline(size, K, N, b, steps, threads):
     """The reference step AS WRITTEN (incl. the generator's unused weight gradients) replayed by the oracle
     with plain PyTorch-CPU ops on this box's host cores.  Bounded sample."""
@@ -180,6 +244,13 @@ def main():
                     "step_achieved_TFLOPs": round(value / world * GFLOP_PER_IMG / 1e3, 2),
                     "step_frac": round(value / world * GFLOP_PER_IMG / 1e3 / peak, 4)}
 
+    hbm = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        try:
+            hbm = hbm_subpaths(eng, dev, args.batch)
+        except Exception as e:  # noqa: BLE001
+            hbm = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -197,7 +268,7 @@ def main():
                                       % (args.size, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "algorithmic_gflop_per_image": GFLOP_PER_IMG},
-               "last_stats": stats, "roofline": roofline, "cpu_baseline": cpu}
+               "last_stats": stats, "roofline": roofline, "hbm_subpaths": hbm, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
