@@ -208,11 +208,16 @@ def main():
     roofline = None
     if not args.no_roofline:
         # HIP events around every implicit-GEMM launch (torch's current stream IS the launch stream)
+        # (single stream for these two steps: with the un-shifted pass on the side stream, kernels of the other stream would
+        # run inside the event pairs and inflate the per-launch durations)
         C.PROFILE = []
         nprof = 2
+        two = eng.two_streams
+        eng.two_streams = False
         for _ in range(nprof):
             eng.step()
         torch.cuda.synchronize()
+        eng.two_streams = two
         recs, C.PROFILE = C.PROFILE, None
         fl = sum(r[1] for r in recs)
         ms = sum(r[2].elapsed_time(r[3]) for r in recs)

@@ -87,6 +87,7 @@ class TrainStep:
         self.B, self.dev, self.world = local_batch, device, world
         self.gen = torch.Generator(device=device)
         self.side_stream = torch.cuda.Stream(device=device)
+        self.two_streams = os.environ.get('WGS_TWO_STREAMS', '1') != '0'      # un-shifted generator pass on the side stream
         if seed is not None:
             self.gen.manual_seed(seed)
         r_params = [p for n, p in reconstructor.named_parameters()
@@ -133,7 +134,7 @@ class TrainStep:
         # The un-shifted pass G(z) (nothing saved, :200) runs on a side stream next to the shifted pass: both are the same
         # network on independent inputs, and their 4x4 .. 16x16 layers each fill only part of the chip.
         cur = torch.cuda.current_stream(self.dev)
-        side = self.side_stream if os.environ.get('WGS_TWO_STREAMS', '1') != '0' else None
+        side = self.side_stream if self.two_streams else None
         if side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
