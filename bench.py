@@ -264,7 +264,7 @@ def main():
             cpu = {"error": repr(e)}
 
     if rank == 0:
-        out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-256 K=128", "value": round(value, 2),
+        out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-%d K=%d" % (args.size, args.K), "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: %s)" % ("exact fp32 MFMA" if args.r_precision == 'fp32' else "split-bf16 x3 convs, fp32 wgrad")
