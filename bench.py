@@ -21,6 +21,9 @@ import sys
 import time
 import types
 
+# multi-process GPU work on this driver needs dmabuf IPC (RCCL / hipIpc*): keep it set before HIP initialises
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -8,6 +8,8 @@ Multi-GPU: launch one process per GPU with torch.distributed.run (see INTEGRATIO
 import argparse
 import os
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for RCCL on this driver
+
 import torch
 import torch.distributed as dist
 
