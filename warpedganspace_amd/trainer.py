@@ -88,6 +88,7 @@ class TrainStep:
         self.gen = torch.Generator(device=device)
         self.side_stream = torch.cuda.Stream(device=device)
         self.two_streams = os.environ.get('WGS_TWO_STREAMS', '1') != '0'      # un-shifted generator pass on the side stream
+        self.steps_done = 0
         if seed is not None:
             self.gen.manual_seed(seed)
         r_params = [p for n, p in reconstructor.named_parameters()
@@ -134,7 +135,9 @@ class TrainStep:
         # The un-shifted pass G(z) (nothing saved, :200) runs on a side stream next to the shifted pass: both are the same
         # network on independent inputs, and their 4x4 .. 16x16 layers each fill only part of the chip.
         cur = torch.cuda.current_stream(self.dev)
-        side = self.side_stream if self.two_streams else None
+        # (not in the very first step: the generator builds its packed / split weight caches lazily in its first forward, and
+        # those must be produced on the main stream, ahead of everything that reads them)
+        side = self.side_stream if (self.two_streams and self.steps_done > 0) else None
         if side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
@@ -184,6 +187,7 @@ class TrainStep:
         self.bucket.adam_step(world=self.world)                               # :253-254
         self.stats_sum += self.stats
         self.stats_n += 1
+        self.steps_done += 1
         return self.stats
 
     def pop_stats(self):
