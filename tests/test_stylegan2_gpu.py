@@ -197,3 +197,32 @@ def test_high_resolution_architectures(dev, size, B):
     assert e0 < 1e-4 and e1 < 1e-4                      # gate of the north_star: 1e-3
     assert rel_err(outs[1], outs[0]) < 1e-4
     assert rel_err(grads[1], grads[0]) < 5e-2           # free-running gradients: leaky-relu gate flips (see above)
+
+
+def test_full_size_batch_consistency(dev):
+    """BASELINE-size property (256x256, batch 32, both arithmetic modes): a sample's image and input gradient do not depend on
+    what else is in the batch.  The batch-32 run takes the large-tile / merged-phase / patch / LDS-DMA kernels, the batch-2
+    run mostly the 128-row and split-K ones, so this also cross-checks the kernel families against each other."""
+    from warpedganspace_amd import conv as C
+    G, _ = build(256, 909, dev)
+    z = GI.rt(910, 32, 512).to(dev)
+    shift = (GI.rt(911, 32, 512) * 0.3).to(dev)
+    probe = GI.rt(912, 32, 3, 256, 256).to(dev)
+    wrap = StyleGAN2Wrapper(G, False)
+    old = C.PRECISION
+    try:
+        for prec, tol in ((1, 2e-5), (0, 2e-5)):
+            C.PRECISION = prec
+            sh = shift.clone().requires_grad_(True)
+            img = wrap(z, sh)
+            (img * probe).sum().backward()
+            for sl in (slice(0, 2), slice(30, 32)):
+                sh2 = shift[sl].clone().requires_grad_(True)
+                img2 = wrap(z[sl], sh2)
+                (img2 * probe[sl]).sum().backward()
+                e_img, e_g = rel_err(img2, img[sl]), rel_err(sh2.grad, sh.grad[sl])
+                print('precision %d rows %s: image %.2e grad %.2e' % (prec, sl, e_img, e_g))
+                assert e_img < tol
+                assert e_g < 5e-2              # free-running gradient: gate flips between two fp32-class evaluations
+    finally:
+        C.PRECISION = old
