@@ -270,7 +270,7 @@ def main():
         out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-%d K=%d" % (args.size, args.K), "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: %s)" % ("exact fp32 MFMA" if args.r_precision == 'fp32' else "split-bf16 x3 convs, fp32 wgrad")
+               "dtype": ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: %s)" % ("exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs" if args.r_precision == 'fp32' else "split-bf16 x3 convs, fp32 wgrad")
                          if args.precision == 'bf16x3' else "fp32 (f32-input MFMA, f32 accumulate)"), "data": "synthetic (random-init weights, z ~ N(0,I))",
                "config": {"workload": "StyleGAN2-FFHQ-%d arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (args.size, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
