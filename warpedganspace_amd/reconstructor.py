@@ -32,7 +32,8 @@ BN_EPS, BN_MOM = 1e-5, 0.1
 R_PRECISION = 1 if os.environ.get('WGS_R_PRECISION', 'fp32').lower() in ('bf16x3', '1') else 0
 # Arithmetic of R's input-gradient (dgrad) convs of the BasicBlocks.  The activation gates and BN statistics that make R's
 # gradients sensitive are fixed by the (exact fp32) forward; the backward is linear in dy, so split-bf16 (~1e-5 relative) is
-# a smooth perturbation there.  WGS_R_DGRAD_PRECISION=fp32 restores the exact kernels.
+# a smooth perturbation there (this includes conv1's image gradient, which with only 6(+2) output channels runs 75 %-empty
+# MFMA tiles either way).  WGS_R_DGRAD_PRECISION=fp32 restores the exact kernels.
 R_DGRAD_PRECISION = 0 if os.environ.get('WGS_R_DGRAD_PRECISION', 'bf16x3').lower() in ('fp32', '0') else 1
 
 
@@ -300,7 +301,7 @@ class Reconstructor(nn.Module):
         if need_x[0] or need_x[1]:
             w1p = torch.zeros(64, 49, Cp, device=dev)
             w1p[:, :, :2 * c] = _packed(fe.conv1)
-            dx = C.conv2d_dgrad(dc1, C.repack_w_t(w1p, 64, 49, Cp), (S['H'], S['W']), 7, stride=2, pad=3, precision=R_PRECISION)
+            dx = C.conv2d_dgrad(dc1, C.repack_w_t(w1p, 64, 49, Cp), (S["H"], S["W"]), 7, stride=2, pad=3, precision=R_DGRAD_PRECISION)
             d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
             d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
             L.check(lib.wgs_unpack_pair_grad(L.ptr(dx), L.ptr(d1), L.ptr(d2), B, c, S['H'] * S['W'], Cp, st), 'unpack_pair')
