@@ -223,7 +223,7 @@ class Reconstructor(nn.Module):
                      B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws) if save else None
         return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
 
-    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None):
+    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None):
         """Returns ({id(param): grad}, d_x1 or None, d_x2 or None).  With `gbuf` ({id(param): zero-initialised
         buffer in the parameter's MEMORY layout, conv weights packed [Co,T,Ci]}) gradients are written /
         accumulated straight into those buffers (the trainer's flat gradient bucket)."""
@@ -236,6 +236,15 @@ class Reconstructor(nn.Module):
         dev = dlogits.device
         K = self.dim
         grads = {}
+
+        # Weight gradients are not on the path to the image gradient.  With `deferred` (a list) they are queued as closures
+        # and the caller runs them where it likes (TrainStep: on a side stream, next to the generator's backward).
+        def wgrad(x, dy, dw, k, stride, pad):
+            if deferred is None:
+                C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad)
+            else:
+                deferred.append((x, dy, lambda: C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad)))
+
         feat = S['feat']
         dmag = dmag.reshape(B, 1)
         dfeat = torch.empty(B, 512, device=dev)
@@ -260,7 +269,7 @@ class Reconstructor(nn.Module):
             w2 = _packed(blk.conv2)
             Co, T, Ci = w2.shape
             dw2 = gbuf[id(blk.conv2.weight)] if gbuf is not None else torch.zeros_like(w2)
-            C.conv2d_wgrad(aa, dcb, dw2, 3, stride=1, pad=1)
+            wgrad(aa, dcb, dw2, 3, 1, 1)
             grads[id(blk.conv2.weight)] = _grad_like(blk.conv2, dw2)
             daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=R_DGRAD_PRECISION)
             dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train, gbuf=gbuf)
@@ -268,7 +277,7 @@ class Reconstructor(nn.Module):
             w1 = _packed(blk.conv1)
             Co, T, Ci = w1.shape
             dw1 = gbuf[id(blk.conv1.weight)] if gbuf is not None else torch.zeros_like(w1)
-            C.conv2d_wgrad(xin, dca, dw1, 3, stride=blk.stride, pad=1)
+            wgrad(xin, dca, dw1, 3, blk.stride, 1)
             grads[id(blk.conv1.weight)] = _grad_like(blk.conv1, dw1)
             dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=R_DGRAD_PRECISION)
             if blk.downsample is not None:
@@ -277,7 +286,7 @@ class Reconstructor(nn.Module):
                 wd = _packed(blk.downsample[0])
                 Co, T, Ci = wd.shape
                 dwd = gbuf[id(blk.downsample[0].weight)] if gbuf is not None else torch.zeros_like(wd)
-                C.conv2d_wgrad(xin, dcd, dwd, 1, stride=blk.stride, pad=0)
+                wgrad(xin, dcd, dwd, 1, blk.stride, 0)
                 grads[id(blk.downsample[0].weight)] = _grad_like(blk.downsample[0], dwd)
                 dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0, precision=R_DGRAD_PRECISION)
             else:

@@ -163,12 +163,25 @@ class TrainStep:
                                    L.ptr(self.stats), L.ptr(self.argmax, torch.int64), L.ptr(self.loss_ws), B, self.K, st),
                 'wgs_ce_l1_loss')                                             # :245-249,257-258
         gb = self.bucket.gview
-        _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb)
+        # R's conv weight gradients are not needed for d_img: they are queued and run on the side stream, next to the
+        # generator's backward (whose 4x4..32x32 layers under-fill the chip); the ResNet path only (LeNet computes them inline)
+        deferred = [] if (side is not None and R.reconstructor_type == 'ResNet' and os.environ.get('WGS_DEFER_WGRAD', '1') != '0') else None
+        _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred)
         del saved
         pending = []
-        if self.world > 1:
-            # R's gradients (the first bucket group, 47 MB at cfg3) are final here: their all-reduce runs on RCCL's
-            # stream while the generator's backward (no trainable parameters) computes d shift
+        if deferred:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for x_, dy_, fn in deferred:
+                    fn()
+                    x_.record_stream(side); dy_.record_stream(side)
+                if self.world > 1:
+                    # R's gradients (the first bucket group, 47 MB at cfg3) are final after these launches: their all-reduce
+                    # is queued behind them and overlaps the generator's backward (no trainable parameters)
+                    _, a, b = self.bucket.groups[0]
+                    pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
+            del deferred
+        elif self.world > 1:
             _, a, b = self.bucket.groups[0]
             pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
         img_shifted.backward(d_img)                                           # G: d image -> d shift
@@ -179,6 +192,8 @@ class TrainStep:
         L.check(lib.wgs_rbf_bwd(L.ptr(S.SUPPORT_SETS), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
                                 L.ptr(idx, torch.int64), L.ptr(code), L.ptr(mag), L.ptr(gshift), L.ptr(self.rbf_ws),
                                 L.ptr(dtable), L.ptr(dlg), L.ptr(dal), None, B, self.K, self.n2, self.d, st), 'wgs_rbf_bwd')
+        if side is not None:
+            cur.wait_stream(side)                                             # deferred weight gradients (and their all-reduce)
         if self.world > 1:
             _, a, b = self.bucket.groups[1]                                   # S's gradients (RCCL sum; Adam divides by world)
             pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
