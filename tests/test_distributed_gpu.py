@@ -1,0 +1,150 @@
+"""GPU, world_size 2: the data-parallel branches of TrainStep itself (lib/trainer.py:162-166 is nn.DataParallel in the
+reference; here one process per rank).
+
+Two processes share cuda:0 (RCCL refuses two ranks on one device, so the process group is gloo, which all-reduces device
+tensors through host staging — the collective calls, streams and ordering in TrainStep.step are the ones the RCCL run
+uses).  Each rank first runs the SAME shard through a world=1 engine, then through a world=2 engine built from identical
+weights; checked:
+  * replicas start from rank 0's parameters (rank 1 is built from different random weights on purpose);
+  * the all-reduced gradient bucket == sum of the two ranks' world=1 gradients (DataParallel semantics: per-rank
+    BatchNorm statistics, loss = mean over the global batch <=> mean of the ranks' means);
+  * post-Adam parameters == Adam on the averaged gradient, identical on both ranks;
+  * pop_stats() averages over ranks; the per-rank sampler draws different z on the two ranks.
+"""
+import os
+import socket
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dev, seed_r, world, rank, B, K=16, N=4, size=32):
+    from tests import golden_inputs as GI
+    from warpedganspace_amd.gan_load import StyleGAN2Wrapper
+    from warpedganspace_amd.reconstructor import Reconstructor
+    from warpedganspace_amd.stylegan2 import Generator
+    from warpedganspace_amd.support_sets import SupportSets
+    from warpedganspace_amd.trainer import TrainStep
+    torch.manual_seed(0)
+    G = Generator(size, 512, 8)
+    sd_g = GI.fill_state_dict(G.state_dict(), 900 + size)
+    for k in sd_g:
+        if k.startswith('style.') and k.endswith('weight'):
+            sd_g[k] = sd_g[k] * 100.0
+    G.load_state_dict(sd_g)
+    c = GI.support_sets_case(K, N, 512, 2 * B, 31, learn_gammas=True)
+    S = SupportSets(K, N, 512, learn_gammas=True, gamma=c['gamma'])
+    S.load_state_dict(c['sd'])
+    torch.manual_seed(seed_r)                  # R's constructor initialisation
+    R = Reconstructor('ResNet', K)
+    params = types.SimpleNamespace(reconstructor_lr=1e-4, support_set_lr=1e-4, min_shift_magnitude=0.25,
+                                   max_shift_magnitude=0.45, lambda_cls=1.0, lambda_reg=0.25, z_truncation=None,
+                                   shift_in_w_space=False)
+    eng = TrainStep(StyleGAN2Wrapper(G, False).to(dev).eval(), S.to(dev).train(), R.to(dev).train(), params, B, dev,
+                    world=world, seed=5, rank=rank)
+    return eng, c
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        B = 2
+        # --- world=1 engines on this rank's shard, from rank 0's weights (seed 11 on both ranks)
+        e1, c = _build(dev, 11, 1, 0, B)
+        sl = slice(rank * B, (rank + 1) * B)
+        z, idx = c['z'][sl].to(dev), c['idx'][sl].to(dev)
+        mag = torch.tensor([0.3, -0.4, 0.35, 0.28])[sl].to(dev)
+        p0 = e1.bucket.flat.clone()
+
+        def warm(e):     # build the generator's lazy weight caches, then take the two-stream schedule of a steady-state step
+            with torch.no_grad():    # (un-shifted pass, deferred weight gradients and R's all-reduce on the side stream)
+                e.G(z)
+            torch.cuda.synchronize()
+            e.steps_done = 1
+        warm(e1)
+        st1 = e1.step(z, idx, mag).clone()
+        g_local = e1.bucket.grad.clone()
+        # --- world=2 engine; rank 1 deliberately starts from DIFFERENT reconstructor weights
+        e2, _ = _build(dev, 11 + rank, world, rank, B)
+        assert torch.equal(e2.bucket.flat, p0), "replicas must start from rank 0's parameters"
+        e2.comm_events = []
+        warm(e2)
+        e2.step(z, idx, mag)
+        torch.cuda.synchronize()
+        g_sum = e2.bucket.grad.clone()
+        expect = g_local.clone()
+        dist.all_reduce(expect)
+        scale = float(expect.abs().max())
+        err_g = float((g_sum - expect).abs().max()) / scale
+        # Adam on the averaged gradient (first step: m = (1-b1) g, v = (1-b2) g^2, bias-corrected)
+        g = (expect / world).double()
+        upd = torch.zeros_like(g)
+        for lr, a, b in e2.bucket.groups:
+            gg = g[a:b]
+            upd[a:b] = lr * gg / (gg.abs() + 1e-8)
+        p_expect = p0.double() - upd
+        big = g.abs() > 1e-3 * g.abs().max()           # entries with a numerically meaningful gradient
+        err_p = float((e2.bucket.flat.double() - p_expect)[big].abs().max())
+        # both ranks hold the same parameters after the step
+        mine = e2.bucket.flat.clone()
+        other = mine.clone()
+        dist.broadcast(other, 0)
+        same = bool(torch.equal(mine, other))
+        # statistics are averaged over ranks
+        st = e2.pop_stats()
+        tot = st1[2:3].clone()
+        dist.all_reduce(tot)
+        err_s = abs(st['total_loss'] - float(tot) / world)
+        # per-rank sampler: different z on the two ranks, same on a re-built engine with the same (seed, rank)
+        zs, _, _ = e2.sample()
+        zo = zs.clone()
+        dist.broadcast(zo, 0)
+        differs = (rank == 0) or (not torch.equal(zs, zo))
+        n_ev = len(e2.comm_events)
+        q.put((rank, err_g, err_p, same, err_s, differs, n_ev, e2.allreduce_bytes, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, None, None, None, None, None, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(900)
+def test_trainstep_world2_matches_sum_of_rank_gradients(dev):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(120)
+    for r in res:
+        assert r[-1] is None, r[-1]
+    for rank, err_g, err_p, same, err_s, differs, n_ev, nbytes, _ in res:
+        print('rank %d: grad err %.2e, param err %.2e, stats err %.2e, all-reduce payload %d B' % (rank, err_g, err_p, err_s, nbytes))
+        assert err_g < 2e-5, err_g           # wgrad split-K atomics reorder fp32 sums between the two runs
+        assert err_p < 2e-6, err_p           # |update| = lr = 1e-4 per entry
+        assert same
+        assert err_s < 1e-5
+        assert differs
+        assert n_ev == 1 and nbytes > 0
+    assert all(p.exitcode == 0 for p in procs)

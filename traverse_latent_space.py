@@ -64,8 +64,14 @@ def main(argv=None):
     if not osp.isdir(models_dir):
         raise NotADirectoryError("Invalid models directory: {}".format(models_dir))
     ss_file = osp.join(models_dir, 'support_sets.pt')
-    if not osp.isfile(ss_file):      # fall back to the lexicographically last support_sets-<iter>.pt (:201-208)
-        cands = sorted(f for f in os.listdir(models_dir) if 'support_sets-' in f)
+    if not osp.isfile(ss_file):      # fall back to the latest support_sets-<iter>.pt (:201-208), by iteration NUMBER (the
+        # reference's plain string sort ranks support_sets-9000.pt above support_sets-10000.pt)
+        def _iter_of(f):
+            digits = ''.join(ch for ch in f[len('support_sets-'):] if ch.isdigit())
+            return int(digits) if digits else -1
+        cands = sorted((f for f in os.listdir(models_dir) if f.startswith('support_sets-')), key=_iter_of)
+        if not cands:
+            raise FileNotFoundError("No support_sets.pt or support_sets-<iter>.pt under {}".format(models_dir))
         ss_file = osp.join(models_dir, cands[-1])
     pool = osp.join(args.pool_root, gan_type + ''.join('-{}'.format(c) for c in (cfg.get("biggan_target_classes") or []))
                     if gan_type == 'BigGAN' else gan_type, args.pool)

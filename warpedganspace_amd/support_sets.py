@@ -98,9 +98,16 @@ class SupportSets(nn.Module):
 
     # -- reference signature -----------------------------------------------------------------------
     def forward(self, support_sets_mask, z):
-        """`support_sets_mask` [B,K] is the reference's one-hot selector (lib/trainer.py:227-231);
-        the selected path index is its argmax (the reference gathers the row with a mask matmul)."""
-        return self.forward_idx(torch.argmax(support_sets_mask, dim=1), z)
+        """`support_sets_mask` [B,K] is the reference's one-hot selector (lib/trainer.py:227-231); the selected path index
+        is its argmax.  The reference gathers the selected rows with `mask @ SUPPORT_SETS` (lib/support_sets.py:84-88), which
+        also accepts soft / multi-hot masks (a blend of warping functions): the kernel evaluates ONE function per sample, so
+        anything but a strict one-hot row is rejected here instead of silently picking one path (this check syncs; the
+        training loop uses forward_idx)."""
+        m = support_sets_mask
+        if m.dim() != 2 or m.shape[1] != self.num_support_sets or not bool(((m.sum(1) == 1) & (m.max(1).values == 1)).all()):
+            raise L.WgsError("SupportSets.forward needs a strict one-hot mask [B, K] (one warping function per sample); "
+                             "soft / multi-hot masks are not supported on the HIP path")
+        return self.forward_idx(torch.argmax(m, dim=1), z)
 
     @torch.no_grad()
     def traverse(self, codes, eps, steps):

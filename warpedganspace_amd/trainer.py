@@ -30,6 +30,27 @@ from .aux import TrainingStatTracker, sample_z, sec2dhms, update_progress, updat
 from .support_sets import rbf_workspace
 
 
+# process-wide switches, read once at import (development A/B only; defaults are the measured-best path)
+_TWO_STREAMS = os.environ.get('WGS_TWO_STREAMS', '1') != '0'
+_DEFER_WGRAD = os.environ.get('WGS_DEFER_WGRAD', '1') != '0'
+
+
+def sampler_seed(seed, rank, world, start_iter, device):
+    """Seed of this rank's device-side sampler.  Every rank must draw DIFFERENT (z, idx, magnitude) samples (the global
+    batch is the union of the ranks' local batches), an unseeded run must not repeat the previous run's sequence (the
+    reference samples from torch's unseeded global RNG, lib/trainer.py:195-221), and a resumed run must not replay the
+    sampler from its start.  base = --seed if given, else a fresh random value drawn on rank 0 and broadcast."""
+    if seed is None:
+        base = torch.seed() % (1 << 40)
+        if world > 1 and dist.is_available() and dist.is_initialized():
+            t = torch.tensor([base], dtype=torch.int64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.broadcast(t, 0)
+            base = int(t.item())
+    else:
+        base = int(seed)
+    return (base * 1000003 + 7919 * int(start_iter)) * max(world, 1) + rank
+
+
 class FlatBucket:
     """Re-homes parameters into one flat fp32 buffer (memory order preserved) with a matching flat gradient
     and Adam moment buffers.  `gview[id(p)]` is the gradient region of p in p's MEMORY layout (conv weights:
@@ -82,15 +103,16 @@ class FlatBucket:
 class TrainStep:
     """One optimisation step of lib/trainer.py:190-261 on this rank's share of the batch."""
 
-    def __init__(self, generator, support_sets, reconstructor, params, local_batch, device, world=1, seed=None):
+    def __init__(self, generator, support_sets, reconstructor, params, local_batch, device, world=1, seed=None, rank=0,
+                 start_iter=0):
         self.G, self.S, self.R, self.p = generator, support_sets, reconstructor, params
-        self.B, self.dev, self.world = local_batch, device, world
+        self.B, self.dev, self.world, self.rank = local_batch, device, world, rank
         self.gen = torch.Generator(device=device)
         self.side_stream = torch.cuda.Stream(device=device)
-        self.two_streams = os.environ.get('WGS_TWO_STREAMS', '1') != '0'      # un-shifted generator pass on the side stream
+        self.two_streams = _TWO_STREAMS      # un-shifted generator pass on the side stream
         self.steps_done = 0
-        if seed is not None:
-            self.gen.manual_seed(seed)
+        self.sampler_seed = sampler_seed(seed, rank, world, start_iter, device)
+        self.gen.manual_seed(self.sampler_seed)
         r_params = [p for n, p in reconstructor.named_parameters()
                     if p.requires_grad and not n.startswith('features_extractor.fc')]
         s_params = [p for p in support_sets.parameters() if p.requires_grad]
@@ -112,6 +134,23 @@ class TrainStep:
         self.argmax = torch.empty(local_batch, dtype=torch.int64, device=device)
         self.loss_ws = torch.empty(2 * local_batch, device=device)
         self.w_space = bool(getattr(params, 'shift_in_w_space', False))
+        self.comm_events = None      # set to a list to collect (start, end) HIP events around the all-reduce waits
+        self.allreduce_bytes = 4 * self.bucket.flat.numel()     # payload of the step's collectives (R group + S group)
+
+    # -- optimizer state (optional 'optim' key of checkpoint.pt; reference readers ignore unknown keys) ---------
+    def optim_state(self):
+        b = self.bucket
+        return {'step': b.step_count, 'exp_avg': b.exp_avg.detach().cpu().clone(), 'exp_avg_sq': b.exp_avg_sq.detach().cpu().clone(),
+                'layout': [(n, off) for (_, off, n) in b.segments]}
+
+    def load_optim_state(self, st):
+        b = self.bucket
+        if st is None or st.get('layout') != [(n, off) for (_, off, n) in b.segments]:
+            return False
+        b.step_count = int(st['step'])
+        b.exp_avg.copy_(st['exp_avg'].to(b.exp_avg.device))
+        b.exp_avg_sq.copy_(st['exp_avg_sq'].to(b.exp_avg_sq.device))
+        return True
 
     # -- sampling (lib/trainer.py:195-221), on the device ---------------------------------------------
     def sample(self):
@@ -165,7 +204,7 @@ class TrainStep:
         gb = self.bucket.gview
         # R's conv weight gradients are not needed for d_img: they are queued and run on the side stream, next to the
         # generator's backward (whose 4x4..32x32 layers under-fill the chip); the ResNet path only (LeNet computes them inline)
-        deferred = [] if (side is not None and R.reconstructor_type == 'ResNet' and os.environ.get('WGS_DEFER_WGRAD', '1') != '0') else None
+        deferred = [] if (side is not None and R.reconstructor_type == 'ResNet' and _DEFER_WGRAD) else None
         _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred)
         del saved
         pending = []
@@ -197,8 +236,15 @@ class TrainStep:
         if self.world > 1:
             _, a, b = self.bucket.groups[1]                                   # S's gradients (RCCL sum; Adam divides by world)
             pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
+            ev = self.comm_events
+            if ev is not None:      # bench.py: how long the main stream sits in front of the collectives (exposed wait)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for w in pending:
                 w.wait()
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
         self.bucket.adam_step(world=self.world)                               # :253-254
         self.stats_sum += self.stats
         self.stats_n += 1
@@ -256,11 +302,15 @@ class Trainer(object):
     def get_starting_iteration(self, support_sets, reconstructor):
         """Resume from models/checkpoint.pt if present (lib/trainer.py:74-89): {'iter','support_sets','reconstructor'}."""
         starting_iter = 1
+        self.resume_optim = None
         if osp.isfile(self.checkpoint):
             ck = torch.load(self.checkpoint, map_location='cpu')
             starting_iter = ck['iter']
             support_sets.load_state_dict(ck['support_sets'])
             reconstructor.load_state_dict(ck['reconstructor'])
+            # extension: Adam moments (the reference restarts its optimizers from zero on resume, lib/trainer.py:153-156,
+            # 288-295 stores only the three keys above; its readers index by key, so the extra key is ignored there)
+            self.resume_optim = ck.get('optim')
         return starting_iter
 
     def log_progress(self, iteration, mean_iter_time, elapsed_time, eta, stats):
@@ -312,27 +362,33 @@ class Trainer(object):
             raise ValueError("--batch-size ({}) is the GLOBAL batch and must divide by the world size ({})".format(
                 p.batch_size, self.world))
         engine = TrainStep(generator, support_sets, reconstructor, p, p.batch_size // self.world, dev, world=self.world,
-                           seed=getattr(p, 'seed', None))
+                           seed=getattr(p, 'seed', None), rank=self.rank, start_iter=starting_iter)
+        if getattr(self, 'resume_optim', None) is not None and engine.load_optim_state(self.resume_optim) and self.rank == 0:
+            print("#. Restored Adam moments (step {}) from the checkpoint".format(engine.bucket.step_count))
         if self.rank == 0:
             print("#. Start training from iteration {}".format(starting_iter))
         t0 = time.time()
+        # Iteration time: the launches are asynchronous, so a per-iteration host clock would measure launch latency.  The
+        # device is synchronised only where statistics are popped (log boundaries): time between those, per iteration.
+        mark_t, mark_iter = t0, starting_iter - 1
         for iteration in range(starting_iter, p.max_iter + 1):
-            iter_t0 = time.time()
             engine.step()
             if self.tb_writer is not None or iteration % p.log_freq == 0:
-                stats = engine.pop_stats()
+                stats = engine.pop_stats()           # one device sync
+                now = time.time()
+                self.iter_times = np.append(self.iter_times, np.full(iteration - mark_iter, (now - mark_t) / (iteration - mark_iter)))
+                mark_t, mark_iter = now, iteration
                 if self.tb_writer is not None:
                     for key, value in stats.items():
                         self.tb_writer.add_scalar(key, value, iteration)
-            iter_t = time.time()
-            self.iter_times = np.append(self.iter_times, iter_t - iter_t0)
-            elapsed_time = iter_t - t0
+            elapsed_time = time.time() - t0
             eta = elapsed_time * ((p.max_iter - iteration) / (iteration - starting_iter + 1))
             if iteration % p.log_freq == 0 and self.rank == 0:
                 self.log_progress(iteration, self.iter_times.mean(), elapsed_time, eta, stats)
             if iteration % p.ckp_freq == 0 and self.rank == 0:
                 torch.save({'iter': iteration, 'support_sets': self._plain(support_sets.state_dict()),
-                            'reconstructor': self._plain(reconstructor.state_dict())}, self.checkpoint)
+                            'reconstructor': self._plain(reconstructor.state_dict()),
+                            'optim': engine.optim_state()}, self.checkpoint)
         elapsed_time = time.time() - t0
         if self.rank == 0:
             torch.save(self._plain(support_sets.state_dict()), osp.join(self.models_dir, 'support_sets.pt'))
