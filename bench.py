@@ -36,7 +36,7 @@ FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 
 
-def build(dev, size, K, N, B, seed, w_space=False):
+def build(dev, size, K, N, B, seed, w_space=False, rank=0):
     from warpedganspace_amd.gan_load import build_stylegan2
     from warpedganspace_amd.reconstructor import Reconstructor
     from warpedganspace_amd.support_sets import SupportSets
@@ -49,7 +49,7 @@ def build(dev, size, K, N, B, seed, w_space=False):
                                    max_shift_magnitude=0.45, lambda_cls=1.0, lambda_reg=0.25, z_truncation=None,
                                    shift_in_w_space=w_space)
     world = dist.get_world_size() if dist.is_initialized() else 1
-    eng = TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), params, B, dev, world=world, seed=seed)
+    eng = TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), params, B, dev, world=world, seed=seed, rank=rank)
     return eng
 
 
@@ -166,7 +166,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--r-precision', choices=['fp32', 'bf16x3'], default='fp32', help='arithmetic of the Reconstructor convs (default exact fp32)')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--precision', choices=('bf16x3', 'fp32'), default='bf16x3',
+    ap.add_argument('--precision', choices=('bf16x3', 'fp32', 'f16', 'f16x2'), default='bf16x3',
                     help="arithmetic of the implicit-GEMM convs: split-bf16 x3 MFMA (fp32-class, ~1e-5) or exact fp32 MFMA")
     args = ap.parse_args()
 
@@ -182,10 +182,10 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from warpedganspace_amd import conv as C
-    C.PRECISION = 1 if args.precision == 'bf16x3' else 0
+    C.set_precision(args.precision)
     from warpedganspace_amd import reconstructor as RR
     RR.R_PRECISION = 1 if args.r_precision == 'bf16x3' else 0
-    eng = build(dev, args.size, args.K, args.N, args.batch, seed=rank)
+    eng = build(dev, args.size, args.K, args.N, args.batch, seed=0, rank=rank)
 
     def barrier():
         if world > 1:
@@ -228,7 +228,7 @@ def main():
         for r in recs:
             k = by_kind.setdefault(r[0], [0.0, 0.0, 0])
             k[0] += r[1]; k[1] += r[2].elapsed_time(r[3]); k[2] += 1
-        bf = args.precision == 'bf16x3'
+        bf = args.precision != 'fp32'
         peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
         # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes (they cannot run inside this
         # process); the committed summary of those passes is reported here, per launch of the named shape.
@@ -244,7 +244,7 @@ def main():
                                if bf else "igemm_nt_kernel / igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)"),
                     "achieved": round(fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(fl / ms / 1e9 / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-                    "executed_mfma_frac": round((3.0 if bf else 1.0) * fl / ms / 1e9 / peak, 4),
+                    "executed_mfma_frac": round({'bf16x3': 3.0, 'f16x2': 2.0}.get(args.precision, 1.0) * fl / ms / 1e9 / peak, 4),
                     "launches_per_step": len(recs) // nprof, "avg_launch_ms": round(ms / len(recs), 4),
                     "conv_ms_per_step": round(ms / nprof, 3), "conv_gflop_per_step": round(fl / nprof / 1e9, 1),
                     "by_kind": {k: {"TFLOP/s": round(v[0] / v[1] / 1e9, 2), "ms_per_step": round(v[1] / nprof, 3),
@@ -270,7 +270,7 @@ def main():
         out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-%d K=%d" % (args.size, args.K), "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: %s)" % ("exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs" if args.r_precision == 'fp32' else "split-bf16 x3 convs, fp32 wgrad")
+               "dtype": ("%s generator convs (f16: fp16 operands, 1 MFMA per product, fp32 accumulate; f16x2: fp16 hi+lo weights, 2 MFMAs); reconstructor exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs" % args.precision) if args.precision in ('f16', 'f16x2') else ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: %s)" % ("exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs" if args.r_precision == 'fp32' else "split-bf16 x3 convs, fp32 wgrad")
                          if args.precision == 'bf16x3' else "fp32 (f32-input MFMA, f32 accumulate)"), "data": "synthetic (random-init weights, z ~ N(0,I))",
                "config": {"workload": "StyleGAN2-FFHQ-%d arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (args.size, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),

@@ -26,6 +26,10 @@ typedef void* wgs_stream_t; /* hipStream_t */
 
 const char* wgs_last_error(void);
 int wgs_abi_version(void);
+/* Development A/B switches (WGS_DMA_ALWAYS, WGS_NO_PATCH, ...: DESIGN.md) are read from the environment ONCE, at the first
+ * launch that consults them, and never change afterwards — except through this test hook, which re-reads them (call it
+ * with no launch in flight on another thread).  All default to off. */
+void wgs_dev_reload_flags(void);
 
 /* ------------------------------------------------------------------------------------------------
  * RBF warping field  —  replaces SupportSets.forward + its autograd backward
@@ -132,14 +136,20 @@ typedef struct wgs_conv_desc {
     int32_t precision;       /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: split-bf16 — every fp32 operand is split
                                 into bf16 hi + lo while it is staged and each product block is 3 x v_mfma_f32_32x32x16_bf16
                                 (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-16 relative per product, 5.3x the fp32 MFMA rate.
-                                Shapes it does not cover (Ci % 32 != 0) silently use the exact kernel. */
+                                2: fp16 — operands rounded to fp16 (RNE) while they are staged, ONE v_mfma_f32_32x32x16_f16 per
+                                product block, fp32 accumulate / demodulation / epilogue (the half dispatch of the reference's
+                                ops, fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:225): 2^-11 per operand, 16x the fp32 MFMA
+                                rate; the activation operand is scaled by a power of two taken from a_amax (below) first.
+                                3: fp16 x2 — as 2, but the (frozen) weights as fp16 hi + lo and 2 MFMAs per product block.
+                                Shapes the 16-bit kernels do not cover (Ci % 32 != 0) silently use the exact kernel. */
     float alpha;             /* accumulator scale (0 = 1): ProgGAN WScale, BigGAN 1/sigma */
     const float* addend;     /* optional tensor added before the activation (residual / bypass), or NULL */
     int64_t w_tap_stride, w_row_stride;
     float act_slope, gain;   /* identity: 1,1;  relu: 0,1;  fused lrelu: 0.2,sqrt(2) */
     int8_t dy[64], dx[64];
     int16_t wt[64];
-    const uint16_t* w_hi;    /* optional pre-split weights: bf16 planes hi = bf16(w), lo = bf16(w - hi) in the layout of w  */
+    const uint16_t* w_hi;    /* optional pre-split weights: 16-bit planes hi = rn(w), lo = rn(w - hi) in the layout of w: bf16 for
+                                precision 1 (wgs_split_bf16), fp16 for precision 2 (hi only) / 3 (wgs_split_f16) */
     const uint16_t* w_lo;    /* (wgs_split_bf16).  With them and a workspace of 4 bytes per INPUT element, precision = 1
                                 launches that take the 8-wave tiles use the LDS-DMA kernel: activations are style-modulated and
                                 split into the workspace by a pre-pass, and both operands are copied global -> LDS without
@@ -149,6 +159,11 @@ typedef struct wgs_conv_desc {
                                 512..2048) split the K = taps*Ci contraction over up to 16 workgroups per tile; the
                                 partial tiles go to ws[split][M][Co] (plain stores, deterministic) and a second kernel
                                 reduces them and applies the epilogue.  Needs 4*ksplit*M*Co bytes; too small => fewer splits. */
+    const float* a_amax;     /* precision 2 / 3: optional DEVICE scalar m >= max|x| (any over-estimate).  The kernels scale the
+                                activation operand x * a_scale by 2^k, k chosen so that m * a_bound * 2^k lies in [2^11, 2^12),
+                                before rounding it to fp16 and multiply the accumulators by 2^-k: gradients (dgrad launches) of
+                                any magnitude keep 11 significant bits and cannot overflow.  NULL: no scaling (k = 0). */
+    float a_bound;           /* bound of |a_scale| (and of any linear map the caller folded into x after measuring m); 0 = 1 */
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
 /* n launches that share every operand and differ only in (Hg, Wg, oy0, ox0, taps) — the 4 sub-pixel phases of a
@@ -174,6 +189,9 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
 
 /* hi[i] = bf16_rn(x[i]), lo[i] = bf16_rn(x[i] - hi[i]) (raw bf16 bit patterns), n % 4 == 0: the split used by precision = 1. */
 int wgs_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_stream_t stream);
+
+/* fp16 planes for precision 2 / 3: hi[i] = f16_rn(x[i]), lo[i] = f16_rn(x[i] - hi[i]) (lo may be NULL), n % 4 == 0. */
+int wgs_split_f16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_stream_t stream);
 
 /* dst[t][ci][co] = src[co][t][ci]  (pack [Cout,T,Cin] weights for the dgrad contraction). */
 int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream);
@@ -226,10 +244,15 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
  *   dOut = sA*gA + sR*(sum_o drgb[b,o,p]*wR[o,c]*rscale);  dy = dOut * lrelu'(out)*sqrt(2)  -> dy [B,P,C]
  *   num[b,c] += sum_p dy*ypre  (ypre = conv output before noise/bias/activation, recovered from `out`)
  *   dsA[b,c] += sum_p out*gA ;  dsR[b,c] += sum_p out*gR       (caller zeroes num/dsA/dsR)
- * gA = UN-scaled dgrad of the consumer conv (or NULL at the last layer), drgb = image gradient (or NULL). */
+ * gA = UN-scaled dgrad of the consumer conv (or NULL at the last layer), drgb = image gradient (or NULL).
+ * post_scale [B,C] or NULL: the STORED gradient is dy * post_scale[b,c] (this layer's demodulation vector, i.e. the
+ *   A-operand factor of its dgrad conv, which then needs no a_scale); num / dsA / dsR use the un-scaled dy.
+ * dy_amax: optional device scalar (caller-zeroed), raised to max |stored gradient| (atomic max) — the magnitude bound the
+ *   fp16 dgrad launches take as wgs_conv_desc.a_amax. */
 int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
                     const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
-                    float* dy, float* num, float* dsA, float* dsR, int B, int P, int C, wgs_stream_t stream);
+                    float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P,
+                    int C, wgs_stream_t stream);
 /* ds[b,c] += sum_p x[(x_batched ? b : 0), p, c] * g[b,p,c] */
 int wgs_xg_reduce(const float* x, int x_batched, const float* g, float* ds, int B, int P, int C, wgs_stream_t stream);
 /* dstyle[b*ld_out + i] = dsdir[b*Ci + i] - s[b*ld_s + i]*scale2 * sum_o num[b,o]*demod[b,o]^2*wsq[o,i]

@@ -33,3 +33,17 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device('cuda:0')
+
+
+@pytest.fixture()
+def dev_flags(monkeypatch):
+    """Set development switches of libwgs_hip.so (read once from the environment) for one test: dev_flags(WGS_DMA_ALWAYS='1')."""
+    from warpedganspace_amd import _lib as L
+
+    def _set(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        L.lib().wgs_dev_reload_flags()
+    yield _set
+    monkeypatch.undo()
+    L.lib().wgs_dev_reload_flags()

@@ -192,11 +192,11 @@ def test_conv_split_bf16_256_row_tiles(dev, B, Ci, Co, H):
 
 
 @pytest.mark.parametrize('B,Ci,Co,H', [(4, 64, 256, 128), (8, 32, 128, 128), (8, 32, 512, 64)])
-def test_conv_split_bf16_lds_dma_path(dev, B, Ci, Co, H, monkeypatch):
+def test_conv_split_bf16_lds_dma_path(dev, B, Ci, Co, H, dev_flags):
     """Pre-split weights (wgs_split_bf16) + workspace => the LDS-DMA kernel: same split values, same product order as the
     register-staged kernel, so the results must be identical; also against the exact-fp32 kernel.  (The library takes the
     DMA form on its own only for Cout >= 512, where it pays; WGS_DMA_ALWAYS forces it for the other 8-wave shapes.)"""
-    monkeypatch.setenv('WGS_DMA_ALWAYS', '1')
+    dev_flags(WGS_DMA_ALWAYS='1')
     torch.manual_seed(Co + 1)
     x = torch.randn(B, H, H, Ci, device=dev)
     wp = C.pack_weight(torch.randn(Co, Ci, 3, 3) / (Ci * 9) ** 0.5).to(dev)
@@ -222,9 +222,9 @@ def test_conv_split_bf16_lds_dma_path(dev, B, Ci, Co, H, monkeypatch):
         assert torch.equal(d1, C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=1))
 
 
-def test_conv_transpose_s2_merged_phases_lds_dma(dev, monkeypatch):
+def test_conv_transpose_s2_merged_phases_lds_dma(dev, dev_flags):
     """Up-conv large enough for the merged 4-phase launch, with and without pre-split weights, vs the exact-fp32 phases."""
-    monkeypatch.setenv('WGS_DMA_ALWAYS', '1')
+    dev_flags(WGS_DMA_ALWAYS='1')
     torch.manual_seed(11)
     B, Ci, Co, H = 8, 64, 128, 64
     x = torch.randn(B, H, H, Ci, device=dev)

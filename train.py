@@ -51,12 +51,15 @@ def parse(argv=None):
     ext = p.add_argument_group('extensions (not stored in args.json)')
     ext.add_argument('--random-init-generator', action='store_true')
     ext.add_argument('--seed', type=int, default=None)
+    ext.add_argument('--precision', choices=('fp32', 'bf16x3', 'f16', 'f16x2'), default=None,
+                     help="arithmetic of the frozen generator's convs (default: warpedganspace_amd.conv.DEFAULT_PRECISION); "
+                          "the reconstructor's forward and weight gradients always run in exact fp32")
     return p.parse_args(argv)
 
 
 def main(argv=None):
     args = parse(argv)
-    ext = {'random_init_generator': args.random_init_generator, 'seed': args.seed}
+    ext = {'random_init_generator': args.random_init_generator, 'seed': args.seed, 'precision': args.precision}
     for k in ext:
         delattr(args, k)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -90,6 +93,9 @@ def main(argv=None):
         print("#. Reconstructor trainable parameters: {:,}".format(sum(p.numel() for p in R.parameters() if p.requires_grad)))
         print("#. Experiment: {}".format(exp_dir))
     args.seed = ext['seed']
+    if ext['precision'] is not None:
+        from warpedganspace_amd import conv as C
+        C.set_precision(ext['precision'])
     trn = Trainer(params=args, exp_dir=exp_dir, use_cuda=use_cuda, multi_gpu=world > 1)
     trn.train(generator=G, support_sets=S, reconstructor=R)
     if world > 1:

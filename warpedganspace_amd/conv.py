@@ -23,7 +23,8 @@ class ConvDesc(ctypes.Structure):
                 ('act_slope', ctypes.c_float), ('gain', ctypes.c_float),
                 ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
                 ('w_hi', ctypes.c_void_p), ('w_lo', ctypes.c_void_p),
-                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64)]
+                ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64),
+                ('a_amax', ctypes.c_void_p), ('a_bound', ctypes.c_float)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -34,9 +35,42 @@ class WgradDesc(ctypes.Structure):
                 ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
 
 
-# Arithmetic of the implicit-GEMM launches: 0 = exact fp32 MFMA (default), 1 = split-bf16 x3 MFMA (see wgs.h).
-# Set through the environment (WGS_CONV_PRECISION=bf16x3) or by assigning conv.PRECISION.
-PRECISION = 1 if os.environ.get('WGS_CONV_PRECISION', 'fp32').lower() in ('bf16x3', '1') else 0
+# Arithmetic of the (frozen) generator's implicit-GEMM launches (wgs_conv_desc.precision, include/wgs.h):
+#   0 'fp32'   exact fp32 MFMA                                   (reference arithmetic, 157 TF ceiling)
+#   1 'bf16x3' split-bf16, 3 MFMAs per product, ~2^-16           (fp32-class: image error ~1e-5)
+#   2 'f16'    fp16 operands, 1 MFMA per product, fp32 accumulate (image error ~4e-4 at 256^2 — inside the 1e-3 gate)
+#   3 'f16x2'  fp16 activations x (hi + lo) fp16 weights, 2 MFMAs (image error ~3e-4)
+# Set with set_precision() / train.py --precision / bench.py --precision, or WGS_CONV_PRECISION at import.
+PRECISION_NAMES = {'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3}
+DEFAULT_PRECISION = 'bf16x3'
+
+
+def precision_code(name):
+    if isinstance(name, int):
+        if name not in PRECISION_NAMES.values():
+            raise L.WgsError("unknown conv precision %r" % (name,))
+        return name
+    key = str(name).lower()
+    if key in PRECISION_NAMES:
+        return PRECISION_NAMES[key]
+    if key.isdigit() and int(key) in PRECISION_NAMES.values():
+        return int(key)
+    raise L.WgsError("unknown conv precision %r (choose from %s)" % (name, ', '.join(PRECISION_NAMES)))
+
+
+PRECISION = precision_code(os.environ.get('WGS_CONV_PRECISION', DEFAULT_PRECISION))
+
+
+def set_precision(name):
+    """Select the arithmetic of the generator convs for subsequent launches; returns the previous code."""
+    global PRECISION
+    old, PRECISION = PRECISION, precision_code(name)
+    return old
+
+
+def precision_name(code=None):
+    code = PRECISION if code is None else code
+    return [k for k, v in PRECISION_NAMES.items() if v == code][0]
 
 # bench.py sets this to a list to collect (kind, algorithmic FLOPs, start event, end event) per launch;
 # the events are recorded on torch's current stream, which is the stream the kernels are launched on.
@@ -63,14 +97,35 @@ def _workspace(device, nbytes=0):
     return ws
 
 
-def split_weight(w):
-    """Pre-split a (frozen) packed fp32 weight into its bf16 hi / lo planes for the LDS-DMA conv path (wgs_split_bf16).
-    Returns (hi, lo) int16 tensors of w's shape; pass them as w_split= to the conv functions."""
+def split_weight(w, precision=1):
+    """Pre-split a (frozen) packed fp32 weight into the 16-bit planes of `precision` for the DMA-fed conv kernels:
+    bf16 hi / lo (1, wgs_split_bf16), fp16 hi (2) or fp16 hi / lo (3, wgs_split_f16).
+    Returns (hi, lo) int16 tensors of w's shape (lo None for precision 2); pass them as w_split= to the conv functions."""
     if not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32 and w.numel() % 4 == 0):
         raise L.WgsError("split_weight needs a contiguous fp32 GPU tensor with numel % 4 == 0")
-    hi, lo = torch.empty_like(w, dtype=torch.int16), torch.empty_like(w, dtype=torch.int16)
-    L.check(L.lib().wgs_split_bf16(L.ptr(w), L.ptr(hi, torch.int16), L.ptr(lo, torch.int16), ctypes.c_int64(w.numel()), L.stream()), 'wgs_split_bf16')
+    hi = torch.empty_like(w, dtype=torch.int16)
+    lo = torch.empty_like(w, dtype=torch.int16) if precision != 2 else None
+    if precision == 1:
+        L.check(L.lib().wgs_split_bf16(L.ptr(w), L.ptr(hi, torch.int16), L.ptr(lo, torch.int16), ctypes.c_int64(w.numel()), L.stream()), 'wgs_split_bf16')
+    elif precision in (2, 3):
+        L.check(L.lib().wgs_split_f16(L.ptr(w), L.ptr(hi, torch.int16), L.ptr(lo, torch.int16), ctypes.c_int64(w.numel()), L.stream()), 'wgs_split_f16')
+    else:
+        raise L.WgsError("split_weight: precision must be 1, 2 or 3")
     return hi, lo
+
+
+class SplitCache:
+    """Lazily built 16-bit planes of one frozen weight tensor, per precision (tests switch the arithmetic at run time)."""
+
+    def __init__(self, w):
+        self.w, self.planes = w, {}
+
+    def get(self, precision):
+        if precision == 0:
+            return None
+        if precision not in self.planes:
+            self.planes[precision] = split_weight(self.w, precision)
+        return self.planes[precision]
 
 
 def _timed(kind, flops, fn):
@@ -86,7 +141,8 @@ def _timed(kind, flops, fn):
 
 def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
-          a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None, w_split=None):
+          a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None, w_split=None,
+          a_amax=None, a_bound=1.0, grad_operand=False):
     """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
         raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
@@ -101,13 +157,22 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     d.ntaps = len(taps)
     d.a_ld, d.col_ld = a_ld, col_ld
     d.ups, d.add_ups, d.act, d.alpha, d.addend = ups, add_ups, act, alpha, _p(addend)
-    d.precision = PRECISION if precision is None else precision
+    prec = PRECISION if precision is None else precision
+    if grad_operand and prec >= 2 and a_amax is None:
+        # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
+        prec = 1
+    d.precision = prec
+    d.a_amax, d.a_bound = _p(a_amax), a_bound
+    if isinstance(w_split, SplitCache):
+        w_split = w_split.get(prec)
     d.w_tap_stride, d.w_row_stride = w_tap_stride, w_row_stride
     d.act_slope, d.gain = act_slope, gain
     ws = _workspace(x.device, x.numel() * 4 if w_split is not None else 0)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if w_split is not None:
-        d.w_hi, d.w_lo = w_split[0].data_ptr(), w_split[1].data_ptr()
+        d.w_hi, d.w_lo = w_split[0].data_ptr(), _p(w_split[1])
+    else:
+        d.w_hi, d.w_lo = None, None
     for i, (ty, tx, ti) in enumerate(taps):
         d.dy[i], d.dx[i], d.wt[i] = ty, tx, ti
     return d, 2.0 * d.B * Hg * Wg * d.Co * d.Ci * len(taps)
@@ -150,7 +215,7 @@ def conv2d_dgrad(dy, wt_packed, in_hw, k, stride=1, pad=0, **epi):
     if stride == 1:
         dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=dy.dtype)
         taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
-        return launch(dy, wt_packed, dx, taps, Hi, Wi, w_tap_stride=Ci * Co, w_row_stride=Co, **epi)
+        return launch(dy, wt_packed, dx, taps, Hi, Wi, w_tap_stride=Ci * Co, w_row_stride=Co, grad_operand=True, **epi)
     if stride != 2:
         raise L.WgsError("conv2d_dgrad: stride must be 1 or 2")
     phases = []
@@ -166,7 +231,7 @@ def conv2d_dgrad(dy, wt_packed, in_hw, k, stride=1, pad=0, **epi):
         Hg, Wg = (Hi - py + 1) // 2, (Wi - px + 1) // 2
         if not taps or Hg <= 0 or Wg <= 0:
             continue
-        launch(dy, wt_packed, dx, taps, Hg, Wg, osy=2, oy0=py, ox0=px, w_tap_stride=Ci * Co, w_row_stride=Co, **epi)
+        launch(dy, wt_packed, dx, taps, Hg, Wg, osy=2, oy0=py, ox0=px, w_tap_stride=Ci * Co, w_row_stride=Co, grad_operand=True, **epi)
     return dx
 
 
@@ -193,7 +258,7 @@ def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
     Hi, Wi = (Ho - k) // 2 + 1, (Wo - k) // 2 + 1
     dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=dy.dtype)
     taps = [(ky, kx, ky * k + kx) for ky in range(k) for kx in range(k)]
-    return launch(dy, wt_packed, dx, taps, Hi, Wi, isy=2, w_tap_stride=Ci * Co, w_row_stride=Co, **epi)
+    return launch(dy, wt_packed, dx, taps, Hi, Wi, isy=2, w_tap_stride=Ci * Co, w_row_stride=Co, grad_operand=True, **epi)
 
 
 def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0):

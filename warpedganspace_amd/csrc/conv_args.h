@@ -27,8 +27,11 @@ struct ConvArgs {
     long w_tap_stride, w_row_stride;
     float act_slope, gain, alpha;
     int HW, Mimg;       // Hg*Wg, and GEMM rows per sample (>= HW; M = B*Mimg).  Mimg == HW except in launch_bf16x3
-    const unsigned short* w_hi;     // pre-split bf16 planes of w (same packed layout), or null
+    const unsigned short* w_hi;     // pre-split 16-bit planes of w (same packed layout; bf16 for sch 0, fp16 for sch 1 / 2), or null
     const unsigned short* w_lo;
+    int sch;                        // operand scheme (conv_scheme.h): precision - 1
+    const float* a_amax;            // fp16 schemes: device scalar bounding |x| (dynamic power-of-two operand scale), or null
+    float a_bound;                  // ... times this factor (bound of |a_scale|, blur gain ...)
     const unsigned short* a_hi;     // split (and style-modulated) activation planes: set by launch_bf16x3 (LDS-DMA path)
     const unsigned short* a_lo;
     float* ws;          // split-K workspace or null
@@ -72,7 +75,7 @@ inline int choose_ksplit(const ConvArgs& a, int tiles, int nk) {
 // second pass of a split-K launch: reduce ws[split][M][Co] and apply the epilogue (conv_igemm_bf16.hip)
 void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st);
 
-// split-bf16 (3 x v_mfma_f32_32x32x16_bf16 per product block) variant; returns 0 when it handled the launch,
+// 16-bit-operand kernels (a.sch selects split-bf16 x3 / fp16 / fp16 x2, conv_scheme.h); returns 0 when it handled the launch,
 // 1 when the shape is not supported (caller falls back to the exact fp32 kernel).
 int launch_bf16x3(const ConvArgs& a, hipStream_t st);
 // the same for n <= 4 launches that differ only in (Hg, Wg, oy0, ox0, taps); 0 = handled as one merged launch
@@ -81,6 +84,9 @@ int launch_bf16x3_multi(const ConvArgs* a, int n, hipStream_t st);
 // LDS-DMA form of the 8-wave kernels (conv_igemm_dma.hip)
 void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
                 int C, hipStream_t st);
+// the same for the fp16 schemes: hi = f16(x * s * mult), lo = f16(residual) (lo may be null); mult from (a_amax, a_bound)
+void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
+               int C, const float* a_amax, float a_bound, hipStream_t st);
 void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st);
 
 // patch form for stride-1 convs (conv_igemm_patch.hip); 0 = launch taken.  Needs x_bytes / w_bytes (fp32 extents) and the

@@ -12,7 +12,8 @@ typedef float epi_f32x16 __attribute__((ext_vector_type(16)));
 // barrier) -> every accumulator gets alpha, demodulation, noise, bias, addend, activation and is stored
 template <int BM, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x16 (&acc)[TM][TN], const unsigned char* smem_b,
-                                                    int n0, int wm, int wn, int l31, int lh) {
+                                                    int n0, int wm, int wn, int l31, int lh, float alpha_mul = 1.f) {
+    const float alpha = p.alpha * alpha_mul;      // alpha_mul: inverse of the fp16 schemes' power-of-two operand scale (exact)
     const int* r_pix = reinterpret_cast<const int*>(smem_b);
     const int* r_b = r_pix + BM;
     const float* r_nz = reinterpret_cast<const float*>(r_b + BM);
@@ -37,7 +38,7 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
                 const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int pix = r_pix[row];
                 if (pix >= 0 && nok) {
-                    float v = acc[i][j][r] * p.alpha;
+                    float v = acc[i][j][r] * alpha;
                     if (p.col_scale) v *= cs_fast ? (r_b[row] == b_lo ? cs0 : cs1) : p.col_scale[(size_t)r_b[row] * p.col_ld + n];
                     v += r_nz[row] + bias;
                     if (p.addend) v += p.addend[(size_t)r_add[row] * p.Co + n];
@@ -51,7 +52,7 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
 
 template <int BM, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs& P, epi_f32x16 (&acc)[TM][TN], unsigned char* smem_b,
-                                              int m0, int n0, int wm, int wn, int tid, int l31, int lh) {
+                                              int m0, int n0, int wm, int wn, int tid, int l31, int lh, float alpha_mul = 1.f) {
     int* r_pix = reinterpret_cast<int*>(smem_b);
     int* r_b = r_pix + BM;
     float* r_nz = reinterpret_cast<float*>(r_b + BM);
@@ -74,7 +75,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs
         r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
     }
     __syncthreads();
-    conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh);
+    conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh, alpha_mul);
 }
 
 // workgroup -> (phase, m-tile, n-tile); false = padding workgroup of a merged launch (exits)

@@ -527,6 +527,13 @@ int wgs_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_st
     return WGS_OK;
 }
 
+int wgs_split_f16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && hi && n > 0 && n % 4 == 0, "wgs_split_f16: bad arguments (n %% 4)");
+    wgsconv::split_f16(x, nullptr, 0, hi, lo, 1, (long)n, 4, nullptr, 1.f, (hipStream_t)stream);
+    WGS_CHECK_LAUNCH("modcvt_f16_kernel");
+    return WGS_OK;
+}
+
 int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream) {
     WGS_CHECK_ARG(src && dst && Co > 0 && T > 0 && Ci > 0, "wgs_repack_w_t: bad arguments");
     dim3 grid((Ci + 31) / 32, (Co + 31) / 32, T);
@@ -561,6 +568,10 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
     a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = nullptr; a.a_lo = nullptr;
+    WGS_CHECK_ARG(d->precision >= 0 && d->precision <= 3, "wgs_conv_igemm: precision=%d (0 fp32, 1 bf16x3, 2 f16, 3 f16x2)", d->precision);
+    a.sch = d->precision > 0 ? d->precision - 1 : 0;
+    a.a_amax = d->precision >= 2 ? d->a_amax : nullptr;
+    a.a_bound = d->a_bound > 0.f ? d->a_bound : 1.f;
     wgsconv::fill_tap_tables(a);
     return WGS_OK;
 }
@@ -578,8 +589,8 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         return WGS_OK;
     }
     const bool k32 = (d->Ci % 32 == 0);
-    if (d->precision == 1 && wgsconv::launch_bf16x3(a, st) == 0) {
-        WGS_CHECK_LAUNCH("igemm_nt_bf16x3_kernel");
+    if (d->precision >= 1 && wgsconv::launch_bf16x3(a, st) == 0) {
+        WGS_CHECK_LAUNCH("igemm_nt16_kernel");
         return WGS_OK;
     }
     if (d->Co > 64) {
@@ -600,12 +611,12 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
 
 int wgs_conv_igemm_multi(const wgs_conv_desc* descs, int n, wgs_stream_t stream) {
     WGS_CHECK_ARG(descs && n > 0, "wgs_conv_igemm_multi: bad arguments");
-    if (n >= 2 && n <= 4 && descs[0].precision == 1) {
+    if (n >= 2 && n <= 4 && descs[0].precision >= 1) {
         ConvArgs as[4];
         bool ok = true;
-        for (int i = 0; i < n && ok; ++i) ok = descs[i].precision == 1 && build_conv_args(&descs[i], as[i]) == WGS_OK;
+        for (int i = 0; i < n && ok; ++i) ok = descs[i].precision == descs[0].precision && descs[i].a_amax == descs[0].a_amax && build_conv_args(&descs[i], as[i]) == WGS_OK;
         if (ok && wgsconv::launch_bf16x3_multi(as, n, (hipStream_t)stream) == 0) {
-            WGS_CHECK_LAUNCH("igemm_nt_bf16x3_kernel<multi>");
+            WGS_CHECK_LAUNCH("igemm_nt16_kernel<multi>");
             return WGS_OK;
         }
     }

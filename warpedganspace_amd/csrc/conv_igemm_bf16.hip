@@ -11,13 +11,16 @@
 // LDS image per stage: A_hi, A_lo [BM][32] bf16 and B_hi, B_lo [BN][32] bf16, rows padded to 80 bytes so that the
 // 16-lane groups of ds_read_b128 (one lane = one row, 8 consecutive k) hit 16 distinct 4-bank slots.
 // 2 stages x 40 KiB = 80 KiB per workgroup -> two workgroups per CU.
-#include <cstdlib>
+//
+// The same kernels also run the fp16 operand schemes (conv_scheme.h: one fp16 plane per operand and 1 MFMA per product
+// block, or two weight planes and 2 MFMAs) — template parameter SCH; everything below that says "hi / lo" then has
+// NA / NB planes per operand.
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
+#include "conv_scheme.h"
 
 typedef wgsconv::epi_f32x16 f32x16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -33,18 +36,14 @@ using wgsconv::PhaseArgs;
 constexpr int BK = 32;          // fp32 values per K-chunk
 constexpr int ROWB = 80;        // bytes per LDS row: 32 bf16 = 64 B + 16 B pad
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// split 4 floats into packed bf16 hi (2 words) and lo (2 words); the casts lower to v_cvt_pk_bf16_f32 (RNE)
+// split 4 floats into packed 16-bit hi (2 words) and lo (2 words) of the scheme; the casts lower to v_cvt_pk_* (RNE)
+template <int SCH>
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
     if (WGS_ABL == 1) { hi = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); lo = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); return; }
     const f32x4 f = {v.x, v.y, v.z, v.w};
-    const bf16x4 h = __builtin_convertvector(f, bf16x4);
-    const f32x4 r = f - __builtin_convertvector(h, f32x4);
-    const bf16x4 l = __builtin_convertvector(r, bf16x4);
-    hi = __builtin_bit_cast(uint2, h);
-    lo = __builtin_bit_cast(uint2, l);
+    wgsconv::Scheme<SCH>::cvt4(f, hi, lo);
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -58,8 +57,11 @@ constexpr int OOB = (int)0x80000000;     // a byte offset beyond any buffer this
 
 // ASCALE: 0 no style, 1 one style vector per tile row (tiles that span several samples), 2 one per tile (every tile
 // lies inside one sample: Hg*Wg is a multiple of BM) — the common case, and three fewer vector loads per thread/chunk.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int ASCALE, bool UPS>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 2 : 1) void igemm_nt_bf16x3_kernel(const ConvArgs p) {
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int ASCALE, bool UPS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 2 : 1) void igemm_nt16_kernel(const ConvArgs p) {
+    typedef wgsconv::Scheme<SCH> SC;
+    typedef typename SC::frag frag;
+    constexpr int NA = SC::NA, NB = SC::NB;
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int CPR = BK / 4;       // float4 chunks per tile row (8)
     constexpr int RPP = NT / CPR;     // rows filled per pass (32 or 64)
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     constexpr int PS = ASCALE == 1 ? PA : 1;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;     // A_hi | A_lo | B_hi | B_lo
+    constexpr int STAGE = NA * A_BYTES + NB * B_BYTES;   // A_hi (| A_lo) | B_hi (| B_lo)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,6 +130,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     const int kbeg = (int)blockIdx.y * kper;
     const int nk = min(kper, nk_all - kbeg);
     const int Hup = p.Hi << p.ups, Wup = p.Wi << p.ups;
+    // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h); undone on the accumulators
+    float op_mult = 1.f, op_inv = 1.f;
+    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_bound, op_mult, op_inv);
 
     // K order: channel chunk OUTER, tap INNER — consecutive iterations re-read the same pixels' channel chunk shifted
     // by one tap, so a tile's activation working set per chunk (~17 KB) stays in L1/L2 across the taps, and the
@@ -195,16 +200,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
                 v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
                 asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (no fma into the residual)
             }
+            if (SCH != 0 && p.a_amax) { v.x *= op_mult; v.y *= op_mult; v.z *= op_mult; v.w *= op_mult; }
             off = (r0 + idx * RPP) * ROWB + q * 8;
         } else {
             v = rb[idx - PA];
-            off = 2 * A_BYTES + (r0 + (idx - PA) * RPP) * ROWB + q * 8;
+            off = NA * A_BYTES + (r0 + (idx - PA) * RPP) * ROWB + q * 8;
         }
         uint2 hi, lo;
-        split4(v, hi, lo);
+        split4<SCH>(v, hi, lo);
         if (WGS_ABL == 2) { asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y)); return; }
         *reinterpret_cast<uint2*>(base + off) = hi;
-        *reinterpret_cast<uint2*>(base + off + (idx < PA ? A_BYTES : B_BYTES)) = lo;
+        if ((idx < PA ? NA : NB) == 2) *reinterpret_cast<uint2*>(base + off + (idx < PA ? A_BYTES : B_BYTES)) = lo;
     };
     auto store_tile = [&](int buf, const Stage& S) {
 #pragma unroll
@@ -238,32 +244,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     auto mma_tile = [&](int cur, int st, Stage& LD, const Stage& ST) {
         const unsigned char* base = smem_b + cur * STAGE;
         const unsigned char* a_hi = base + (wm * WM + l31) * ROWB + lh * 16;
-        const unsigned char* b_hi = base + 2 * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
-        auto read_a = [&](int slot, bf16x8& h, bf16x8& l) {
+        const unsigned char* b_hi = base + NA * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
+        auto read_a = [&](int slot, frag* f) {
             const int ks = slot / TM, i = slot % TM;
-            if (WGS_ABL == 10) { asm volatile("" : "=v"(h), "=v"(l)); return; }
-            h = *reinterpret_cast<const bf16x8*>(a_hi + i * 32 * ROWB + ks * 32);
-            l = *reinterpret_cast<const bf16x8*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
-        };
-        auto read_b = [&](int ks, bf16x8* h, bf16x8* l) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (WGS_ABL == 10) { asm volatile("" : "=v"(h[j]), "=v"(l[j])); continue; }
-                h[j] = *reinterpret_cast<const bf16x8*>(b_hi + j * 32 * ROWB + ks * 32);
-                l[j] = *reinterpret_cast<const bf16x8*>(b_hi + B_BYTES + j * 32 * ROWB + ks * 32);
+            for (int pl = 0; pl < NA; ++pl) {
+                if (WGS_ABL == 10) { asm volatile("" : "=v"(f[pl])); continue; }
+                f[pl] = *reinterpret_cast<const frag*>(a_hi + pl * A_BYTES + i * 32 * ROWB + ks * 32);
             }
         };
-        bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
-        read_b(0, bh[0], bl[0]);
-        read_a(0, ah[0], al[0]);
+        auto read_b = [&](int ks, frag (*f)[NB]) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NB; ++pl) {
+                    if (WGS_ABL == 10) { asm volatile("" : "=v"(f[j][pl])); continue; }
+                    f[j][pl] = *reinterpret_cast<const frag*>(b_hi + pl * B_BYTES + j * 32 * ROWB + ks * 32);
+                }
+        };
+        frag bf[2][TN][NB], af[2][NA];
+        read_b(0, bf[0]);
+        read_a(0, af[0]);
         begin_scale();
         begin_tile();
 #pragma unroll
         for (int slot = 0; slot < SLOTS; ++slot) {
             const int ks = slot / TM, i = slot % TM;
             if (slot + 1 < SLOTS) {
-                read_a(slot + 1, ah[(slot + 1) & 1], al[(slot + 1) & 1]);
-                if ((slot + 1) % TM == 0) read_b(ks + 1, bh[(ks + 1) & 1], bl[(ks + 1) & 1]);
+                read_a(slot + 1, af[(slot + 1) & 1]);
+                if ((slot + 1) % TM == 0) read_b(ks + 1, bf[(ks + 1) & 1]);
             }
             if (slot < LSLOTS) {
 #pragma unroll
@@ -274,10 +283,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (WGS_ABL == 3) { asm volatile("" :: "v"(al[slot & 1]), "v"(ah[slot & 1]), "v"(bh[ks & 1][j]), "v"(bl[ks & 1][j])); continue; }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bl[ks & 1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
+                if (WGS_ABL == 3) { asm volatile("" :: "v"(af[slot & 1][0]), "v"(bf[ks & 1][j][0])); continue; }
+                acc[i][j] = SC::mma(af[slot & 1], bf[ks & 1][j], acc[i][j]);
             }
             if (slot >= SFIRST && st >= 0) {
 #pragma unroll
@@ -328,12 +335,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < P.M && n < p.Co) part[(size_t)m * p.Co + n] = acc[i][j][r];
+                    if (m < P.M && n < p.Co) part[(size_t)m * p.Co + n] = acc[i][j][r] * op_inv;
                 }
         }
         return;
     }
-    wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh);
+    wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh, op_inv);
 }
 
 // Second pass of a split-K launch: y[pix(m)][n] = epilogue(sum_s ws[s][m][n]) — the same epilogue as above
@@ -374,16 +381,16 @@ void single_phase(ConvArgs& a) {
     for (int t = 0; t < a.ntaps; ++t) { P.tap_yx[t] = a.tap_yx[t]; P.tap_a[t] = a.tap_a[t]; P.tap_w[t] = a.tap_w[t]; }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch(ConvArgs& a, hipStream_t st) {
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_s(ConvArgs& a, hipStream_t st) {
     single_phase(a);
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
-    const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
+    const size_t sm = (size_t)2 * (wgsconv::Scheme<SCH>::NA * BM + wgsconv::Scheme<SCH>::NB * BN) * ROWB;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a.ksplit), block(64 * WAVES_M * WAVES_N);
     const int mode = !a.a_scale ? 0 : (a.Mimg % BM == 0 ? 2 : 1);
 #define WGS_BF16_LAUNCH(AS, UP)                                                                             \
     {                                                                                                       \
-        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, AS, UP>;                                  \
+        auto k = igemm_nt16_kernel<SCH, BM, BN, WAVES_M, WAVES_N, AS, UP>;                                  \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);     \
         hipLaunchKernelGGL(k, grid, block, sm, st, a);                                                      \
     }
@@ -394,23 +401,35 @@ void launch(ConvArgs& a, hipStream_t st) {
     }
 #undef WGS_BF16_LAUNCH
 }
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch(ConvArgs& a, hipStream_t st) {
+    if (a.sch == 0) launch_s<0, BM, BN, WAVES_M, WAVES_N>(a, st);
+    else if (a.sch == 1) launch_s<1, BM, BN, WAVES_M, WAVES_N>(a, st);
+    else launch_s<2, BM, BN, WAVES_M, WAVES_N>(a, st);
+}
 
 // 8-wave 256-row tiles (one workgroup per CU): only the non-upsampling forms are instantiated
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_big(ConvArgs& a, hipStream_t st, int nblocks = 0) {
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_big_s(ConvArgs& a, hipStream_t st, int nblocks) {
     if (!nblocks) single_phase(a);
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.Co + BN - 1) / BN;
-    const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
+    const size_t sm = (size_t)2 * (wgsconv::Scheme<SCH>::NA * BM + wgsconv::Scheme<SCH>::NB * BN) * ROWB;
     dim3 grid((unsigned)(nblocks ? nblocks : ntm * ntn)), block(64 * WAVES_M * WAVES_N);
     if (!a.a_scale) {
-        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, 0, false>;
+        auto k = igemm_nt16_kernel<SCH, BM, BN, WAVES_M, WAVES_N, 0, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         hipLaunchKernelGGL(k, grid, block, sm, st, a);
     } else {
-        auto k = igemm_nt_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N, 2, false>;
+        auto k = igemm_nt16_kernel<SCH, BM, BN, WAVES_M, WAVES_N, 2, false>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         hipLaunchKernelGGL(k, grid, block, sm, st, a);
     }
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_big(ConvArgs& a, hipStream_t st, int nblocks = 0) {
+    if (a.sch == 0) launch_big_s<0, BM, BN, WAVES_M, WAVES_N>(a, st, nblocks);
+    else if (a.sch == 1) launch_big_s<1, BM, BN, WAVES_M, WAVES_N>(a, st, nblocks);
+    else launch_big_s<2, BM, BN, WAVES_M, WAVES_N>(a, st, nblocks);
 }
 
 }  // namespace
@@ -437,13 +456,14 @@ static bool set_extents(ConvArgs& a, int wt_max) {
 // the split activation planes (4 bytes per input element).  Runs the modulate+split pre-pass and the DMA kernel.
 static bool try_dma(ConvArgs& a, int bn, int nblocks, hipStream_t st) {
     const long elems = (long)a.B * a.Hi * a.Wi * a.Ci;
-    if (!a.w_hi || !a.w_lo || !a.ws || a.ws_bytes < elems * 4 || WGS_ABL == 15) return false;
+    if (!a.w_hi || (!a.w_lo && a.sch != 1) || !a.ws || a.ws_bytes < elems * 4 || WGS_ABL == 15) return false;
     // the pre-pass reads + writes 8 bytes per input element whatever Cout is; measured (B=32): Cout=512 +15 % net,
     // Cout=256 / 128 -2 % net (the DMA kernel alone is 13-21 % faster) — take it only where it pays
-    if (a.Co < 512 && !getenv("WGS_DMA_ALWAYS")) return false;
+    if (a.Co < 512 && !wgs_flags().dma_always) return false;
     unsigned short* hi = reinterpret_cast<unsigned short*>(a.ws);
     unsigned short* lo = hi + elems;
-    split_bf16(a.x, a.a_scale, a.a_ld, hi, lo, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, st);
+    if (a.sch == 0) split_bf16(a.x, a.a_scale, a.a_ld, hi, lo, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, st);
+    else split_f16(a.x, a.a_scale, a.a_ld, hi, nullptr, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, a.a_amax, a.a_bound, st);
     a.a_hi = hi; a.a_lo = lo;
     a.x_bytes /= 2; a.w_bytes /= 2;            // extents of the bf16 planes
     launch_dma_bf16x3(a, bn, nblocks, st);
@@ -454,7 +474,7 @@ static bool try_dma(ConvArgs& a, int bn, int nblocks, hipStream_t st) {
 // of the 8-wave kernel: 4x the workgroups per launch (short K loops: 1, 2, 2 and 4 taps) and one tail instead of four.
 int launch_bf16x3_multi(const ConvArgs* as, int n, hipStream_t st) {
     if (n < 2 || n > 4) return 1;
-    if (as[0].w_hi && getenv("WGS_PHASE_PATCH")) return 1;      // experiment: phases one by one through the patch form
+    if (as[0].w_hi && wgs_flags().phase_patch) return 1;      // experiment: phases one by one through the patch form
     ConvArgs a = as[0];
     if (a.Ci % 32 != 0 || a.ups || a.Co % 128 != 0) return 1;
     int wt_max = 0, ntm_all = 0;
@@ -504,7 +524,7 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     if (!set_extents(a, wt_max)) return 1;
     fill_tap_tables(a);
     // stride-1 3x3 convs with pre-split weights: the patch form stages the activation halo patch once per channel chunk
-    if (WGS_ABL != 16 && !getenv("WGS_NO_PATCH") && launch_patch_bf16x3(a, st) == 0) return 0;
+    if (WGS_ABL != 16 && !wgs_flags().no_patch && launch_patch_bf16x3(a, st) == 0) return 0;
     // Styled launches want every tile inside one sample (one style vector per tile, and the only form the 8-wave
     // tiles support).  When Hg*Wg is not a multiple of the tile height (the sub-pixel phases of the up-convs: 65x65,
     // 129x129 ...) each sample's row range is padded up to it, if that costs < 13 % extra rows.

@@ -11,12 +11,14 @@
 // wave-uniform base + lane*16: one instruction fills 16 rows x 64 B.  Bank conflicts of the per-lane ds_read_b128 (lane =
 // row) are avoided by an XOR swizzle of the four 16-B chunks of a row with (row >> 2) & 3, applied on the SOURCE address of
 // the DMA (lane -> row = lane/4, slot = lane%4 fetches logical chunk slot ^ swz) and on the ds_read address.
+//
+// Template parameter SCH: the same kernel for the fp16 schemes (conv_scheme.h) — one activation plane, one or two weight planes.
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
+#include "conv_scheme.h"
 
 typedef wgsconv::epi_f32x16 f32x16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -31,12 +33,15 @@ constexpr int OOB = (int)0x80000000;   // byte offset beyond any buffer this ker
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_kernel(const ConvArgs p) {
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(const ConvArgs p) {
+    typedef wgsconv::Scheme<SCH> SC;
+    typedef typename SC::frag frag;
+    constexpr int NA = SC::NA, NB = SC::NB;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW;
-    constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+    constexpr int STAGE = NA * A_BYTES + NB * B_BYTES;
     constexpr int AI = BM / 16 / NW, BI = BN / 16 / NW;     // 16-row DMA instructions per wave and plane
     static_assert(AI >= 1 && BI >= 1 && AI * 16 * NW == BM && BI * 16 * NW == BN, "tile / wave count mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
     int tC = 0, cC = 0, nC = 0;
     // DMA of the next chunk, as 2*(AI+BI) pieces (activation hi/lo per 16-row group, then weight hi/lo) so that the
     // issue can be spread between the MFMA slots; past the last chunk everything is OOB (zeros, no memory traffic)
-    constexpr int NPIECE = 2 * (AI + BI);
+    constexpr int NPIECE = NA * AI + NB * BI;
     int u_dy = 0, u_dx = 0;
     unsigned u_adelta = 0, u_bdelta = 0;
     auto begin_chunk = [&]() {
@@ -100,18 +105,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
     };
     auto issue_piece = [&](int buf, int idx) {
         lds_byte* st = (lds_byte*)(smem_b + buf * STAGE);
-        if (idx < 2 * AI) {
-            const int j = idx >> 1;
+        if (idx < NA * AI) {
+            const int j = idx / NA, pl = idx % NA;
             const int iy = a_iy0[j] + u_dy, ix = a_ix0[j] + u_dx;
             const bool v = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             const int off = v ? (int)((unsigned)a_off[j] + u_adelta) : OOB;
-            lds_byte* d = st + (wave * AI + j) * 16 * ROW + (idx & 1) * A_BYTES;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds((idx & 1) ? ral : rah, d, 16, off, 0, 0, 0);
+            lds_byte* d = st + (wave * AI + j) * 16 * ROW + pl * A_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? ral : rah, d, 16, off, 0, 0, 0);
         } else {
-            const int j = (idx - 2 * AI) >> 1;
+            const int j = (idx - NA * AI) / NB, pl = (idx - NA * AI) % NB;
             const int off = (int)((unsigned)b_off[j] + u_bdelta);
-            lds_byte* d = st + 2 * A_BYTES + (wave * BI + j) * 16 * ROW + (idx & 1) * B_BYTES;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds((idx & 1) ? rbl : rbh, d, 16, off, 0, 0, 0);
+            lds_byte* d = st + NA * A_BYTES + (wave * BI + j) * 16 * ROW + pl * B_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? rbl : rbh, d, 16, off, 0, 0, 0);
         }
     };
     auto issue = [&](int buf) {
@@ -131,7 +136,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
     const int l31 = lane & 31, lh = lane >> 5;
     const int swz = (l31 >> 2) & 3;
     const int kc0 = ((0 + lh) ^ swz) * 16, kc1 = ((2 + lh) ^ swz) * 16;       // byte offset of this lane's 8 k-values, k-step 0 / 1
-    const int a_rd = (wm * WM + l31) * ROW, b_rd = 2 * A_BYTES + (wn * WN + l31) * ROW;
+    const int a_rd = (wm * WM + l31) * ROW, b_rd = NA * A_BYTES + (wn * WN + l31) * ROW;
+    float op_mult = 1.f, op_inv = 1.f;       // fp16 schemes: the pre-pass scaled the activations by op_mult (conv_scheme.h)
+    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_bound, op_mult, op_inv);
 
     // Multiply stage `cur` while the DMA of the next chunk is issued into stage `nxt` between the first MFMA slots; the
     // operand fragments of slot s+1 are read from LDS before the MFMAs of slot s.
@@ -140,29 +147,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
     constexpr int LPS = (NPIECE + LSLOTS - 1) / LSLOTS;
     auto mma_tile = [&](int cur, int nxt) {
         const unsigned char* base = smem_b + cur * STAGE;
-        auto read_a = [&](int slot, bf16x8& h, bf16x8& l) {
+        auto read_a = [&](int slot, frag* f) {
             const int i = slot % TM, kc = (slot / TM) ? kc1 : kc0;
-            h = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * ROW + kc);
-            l = *reinterpret_cast<const bf16x8*>(base + a_rd + A_BYTES + i * 32 * ROW + kc);
+#pragma unroll
+            for (int pl = 0; pl < NA; ++pl) f[pl] = *reinterpret_cast<const frag*>(base + a_rd + pl * A_BYTES + i * 32 * ROW + kc);
         };
-        auto read_b = [&](int ks, bf16x8* h, bf16x8* l) {
+        auto read_b = [&](int ks, frag (*f)[NB]) {
             const int kc = ks ? kc1 : kc0;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                h[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * ROW + kc);
-                l[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + B_BYTES + j * 32 * ROW + kc);
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NB; ++pl) f[j][pl] = *reinterpret_cast<const frag*>(base + b_rd + pl * B_BYTES + j * 32 * ROW + kc);
         };
-        bf16x8 bh[2][TN], bl[2][TN], ah[2], al[2];
-        read_b(0, bh[0], bl[0]);
-        read_a(0, ah[0], al[0]);
+        frag bf[2][TN][NB], af[2][NA];
+        read_b(0, bf[0]);
+        read_a(0, af[0]);
         begin_chunk();
 #pragma unroll
         for (int slot = 0; slot < SLOTS; ++slot) {
             const int ks = slot / TM, i = slot % TM;
             if (slot + 1 < SLOTS) {
-                read_a(slot + 1, ah[(slot + 1) & 1], al[(slot + 1) & 1]);
-                if ((slot + 1) % TM == 0) read_b(ks + 1, bh[(ks + 1) & 1], bl[(ks + 1) & 1]);
+                read_a(slot + 1, af[(slot + 1) & 1]);
+                if ((slot + 1) % TM == 0) read_b(ks + 1, bf[(ks + 1) & 1]);
             }
             if (slot < LSLOTS) {
 #pragma unroll
@@ -170,11 +176,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
                     if (slot * LPS + u < NPIECE) issue_piece(nxt, slot * LPS + u);
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bl[ks & 1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[slot & 1], bh[ks & 1][j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(af[slot & 1], bf[ks & 1][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -186,7 +188,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma_bf16x3_ke
         mma_tile(cur, cur ^ 1);       // chunk kt+1 lands while chunk kt is multiplied
         __syncthreads();
     }
-    wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh);
+    wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh, op_inv);
+}
+
+// fp16 schemes: hi = f16_rn(v * mult), lo = f16_rn(residual) (lo may be null) of v = x * style; mult: conv_scheme.h
+__global__ __launch_bounds__(256) void modcvt_f16_kernel(const float* __restrict__ x, const float* __restrict__ s, int s_ld,
+                                                         unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                                         long per_sample4, int c4n, long total4, const float* a_amax, float a_bound) {
+    float mult, inv;
+    wgsconv::operand_scale(a_amax, a_bound, mult, inv);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(x)[e];
+        if (s) {
+            const long b = e / per_sample4;
+            const int c = (int)(e % c4n) * 4;
+            const float4 sc = *reinterpret_cast<const float4*>(s + b * s_ld + c);
+            v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
+        }
+        const f32x4 f = {v.x * mult, v.y * mult, v.z * mult, v.w * mult};
+        uint2 h, l;
+        if (lo) { wgsconv::Scheme<2>::cvt4(f, h, l); reinterpret_cast<uint2*>(lo)[e] = l; }
+        else wgsconv::Scheme<1>::cvt4(f, h, l);
+        reinterpret_cast<uint2*>(hi)[e] = h;
+    }
 }
 
 // hi = bf16_rn(v), lo = bf16_rn(v - hi) of v = x * style (style per sample and channel, or none)
@@ -211,12 +235,18 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float* __restrict__
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_dma(const ConvArgs& a, hipStream_t st, int nblocks) {
-    const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROW;
-    auto k = igemm_dma_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N>;
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_dma_s(const ConvArgs& a, hipStream_t st, int nblocks) {
+    const size_t sm = (size_t)2 * (wgsconv::Scheme<SCH>::NA * BM + wgsconv::Scheme<SCH>::NB * BN) * ROW;
+    auto k = igemm_dma16_kernel<SCH, BM, BN, WAVES_M, WAVES_N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_dma(const ConvArgs& a, hipStream_t st, int nblocks) {
+    if (a.sch == 0) launch_dma_s<0, BM, BN, WAVES_M, WAVES_N>(a, st, nblocks);
+    else if (a.sch == 1) launch_dma_s<1, BM, BN, WAVES_M, WAVES_N>(a, st, nblocks);
+    else launch_dma_s<2, BM, BN, WAVES_M, WAVES_N>(a, st, nblocks);
 }
 
 }  // namespace
@@ -229,6 +259,14 @@ void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, un
     long grid = (total4 + 255) / 256;
     if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(modsplit_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4);
+}
+
+void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
+               int C, const float* a_amax, float a_bound, hipStream_t st) {
+    const long total4 = nsamples * per_sample / 4;
+    long grid = (total4 + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(modcvt_f16_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4, a_amax, a_bound);
 }
 
 // a: fully prepared arguments (phases filled, a_hi/a_lo/w_hi/w_lo and extents set); bn = 256 or 128

@@ -1,4 +1,5 @@
-// Split-bf16 implicit-GEMM convolution, PATCH form, for stride-1 convs with a small tap neighbourhood (3x3): the
+// 16-bit-operand implicit-GEMM convolution (split-bf16 x3 / fp16 / fp16 x2, conv_scheme.h), PATCH form, for stride-1 convs
+// with a small tap neighbourhood (3x3): the
 // activation operand of a 256-pixel tile is staged ONCE per 32-channel chunk as the tile's input patch (tile + halo), and
 // all taps of the chunk read their rows from that patch with a shifted row index.
 //
@@ -11,16 +12,16 @@
 //
 // Tile = R x Wt output pixels of ONE sample (Wt = min(W, 128), R = 256 / Wt): every tile has one style vector.
 // Weights come pre-split (wgs_split_bf16) and are copied global -> LDS by DMA per (chunk, tap), double-buffered.
-// LDS: patch hi | lo (unpadded 64-B rows, XOR-swizzled 16-B chunks) single-buffered — the next chunk's patch waits in
-// registers during the 9 tap steps and is written between two barriers at the chunk boundary — plus two weight stages.
-#include <cstdlib>
+// LDS: patch planes (unpadded 64-B rows, XOR-swizzled 16-B chunks) single-buffered — the next chunk's patch waits in
+// registers during the tap steps and is written between two barriers at the chunk boundary — plus two weight stages of
+// TPS taps each: one barrier per TPS taps.  The single-plane fp16 schemes spend a third of the MFMA time per tap, so they
+// take a whole tap row (TPS = 3) per step to keep the MFMAs-per-barrier ratio of the split-bf16 form (48 per wave).
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
+#include "conv_scheme.h"
 
 typedef wgsconv::epi_f32x16 f32x16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -46,20 +47,24 @@ struct PatchGeom {       // uniform per launch
 
 // BM = 256 (8 waves, one workgroup per CU) or 128 (4 waves, 100 KB less LDS: two workgroups per CU, whose barriers,
 // patch stores and epilogues overlap each other's MFMAs — the better shape when K is short, i.e. Cin = 128).
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void igemm_patch_bf16x3_kernel(const ConvArgs p, const PatchGeom g) {
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void igemm_patch_kernel(const ConvArgs p, const PatchGeom g) {
+    typedef wgsconv::Scheme<SCH> SC;
+    typedef typename SC::frag frag;
+    constexpr int NA = SC::NA, NB = SC::NB;
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int PMAX = pmax_of(BM);
     constexpr int NPL = (PMAX * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (9)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int P_BYTES = PMAX * ROW;                 // one patch plane
-    constexpr int B_BYTES = BN * ROW;                   // one weight plane of a stage
-    constexpr int B_STAGE = 2 * B_BYTES;
+    constexpr int B_BYTES = BN * ROW;                   // one weight plane of one tap
+    constexpr int B_TAP = NB * B_BYTES;
+    constexpr int B_STAGE = TPS * B_TAP;
     constexpr int BI = BN / 16 / NW;                    // 16-row DMA instructions per wave and plane
     static_assert(BI >= 1 && BI * 16 * NW == BN, "tile / wave count mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* patch = smem_b;                      // hi | lo
-    unsigned char* bst = smem_b + 2 * P_BYTES;          // two weight stages
+    unsigned char* patch = smem_b;                      // hi (| lo)
+    unsigned char* bst = smem_b + NA * P_BYTES;         // two weight stages
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,7 +117,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     }
     const float* sc_ptr = p.a_scale ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
     float4 pr_[NPL];
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h), folded into the style vector / undone in the epilogue
+    float op_mult = 1.f, op_inv = 1.f;
+    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_bound, op_mult, op_inv);
+    float4 sc = make_float4(op_mult, op_mult, op_mult, op_mult);
     const int cpt = p.Ci / BK;
     auto load_patch = [&](int c) {
         const int cbyte = c < cpt ? c * (BK * 4) : OOB;
@@ -121,7 +129,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
             pr_[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
-        if (sc_ptr && c < cpt) sc = *reinterpret_cast<const float4*>(sc_ptr + c * BK);
+        if (sc_ptr && c < cpt) {
+            sc = *reinterpret_cast<const float4*>(sc_ptr + c * BK);
+            if (SCH != 0) { sc.x *= op_mult; sc.y *= op_mult; sc.z *= op_mult; sc.w *= op_mult; }
+        }
     };
     auto store_patch = [&]() {
 #pragma unroll
@@ -130,12 +141,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
             asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (no fma into the residual)
             const f32x4 f = {v.x, v.y, v.z, v.w};
-            const bf16x4 h = __builtin_convertvector(f, bf16x4);
-            const f32x4 r = f - __builtin_convertvector(h, f32x4);
-            const bf16x4 l = __builtin_convertvector(r, bf16x4);
+            uint2 h, l;
+            SC::cvt4(f, h, l);
             if (p_loff[j] >= 0) {
-                *reinterpret_cast<uint2*>(patch + p_loff[j]) = __builtin_bit_cast(uint2, h);
-                *reinterpret_cast<uint2*>(patch + P_BYTES + p_loff[j]) = __builtin_bit_cast(uint2, l);
+                *reinterpret_cast<uint2*>(patch + p_loff[j]) = h;
+                if (NA == 2) *reinterpret_cast<uint2*>(patch + P_BYTES + p_loff[j]) = l;
             }
         }
     };
@@ -149,15 +159,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         const int lc = slot ^ ((row >> 2) & 3);
         b_off[j] = (int)((long)(n0 + row) * p.w_row_stride + lc * 8) * 2;
     }
-    auto issue_b = [&](int stage, int c, int t) {        // weights of (chunk c, tap t) -> stage; past the end: zeros
-        const unsigned delta = c < cpt ? (unsigned)((p.tap_w[t] >> 1) + c * (BK * 2)) : (unsigned)OOB;
-        lds_byte* st = (lds_byte*)(bst + stage * B_STAGE);
+    auto issue_b = [&](int stage, int c, int t) {        // weights of (chunk c, taps t .. t+TPS-1) -> stage; past the end: zeros
 #pragma unroll
-        for (int j = 0; j < BI; ++j) {
-            const int off = (int)((unsigned)b_off[j] + delta);
-            lds_byte* d = st + (wave * BI + j) * 16 * ROW;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, d, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbl, d + B_BYTES, 16, off, 0, 0, 0);
+        for (int u = 0; u < TPS; ++u) {
+            const unsigned delta = c < cpt ? (unsigned)((p.tap_w[t + u] >> 1) + c * (BK * 2)) : (unsigned)OOB;
+            lds_byte* st = (lds_byte*)(bst + stage * B_STAGE + u * B_TAP);
+#pragma unroll
+            for (int j = 0; j < BI; ++j) {
+                const int off = (int)((unsigned)b_off[j] + delta);
+                lds_byte* d = st + (wave * BI + j) * 16 * ROW;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, d, 16, off, 0, 0, 0);
+                if (NB == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rbl, d + B_BYTES, 16, off, 0, 0, 0);
+            }
         }
     };
 
@@ -183,29 +196,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     const int b_rd = (wn * WN + l31) * ROW;
     const int bk0 = ((0 + lh) ^ bswz) << 4, bk1 = ((2 + lh) ^ bswz) << 4;
 
-    auto mma_tap = [&](int stage, int tapoff) {
-        const unsigned char* bb = bst + stage * B_STAGE + b_rd;
+    auto mma_tap = [&](int stage, int u, int tapoff) {
+        const unsigned char* bb = bst + stage * B_STAGE + u * B_TAP + b_rd;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int kc = ks * 2 + lh;
-            bf16x8 bh[TN], bl[TN];
+            frag bf[TN][NB];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(bb + j * 32 * ROW + (ks ? bk1 : bk0));
-                bl[j] = *reinterpret_cast<const bf16x8*>(bb + B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NB; ++pl)
+                    bf[j][pl] = *reinterpret_cast<const frag*>(bb + pl * B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int pp = pp0[i] + tapoff;
                 const unsigned char* pa = patch + pp * ROW + ((kc ^ ((pp >> 2) & 3)) << 4);
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pa);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(pa + P_BYTES);
+                frag af[NA];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int pl = 0; pl < NA; ++pl) af[pl] = *reinterpret_cast<const frag*>(pa + pl * P_BYTES);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(af, bf[j], acc[i][j]);
             }
         }
     };
@@ -218,12 +228,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     int stage = 0;
     for (int c = 0; c < cpt; ++c) {
         load_patch(c + 1);                       // waits in registers through the tap steps (OOB past the last chunk)
-        for (int t = 0; t < p.ntaps; ++t) {
-            const bool last = (t + 1 == p.ntaps);
-            issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + 1);
-            const int yx = p.tap_yx[t];
-            const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
-            mma_tap(stage, (dy - g.dy_min) * g.PW + (dx - g.dx_min));
+        for (int t = 0; t < p.ntaps; t += TPS) {
+            const bool last = (t + TPS >= p.ntaps);
+            issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + TPS);
+#pragma unroll
+            for (int u = 0; u < TPS; ++u) {
+                const int yx = p.tap_yx[t + u];
+                const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+                mma_tap(stage, u, (dy - g.dy_min) * g.PW + (dx - g.dx_min));
+            }
             __syncthreads();                     // weight stage swap; after the last tap also: patch no longer read
             stage ^= 1;
         }
@@ -249,15 +262,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         r_add[tid] = (b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
     }
     __syncthreads();
-    wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh);
+    wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh, op_inv);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_patch(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
-    const size_t sm = (size_t)2 * pmax_of(BM) * ROW + (size_t)2 * 2 * BN * ROW;
-    auto k = igemm_patch_bf16x3_kernel<BM, BN, WAVES_M, WAVES_N>;
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
+void launch_patch_t(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
+    typedef wgsconv::Scheme<SCH> SC;
+    const size_t sm = (size_t)SC::NA * pmax_of(BM) * ROW + (size_t)2 * TPS * SC::NB * BN * ROW;
+    auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
+}
+
+// tile shape x scheme dispatch; the fp16 schemes take a tap row per barrier when the tap count allows it
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_patch(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
+    const bool tps3 = a.ntaps % 3 == 0 && !wgs_flags().patch_tps1;
+    if (a.sch == 0) launch_patch_t<0, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st);
+    else if (a.sch == 1) { if (tps3) launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
+    else { if (tps3 && BN <= 128) launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
 }
 
 }  // namespace
@@ -268,7 +291,7 @@ namespace wgsconv {
 // neighbourhood whose patch fits, power-of-two width >= 32, Cout a multiple of 128, enough tiles for the chip.
 int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     const ConvArgs& a = a0;
-    if (!a.w_hi || !a.w_lo || a.ups || a.isy != 1 || a.isx != 1) return 1;
+    if (!a.w_hi || (!a.w_lo && a.sch != 1) || a.ups || a.isy != 1 || a.isx != 1) return 1;
     if (a.Ci % 32 || a.Co % 128 || a.ntaps < 2 || a.ntaps > 16) return 1;
     int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
     for (int t = 0; t < a.ntaps; ++t) {
@@ -304,13 +327,13 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
         if (nb < 200) return;
         bm = tbm; bn = tbn; nblocks = nb; g = t;
     };
-    if (a.Co == 128 && a.Ci <= 128 && !getenv("WGS_PATCH_BM256")) try_shape(128, 128);
+    if (a.Co == 128 && a.Ci <= 128 && !wgs_flags().patch_bm256) try_shape(128, 128);
     try_shape(256, 256);
     try_shape(256, 128);
     try_shape(128, 128);
     if (!bm) return 1;
     ConvArgs b = a;
-    b.w_bytes = a.w_bytes / 2;          // extents of the bf16 weight planes (x stays fp32)
+    b.w_bytes = a.w_bytes / 2;          // extents of the 16-bit weight planes (x stays fp32)
     if (bm == 256 && bn == 256) launch_patch<256, 256, 2, 4>(b, g, nblocks, st);
     else if (bm == 256) launch_patch<256, 128, 4, 2>(b, g, nblocks, st);
     else launch_patch<128, 128, 2, 2>(b, g, nblocks, st);

@@ -1,0 +1,91 @@
+// Operand schemes of the 16-bit-input implicit-GEMM kernels (wgs_conv_desc.precision 1..3).  A product block of the GEMM is a
+// sum of NP v_mfma_f32_32x32x16_{bf16,f16} instructions over the (plane of A) x (plane of B) pairs listed below; the
+// accumulator, the style / demodulation factors and the whole epilogue stay fp32 in every scheme.
+//
+//   SCH 0  split-bf16 x3 : A = {hi, lo}, B = {hi, lo} bf16;  lo*hi + hi*lo + hi*hi         ~2^-16 per product, 3 MFMAs
+//   SCH 1  fp16          : A = {hi},     B = {hi}     fp16;  hi*hi                          ~2^-11 per operand, 1 MFMA
+//   SCH 2  fp16 x2       : A = {hi},     B = {hi, lo} fp16;  hi*lo + hi*hi (weights ~2^-22) ~2^-11 on the activation only, 2 MFMAs
+//
+// fp16 has 5 exponent bits: the activation operand is multiplied by a power of two chosen from a device-resident bound of
+// its magnitude (wgs_conv_desc.a_amax) before it is rounded, and the accumulator is multiplied back in the epilogue, so
+// that gradients of any magnitude keep their 11 significant bits (see operand_scale below).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wgsconv {
+
+typedef float sch_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sch_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 sch_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sch_bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sch_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sch_f16x4 __attribute__((ext_vector_type(4)));
+
+template <int SCH> struct Scheme;
+
+template <> struct Scheme<0> {
+    static constexpr int NA = 2, NB = 2, NP = 3;
+    typedef sch_bf16x8 frag;
+    // 4 floats -> packed 16-bit hi (and lo) words
+    static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) {
+        const sch_bf16x4 h = __builtin_convertvector(f, sch_bf16x4);
+        const sch_f32x4 r = f - __builtin_convertvector(h, sch_f32x4);
+        const sch_bf16x4 l = __builtin_convertvector(r, sch_bf16x4);
+        hi = __builtin_bit_cast(uint2, h);
+        lo = __builtin_bit_cast(uint2, l);
+    }
+    // a[0] = hi, a[1] = lo; same for b
+    static __device__ __forceinline__ sch_f32x16 mma(const frag* a, const frag* b, sch_f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <> struct Scheme<1> {
+    static constexpr int NA = 1, NB = 1, NP = 1;
+    typedef sch_f16x8 frag;
+    static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) {
+        const sch_f16x4 h = __builtin_convertvector(f, sch_f16x4);      // round to nearest even
+        hi = __builtin_bit_cast(uint2, h);
+        lo = hi;
+    }
+    static __device__ __forceinline__ sch_f32x16 mma(const frag* a, const frag* b, sch_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
+    }
+};
+
+template <> struct Scheme<2> {
+    static constexpr int NA = 1, NB = 2, NP = 2;
+    typedef sch_f16x8 frag;
+    static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) {
+        const sch_f16x4 h = __builtin_convertvector(f, sch_f16x4);
+        const sch_f32x4 r = f - __builtin_convertvector(h, sch_f32x4);
+        const sch_f16x4 l = __builtin_convertvector(r, sch_f16x4);
+        hi = __builtin_bit_cast(uint2, h);
+        lo = __builtin_bit_cast(uint2, l);
+    }
+    static __device__ __forceinline__ sch_f32x16 mma(const frag* a, const frag* b, sch_f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// Power-of-two operand scale for the fp16 schemes.  `amax` bounds |A| (before the per-sample a_scale factor, which the
+// caller's bound must include).  Returns mult = 2^k with amax * mult in [2^11, 2^12) — four binades below the fp16 maximum
+// (2^16), 26 above its smallest normal number — and inv = 2^-k for the accumulator.  amax == 0 / NaN / inf: no scaling.
+__device__ __forceinline__ void operand_scale(const float* amax_ptr, float bound, float& mult, float& inv) {
+    mult = 1.f; inv = 1.f;
+    if (!amax_ptr) return;
+    const float am = amax_ptr[0] * bound;
+    const int e = (__float_as_int(am) >> 23) & 0xff;       // am in [2^(e-127), 2^(e-126))
+    if (!(am > 0.f) || e == 0 || e == 255) return;
+    int k = 127 + 12 - (e - 126);                         // biased exponent of 2^(12 - (e - 126))
+    k = k < 1 ? 1 : (k > 253 ? 253 : k);
+    mult = __int_as_float(k << 23);
+    inv = __int_as_float((254 - k) << 23);
+}
+
+}  // namespace wgsconv

@@ -2,6 +2,7 @@
 #include "wgs_common.h"
 #include "../../include/wgs.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -12,7 +13,24 @@ void wgs_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static WgsFlags read_flags() {
+    WgsFlags g;
+    g.dma_always = getenv("WGS_DMA_ALWAYS") != nullptr;
+    g.phase_patch = getenv("WGS_PHASE_PATCH") != nullptr;
+    g.no_patch = getenv("WGS_NO_PATCH") != nullptr;
+    g.patch_bm256 = getenv("WGS_PATCH_BM256") != nullptr;
+    g.patch_tps1 = getenv("WGS_PATCH_TPS1") != nullptr;
+    g.no_fused_up = getenv("WGS_NO_FUSED_UP") != nullptr;
+    return g;
+}
+static WgsFlags& flags_storage() {
+    static WgsFlags f = read_flags();      // first use: thread-safe one-time initialisation
+    return f;
+}
+const WgsFlags& wgs_flags() { return flags_storage(); }
+
 extern "C" {
 const char* wgs_last_error(void) { return g_err; }
-int wgs_abi_version(void) { return 1; }
+int wgs_abi_version(void) { return 2; }
+void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
 }

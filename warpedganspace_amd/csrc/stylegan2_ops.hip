@@ -262,9 +262,10 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     const float* __restrict__ out, const float* __restrict__ gA, const float* __restrict__ sA,
     const float* __restrict__ drgb, const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
     const float* __restrict__ noise, const float* __restrict__ noise_w, const float* __restrict__ bias,
-    float* __restrict__ dy, float* __restrict__ num, float* __restrict__ dsA, float* __restrict__ dsR, int P, int C,
-    int chunk) {
+    float* __restrict__ dy, float* __restrict__ num, float* __restrict__ dsA, float* __restrict__ dsR,
+    const float* __restrict__ post_scale, float* __restrict__ dy_amax, int P, int C, int chunk) {
     __shared__ double red[3][256][4];
+    float amax = 0.f;          // max |stored dy| seen by this thread
     const int b = blockIdx.y;
     const int c4n = C >> 2;
     const int tpp = c4n < 256 ? c4n : 256;  // threads per pixel
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
             w2 = *reinterpret_cast<const float4*>(wR + 2 * C + c);
         }
         const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+        const float4 ps = post_scale ? *reinterpret_cast<const float4*>(post_scale + (size_t)b * C + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         // fp64 partial sums: these reductions run over up to 65536 pixels with heavy cancellation
         double r_num[4] = {0, 0, 0, 0}, r_a[4] = {0, 0, 0, 0}, r_r[4] = {0, 0, 0, 0};
         for (int p = p_begin + sub; p < p_end; p += ppi) {
@@ -311,6 +313,10 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     }
             WGS_ONE(x, 0) WGS_ONE(y, 1) WGS_ONE(z, 2) WGS_ONE(w, 3)
 #undef WGS_ONE
+            // stored gradient = dy * post_scale (the dgrad conv's demodulation factor: rounded fp32 product, exactly what the
+            // conv kernels' A-operand prologue computes when it is handed dy and the factor separately)
+            d.x = __fmul_rn(d.x, ps.x); d.y = __fmul_rn(d.y, ps.y); d.z = __fmul_rn(d.z, ps.z); d.w = __fmul_rn(d.w, ps.w);
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
             *reinterpret_cast<float4*>(dy + off) = d;
         }
         // combine the `ppi` pixel sub-streams that share this channel group
@@ -343,6 +349,10 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
                 for (int q = 0; q < 4; ++q) unsafeAtomicAdd(pr + q, (float)r_r[q]);
             }
         }
+    }
+    if (dy_amax) {      // non-negative floats order like their bit patterns
+        amax = wave_max(amax);
+        if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dy_amax), __float_as_uint(amax));
     }
 }
 
@@ -494,7 +504,8 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
 
 int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
                     const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
-                    float* dy, float* num, float* dsA, float* dsR, int B, int P, int C, wgs_stream_t stream) {
+                    float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P, int C,
+                    wgs_stream_t stream) {
     WGS_CHECK_ARG(out && bias && dy && num, "wgs_sg2_act_bwd: null pointer");
     WGS_CHECK_ARG(gA || drgb, "wgs_sg2_act_bwd: needs at least one gradient source");
     WGS_CHECK_ARG(!gA || (sA && dsA), "wgs_sg2_act_bwd: gA needs sA and dsA");
@@ -507,7 +518,7 @@ int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const fl
     if (chunk < 16) chunk = 16;
     chunks = wgs_cdiv(P, chunk);
     hipLaunchKernelGGL(sg2_act_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
-                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, P, C, chunk);
+                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk);
     WGS_CHECK_LAUNCH("sg2_act_bwd_kernel");
     return WGS_OK;
 }

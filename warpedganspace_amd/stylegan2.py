@@ -210,8 +210,8 @@ class Generator(nn.Module):
                 m = sc.conv
                 wp = C.pack_weight(m.weight[0].float())             # [Co, 9, Ci]
                 wt = C.repack_w_t(wp, m.out_channel, 9, m.in_channel)
-                # frozen weights: bf16 hi/lo planes for the LDS-DMA form of the split-bf16 conv kernels
-                wp_s, wt_s = C.split_weight(wp), C.split_weight(wt)
+                # frozen weights: 16-bit planes (per arithmetic mode, built on first use) for the DMA-fed conv kernels
+                wp_s, wt_s = C.SplitCache(wp), C.SplitCache(wt)
                 wsq = torch.empty(m.out_channel, m.in_channel, device=dev)
                 L.check(L.lib().wgs_sg2_wsq(L.ptr(wp), L.ptr(wsq), m.out_channel, 9, m.in_channel, L.stream()), 'wsq')
                 P['layers'].append(dict(
@@ -352,6 +352,7 @@ class Generator(nn.Module):
         layers, rgbs = P['layers'], P['rgbs']
         dS = torch.zeros(B, sumC, device=dev)       # d loss / d modulation outputs, all layers
         dskip = dimg
+        amax = torch.zeros(len(layers), device=dev)  # per layer: max |dy * demod| (magnitude bound of the fp16 dgrad operand)
         gA, sA_off, cons = None, None, None          # un-scaled dgrad of the consumer conv, its style slice
         num_next = None
         for i in range(len(layers) - 1, -1, -1):
@@ -371,8 +372,9 @@ class Generator(nn.Module):
             L.check(lib.wgs_sg2_act_bwd(L.ptr(out), L.ptr(gA), L.ptr(sA), L.ptr(dskip if has_rgb else None),
                                         L.ptr(r['w']) if has_rgb else None, L.ptr(sR),
                                         L.c_float(r['scale'] if has_rgb else 0.0), L.ptr(ly['noise']), L.ptr(ly['noise_w']),
-                                        L.ptr(ly['bias']), L.ptr(dy), L.ptr(num), L.ptr(dsA), L.ptr(dsR), B, Pn, Co, st),
-                    'sg2_act_bwd')
+                                        L.ptr(ly['bias']), L.ptr(dy), L.ptr(num), L.ptr(dsA), L.ptr(dsR), L.ptr(demods[i]),
+                                        L.rawptr(amax[i:]), B, Pn, Co, st),
+                    'sg2_act_bwd')           # dy is stored already multiplied by this layer's demodulation vector
             # style gradient of the consumer conv (layer i+1) is now complete: direct term dsA + demod path
             if gA is not None:
                 c = layers[i + 1]
@@ -385,11 +387,11 @@ class Generator(nn.Module):
                     dskip = g.reshape(B, 3, Hc // 2, Hc // 2)
             # input gradient of this layer (un-scaled by its own style: the producer applies it)
             if ly['up']:
-                dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)
-                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], a_scale=demods[i], w_split=ly['wt_s'])
+                dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)     # |dt| <= 4 max|dy|: the kernel sums to 4
+                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0)
                 del dt
             else:
-                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, a_scale=demods[i], w_split=ly['wt_s'])
+                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0)
             del dy
             sA_off, num_next = ly['off'], num
         # bottom layer: its input is the ConstantInput -> only the style gradient remains

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import conv as C
 from .aux import TrainingStatTracker, sample_z, sec2dhms, update_progress, update_stdout
 from .support_sets import rbf_workspace
 
@@ -134,6 +135,7 @@ class TrainStep:
         self.argmax = torch.empty(local_batch, dtype=torch.int64, device=device)
         self.loss_ws = torch.empty(2 * local_batch, device=device)
         self.w_space = bool(getattr(params, 'shift_in_w_space', False))
+        self._last_precision = None
         self.comm_events = None      # set to a list to collect (start, end) HIP events around the all-reduce waits
         self.allreduce_bytes = 4 * self.bucket.flat.numel()     # payload of the step's collectives (R group + S group)
 
@@ -176,7 +178,9 @@ class TrainStep:
         cur = torch.cuda.current_stream(self.dev)
         # (not in the very first step: the generator builds its packed / split weight caches lazily in its first forward, and
         # those must be produced on the main stream, ahead of everything that reads them)
-        side = self.side_stream if (self.two_streams and self.steps_done > 0) else None
+        # (the same after a change of the conv arithmetic: the 16-bit weight planes of a mode are built on first use)
+        side = self.side_stream if (self.two_streams and self.steps_done > 0 and self._last_precision == C.PRECISION) else None
+        self._last_precision = C.PRECISION
         if side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
