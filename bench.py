@@ -1,22 +1,32 @@
 #!/usr/bin/env python
 """bench.py — training-step images/sec (warp -> G -> R -> loss -> backward -> Adam) on MI355X.
 
-Workload (BASELINE.json `metric`, configs[2]): StyleGAN2-FFHQ-256 architecture (random-init weights drawn
-exactly as the reference constructors do; no checkpoints offline), K=128 warping functions x N=32 dipoles,
-ResNet-18 reconstructor, batch 32 per GPU, Z-space shifts, --learn-gammas, synthetic z ~ N(0, I).
+Headline workload (BASELINE.json `metric`, configs[2]): StyleGAN2-FFHQ-256 architecture (random-init weights drawn exactly
+as the reference constructors do; no checkpoints offline), K=128 warping functions x N=32 dipoles, ResNet-18
+reconstructor, batch 32 per GPU, Z-space shifts, --learn-gammas, synthetic z ~ N(0, I) sampled in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches one rank per GPU (torch.distributed.run); gradients of R and S are
-all-reduced over RCCL once per step; per-GPU batch is fixed (weak scaling).
+With N > 1 and no torch.distributed environment, bench.py starts the N ranks ITSELF (torch.distributed.run, one rank per
+GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line; under an external launcher (RANK / WORLD_SIZE set) it runs
+as one rank of that job and checks that WORLD_SIZE == --gpus.  Gradients of R and S are all-reduced over RCCL once per
+step; per-GPU batch is fixed (weak scaling); the generator is never communicated.
 
-Prints ONE JSON line on rank 0: metric/value (whole-job images/sec), ms_per_step, `roofline` for the dominant
-kernel family (implicit-GEMM MFMA conv: algorithmic FLOPs of its launches / their HIP-event durations,
-against the fp32-MFMA peak) and `cpu_baseline` (the oracle's replay of the reference step, as written,
-on this box's host cores — a bounded sample).
+Prints ONE JSON line on rank 0:
+  value / ms_per_step  whole-job images/sec over exactly --steps timed steps (barrier + device sync on both sides, max over ranks)
+  roofline             the DOMINANT conv kernel shape (largest share of the step): its algorithmic FLOPs / its own HIP-event
+                       durations (2 extra single-stream steps), against the dense MFMA peak of the operand dtype; the family
+                       average and the whole-step rate are reported next to it
+  comm                 (N > 1) RCCL world size, all-reduce payload per step, exposed wait of the main stream per step
+  hbm_subpaths         achieved GB/s of the HBM-bound sub-kernels (RBF fwd/bwd, Adam, blur, ToRGB, BN) on their cfg3 operands
+  extra                short runs of the other arithmetic modes and BASELINE configs (exact fp32, bf16x3, f16x2, W space,
+                       ProgGAN cfg2 native + 256^2 truncation, BigGAN cfg4, StyleGAN2-1024 cfg5): img/s and conv TFLOP/s each
+  cpu_baseline         the oracle's replay of the reference step as written on this box's host cores (bounded sample)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -31,43 +41,143 @@ if REPO not in sys.path:
 import torch
 import torch.distributed as dist
 
-GFLOP_PER_IMG = 285.8          # G fwd x2 + G dgrad + R fwd + R bwd, StyleGAN2-256 / ResNet-18
+# SURVEY.md section 8(d) / BASELINE.md section 3: algorithmic GFLOP per training image (G fwd x2 + G dgrad + R fwd + R bwd)
+GFLOP_PER_IMG = {'stylegan2-256': 285.8, 'stylegan2-1024': 687.8, 'proggan-1024': 498.7, 'proggan-256': 184.3, 'biggan-128': 127.5}
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf16,f16}, dense (no sparsity)
+MFMA_PER_PRODUCT = {'fp32': 1.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}
+DTYPE_TEXT = {
+    'fp32': "fp32 (f32-input MFMA, f32 accumulate) everywhere",
+    'bf16x3': "bf16x3: generator convs split every fp32 operand into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (~2^-16)",
+    'f16': "f16: generator convs round operands to fp16 (dynamic power-of-two scale on gradient operands), 1 fp16 MFMA per product, "
+           "fp32 accumulate / demodulation / epilogue (image error vs the fp32 reference ~4e-4, gate 1e-3)",
+    'f16x2': "f16x2: as f16 with the frozen weights as fp16 hi+lo, 2 fp16 MFMAs per product",
+}
+R_TEXT = "; reconstructor: exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs"
 
 
-def build(dev, size, K, N, B, seed, w_space=False, rank=0):
-    from warpedganspace_amd.gan_load import build_stylegan2
+def make_params(w_space=False):
+    return types.SimpleNamespace(reconstructor_lr=1e-4, support_set_lr=1e-4, min_shift_magnitude=0.25,
+                                 max_shift_magnitude=0.45, lambda_cls=1.0, lambda_reg=0.25, z_truncation=None,
+                                 shift_in_w_space=w_space)
+
+
+def build(dev, gan, K, N, B, rank=0, w_space=False, size=256):
+    """gan: 'stylegan2' (size 256 / 1024), 'proggan' (size 1024 native or 256 = first 14 blocks), 'biggan' (size 128 / 256)."""
     from warpedganspace_amd.reconstructor import Reconstructor
     from warpedganspace_amd.support_sets import SupportSets
     from warpedganspace_amd.trainer import TrainStep
-    torch.manual_seed(0)          # identical random-init G / S / R on every rank; `seed` only drives the per-rank sampling
-    G = build_stylegan2(None, resolution=size, shift_in_w_space=w_space)
+    torch.manual_seed(0)          # identical random-init G / S / R on every rank; the sampler seed is derived per rank
+    if gan == 'stylegan2':
+        from warpedganspace_amd.gan_load import build_stylegan2
+        G = build_stylegan2(None, resolution=size, shift_in_w_space=w_space)
+    elif gan == 'proggan':
+        from warpedganspace_amd.proggan import build_proggan
+        G = build_proggan(None, num_blocks={1024: 18, 512: 16, 256: 14}[size])
+    elif gan == 'biggan':
+        from warpedganspace_amd.biggan import BigGANWrapper, Generator
+        G = BigGANWrapper(Generator(G_ch=96, dim_z=120, shared_dim=128, hier=True, G_attn='64', BN_eps=1e-5, SN_eps=1e-6,
+                                    resolution=size, n_classes=1000), (239,))
+    else:
+        raise ValueError(gan)
     S = SupportSets(K, N, G.dim_z, learn_alphas=False, learn_gammas=True, gamma=1.0 / G.dim_z)
     R = Reconstructor('ResNet', K, channels=3)
-    params = types.SimpleNamespace(reconstructor_lr=1e-4, support_set_lr=1e-4, min_shift_magnitude=0.25,
-                                   max_shift_magnitude=0.45, lambda_cls=1.0, lambda_reg=0.25, z_truncation=None,
-                                   shift_in_w_space=w_space)
     world = dist.get_world_size() if dist.is_initialized() else 1
-    eng = TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), params, B, dev, world=world, seed=seed, rank=rank)
-    return eng
+    return TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), make_params(w_space), B, dev, world=world, seed=0,
+                     rank=rank)
+
+
+def timed_steps(eng, steps, warmup, world, dev):
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        eng.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def conv_profile(eng, nprof=2):
+    """HIP events around every implicit-GEMM launch of `nprof` extra steps.  torch's current stream IS the launch stream, and
+    the steps run single-stream (with the un-shifted pass on the side stream, kernels of the other stream would run inside
+    the event pairs and inflate the per-launch durations).  Returns {label: [flops, ms, launches]} per step."""
+    from warpedganspace_amd import conv as C
+    C.PROFILE = []
+    two, eng.two_streams = eng.two_streams, False
+    for _ in range(nprof):
+        eng.step()
+    torch.cuda.synchronize()
+    eng.two_streams = two
+    recs, C.PROFILE = C.PROFILE, None
+    by = {}
+    for kind, fl, s, e in recs:
+        k = by.setdefault(kind, [0.0, 0.0, 0])
+        k[0] += fl / nprof; k[1] += s.elapsed_time(e) / nprof; k[2] += 1.0 / nprof
+    return by
+
+
+def roofline_of(by, precision, img_per_s_per_gpu, gflop_per_img):
+    gen = {k: v for k, v in by.items() if k.startswith('conv ' + precision + ' ')}
+    pool = gen if gen else by
+    dom = max(pool, key=lambda k: pool[k][1])
+    fl, ms, n = pool[dom]
+    peak = FP32_MFMA_PEAK_TF if precision == 'fp32' else F16_MFMA_PEAK_TF
+    tf = fl / ms / 1e9
+    g_fl, g_ms = sum(v[0] for v in gen.values()), sum(v[1] for v in gen.values())
+    a_fl, a_ms = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
+    top = sorted(by.items(), key=lambda kv: -kv[1][1])[:8]
+    pmc = os.path.join(REPO, 'profiles', 'r2_conv_pmc.json')
+    traffic, note = None, "not measured in this run (PMC counters need separate rocprofv3 --pmc passes: profiles/)"
+    if os.path.exists(pmc):
+        try:
+            rec = [r for r in json.load(open(pmc))['launches'] if r.get('label') == dom]
+            if rec:
+                traffic = round((rec[0]['fetch_bytes'] + rec[0]['write_bytes']) / 1e9, 3)
+                note = ("STATIC: GB per launch from the committed rocprofv3 --pmc passes profiles/r2_conv_pmc.json (FETCH_SIZE x2 on gfx950 "
+                        "+ WRITE_SIZE), same kernel and shape; algorithmic %.3f GB" % ((rec[0]['algorithmic_read_bytes'] + rec[0]['algorithmic_write_bytes']) / 1e9))
+        except Exception:  # noqa: BLE001
+            pass
+    out = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+           "traffic": traffic, "traffic_note": note,
+           "executed_mfma_frac": round(MFMA_PER_PRODUCT[precision] * tf / peak, 4),
+           "kernel_launches_per_step": round(n, 1), "kernel_ms_per_step": round(ms, 3), "kernel_avg_launch_ms": round(ms / n, 4),
+           "kernel_gflop_per_step": round(fl / 1e9, 1),
+           "generator_conv_family": {"TFLOP/s": round(g_fl / g_ms / 1e9, 2) if g_ms else None, "ms_per_step": round(g_ms, 3),
+                                     "frac": round(g_fl / g_ms / 1e9 / peak, 4) if g_ms else None},
+           "all_conv_launches": {"TFLOP/s": round(a_fl / a_ms / 1e9, 2), "ms_per_step": round(a_ms, 3), "gflop_per_step": round(a_fl / 1e9, 1)},
+           "top_shapes": [{"shape": k, "ms_per_step": round(v[1], 3), "TFLOP/s": round(v[0] / v[1] / 1e9, 1), "launches": round(v[2], 1)} for k, v in top]}
+    if gflop_per_img:
+        out["step_achieved_TFLOPs"] = round(img_per_s_per_gpu * gflop_per_img / 1e3, 2)
+        out["step_frac"] = round(img_per_s_per_gpu * gflop_per_img / 1e3 / peak, 4)
+    return out
 
 
 def hbm_subpaths(eng, dev, B):
     """Achieved GB/s of the HBM-bound sub-kernels of the step on their cfg3-sized operands:
     algorithmic bytes / HIP-event time of the standalone launch (on torch's current stream = the launch stream)."""
-    import ctypes
     from warpedganspace_amd import _lib as L
     lib, st = L.lib(), L.stream()
 
-    def timed(fn, n=5):
+    def timed(fn, n=5, pre=None):
         fn(); torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+        tot = 0.0
         for _ in range(n):
-            fn()
-        b.record(); torch.cuda.synchronize()
-        return a.elapsed_time(b) / n * 1e-3
+            if pre is not None:
+                pre()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            tot += a.elapsed_time(b)
+        return tot / n * 1e-3
 
     out = {}
     S = eng.S
@@ -81,6 +191,15 @@ def hbm_subpaths(eng, dev, B):
                                               B, K, n2, d, st), 'rbf'))
     by = B * ((n2 * d + n2 + 1 + d) * 4 + d * 4)
     out['rbf_fwd'] = {"bytes": by, "us": round(t * 1e6, 1), "GB/s": round(by / t / 1e9, 1), "note": "latency-bound: 4.3 MB per launch"}
+    # RBF backward: re-reads the selected rows + z + gout, writes the selected rows' gradients (atomics; the dense zero-fill
+    # of the [K, 2N*d] gradient is the bucket memset, counted with Adam's traffic below)
+    gout = torch.randn(B, d, device=dev)
+    dtable = torch.zeros_like(S.SUPPORT_SETS); dlg = torch.zeros(K, device=dev)
+    t = timed(lambda: L.check(lib.wgs_rbf_bwd(L.ptr(S.SUPPORT_SETS), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
+                                              L.ptr(idx, torch.int64), L.ptr(z), L.ptr(mag), L.ptr(gout), L.ptr(eng.rbf_ws),
+                                              L.ptr(dtable), L.ptr(dlg), None, None, B, K, n2, d, st), 'rbf_bwd'))
+    by = B * ((2 * n2 * d + n2 + 1 + 3 * d) * 4)
+    out['rbf_bwd'] = {"bytes": by, "us": round(t * 1e6, 1), "GB/s": round(by / t / 1e9, 1), "note": "latency-bound; rows read once, gradient rows written once"}
     # Adam on the flat [R | S] bucket: 4 reads + 3 writes per element
     bk = eng.bucket
     n = bk.flat.numel()
@@ -150,12 +269,67 @@ def cpu_baseline(size, K, N, b, steps, threads):
                       "(lib/trainer.py:190-254) replayed by oracle/wgs_oracle.py on PyTorch-CPU" % (steps, b, size, K, N)}
 
 
+EXTRA = [   # (name, gan, size, K, N, batch, precision or None = headline's, w_space, steps, GFLOP-per-image key or None)
+    ("cfg3 StyleGAN2-256 exact fp32", 'stylegan2', 256, 128, 32, 32, 'fp32', False, 6, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 bf16x3", 'stylegan2', 256, 128, 32, 32, 'bf16x3', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 W-space", 'stylegan2', 256, 128, 32, 32, None, True, 10, 'stylegan2-256'),
+    ("cfg2 ProgGAN native 1024, K=64 N=16 B=32", 'proggan', 1024, 64, 16, 32, None, False, 4, 'proggan-1024'),
+    ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32", 'proggan', 256, 64, 16, 32, None, False, 8, 'proggan-256'),
+    ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16", 'biggan', 128, 128, 32, 16, None, False, 8, 'biggan-128'),
+    ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16", 'biggan', 256, 128, 32, 16, None, False, 6, None),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path", 'stylegan2', 1024, 200, 64, 8, 'f16', False, 6, 'stylegan2-1024'),
+]
+
+
+def run_extra(dev, headline_precision, skip_name=None):
+    from warpedganspace_amd import conv as C
+    out = []
+    for name, gan, size, K, N, B, prec, w_space, steps, gkey in EXTRA:
+        prec = prec or headline_precision
+        if skip_name is not None and (gan, size, K, N, B, prec, w_space) == skip_name:
+            continue
+        try:
+            old = C.set_precision(prec)
+            eng = build(dev, gan, K, N, B, w_space=w_space, size=size)
+            dt = timed_steps(eng, steps, 3, 1, dev)
+            by = conv_profile(eng, 1)
+            a_fl, a_ms = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
+            rec = {"config": name, "precision": prec, "value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+                   "steps": steps, "conv_TFLOP/s": round(a_fl / a_ms / 1e9, 1), "conv_ms_per_step": round(a_ms, 2),
+                   "conv_gflop_per_step": round(a_fl / 1e9, 1)}
+            if gkey:
+                rec["step_achieved_TFLOPs"] = round(B * steps / dt * GFLOP_PER_IMG[gkey] / 1e3, 1)
+            out.append(rec)
+            del eng
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            out.append({"config": name, "precision": prec, "error": repr(e)[:300]})
+        finally:
+            C.PRECISION = old
+    return out
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start N ranks of this script (one per GPU) and relay their output."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, have))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+
+
 def main():
+    from warpedganspace_amd import conv as C
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
+    ap.add_argument('--gan', choices=('stylegan2', 'proggan', 'biggan'), default='stylegan2')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('-K', type=int, default=128)
     ap.add_argument('-N', type=int, default=32)
@@ -166,91 +340,56 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--r-precision', choices=['fp32', 'bf16x3'], default='fp32', help='arithmetic of the Reconstructor convs (default exact fp32)')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--precision', choices=('bf16x3', 'fp32', 'f16', 'f16x2'), default='bf16x3',
-                    help="arithmetic of the implicit-GEMM convs: split-bf16 x3 MFMA (fp32-class, ~1e-5) or exact fp32 MFMA")
+    ap.add_argument('--no-extra', action='store_true', help='skip the short runs of the other arithmetic modes / configs')
+    ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default=C.DEFAULT_PRECISION,
+                    help="arithmetic of the generator's implicit-GEMM convs (warpedganspace_amd/conv.py)")
     args = ap.parse_args()
 
+    in_job = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if args.gpus > 1 and not in_job:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
-    from warpedganspace_amd import conv as C
     C.set_precision(args.precision)
     from warpedganspace_amd import reconstructor as RR
     RR.R_PRECISION = 1 if args.r_precision == 'bf16x3' else 0
-    eng = build(dev, args.size, args.K, args.N, args.batch, seed=0, rank=rank)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    eng = build(dev, args.gan, args.K, args.N, args.batch, rank=rank, w_space=args.w_space, size=args.size)
+    dt = timed_steps(eng, args.steps, args.warmup, world, dev)
     stats = eng.pop_stats()
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
+    gkey = '%s-%d' % (args.gan, args.size)
+
+    comm = None
+    if world > 1:
+        eng.comm_events = []
+        for _ in range(5):
+            eng.step()
+        torch.cuda.synchronize()
+        waits = [a.elapsed_time(b) for a, b in eng.comm_events]
+        eng.comm_events = None
+        comm = {"backend": "RCCL (torch.distributed 'nccl')", "world_size_observed": dist.get_world_size(),
+                "allreduce_bytes_per_step": eng.allreduce_bytes, "collectives_per_step": 2,
+                "exposed_wait_ms_per_step": round(sum(waits) / len(waits), 3),
+                "note": "main-stream time between reaching the wait for the two all-reduces (R group, queued behind R's weight gradients on "
+                        "the side stream; S group, after the RBF backward) and their completion, mean of 5 extra steps on rank 0"}
 
     roofline = None
     if not args.no_roofline:
-        # HIP events around every implicit-GEMM launch (torch's current stream IS the launch stream)
-        # (single stream for these two steps: with the un-shifted pass on the side stream, kernels of the other stream would
-        # run inside the event pairs and inflate the per-launch durations)
-        C.PROFILE = []
-        nprof = 2
-        two = eng.two_streams
-        eng.two_streams = False
-        for _ in range(nprof):
-            eng.step()
-        torch.cuda.synchronize()
-        eng.two_streams = two
-        recs, C.PROFILE = C.PROFILE, None
-        fl = sum(r[1] for r in recs)
-        ms = sum(r[2].elapsed_time(r[3]) for r in recs)
-        by_kind = {}
-        for r in recs:
-            k = by_kind.setdefault(r[0], [0.0, 0.0, 0])
-            k[0] += r[1]; k[1] += r[2].elapsed_time(r[3]); k[2] += 1
-        bf = args.precision != 'fp32'
-        peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
-        # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes (they cannot run inside this
-        # process); the committed summary of those passes is reported here, per launch of the named shape.
-        traffic, traffic_note = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_conv_pmc.json')
-        if bf and os.path.exists(pmc):
-            rec = json.load(open(pmc))['launches'][0]
-            traffic = round((rec['fetch_bytes'] + rec['write_bytes']) / 1e9, 3)
-            traffic_note = ("GB per launch of %s, %s: FETCH_SIZE x2 (gfx950) + WRITE_SIZE from profiles/r1_conv_pmc.json; algorithmic %.3f GB"
-                            % (rec['kernel'], rec['shape'], (rec['algorithmic_read_bytes'] + rec['algorithmic_write_bytes']) / 1e9))
-        roofline = {"bound": "mfma",
-                    "kernel": ("split-bf16 implicit-GEMM family: igemm_patch_bf16x3_kernel (dominant), igemm_nt_bf16x3_kernel, igemm_dma_bf16x3_kernel (3 x v_mfma_f32_32x32x16_bf16 per product block) + exact-fp32 igemm_nt / igemm_wgrad for the Reconstructor"
-                               if bf else "igemm_nt_kernel / igemm_wgrad_kernel (fp32 v_mfma_f32_32x32x2_f32)"),
-                    "achieved": round(fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(fl / ms / 1e9 / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-                    "executed_mfma_frac": round({'bf16x3': 3.0, 'f16x2': 2.0}.get(args.precision, 1.0) * fl / ms / 1e9 / peak, 4),
-                    "launches_per_step": len(recs) // nprof, "avg_launch_ms": round(ms / len(recs), 4),
-                    "conv_ms_per_step": round(ms / nprof, 3), "conv_gflop_per_step": round(fl / nprof / 1e9, 1),
-                    "by_kind": {k: {"TFLOP/s": round(v[0] / v[1] / 1e9, 2), "ms_per_step": round(v[1] / nprof, 3),
-                                    "launches": v[2] // nprof} for k, v in by_kind.items()},
-                    "step_achieved_TFLOPs": round(value / world * GFLOP_PER_IMG / 1e3, 2),
-                    "step_frac": round(value / world * GFLOP_PER_IMG / 1e3 / peak, 4)}
+        roofline = roofline_of(conv_profile(eng, 2), args.precision, value / world, GFLOP_PER_IMG.get(gkey))
 
     hbm = None
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -258,25 +397,31 @@ def main():
             hbm = hbm_subpaths(eng, dev, args.batch)
         except Exception as e:  # noqa: BLE001
             hbm = {"error": repr(e)}
+    del eng
+    torch.cuda.empty_cache()
+
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = run_extra(dev, args.precision, skip_name=(args.gan, args.size, args.K, args.N, args.batch, args.precision, args.w_space))
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.gan == 'stylegan2':
         try:
             cpu = cpu_baseline(args.size, args.K, args.N, args.cpu_batch, args.cpu_steps, min(os.cpu_count() or 1, args.cpu_threads))
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
 
     if rank == 0:
-        out = {"metric": "training images/sec (warp->G->R->loss) StyleGAN2-%d K=%d" % (args.size, args.K), "value": round(value, 2),
-               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        arch = {'stylegan2': 'StyleGAN2-FFHQ-%d' % args.size, 'proggan': 'ProgGAN (%d)' % args.size, 'biggan': 'BigGAN-%d' % args.size}[args.gan]
+        out = {"metric": "training images/sec (warp->G->R->loss) %s K=%d" % ({'stylegan2': 'StyleGAN2-%d' % args.size}.get(args.gan, arch), args.K),
+               "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": ("%s generator convs (f16: fp16 operands, 1 MFMA per product, fp32 accumulate; f16x2: fp16 hi+lo weights, 2 MFMAs); reconstructor exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs" % args.precision) if args.precision in ('f16', 'f16x2') else ("bf16x3 (generator convs: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; reconstructor: %s)" % ("exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs" if args.r_precision == 'fp32' else "split-bf16 x3 convs, fp32 wgrad")
-                         if args.precision == 'bf16x3' else "fp32 (f32-input MFMA, f32 accumulate)"), "data": "synthetic (random-init weights, z ~ N(0,I))",
-               "config": {"workload": "StyleGAN2-FFHQ-%d arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
-                                      % (args.size, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
-                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                          "algorithmic_gflop_per_image": GFLOP_PER_IMG},
-               "last_stats": stats, "roofline": roofline, "hbm_subpaths": hbm, "cpu_baseline": cpu}
+               "dtype": DTYPE_TEXT[args.precision] + R_TEXT, "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
+               "config": {"workload": "%s arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
+                                      % (arch, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": args.precision,
+                          "algorithmic_gflop_per_image": GFLOP_PER_IMG.get(gkey)},
+               "last_stats": stats, "roofline": roofline, "comm": comm, "hbm_subpaths": hbm, "extra": extra, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -40,7 +40,12 @@ def test_train_checkpoint_traverse_roundtrip(tmp_path):
         assert osp.isfile(osp.join(wip, 'models', f)), f
     assert osp.isfile(osp.join(done, 'models', 'support_sets.pt')) and not osp.exists(osp.join(done, 'models', 'checkpoint.pt'))
     ck = torch.load(osp.join(wip, 'models', 'checkpoint.pt'), map_location='cpu')
-    assert set(ck) == {'iter', 'support_sets', 'reconstructor'} and ck['iter'] == 4
+    # the reference's three keys (lib/trainer.py:290-295) + the optional Adam-moment key its readers never look at
+    assert set(ck) == {'iter', 'support_sets', 'reconstructor', 'optim'} and ck['iter'] == 4
+    assert ck['optim']['step'] == 4 and ck['optim']['exp_avg'].numel() == ck['optim']['exp_avg_sq'].numel() > 0
+    assert float(ck['optim']['exp_avg_sq'].max()) > 0
+    # a checkpoint in the REFERENCE's layout (no 'optim') resumes as well: optimizers restart from zero moments, like the reference
+    ref_like = {k: ck[k] for k in ('iter', 'support_sets', 'reconstructor')}
     ss = ck['support_sets']
     assert ss['SUPPORT_SETS'].shape == (4, 2 * 2 * 512) and ss['ALPHAS'].shape == (4, 4) and ss['LOGGAMMA'].shape == (4, 1)
     r = ck['reconstructor']
@@ -63,5 +68,16 @@ def test_train_checkpoint_traverse_roundtrip(tmp_path):
         assert plc.shape == (4, 5, 512)                                        # [K, 2*steps/leap + 1, d]
         assert osp.isfile(osp.join(out, h, 'original_image.jpg'))
         assert sorted(os.listdir(osp.join(out, h, 'paths_images', 'path_003'))) == ['%06d.jpg' % t for t in range(5)]
+    # resume: continue the finished experiment to iteration 6, once from our checkpoint (moments restored) and once from a
+    # reference-layout checkpoint
+    common = ['--gan-type', 'StyleGAN2', '--stylegan2-resolution', '256', '-K', '4', '-D', '2', '--learn-gammas', '--batch-size', '2',
+              '--log-freq', '2', '--ckp-freq', '2', '--random-init-generator', '--seed', '0']
+    out1 = run([osp.join(REPO, 'train.py')] + common + ['--max-iter', '6'], cwd)
+    assert 'Restored Adam moments (step 4)' in out1 and 'Start training from iteration 4' in out1
+    ck6 = torch.load(osp.join(wip, 'models', 'checkpoint.pt'), map_location='cpu')
+    assert ck6['iter'] == 6 and ck6['optim']['step'] == 4 + 3          # iterations 4, 5, 6 ran (the reference re-runs `iter` too)
+    torch.save(dict(ref_like, iter=6), osp.join(wip, 'models', 'checkpoint.pt'))
+    out2 = run([osp.join(REPO, 'train.py')] + common + ['--max-iter', '8'], cwd)
+    assert 'Restored Adam moments' not in out2 and 'Start training from iteration 6' in out2
     z0 = torch.load(osp.join(cwd, 'experiments', 'latent_codes', 'StyleGAN2', 'pool2', 'aaaa', 'latent_code.pt'))
     assert torch.allclose(plc.new_tensor(torch.load(osp.join(out, 'aaaa', 'paths_latent_codes.pt'))[0, 2]), z0[0], atol=1e-6)

@@ -117,7 +117,8 @@ class _BG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        return None, ctx.G._bwd(ctx.saved, gimg.contiguous()), None
+        with C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
+            return None, ctx.G._bwd(ctx.saved, gimg.contiguous()), None
 
 
 class Generator(nn.Module):

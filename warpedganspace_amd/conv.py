@@ -128,6 +128,22 @@ class SplitCache:
         return self.planes[precision]
 
 
+_GRAD_CTX = False
+
+
+class grad_operands:
+    """Context manager for a generator's backward pass: every conv launch inside has a GRADIENT as its activation operand.
+    In the fp16 modes such a launch needs a magnitude bound (a_amax); launches that do not provide one run in split-bf16."""
+
+    def __enter__(self):
+        global _GRAD_CTX
+        self.old, _GRAD_CTX = _GRAD_CTX, True
+
+    def __exit__(self, *exc):
+        global _GRAD_CTX
+        _GRAD_CTX = self.old
+
+
 def _timed(kind, flops, fn):
     if PROFILE is None:
         return fn()
@@ -158,7 +174,7 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     d.a_ld, d.col_ld = a_ld, col_ld
     d.ups, d.add_ups, d.act, d.alpha, d.addend = ups, add_ups, act, alpha, _p(addend)
     prec = PRECISION if precision is None else precision
-    if grad_operand and prec >= 2 and a_amax is None:
+    if (grad_operand or _GRAD_CTX) and prec >= 2 and a_amax is None:
         # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
         prec = 1
     d.precision = prec
@@ -178,10 +194,18 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     return d, 2.0 * d.B * Hg * Wg * d.Co * d.Ci * len(taps)
 
 
+def _kind(d, nphase):
+    """Label of a launch for bench.py's per-shape accounting: arithmetic, channels, input grid, taps / phases, batch."""
+    if PROFILE is None:
+        return None
+    form = 'up-conv x%d phases' % nphase if nphase > 1 else ('%d taps%s' % (d.ntaps, ' stride %d' % d.isy if d.isy > 1 else ''))
+    return 'conv %s %d->%d @%dx%d %s B%d' % (precision_name(d.precision), d.Ci, d.Co, d.Hi << d.ups, d.Wi << d.ups, form, d.B)
+
+
 def launch(x, w, y, taps, Hg, Wg, **kw):
     """One implicit-GEMM launch (wgs_conv_igemm)."""
     d, flops = _desc(x, w, y, taps, Hg, Wg, **kw)
-    _timed('igemm_nt', flops, lambda: L.check(L.lib().wgs_conv_igemm(ctypes.byref(d), L.stream()), 'wgs_conv_igemm'))
+    _timed(_kind(d, 1), flops, lambda: L.check(L.lib().wgs_conv_igemm(ctypes.byref(d), L.stream()), 'wgs_conv_igemm'))
     return y
 
 
@@ -192,7 +216,7 @@ def launch_multi(x, w, y, phases, **kw):
     flops = 0.0
     for i, (taps, Hg, Wg, oy0, ox0) in enumerate(phases):
         flops += _desc(x, w, y, taps, Hg, Wg, oy0=oy0, ox0=ox0, into=descs[i], **kw)[1]
-    _timed('igemm_nt', flops, lambda: L.check(L.lib().wgs_conv_igemm_multi(descs, len(phases), L.stream()), 'wgs_conv_igemm_multi'))
+    _timed(_kind(descs[0], len(phases)), flops, lambda: L.check(L.lib().wgs_conv_igemm_multi(descs, len(phases), L.stream()), 'wgs_conv_igemm_multi'))
     return y
 
 
@@ -276,7 +300,7 @@ def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0):
             d.dy_t[i], d.dx_t[i], d.wt[i] = ky - pad, kx - pad, i
             i += 1
     flops = 2.0 * B * Ho * Wo * Co * Ci * k * k
-    _timed('igemm_wgrad', flops, lambda: L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad'))
+    _timed('wgrad fp32 %d->%d @%dx%d %d taps B%d' % (Ci, Co, Hi, Wi, k * k, B) if PROFILE is not None else None, flops, lambda: L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad'))
     return dw_packed
 
 

@@ -49,7 +49,8 @@ class _PG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
+        with C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
+            return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
 
 
 class Generator(nn.Module):
@@ -83,7 +84,10 @@ class Generator(nn.Module):
         with torch.no_grad():
             for blk, (ci, co, k, pad, up) in zip(self.features, BLOCKS):
                 wp = C.pack_weight(blk.conv.weight.float())
-                P['layers'].append(dict(wp=wp, wt=C.repack_w_t(wp, co, k * k, ci), ci=ci, co=co, k=k, pad=pad, up=up,
+                wt = C.repack_w_t(wp, co, k * k, ci)
+                # frozen weights: 16-bit planes (built per arithmetic mode on first use) for the patch / DMA conv kernels
+                ws, wts = (C.SplitCache(wp), C.SplitCache(wt)) if (wp.numel() % 4 == 0 and ci % 32 == 0) else (None, None)
+                P['layers'].append(dict(wp=wp, wt=wt, ws=ws, wts=wts, ci=ci, co=co, k=k, pad=pad, up=up,
                                         scale=float(blk.wscale.scale.item()), b=blk.wscale.b.contiguous()))
             co = self.output.conv.weight.shape[0]
             ci = self.output.conv.weight.shape[1]
@@ -124,7 +128,7 @@ class Generator(nn.Module):
             k, pad = ly['k'], ly['pad']
             taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
             C.launch(xn, ly['wp'], y, taps, Ho, Ho, w_tap_stride=ly['ci'], w_row_stride=k * k * ly['ci'], ups=1 if ly['up'] else 0,
-                     alpha=ly['scale'], bias=ly['b'], act_slope=0.2, gain=1.0)
+                     alpha=ly['scale'], bias=ly['b'], act_slope=0.2, gain=1.0, w_split=ly['ws'])
             if save:
                 saved.append((x, xn, y))
             x = y
@@ -158,7 +162,8 @@ class Generator(nn.Module):
             Hup = x.shape[1] << (1 if ly['up'] else 0)
             dup = torch.empty(B, Hup, Hup, ly['ci'], device=dev)
             taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
-            C.launch(dpre, ly['wt'], dup, taps, Hup, Hup, w_tap_stride=ly['ci'] * ly['co'], w_row_stride=ly['co'], alpha=ly['scale'])
+            C.launch(dpre, ly['wt'], dup, taps, Hup, Hup, w_tap_stride=ly['ci'] * ly['co'], w_row_stride=ly['co'], alpha=ly['scale'],
+                     w_split=ly['wts'])
             if ly['up']:
                 gxn = torch.empty_like(xn)
                 L.check(lib.wgs_upsample2x_bwd(L.ptr(dup), L.ptr(gxn), B, x.shape[1], x.shape[2], ly['ci'], st), 'upsample_bwd')

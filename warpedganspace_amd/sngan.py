@@ -65,7 +65,8 @@ class _SN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
+        with C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
+            return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
 
 
 class GenModel(nn.Module):
