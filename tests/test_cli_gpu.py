@@ -81,3 +81,29 @@ def test_train_checkpoint_traverse_roundtrip(tmp_path):
     assert 'Restored Adam moments' not in out2 and 'Start training from iteration 6' in out2
     z0 = torch.load(osp.join(cwd, 'experiments', 'latent_codes', 'StyleGAN2', 'pool2', 'aaaa', 'latent_code.pt'))
     assert torch.allclose(plc.new_tensor(torch.load(osp.join(out, 'aaaa', 'paths_latent_codes.pt'))[0, 2]), z0[0], atol=1e-6)
+
+
+def test_sample_gan_pool_layout_feeds_traversal(tmp_path):
+    """sample_gan.py writes the reference's pool layout (sample_gan.py:70-91,156-179) and traverse_latent_space.py reads it."""
+    from hashlib import sha1
+    cwd = str(tmp_path)
+    run([osp.join(REPO, 'sample_gan.py'), '-v', '--gan-type', 'StyleGAN2', '--stylegan2-resolution', '256', '--num-samples', '3',
+         '--pool', 'p3', '--z-truncation', '0.7', '--random-init-generator', '--seed', '1', '--batch-size', '2'], cwd)
+    pool = osp.join(cwd, 'experiments', 'latent_codes', 'StyleGAN2', 'p3')
+    a = json.load(open(osp.join(pool, 'args.json')))
+    assert set(a) == {'verbose', 'gan_type', 'shift_in_w_space', 'z_truncation', 'biggan_target_classes', 'stylegan2_resolution',
+                      'num_samples', 'pool', 'cuda'} and a['z_truncation'] == 0.7
+    dirs = sorted(d for d in os.listdir(pool) if osp.isdir(osp.join(pool, d)))
+    assert len(dirs) == 3
+    from PIL import Image
+    for d in dirs:
+        z = torch.load(osp.join(pool, d, 'latent_code.pt'))
+        assert z.shape == (1, 512) and z.dtype == torch.float32 and float(z.abs().max()) <= 0.7
+        assert sha1(z.numpy()).hexdigest() == d
+        assert Image.open(osp.join(pool, d, 'image.jpg')).size == (256, 256)
+    # default pool name <gan_type>_<num_samples>; BigGAN needs its classes and names the directory after them
+    run([osp.join(REPO, 'sample_gan.py'), '--gan-type', 'SNGAN_MNIST', '--num-samples', '2', '--random-init-generator'], cwd)
+    assert len([d for d in os.listdir(osp.join(cwd, 'experiments', 'latent_codes', 'SNGAN_MNIST', 'SNGAN_MNIST_2')) if d != 'args.json']) == 2
+    run([osp.join(REPO, 'sample_gan.py'), '--gan-type', 'BigGAN', '--biggan-target-classes', '14', '239', '--num-samples', '1',
+         '--random-init-generator'], cwd)
+    assert osp.isdir(osp.join(cwd, 'experiments', 'latent_codes', 'BigGAN-14-239', 'BigGAN-14-239_1'))

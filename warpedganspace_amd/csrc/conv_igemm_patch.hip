@@ -105,7 +105,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     const int q = tid & 7;
     const int npatch = g.PH * g.PW;
     int p_goff[NPL];        // byte offset of (pixel, q) in x for chunk 0, or OOB
-    int p_loff[NPL];        // byte offset in the hi patch plane
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         const int pp = (tid + j * NT) >> 3;
@@ -113,8 +112,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         const int iy = ty0 + g.dy_min + pr, ix = tx0 + g.dx_min + pc;
         const bool v = pp < npatch && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         p_goff[j] = v ? (((b * p.Hi + iy) * p.Wi + ix) * p.Ci + q * 4) * 4 : OOB;
-        p_loff[j] = pp < PMAX ? pp * ROW + (((q >> 1) ^ ((pp >> 2) & 3)) << 4) + ((q & 1) << 3) : -1;
     }
+    // byte offset of staging element j in the hi patch plane (recomputed at store time: 9 registers fewer across the MFMA steps)
+    auto p_loff_of = [&](int j) {
+        const int pp = (tid + j * NT) >> 3;
+        return pp < PMAX ? pp * ROW + (((q >> 1) ^ ((pp >> 2) & 3)) << 4) + ((q & 1) << 3) : -1;
+    };
     const float* sc_ptr = p.a_scale ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
     float4 pr_[NPL];
     // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h), folded into the style vector / undone in the epilogue
@@ -143,9 +146,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             const f32x4 f = {v.x, v.y, v.z, v.w};
             uint2 h, l;
             SC::cvt4(f, h, l);
-            if (p_loff[j] >= 0) {
-                *reinterpret_cast<uint2*>(patch + p_loff[j]) = h;
-                if (NA == 2) *reinterpret_cast<uint2*>(patch + P_BYTES + p_loff[j]) = l;
+            const int lo_ = p_loff_of(j);
+            if (lo_ >= 0) {
+                *reinterpret_cast<uint2*>(patch + lo_) = h;
+                if (NA == 2) *reinterpret_cast<uint2*>(patch + P_BYTES + lo_) = l;
             }
         }
     };
@@ -220,6 +224,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         }
     };
 
+    // Single-plane schemes: one A fragment feeds only TN MFMAs (64 .. 128 matrix-pipe cycles) — less than an LDS round trip,
+    // and the compiler's own schedule is {ds_read A; wait; TN MFMAs} per fragment, i.e. the latency is exposed every time.
+    // So the step is software-pipelined by hand over its 2*TPS (tap, k-step) groups: the TM + TN fragment reads of group
+    // g+1 are issued before the TM*TN MFMAs of group g (two register sets, pinned with sched_barrier).
+    constexpr bool PIPE = (NA == 1 && NB == 1);
+    auto mma_step = [&](int stage, int t0) {
+        constexpr int G = 2 * TPS;
+        int tapoff[TPS];
+#pragma unroll
+        for (int u = 0; u < TPS; ++u) {
+            const int yx = p.tap_yx[t0 + u];
+            const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+            tapoff[u] = (dy - g.dy_min) * g.PW + (dx - g.dx_min);
+        }
+        frag af[2][TM], bf[2][TN];
+        auto load_group = [&](int gi, frag* a, frag* bq) {
+            const int u = gi >> 1, ks = gi & 1;
+            const unsigned char* bb = bst + stage * B_STAGE + u * B_TAP + b_rd + (ks ? bk1 : bk0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[j] = *reinterpret_cast<const frag*>(bb + j * 32 * ROW);
+            const int kc = ks * 2 + lh;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int pp = pp0[i] + tapoff[u];
+                a[i] = *reinterpret_cast<const frag*>(patch + pp * ROW + ((kc ^ ((pp >> 2) & 3)) << 4));
+            }
+        };
+        load_group(0, af[0], bf[0]);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            if (gi + 1 < G) load_group(gi + 1, af[(gi + 1) & 1], bf[(gi + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(&af[gi & 1][i], &bf[gi & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // ---- main loop: chunk outer, tap inner
     load_patch(0);
     issue_b(0, 0, 0);
@@ -231,11 +274,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         for (int t = 0; t < p.ntaps; t += TPS) {
             const bool last = (t + TPS >= p.ntaps);
             issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + TPS);
+            if (PIPE) mma_step(stage, t);
+            else {
 #pragma unroll
-            for (int u = 0; u < TPS; ++u) {
-                const int yx = p.tap_yx[t + u];
-                const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
-                mma_tap(stage, u, (dy - g.dy_min) * g.PW + (dx - g.dx_min));
+                for (int u = 0; u < TPS; ++u) {
+                    const int yx = p.tap_yx[t + u];
+                    const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
+                    mma_tap(stage, u, (dy - g.dy_min) * g.PW + (dx - g.dx_min));
+                }
             }
             __syncthreads();                     // weight stage swap; after the last tap also: patch no longer read
             stage ^= 1;
