@@ -280,6 +280,7 @@ EXTRA = [   # (name, gan, size, K, N, batch, precision or None = headline's, w_s
     ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16", 'biggan', 128, 128, 32, 16, None, False, 8, 'biggan-128'),
     ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16", 'biggan', 256, 128, 32, 16, None, False, 6, None),
     ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path", 'stylegan2', 1024, 200, 64, 8, 'f16', False, 6, 'stylegan2-1024'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, default arithmetic of this architecture", 'stylegan2', 1024, 200, 64, 8, 'auto', False, 6, 'stylegan2-1024'),
 ]
 
 
@@ -288,10 +289,11 @@ def run_extra(dev, headline_precision, skip_name=None):
     out = []
     for name, gan, size, K, N, B, prec, w_space, steps, gkey in EXTRA:
         prec = prec or headline_precision
-        if skip_name is not None and (gan, size, K, N, B, prec, w_space) == skip_name:
-            continue
         try:
             old = C.set_precision(prec)
+            prec = C.precision_name(C.resolve_auto(gan, size))        # 'auto' -> the concrete mode of this architecture
+            if skip_name is not None and (gan, size, K, N, B, prec, w_space) == skip_name:
+                continue
             eng = build(dev, gan, K, N, B, w_space=w_space, size=size)
             dt = timed_steps(eng, steps, 3, 1, dev)
             by = conv_profile(eng, 1)
@@ -364,6 +366,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     C.set_precision(args.precision)
+    precision = C.precision_name(C.resolve_auto(args.gan, args.size))      # 'auto' -> the concrete mode of this architecture
     from warpedganspace_amd import reconstructor as RR
     RR.R_PRECISION = 1 if args.r_precision == 'bf16x3' else 0
     eng = build(dev, args.gan, args.K, args.N, args.batch, rank=rank, w_space=args.w_space, size=args.size)
@@ -389,7 +392,7 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        roofline = roofline_of(conv_profile(eng, 2), args.precision, value / world, GFLOP_PER_IMG.get(gkey))
+        roofline = roofline_of(conv_profile(eng, 2), precision, value / world, GFLOP_PER_IMG.get(gkey))
 
     hbm = None
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -402,7 +405,7 @@ def main():
 
     extra = None
     if rank == 0 and world == 1 and not args.no_extra:
-        extra = run_extra(dev, args.precision, skip_name=(args.gan, args.size, args.K, args.N, args.batch, args.precision, args.w_space))
+        extra = run_extra(dev, args.precision, skip_name=(args.gan, args.size, args.K, args.N, args.batch, precision, args.w_space))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.gan == 'stylegan2':
@@ -416,10 +419,10 @@ def main():
         out = {"metric": "training images/sec (warp->G->R->loss) %s K=%d" % ({'stylegan2': 'StyleGAN2-%d' % args.size}.get(args.gan, arch), args.K),
                "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": DTYPE_TEXT[args.precision] + R_TEXT, "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
+               "dtype": DTYPE_TEXT[precision] + R_TEXT, "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
                "config": {"workload": "%s arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (arch, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
-                          "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": args.precision,
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": precision, "precision_requested": args.precision,
                           "algorithmic_gflop_per_image": GFLOP_PER_IMG.get(gkey)},
                "last_stats": stats, "roofline": roofline, "comm": comm, "hbm_subpaths": hbm, "extra": extra, "cpu_baseline": cpu}
         print(json.dumps(out))

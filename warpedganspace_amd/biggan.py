@@ -106,7 +106,9 @@ class GBlock(nn.Module):
 class _BG(torch.autograd.Function):
     @staticmethod
     def forward(ctx, G, z, y):
-        img, saved = G._fwd(z, y, save=ctx.needs_input_grad[1])
+        ctx.prec = C.resolve_auto('biggan', G.resolution)
+        with C.resolved(ctx.prec):
+            img, saved = G._fwd(z, y, save=ctx.needs_input_grad[1])
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:     # ReLU gates in execution order, NCHW (tests)
             gates = []
@@ -117,7 +119,7 @@ class _BG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        with C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
+        with C.resolved(ctx.prec), C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
             return None, ctx.G._bwd(ctx.saved, gimg.contiguous()), None
 
 
@@ -210,19 +212,45 @@ class Generator(nn.Module):
         return P
 
     # -- small helpers ------------------------------------------------------------------------------------
-    @staticmethod
-    def _lin(x, w, inv, bias=None, bscale=1.0):
+    _PADDED = {}     # frozen weights whose K is not a multiple of 4 (the 256 / 512 architectures: z chunks of 17 / 15), zero-padded once
+
+    @classmethod
+    def _pad_k(cls, w):
+        K = w.shape[1]
+        Kp = (K + 3) & ~3
+        key = (w.data_ptr(), tuple(w.shape), str(w.device))
+        if key not in cls._PADDED:
+            wp = torch.zeros(w.shape[0], Kp, device=w.device)
+            wp[:, :K] = w
+            cls._PADDED[key] = wp
+        return cls._PADDED[key], Kp
+
+    @classmethod
+    def _lin(cls, x, w, inv, bias=None, bscale=1.0):
         B, K = x.shape
+        if K % 4:
+            w, Kp = cls._pad_k(w)
+            x = torch.nn.functional.pad(x, (0, Kp - K))
+            K = Kp
         N = w.shape[0]
         y = torch.empty(B, N, device=x.device)
         L.check(L.lib().wgs_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, N, K, K, N, L.c_float(inv), L.c_float(bscale),
                                        0, 0, L.c_float(0.0), L.c_float(1.0), L.stream()), 'biggan_linear')
         return y
 
-    @staticmethod
-    def _lin_dgrad(g, w, inv, out, accumulate):
+    @classmethod
+    def _lin_dgrad(cls, g, w, inv, out, accumulate):
         B, N = g.shape
         K = w.shape[1]
+        if K % 4:
+            wp, Kp = cls._pad_k(w)
+            tmp = torch.empty(B, Kp, device=g.device)
+            cls._lin_dgrad(g, wp, inv, tmp, accumulate=False)
+            if accumulate:
+                out += tmp[:, :K]
+            else:
+                out.copy_(tmp[:, :K])
+            return
         L.check(L.lib().wgs_linear_dgrad(L.ptr(g), L.ptr(w), None, L.ptr(out), B, N, K, N, K, L.c_float(inv), L.c_float(1.0),
                                          L.c_float(1.0), int(accumulate), L.stream()), 'biggan_linear_dgrad')
 

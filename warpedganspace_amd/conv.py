@@ -41,8 +41,37 @@ class WgradDesc(ctypes.Structure):
 #   2 'f16'    fp16 operands, 1 MFMA per product, fp32 accumulate (image error ~4e-4 at 256^2 — inside the 1e-3 gate)
 #   3 'f16x2'  fp16 activations x (hi + lo) fp16 weights, 2 MFMAs (image error ~3e-4)
 # Set with set_precision() / train.py --precision / bench.py --precision, or WGS_CONV_PRECISION at import.
-PRECISION_NAMES = {'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3}
-DEFAULT_PRECISION = 'bf16x3'
+#  -1 'auto'   per generator: the cheapest mode whose measured image error stays inside the north_star's 1e-3 gate for that
+#              architecture (tests/test_precision_schemes_gpu.py): see AUTO_TABLE
+PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3}
+DEFAULT_PRECISION = 'auto'
+AUTO = -1
+# (generator family, output resolution) -> mode for 'auto'.  Error accumulates with depth (each fp16 layer adds ~2e-4):
+# StyleGAN2-256 (13 modulated 3x3 layers) measures 7e-4 .. 9e-4 in f16, StyleGAN2-1024 (17 layers) 1.5e-3 -> split-bf16 there.
+AUTO_TABLE = {('stylegan2', 256): 'f16', ('stylegan2', 128): 'f16', ('stylegan2', 64): 'f16', ('stylegan2', 32): 'f16'}
+AUTO_FALLBACK = 'bf16x3'
+
+
+def resolve_auto(family, resolution):
+    """Concrete precision code for generator `family` at `resolution` under the current setting."""
+    if PRECISION != AUTO:
+        return PRECISION
+    return PRECISION_NAMES[AUTO_TABLE.get((family, resolution), AUTO_FALLBACK)]
+
+
+class resolved:
+    """Context manager: run the enclosed launches with the concrete precision `code` (a generator's forward / backward)."""
+
+    def __init__(self, code):
+        self.code = code
+
+    def __enter__(self):
+        global PRECISION
+        self.old, PRECISION = PRECISION, self.code
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.old
 
 
 def precision_code(name):
@@ -174,6 +203,8 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     d.a_ld, d.col_ld = a_ld, col_ld
     d.ups, d.add_ups, d.act, d.alpha, d.addend = ups, add_ups, act, alpha, _p(addend)
     prec = PRECISION if precision is None else precision
+    if prec == AUTO:           # a bare conv call outside a generator: the fp32-class mode
+        prec = PRECISION_NAMES[AUTO_FALLBACK]
     if (grad_operand or _GRAD_CTX) and prec >= 2 and a_amax is None:
         # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
         prec = 1

@@ -41,7 +41,9 @@ class _Block(nn.Module):
 class _PG(torch.autograd.Function):
     @staticmethod
     def forward(ctx, G, z):
-        img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
+        ctx.prec = C.resolve_auto('proggan', 4 << ((G.num_blocks - 2) // 2))
+        with C.resolved(ctx.prec):
+            img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:     # leaky-relu gates, NCHW (tests)
             G.debug_keep['gates'] = [(y > 0).permute(0, 3, 1, 2) for (_, _, y) in saved[0]]
@@ -49,7 +51,7 @@ class _PG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        with C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
+        with C.resolved(ctx.prec), C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
             return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
 
 

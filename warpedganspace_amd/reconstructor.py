@@ -162,6 +162,21 @@ class Reconstructor(nn.Module):
     def _param_list(self):
         return list(self.parameters())
 
+    # -- persistent per-device scratch (allocated once, not per step) -----------------------------------------------
+    def _scratch(self, name, shape, dtype, dev, zero=False):
+        store = self.__dict__.setdefault('_scratch_bufs', {})
+        key = (name, tuple(shape), dtype, str(dev))
+        if key not in store:
+            store[key] = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=dev)
+        return store[key]
+
+    def _conv1_padded(self, c, Cp, dev):
+        """conv1's packed weight [64, 49, 2c] widened to Cp input channels (zero padding written once; the live 2c channels are
+        refreshed from the parameter on every call — one small strided copy instead of a zero-fill + copy)."""
+        w1p = self._scratch('w1p', (64, 49, Cp), torch.float32, dev, zero=True)
+        w1p[:, :, :2 * c].copy_(_packed(self.features_extractor.conv1))
+        return w1p
+
     # -- reference signature ---------------------------------------------------------------------------
     def forward(self, x1, x2):
         if not x1.is_cuda:
@@ -179,14 +194,12 @@ class Reconstructor(nn.Module):
         dev = x1.device
         x1, x2 = x1.contiguous(), x2.contiguous()
         B, c, H, W = x1.shape
-        ws = torch.empty(64 * 512, dtype=torch.float64, device=dev)      # WGS_BN_WS_DOUBLES(512)
+        ws = self._scratch('bn_ws', (64 * 512,), torch.float64, dev)      # WGS_BN_WS_DOUBLES(512), reused every step
         Cp = 8
         x = torch.empty(B, H, W, Cp, device=dev)
         L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
         # stem: conv1 weights padded from 2c to Cp input channels
-        w1 = _packed(fe.conv1)
-        w1p = torch.zeros(64, 49, Cp, device=dev)
-        w1p[:, :, :2 * c] = w1
+        w1p = self._conv1_padded(c, Cp, dev)
         c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=R_PRECISION)
         a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
         Hp = (a1.shape[1] + 2 - 3) // 2 + 1
@@ -308,9 +321,9 @@ class Reconstructor(nn.Module):
         grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, dw1p[:, :, :2 * c].contiguous())
         d1 = d2 = None
         if need_x[0] or need_x[1]:
-            w1p = torch.zeros(64, 49, Cp, device=dev)
-            w1p[:, :, :2 * c] = _packed(fe.conv1)
-            dx = C.conv2d_dgrad(dc1, C.repack_w_t(w1p, 64, 49, Cp), (S["H"], S["W"]), 7, stride=2, pad=3, precision=R_DGRAD_PRECISION)
+            w1p = self._conv1_padded(c, Cp, dev)        # same weights as in the forward of this step (Adam runs after the backward)
+            w1t = C.repack_w_t(w1p, 64, 49, Cp, out=self._scratch('w1t', (49, Cp, 64), torch.float32, dev))
+            dx = C.conv2d_dgrad(dc1, w1t, (S["H"], S["W"]), 7, stride=2, pad=3, precision=R_DGRAD_PRECISION)
             d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
             d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
             L.check(lib.wgs_unpack_pair_grad(L.ptr(dx), L.ptr(d1), L.ptr(d2), B, c, S['H'] * S['W'], Cp, st), 'unpack_pair')

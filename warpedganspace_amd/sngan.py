@@ -54,7 +54,9 @@ class ResBlockGenerator(nn.Module):
 class _SN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, G, z):
-        img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
+        ctx.prec = C.resolve_auto('sngan', 0)
+        with C.resolved(ctx.prec):
+            img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:     # ReLU gates in execution order, NCHW (tests)
             gates = []
@@ -65,7 +67,7 @@ class _SN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        with C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
+        with C.resolved(ctx.prec), C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
             return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
 
 

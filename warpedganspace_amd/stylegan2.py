@@ -132,7 +132,9 @@ class _Mapping(torch.autograd.Function):
 class _Synthesis(torch.autograd.Function):
     @staticmethod
     def forward(ctx, G, w):
-        img, saved = G._synthesis_fwd(w, save=ctx.needs_input_grad[1])
+        ctx.prec = C.resolve_auto('stylegan2', G.size)      # the backward runs in the arithmetic its forward ran in
+        with C.resolved(ctx.prec):
+            img, saved = G._synthesis_fwd(w, save=ctx.needs_input_grad[1])
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:   # leaky-relu gates of every StyledConv, NCHW (tests)
             G.debug_keep['synthesis'] = [(o > 0).permute(0, 3, 1, 2) for o in saved[1]]
@@ -140,7 +142,8 @@ class _Synthesis(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous())
+        with C.resolved(ctx.prec):
+            return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous())
 
 
 class Generator(nn.Module):
