@@ -184,6 +184,9 @@ typedef struct wgs_wgrad_desc {
     int64_t w_tap_stride, w_row_stride;
     int8_t dy_t[64], dx_t[64];
     int16_t wt[64];
+    int32_t precision;   /* 0: exact fp32 MFMA.  1: split-bf16 x3 (operands split into bf16 hi + lo while they are transposed into the
+                            [channel][pixel] LDS image, 3 bf16 MFMAs per product, fp32 accumulate: ~2^-16 per product) for
+                            Ci % 64 == 0 and Co % 64 == 0; other shapes use the exact kernel. */
 } wgs_wgrad_desc;
 int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
 

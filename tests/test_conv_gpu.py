@@ -270,3 +270,26 @@ def test_conv_split_bf16_patch_form(dev, B, Ci, Co, H):
         d_p = C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=1, w_split=C.split_weight(wt))
         assert torch.equal(d_p, C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=1))
         assert rel_err(d_p, C.conv2d_dgrad(g, wt, (H, H), 3, pad=1, a_scale=dm, precision=0)) < 2e-5
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,k,s,p', [(4, 64, 64, 16, 3, 1, 1), (3, 64, 128, 17, 3, 2, 1), (2, 128, 128, 9, 3, 1, 1),
+                                             (2, 256, 512, 8, 1, 2, 0), (5, 128, 64, 7, 3, 1, 1), (32, 64, 64, 64, 3, 1, 1)])
+def test_conv_wgrad_split_bf16(dev, B, Ci, Co, H, k, s, p):
+    """wgs_wgrad_desc.precision = 1: operands transposed in registers into the [channel][pixel] LDS image and split into
+    bf16 hi / lo, 3 MFMAs per product — within ~2e-5 of float64 (the exact kernel: ~1e-6), any K split."""
+    torch.manual_seed(Ci + Co + H)
+    x = torch.randn(B, Ci, H, H, dtype=torch.float64)
+    w = (torch.randn(Co, Ci, k, k, dtype=torch.float64) / (Ci * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    dw_ref = w.grad.permute(0, 2, 3, 1).reshape(Co, k * k, Ci)
+    xd, gd = nhwc(x.float()).to(dev), nhwc(g.float()).to(dev)
+    for ksplit in (0, 1, 3):
+        dw = torch.zeros(Co, k * k, Ci, device=dev)
+        C.conv2d_wgrad(xd, gd, dw, k, stride=s, pad=p, ksplit=ksplit, precision=1)
+        e = rel_err(dw, dw_ref)
+        assert e < 5e-5, (ksplit, e)
+    dw0 = torch.zeros(Co, k * k, Ci, device=dev)
+    C.conv2d_wgrad(xd, gd, dw0, k, stride=s, pad=p, precision=0)
+    assert rel_err(dw, dw0) < 5e-5

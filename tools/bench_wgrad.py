@@ -1,23 +1,31 @@
-"""Weight-gradient kernel (exact fp32) on the ResNet-18 layer shapes of the bench (B=32 pairs)."""
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+#!/usr/bin/env python
+"""Micro-benchmark of the weight-gradient kernels on the ResNet-18 reconstructor's conv shapes at 256x256 input, B=32."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from warpedganspace_amd import conv as C
 dev = torch.device('cuda:0')
-def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
+B = 32
+
+
+def timeit(fn, n=8):
+    fn(); fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(n): fn()
+    for _ in range(n):
+        fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
-B = 32
-tot = 0.0
-for ci, co, h, s in [(64, 64, 64, 1), (64, 128, 64, 2), (128, 128, 32, 1), (128, 256, 32, 2), (256, 256, 16, 1), (256, 512, 16, 2), (512, 512, 8, 1)]:
-    ho = (h + 2 - 3) // s + 1
-    x = torch.randn(B, h, h, ci, device=dev); g = torch.randn(B, ho, ho, co, device=dev)
-    dw = torch.zeros(co, 9, ci, device=dev)
-    fl = 2.0 * B * ho * ho * co * ci * 9
-    t0 = timeit(lambda: C.conv2d_wgrad(x, g, dw, 3, stride=s, pad=1))
-    tot += t0
-    print(os.environ.get('WGS_LIB', 'default').split('/')[-1], ci, co, h, s, 'fp32 wgrad %.1f us %.1f TF' % (t0 * 1e3, fl / t0 / 1e9))
-print('sum %.1f us' % (tot * 1e3))
+
+for ci, co, h, k, s in [(64, 64, 64, 3, 1), (64, 128, 64, 3, 2), (128, 128, 32, 3, 1), (128, 256, 32, 3, 2), (256, 256, 16, 3, 1),
+                        (256, 512, 16, 3, 2), (512, 512, 8, 3, 1), (64, 128, 64, 1, 2)]:
+    x = torch.randn(B, h, h, ci, device=dev)
+    ho = (h + 2 * (k // 2) - k) // s + 1
+    dy = torch.randn(B, ho, ho, co, device=dev)
+    dw = torch.zeros(co, k * k, ci, device=dev)
+    fl = 2.0 * B * ho * ho * co * ci * k * k
+    line = 'wgrad %3d->%3d @%2d k%d s%d: ' % (ci, co, h, k, s)
+    for prec in (0, 1):
+        ms = timeit(lambda: C.conv2d_wgrad(x, dy, dw, k, stride=s, pad=k // 2, precision=prec))
+        line += ' %s %7.3f ms %6.1f TF |' % ('fp32  ' if prec == 0 else 'bf16x3', ms, fl / ms / 1e9)
+    print(line, flush=True)

@@ -1,13 +1,17 @@
 #!/usr/bin/env bash
-# Build development variants of the library with -DWGS_ABL=<n> for the split-bf16 conv kernel -> tools/_bin/libwgs_abl<n>.so
+# Build development variants of the library -> tools/_bin/libwgs_<tag><n>.so
+#   tools/build_abl.sh abl 3 4      : -DWGS_ABL=<n>  on conv_igemm_bf16.hip  (register-staged kernel ablations)
+#   tools/build_abl.sh pabl 1 2 3   : -DWGS_PABL=<n> on conv_igemm_patch.hip (patch kernel ablations)
 set -euo pipefail
 cd "$(dirname "$0")/../warpedganspace_amd/csrc"
 mkdir -p ../../tools/_bin
+tag=$1; shift
+if [ "$tag" = pabl ]; then src=conv_igemm_patch; def=WGS_PABL; else src=conv_igemm_bf16; def=WGS_ABL; fi
 for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -DWGS_ABL=$n -c conv_igemm_bf16.hip -o /tmp/abl$n.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -D$def=$n -c $src.hip -o /tmp/$tag$n.o &
 done
 wait
 for n in "$@"; do
-  objs=$(ls build/*.o | grep -v conv_igemm_bf16)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_bin/libwgs_abl$n.so $objs /tmp/abl$n.o
+  objs=$(ls build/*.o | grep -v "build/$src.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_bin/libwgs_$tag$n.so $objs /tmp/$tag$n.o
 done

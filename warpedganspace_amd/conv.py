@@ -32,7 +32,8 @@ class WgradDesc(ctypes.Structure):
                [(n, ctypes.c_int32) for n in ('B', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'isy', 'isx', 'ntaps',
                                               'ksplit')] + \
                [('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
-                ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64)]
+                ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
+                ('precision', ctypes.c_int32)]
 
 
 # Arithmetic of the (frozen) generator's implicit-GEMM launches (wgs_conv_desc.precision, include/wgs.h):
@@ -48,7 +49,8 @@ DEFAULT_PRECISION = 'auto'
 AUTO = -1
 # (generator family, output resolution) -> mode for 'auto'.  Error accumulates with depth (each fp16 layer adds ~2e-4):
 # StyleGAN2-256 (13 modulated 3x3 layers) measures 7e-4 .. 9e-4 in f16, StyleGAN2-1024 (17 layers) 1.5e-3 -> split-bf16 there.
-AUTO_TABLE = {('stylegan2', 256): 'f16', ('stylegan2', 128): 'f16', ('stylegan2', 64): 'f16', ('stylegan2', 32): 'f16'}
+AUTO_TABLE = {('stylegan2', 256): 'f16', ('stylegan2', 128): 'f16', ('stylegan2', 64): 'f16', ('stylegan2', 32): 'f16',
+              ('proggan', 256): 'f16'}       # ProgGAN truncated to 256^2: 4e-4; BigGAN-128 measures 1.3e-3 .. 1.7e-3 in f16 -> fallback
 AUTO_FALLBACK = 'bf16x3'
 
 
@@ -316,14 +318,16 @@ def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
     return launch(dy, wt_packed, dx, taps, Hi, Wi, isy=2, w_tap_stride=Ci * Co, w_row_stride=Co, grad_operand=True, **epi)
 
 
-def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0):
-    """Accumulate the weight gradient into the zero-initialised dw_packed [Co, k*k, Ci] memory."""
+def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0, precision=0):
+    """Accumulate the weight gradient into the zero-initialised dw_packed [Co, k*k, Ci] memory.
+    precision 0: exact fp32 MFMA; 1: split-bf16 x3 (fp32-class) where the shape allows it."""
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
     d = WgradDesc()
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw_packed.data_ptr()
     d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = B, Hi, Wi, Ci, Ho, Wo, Co
     d.isy, d.isx, d.ntaps, d.ksplit = stride, stride, k * k, ksplit
+    d.precision = precision
     d.w_tap_stride, d.w_row_stride = Ci, k * k * Ci
     i = 0
     for ky in range(k):
@@ -331,7 +335,7 @@ def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0):
             d.dy_t[i], d.dx_t[i], d.wt[i] = ky - pad, kx - pad, i
             i += 1
     flops = 2.0 * B * Ho * Wo * Co * Ci * k * k
-    _timed('wgrad fp32 %d->%d @%dx%d %d taps B%d' % (Ci, Co, Hi, Wi, k * k, B) if PROFILE is not None else None, flops, lambda: L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad'))
+    _timed('wgrad %s %d->%d @%dx%d %d taps B%d' % ('bf16x3' if precision == 1 and Ci % 64 == 0 and Co % 64 == 0 else 'fp32', Ci, Co, Hi, Wi, k * k, B) if PROFILE is not None else None, flops, lambda: L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad'))
     return dw_packed
 
 

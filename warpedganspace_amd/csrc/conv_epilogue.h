@@ -20,6 +20,49 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
     const int* r_add = reinterpret_cast<const int*>(r_nz + BM);
     // demodulation factors: a tile usually covers one or two samples -> two registers per column
     const int b_lo = r_b[0], b_hi2 = r_b[BM - 1];
+    // Fast path (every StyleGAN2 / ProgGAN layer launch of the 8-wave and patch tiles): leaky-relu epilogue, no addend, the
+    // wave's columns all inside Co, one sample per tile.  Branch-free: rows past the end get an out-of-range offset that the
+    // buffer store drops; per element = 2 mul + add + max-form leaky-relu + gain + one address add + one store.  (The general
+    // path below costs ~4x the instructions per element, and for the short-K layers — Cin = 128: 288 MFMAs per wave —
+    // the epilogue was a quarter of the kernel's instruction stream.)
+    {
+        const long ybytes = (long)p.B * p.Ho * p.Wo * p.Co * 4;
+        const bool all_cols = n0 + wn * WN + TN * 32 <= p.Co;
+        if (p.act == 0 && !p.addend && all_cols && (!p.col_scale || b_lo == b_hi2) && p.act_slope >= 0.f && p.act_slope <= 1.f &&
+            ybytes < 0x7fffffffL) {
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)ybytes, 0x00020000);
+            float cs[TN], bs[TN];
+            int noff[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 32 + l31;
+                cs[j] = p.col_scale ? p.col_scale[(size_t)b_lo * p.col_ld + n] : 1.f;
+                bs[j] = p.bias ? p.bias[n] : 0.f;
+                noff[j] = n * 4;
+            }
+            const int rowbytes = p.Co * 4;
+            const float slope = p.act_slope, gain = p.gain;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int pix = r_pix[row];
+                    const float nz = r_nz[row];
+                    const int ro = pix >= 0 ? pix * rowbytes : (int)0x80000000;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float v = acc[i][j][r] * alpha;
+                        v *= cs[j];
+                        v += nz + bs[j];
+                        v = fmaxf(v, v * slope) * gain;           // == (v > 0 ? v : v * slope) * gain for slope in [0, 1]
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)((unsigned)ro + (unsigned)noff[j]), 0, 0);
+                    }
+                }
+            }
+            return;
+        }
+    }
     const bool cs_fast = p.col_scale && (b_hi2 - b_lo <= 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

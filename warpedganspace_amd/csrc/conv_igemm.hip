@@ -518,6 +518,8 @@ __global__ __launch_bounds__(256) void repack_w_t_kernel(const float* __restrict
 
 }  // namespace
 
+int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st);      // conv_wgrad16.hip
+
 extern "C" {
 
 int wgs_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_stream_t stream) {
@@ -640,6 +642,10 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
     hipStream_t st = (hipStream_t)stream;
+    if (d->precision == 1 && wgs_conv_wgrad16(d, st) == 0) {
+        WGS_CHECK_LAUNCH("igemm_wgrad16_kernel");
+        return WGS_OK;
+    }
     if (d->Ci < 32 && d->ntaps * d->Ci >= 64) {
         // few input channels: flatten (tap, ci) into the GEMM columns — one pass over dy instead of one per tap
         const int ncol = d->ntaps * d->Ci;

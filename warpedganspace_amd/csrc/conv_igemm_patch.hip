@@ -12,7 +12,9 @@
 //
 // Tile = R x Wt output pixels of ONE sample (Wt = min(W, 128), R = 256 / Wt): every tile has one style vector.
 // Weights come pre-split (wgs_split_bf16) and are copied global -> LDS by DMA per (chunk, tap), double-buffered.
-// LDS: patch planes (unpadded 64-B rows, XOR-swizzled 16-B chunks) single-buffered — the next chunk's patch waits in
+// LDS: patch planes (64-B rows padded to 80 B: conflict-free ds_read_b128 with addresses that are LINEAR in the patch pixel,
+// so a tap's fragment address is one add of a per-launch table entry — the fp16 form is instruction-issue bound, PMC:
+// 4.5 VALU per MFMA with the XOR-swizzled image the DMA-fed weight stages still use) single-buffered — the next chunk's patch waits in
 // registers during the tap steps and is written between two barriers at the chunk boundary — plus two weight stages of
 // TPS taps each: one barrier per TPS taps.  The single-plane fp16 schemes spend a third of the MFMA time per tap, so they
 // take a whole tap row (TPS = 3) per step to keep the MFMAs-per-barrier ratio of the split-bf16 form (48 per wave).
@@ -29,8 +31,14 @@ namespace {
 
 using wgsconv::ConvArgs;
 
+#ifndef WGS_PABL
+#define WGS_PABL 0   // development ablations of the patch kernel (tools/build_abl.sh): 1 no weight DMA, 2 no patch global loads,
+                     // 3 no patch LDS stores, 4 no MFMA, 5 no fragment LDS reads, 6 no barriers in the tap steps, 7 no epilogue stores
+#endif
+
 constexpr int BK = 32;
-constexpr int ROW = 64;                  // bytes per LDS row and plane (32 bf16)
+constexpr int ROW = 64;                  // bytes per LDS row of a weight plane (32 x 16 bit; filled by DMA: unpadded, swizzled)
+constexpr int PROW = 80;                 // bytes per LDS row of a patch plane (filled from registers: padded, linear)
 constexpr int OOB = (int)0x80000000;
 // patch pixels the LDS image holds: 256-pixel tiles 4 x 130 = 520, 128-pixel tiles 4 x 66 = 264 (3x3 taps)
 constexpr int pmax_of(int bm) { return bm == 256 ? 528 : 272; }
@@ -43,6 +51,7 @@ struct PatchGeom {       // uniform per launch
     // 129 x 129 grids of the up-conv phases) and its patch is the full-width band of input rows those pixels touch;
     // flat == 0: rectangular R x Wt tiles (the 256-wide maps, whose full-width band would not fit)
     int flat, Wg, HW;
+    int tapoff[16];      // byte offset of tap t's rows in a patch plane: ((dy - dy_min) * PW + (dx - dx_min)) * PROW
 };
 
 // BM = 256 (8 waves, one workgroup per CU) or 128 (4 waves, 100 KB less LDS: two workgroups per CU, whose barriers,
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     constexpr int PMAX = pmax_of(BM);
     constexpr int NPL = (PMAX * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (9)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
-    constexpr int P_BYTES = PMAX * ROW;                 // one patch plane
+    constexpr int P_BYTES = PMAX * PROW;                // one patch plane
     constexpr int B_BYTES = BN * ROW;                   // one weight plane of one tap
     constexpr int B_TAP = NB * B_BYTES;
     constexpr int B_STAGE = TPS * B_TAP;
@@ -113,11 +122,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         const bool v = pp < npatch && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         p_goff[j] = v ? (((b * p.Hi + iy) * p.Wi + ix) * p.Ci + q * 4) * 4 : OOB;
     }
-    // byte offset of staging element j in the hi patch plane (recomputed at store time: 9 registers fewer across the MFMA steps)
-    auto p_loff_of = [&](int j) {
-        const int pp = (tid + j * NT) >> 3;
-        return pp < PMAX ? pp * ROW + (((q >> 1) ^ ((pp >> 2) & 3)) << 4) + ((q & 1) << 3) : -1;
-    };
+    // byte offset of staging element j in the hi patch plane: linear in j (one base register + immediates)
+    const int p_lbase = (tid >> 3) * PROW + q * 8;
+    auto p_loff_of = [&](int j) { return ((tid + j * NT) >> 3) < PMAX ? p_lbase + j * (NT / 8) * PROW : -1; };
     const float* sc_ptr = p.a_scale ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
     float4 pr_[NPL];
     // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h), folded into the style vector / undone in the epilogue
@@ -129,7 +136,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         const int cbyte = c < cpt ? c * (BK * 4) : OOB;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (WGS_PABL != 2) v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
+            else asm volatile("" : "+v"(v));
             pr_[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
         if (sc_ptr && c < cpt) {
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             uint2 h, l;
             SC::cvt4(f, h, l);
             const int lo_ = p_loff_of(j);
+            if (WGS_PABL == 3) { asm volatile("" :: "v"(h.x), "v"(h.y)); continue; }
             if (lo_ >= 0) {
                 *reinterpret_cast<uint2*>(patch + lo_) = h;
                 if (NA == 2) *reinterpret_cast<uint2*>(patch + P_BYTES + lo_) = l;
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             for (int j = 0; j < BI; ++j) {
                 const int off = (int)((unsigned)b_off[j] + delta);
                 lds_byte* d = st + (wave * BI + j) * 16 * ROW;
+                if (WGS_PABL == 1) { asm volatile("" :: "v"(off)); continue; }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, d, 16, off, 0, 0, 0);
                 if (NB == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rbl, d + B_BYTES, 16, off, 0, 0, 0);
             }
@@ -188,13 +199,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
 
     // ---- operand fragment addressing
     const int l31 = lane & 31, lh = lane >> 5;
-    int pp0[TM];             // patch pixel of this lane's row for tap offset 0
+    int pa0[TM];             // byte address (in a patch plane) of this lane's fragment row for tap offset 0, k-step 0
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + l31;
         int ty, tx;
         row_of(r, ty, tx);
-        pp0[i] = ty * g.PW + tx;
+        pa0[i] = (ty * g.PW + tx) * PROW + lh * 16;
     }
     const int bswz = (l31 >> 2) & 3;
     const int b_rd = (wn * WN + l31) * ROW;
@@ -204,7 +215,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         const unsigned char* bb = bst + stage * B_STAGE + u * B_TAP + b_rd;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int kc = ks * 2 + lh;
             frag bf[TN][NB];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -213,8 +223,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
                     bf[j][pl] = *reinterpret_cast<const frag*>(bb + pl * B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int pp = pp0[i] + tapoff;
-                const unsigned char* pa = patch + pp * ROW + ((kc ^ ((pp >> 2) & 3)) << 4);
+                const unsigned char* pa = patch + pa0[i] + tapoff + ks * 32;
                 frag af[NA];
 #pragma unroll
                 for (int pl = 0; pl < NA; ++pl) af[pl] = *reinterpret_cast<const frag*>(pa + pl * P_BYTES);
@@ -233,23 +242,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
         constexpr int G = 2 * TPS;
         int tapoff[TPS];
 #pragma unroll
-        for (int u = 0; u < TPS; ++u) {
-            const int yx = p.tap_yx[t0 + u];
-            const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
-            tapoff[u] = (dy - g.dy_min) * g.PW + (dx - g.dx_min);
-        }
+        for (int u = 0; u < TPS; ++u) tapoff[u] = g.tapoff[t0 + u];
         frag af[2][TM], bf[2][TN];
         auto load_group = [&](int gi, frag* a, frag* bq) {
             const int u = gi >> 1, ks = gi & 1;
             const unsigned char* bb = bst + stage * B_STAGE + u * B_TAP + b_rd + (ks ? bk1 : bk0);
+            if (WGS_PABL == 5) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "=v"(bq[j]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(a[i]));
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) bq[j] = *reinterpret_cast<const frag*>(bb + j * 32 * ROW);
-            const int kc = ks * 2 + lh;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int pp = pp0[i] + tapoff[u];
-                a[i] = *reinterpret_cast<const frag*>(patch + pp * ROW + ((kc ^ ((pp >> 2) & 3)) << 4));
-            }
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const frag*>(patch + pa0[i] + tapoff[u] + ks * 32);
         };
         load_group(0, af[0], bf[0]);
 #pragma unroll
@@ -258,7 +266,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(&af[gi & 1][i], &bf[gi & 1][j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) {
+                    if (WGS_PABL == 4) { asm volatile("" :: "v"(af[gi & 1][i]), "v"(bf[gi & 1][j])); continue; }
+                    acc[i][j] = SC::mma(&af[gi & 1][i], &bf[gi & 1][j], acc[i][j]);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -277,13 +288,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             if (PIPE) mma_step(stage, t);
             else {
 #pragma unroll
-                for (int u = 0; u < TPS; ++u) {
-                    const int yx = p.tap_yx[t + u];
-                    const int dy = (int)(short)(yx & 0xffff), dx = yx >> 16;
-                    mma_tap(stage, u, (dy - g.dy_min) * g.PW + (dx - g.dx_min));
-                }
+                for (int u = 0; u < TPS; ++u) mma_tap(stage, u, g.tapoff[t + u]);
             }
-            __syncthreads();                     // weight stage swap; after the last tap also: patch no longer read
+            if (WGS_PABL != 6) __syncthreads();  // weight stage swap; after the last tap also: patch no longer read
             stage ^= 1;
         }
         if (c + 1 < cpt) {
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
 template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
 void launch_patch_t(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
     typedef wgsconv::Scheme<SCH> SC;
-    const size_t sm = (size_t)SC::NA * pmax_of(BM) * ROW + (size_t)2 * TPS * SC::NB * BN * ROW;
+    const size_t sm = (size_t)SC::NA * pmax_of(BM) * PROW + (size_t)2 * TPS * SC::NB * BN * ROW;
     auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
@@ -326,7 +333,7 @@ void launch_patch(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_
     const bool tps3 = a.ntaps % 3 == 0 && !wgs_flags().patch_tps1;
     if (a.sch == 0) launch_patch_t<0, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st);
     else if (a.sch == 1) { if (tps3) launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
-    else { if (tps3 && BN <= 128) launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
+    else { if (tps3 && BN == 128 && BM == 256) launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
 }
 
 }  // namespace
@@ -372,6 +379,7 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
         const int nb = a.B * t.tiles_per_img * (a.Co / tbn);
         if (nb < 200) return;
         bm = tbm; bn = tbn; nblocks = nb; g = t;
+        for (int i = 0; i < 16; ++i) g.tapoff[i] = i < a.ntaps ? ((a.dy[i] - dy0) * t.PW + (a.dx[i] - dx0)) * PROW : 0;
     };
     if (a.Co == 128 && a.Ci <= 128 && !wgs_flags().patch_bm256) try_shape(128, 128);
     try_shape(256, 256);

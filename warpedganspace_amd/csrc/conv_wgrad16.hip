@@ -1,0 +1,212 @@
+// Weight gradient of a conv on the bf16 matrix cores with fp32-class accuracy (split-bf16 x3, conv_scheme.h Scheme<0>):
+//     dW[co][t][ci] (+)= sum over output pixels m of dy[m][co] * x[pix_t(m)][ci]
+// GEMM view: M' = Cout, N' = Cin, K' = pixels.  Both operands are k-MAJOR in memory (a pixel row is contiguous over
+// channels) while a 16-bit MFMA fragment wants 8 consecutive k per lane, so the tile is transposed IN REGISTERS while it is
+// staged: a thread loads the same 4 channels of 8 consecutive pixels (8 coalesced float4 loads: the lanes of a wave cover
+// 512 contiguous bytes of each pixel row), splits the 32 values into bf16 hi / lo and writes, per channel, the 8 k-values
+// as one 16-byte LDS store into the [channel][k] image (rows of 32 k = 64 B padded to 80 B: conflict-free ds_read_b128 of
+// the fragments, exactly the image of conv_igemm_bf16.hip).  Main loop = that kernel's: 3 x v_mfma_f32_32x32x16_bf16 per
+// product block, fp32 accumulate.  grid = (co tiles x ci tiles, taps, K splits); K splits combine with atomicAdd into the
+// caller-zeroed gradient, like the exact-fp32 kernel (conv_igemm.hip) this one replaces for the Reconstructor's 3x3 / 1x1
+// convs: 63 TFLOP/s -> see DESIGN.md.
+#include "wgs_common.h"
+#include "conv_scheme.h"
+#include "../../include/wgs.h"
+
+namespace {
+
+typedef wgsconv::sch_f32x16 f32x16;
+typedef wgsconv::sch_f32x4 f32x4;
+typedef wgsconv::Scheme<0> SC;
+typedef SC::frag frag;
+
+struct Wgrad16Args {
+    const float* x;   // [B,Hi,Wi,Ci]
+    const float* dy;  // [B,Ho,Wo,Co]
+    float* dw;        // dw[co*row_stride + wt[t]*tap_stride + ci]
+    int B, Hi, Wi, Ci, Ho, Wo, Co, isy, isx, ntaps, M, ksplit;
+    long w_tap_stride, w_row_stride;
+    signed char dy_[64], dx_[64];
+    short wt[64];
+};
+
+constexpr int BK = 32;          // pixels per chunk
+constexpr int ROWB = 80;        // bytes per LDS row: 32 bf16 + 16 B pad
+
+// BM x BN output tile (BM, BN in {64, 128}), 4 waves as 2 x 2
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args p) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;            // A_hi | A_lo | B_hi | B_lo
+    // staging units: (channel quad, pixel octet); A has BM/4 * 4 units, B has BN/4 * 4
+    constexpr int UA = BM, UB = BN, UT = UA + UB;               // units per chunk (BM/4*4 + BN/4*4)
+    constexpr int UPT = (UT + 255) / 256;                       // units per thread (1 for 128+128)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.Ci + BN - 1) / BN;
+    const int co0 = (blockIdx.x / ntn) * BM, ci0 = (blockIdx.x % ntn) * BN;
+    const int t = blockIdx.y;
+    const int dyt = p.dy_[t], dxt = p.dx_[t];
+    const int nchunks = (p.M + BK - 1) / BK;
+    const int per = (nchunks + p.ksplit - 1) / p.ksplit;
+    const int c_begin = blockIdx.z * per, c_end = min(nchunks, c_begin + per);
+    if (c_begin >= c_end) return;
+
+    // this thread's staging units
+    int u_isA[UPT], u_cq[UPT], u_po[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+        const int e = tid + u * 256;
+        const bool isA = e < UA;
+        const int f = isA ? e : e - UA;
+        const int nq = (isA ? BM : BN) / 4;
+        u_isA[u] = e < UT ? (isA ? 1 : 0) : -1;
+        u_cq[u] = f % nq;
+        u_po[u] = f / nq;
+    }
+    float4 rg[UPT][8];
+    auto load_chunk = [&](int c) {
+        const int mbase = c * BK;
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            if (u_isA[u] < 0) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = mbase + u_po[u] * 8 + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u_isA[u] == 1) {
+                    const int co = co0 + u_cq[u] * 4;
+                    if (m < p.M && co < p.Co) v = *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.Co + co);
+                } else {
+                    const int ci = ci0 + u_cq[u] * 4;
+                    if (m < p.M && ci < p.Ci) {
+                        const int ox = m % p.Wo;
+                        const int tt = m / p.Wo;
+                        const int oy = tt % p.Ho;
+                        const int b = tt / p.Ho;
+                        const int iy = oy * p.isy + dyt, ix = ox * p.isx + dxt;
+                        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+                            v = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci);
+                    }
+                }
+                rg[u][j] = v;
+            }
+        }
+    };
+    // register transpose + split + 16-byte LDS stores: channel c of the quad gets the 8 k-values {rg[j].c}
+    auto store_chunk = [&](int buf) {
+        unsigned char* base = smem_b + buf * STAGE;
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            if (u_isA[u] < 0) continue;
+            unsigned char* plane = base + (u_isA[u] == 1 ? 0 : 2 * A_BYTES);
+            const int pbytes = u_isA[u] == 1 ? A_BYTES : B_BYTES;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = cc == 0 ? rg[u][j].x : (cc == 1 ? rg[u][j].y : (cc == 2 ? rg[u][j].z : rg[u][j].w));
+                uint2 h0, l0, h1, l1;
+                SC::cvt4(f32x4{e[0], e[1], e[2], e[3]}, h0, l0);
+                SC::cvt4(f32x4{e[4], e[5], e[6], e[7]}, h1, l1);
+                const int off = (u_cq[u] * 4 + cc) * ROWB + u_po[u] * 16;
+                *reinterpret_cast<uint4*>(plane + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                *reinterpret_cast<uint4*>(plane + pbytes + off) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    load_chunk(c_begin);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        if (c + 1 < c_end) load_chunk(c + 1);
+        const unsigned char* base = smem_b + cur * STAGE;
+        const unsigned char* a_hi = base + (wm * WM + l31) * ROWB + lh * 16;
+        const unsigned char* b_hi = base + 2 * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            frag bf[TN][2], af[TM][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bf[j][0] = *reinterpret_cast<const frag*>(b_hi + j * 32 * ROWB + ks * 32);
+                bf[j][1] = *reinterpret_cast<const frag*>(b_hi + B_BYTES + j * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                af[i][0] = *reinterpret_cast<const frag*>(a_hi + i * 32 * ROWB + ks * 32);
+                af[i][1] = *reinterpret_cast<const frag*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(af[i], bf[j], acc[i][j]);
+        }
+        if (c + 1 < c_end) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+    float* out = p.dw + (size_t)p.wt[t] * p.w_tap_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + wn * WN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Co && ci < p.Ci) unsafeAtomicAdd(out + (size_t)co * p.w_row_stride + ci, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+void launch16(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
+    const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
+    auto k = igemm_wgrad16_kernel<BM, BN>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k, grid, dim3(256), sm, st, a);
+}
+
+}  // namespace
+
+// precision-1 form of wgs_conv_wgrad (called from conv_igemm.hip); returns 0 when it took the launch, 1 when the shape is
+// left to the exact kernel (few input channels / flattened taps, channel counts that are not multiples of 64)
+int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st) {
+    if (d->Ci % 64 != 0 || d->Co % 64 != 0 || d->ntaps > 64) return 1;
+    Wgrad16Args a;
+    a.x = d->x; a.dy = d->dy; a.dw = d->dw;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
+    a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
+    for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
+    const int BM = d->Co >= 128 ? 128 : 64, BN = d->Ci >= 128 ? 128 : 64;
+    const int tiles = ((d->Co + BM - 1) / BM) * ((d->Ci + BN - 1) / BN);
+    const int nchunks = (a.M + BK - 1) / BK;
+    int ks = d->ksplit;
+    if (ks <= 0) {
+        ks = (1024 + tiles * d->ntaps - 1) / (tiles * d->ntaps);
+        if (ks > nchunks / 4) ks = nchunks / 4;
+        if (ks < 1) ks = 1;
+    }
+    a.ksplit = ks;
+    dim3 grid((unsigned)tiles, (unsigned)d->ntaps, (unsigned)ks);
+    if (BM == 128 && BN == 128) launch16<128, 128>(a, grid, st);
+    else if (BM == 128) launch16<128, 64>(a, grid, st);
+    else if (BN == 128) launch16<64, 128>(a, grid, st);
+    else launch16<64, 64>(a, grid, st);
+    return 0;
+}

@@ -35,6 +35,12 @@ R_PRECISION = 1 if os.environ.get('WGS_R_PRECISION', 'fp32').lower() in ('bf16x3
 # a smooth perturbation there (this includes conv1's image gradient, which with only 6(+2) output channels runs 75 %-empty
 # MFMA tiles either way).  WGS_R_DGRAD_PRECISION=fp32 restores the exact kernels.
 R_DGRAD_PRECISION = 0 if os.environ.get('WGS_R_DGRAD_PRECISION', 'bf16x3').lower() in ('fp32', '0') else 1
+# Arithmetic of R's weight-gradient contractions (over pixels; gates and statistics are fixed by the forward, the result is
+# linear in dy like the input gradients): split-bf16 x3 (~1e-5 relative) for the layers with >= 128 channels on both sides,
+# where the transposing 16-bit kernel measures 1.2-1.3x the exact one (62-90 vs 55-70 TFLOP/s; at 64 channels its staging
+# costs more than the MFMAs save: 45-50 vs 63 TFLOP/s, so those layers and conv1 keep the exact kernel).
+# WGS_R_WGRAD_PRECISION=fp32 selects the exact kernel everywhere.
+R_WGRAD_PRECISION = 0 if os.environ.get('WGS_R_WGRAD_PRECISION', 'bf16x3').lower() in ('fp32', '0') else 1
 
 
 def _conv(ci, co, k, stride, pad):
@@ -253,10 +259,11 @@ class Reconstructor(nn.Module):
         # Weight gradients are not on the path to the image gradient.  With `deferred` (a list) they are queued as closures
         # and the caller runs them where it likes (TrainStep: on a side stream, next to the generator's backward).
         def wgrad(x, dy, dw, k, stride, pad):
+            prec = R_WGRAD_PRECISION if min(x.shape[-1], dy.shape[-1]) >= 128 else 0
             if deferred is None:
-                C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad)
+                C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad, precision=prec)
             else:
-                deferred.append((x, dy, lambda: C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad)))
+                deferred.append((x, dy, lambda: C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad, precision=prec)))
 
         feat = S['feat']
         dmag = dmag.reshape(B, 1)
