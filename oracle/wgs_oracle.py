@@ -372,13 +372,15 @@ class ReferenceStep:
     def __init__(self, sd_g, sd_s, sd_r, size, learn_gammas=True, gamma=None, lambda_cls=1.0, lambda_reg=0.25,
                  lr_s=1e-4, lr_r=1e-4, shift_in_w_space=False, g_requires_grad=True, reconstructor='ResNet',
                  generator='StyleGAN2', gen_kwargs=None):
-        """generator: 'StyleGAN2' (size = resolution), 'SNGAN' (gen_kwargs: channels=...), 'ProgGAN' (num_blocks=...)."""
+        """generator: 'StyleGAN2' (size = resolution), 'SNGAN' (gen_kwargs: channels=...), 'ProgGAN' (num_blocks=...),
+        'BigGAN' (gen_kwargs: class_ids=..., resolution=...)."""
         self.size, self.learn_gammas, self.gamma = size, learn_gammas, gamma
         self.lc, self.lr_, self.w_space, self.rtype = lambda_cls, lambda_reg, shift_in_w_space, reconstructor
         self.gtype, self.gkw = generator, (gen_kwargs or {})
         self.g = {k: v.detach().clone().requires_grad_(g_requires_grad and v.is_floating_point() and
                                                         not k.startswith('noises.') and not k.endswith('kernel') and
-                                                        'running' not in k)
+                                                        'running' not in k and 'stored' not in k and not k.endswith('.u0') and
+                                                        not k.endswith('.sv0'))
                   for k, v in sd_g.items()}
         self.s = {k: v.detach().clone() for k, v in sd_s.items()}
         self.s['SUPPORT_SETS'].requires_grad_(True)
@@ -400,6 +402,9 @@ class ReferenceStep:
             return sngan_generate(self.g, z, shift, **self.gkw)
         if self.gtype == 'ProgGAN':
             return proggan_generate(self.g, z, shift, **self.gkw)
+        if self.gtype == 'BigGAN':      # gen_kwargs: class_ids (fixed per sample here; the wrapper draws them), resolution
+            kw = dict(self.gkw)
+            return biggan_generate(self.g, z, kw.pop('class_ids'), shift, **kw)
         raise ValueError(self.gtype)
 
     def step(self, z, idx, mag):
@@ -513,12 +518,14 @@ def _sn_weight(sd, prefix, eps):
 def biggan_generate(sd, z, class_ids, shift=None, ch=96, resolution=128, shared_dim=128, attention_res=64, bn_eps=1e-5,
                     sn_eps=1e-6, bottom_width=4):
     """BigGANWrapper.forward (models/gan_load.py:79-81) + Generator.forward with hier=True, G_shared=True."""
-    arch = {128: ([16, 16, 8, 4, 2], [16, 8, 4, 2, 1], [8, 16, 32, 64, 128])}[resolution]
+    # channel plans of models/BigGAN/BigGAN.py:23-36 (in multiples of ch, out multiples, block output resolutions)
+    arch = {128: ([16, 16, 8, 4, 2], [16, 8, 4, 2, 1], [8, 16, 32, 64, 128]),
+            256: ([16, 16, 8, 8, 4, 2], [16, 8, 8, 4, 2, 1], [8, 16, 32, 64, 128, 256])}[resolution]
     z = z if shift is None else z + shift
     y = F.embedding(class_ids, sd['shared.weight'])
     nslots = len(arch[0]) + 1
-    cs = z.shape[1] // nslots
-    zs = torch.split(z, cs, 1)
+    cs = z.shape[1] // nslots           # BigGAN.py:106-108: dim_z is truncated to a multiple of the slot count (120 -> 119 at 256)
+    zs = torch.split(z[:, :cs * nslots], cs, 1)
     ys = [torch.cat([y, item], 1) for item in zs[1:]]
     h = F.linear(zs[0], _sn_weight(sd, 'linear', sn_eps), sd['linear.bias'])
     h = h.view(h.size(0), -1, bottom_width, bottom_width)

@@ -126,11 +126,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     const int p_lbase = (tid >> 3) * PROW + q * 8;
     auto p_loff_of = [&](int j) { return ((tid + j * NT) >> 3) < PMAX ? p_lbase + j * (NT / 8) * PROW : -1; };
     const float* sc_ptr = p.a_scale ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
+    constexpr bool PIPE = (NA == 1 && NB == 1);       // single-plane (fp16) form: hand-pipelined steps, counted waits
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_scale ? p.a_scale : p.x), 0, p.a_scale ? p.s_bytes : 0, 0x00020000);
     float4 pr_[NPL];
     // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h), folded into the style vector / undone in the epilogue
     float op_mult = 1.f, op_inv = 1.f;
     if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_bound, op_mult, op_inv);
-    float4 sc = make_float4(op_mult, op_mult, op_mult, op_mult);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
     const int cpt = p.Ci / BK;
     auto load_patch = [&](int c) {
         const int cbyte = c < cpt ? c * (BK * 4) : OOB;
@@ -141,10 +143,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             else asm volatile("" : "+v"(v));
             pr_[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
-        if (sc_ptr && c < cpt) {
-            sc = *reinterpret_cast<const float4*>(sc_ptr + c * BK);
-            if (SCH != 0) { sc.x *= op_mult; sc.y *= op_mult; sc.z *= op_mult; sc.w *= op_mult; }
-        }
+        // (no use of the loaded style vector here: touching it would make the compiler wait for it — and, vmcnt being in-order,
+        // for the nine patch loads in front of it — at the top of every chunk; the operand scale is applied in store_patch)
+        if (PIPE) {      // always exactly one VMEM operation (the step barrier below counts them); range-checked past the end
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsc, (sc_ptr && c < cpt) ? (b * p.a_ld + q * 4 + c * BK) * 4 : OOB, 0, 0);
+            if (sc_ptr && c < cpt) sc = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else if (sc_ptr && c < cpt) sc = *reinterpret_cast<const float4*>(sc_ptr + c * BK);
     };
     auto store_patch = [&]() {
 #pragma unroll
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             float4 v = pr_[j];
             v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
             asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (no fma into the residual)
+            if (SCH != 0) { v.x *= op_mult; v.y *= op_mult; v.z *= op_mult; v.w *= op_mult; }   // power of two: exact
             const f32x4 f = {v.x, v.y, v.z, v.w};
             uint2 h, l;
             SC::cvt4(f, h, l);
@@ -237,7 +242,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     // and the compiler's own schedule is {ds_read A; wait; TN MFMAs} per fragment, i.e. the latency is exposed every time.
     // So the step is software-pipelined by hand over its 2*TPS (tap, k-step) groups: the TM + TN fragment reads of group
     // g+1 are issued before the TM*TN MFMAs of group g (two register sets, pinned with sched_barrier).
-    constexpr bool PIPE = (NA == 1 && NB == 1);
     auto mma_step = [&](int stage, int t0) {
         constexpr int G = 2 * TPS;
         int tapoff[TPS];
@@ -281,16 +285,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     __syncthreads();
     int stage = 0;
     for (int c = 0; c < cpt; ++c) {
-        load_patch(c + 1);                       // waits in registers through the tap steps (OOB past the last chunk)
+        if (!PIPE) load_patch(c + 1);            // waits in registers through the tap steps (OOB past the last chunk)
         for (int t = 0; t < p.ntaps; t += TPS) {
             const bool last = (t + TPS >= p.ntaps);
             issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + TPS);
-            if (PIPE) mma_step(stage, t);
-            else {
+            if (PIPE) {
+                // The next chunk's patch loads go out BEHIND the first step's weight DMAs: vmcnt retires in order, so that
+                // step's barrier can wait for the DMAs only (vmcnt(NPL + 1)) and leave the HBM-latency loads in flight for
+                // a second step — with 48 single MFMAs per step (~1.6 us) one step does not cover an HBM miss under load.
+                if (t == 0) load_patch(c + 1);
+                mma_step(stage, t);
+                if (t == 0 && !last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (WGS_PABL != 6) __builtin_amdgcn_s_barrier();
+            } else {
 #pragma unroll
                 for (int u = 0; u < TPS; ++u) mma_tap(stage, u, g.tapoff[t + u]);
+                if (WGS_PABL != 6) __syncthreads();  // weight stage swap; after the last tap also: patch no longer read
             }
-            if (WGS_PABL != 6) __syncthreads();  // weight stage swap; after the last tap also: patch no longer read
             stage ^= 1;
         }
         if (c + 1 < cpt) {
