@@ -45,13 +45,17 @@ import torch.distributed as dist
 GFLOP_PER_IMG = {'stylegan2-256': 285.8, 'stylegan2-1024': 687.8, 'proggan-1024': 498.7, 'proggan-256': 184.3, 'biggan-128': 127.5}
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf16,f16}, dense (no sparsity)
-MFMA_PER_PRODUCT = {'fp32': 1.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}
+MFMA_PER_PRODUCT = {'fp32': 1.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}        # per launch label (a 'mixed' run has all three 16-bit kinds)
 DTYPE_TEXT = {
     'fp32': "fp32 (f32-input MFMA, f32 accumulate) everywhere",
     'bf16x3': "bf16x3: generator convs split every fp32 operand into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (~2^-16)",
     'f16': "f16: generator convs round operands to fp16 (dynamic power-of-two scale on gradient operands), 1 fp16 MFMA per product, "
            "fp32 accumulate / demodulation / epilogue (image error vs the fp32 reference ~4e-4, gate 1e-3)",
     'f16x2': "f16x2: as f16 with the frozen weights as fp16 hi+lo, 2 fp16 MFMAs per product",
+    'mixed': "mixed fp16: per-layer arithmetic of the generator by an image-error budget (gate 1e-3) - the stride-1 3x3 convs at >= 64x64 "
+             "(64 % of the MACs) round both operands to fp16 (1 MFMA per product), the up-convs at >= 64x64 use fp16 activations x fp16 hi+lo "
+             "weights (2 MFMAs), the seven layers below 64x64 split-bf16 (3 MFMAs, fp32-class); fp32 accumulate / demodulation / epilogue "
+             "everywhere; dynamic power-of-two scale on fp16 gradient operands",
 }
 R_TEXT = "; reconstructor: exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs"
 
@@ -127,10 +131,13 @@ def conv_profile(eng, nprof=2):
 
 
 def roofline_of(by, precision, img_per_s_per_gpu, gflop_per_img):
-    gen = {k: v for k, v in by.items() if k.startswith('conv ' + precision + ' ')}
+    # the generator's conv family: the launches in the run's arithmetic ('mixed': every 16-bit kind)
+    kinds = ('f16', 'f16x2', 'bf16x3') if precision == 'mixed' else (precision,)
+    gen = {k: v for k, v in by.items() if k.startswith('conv ') and k.split()[1] in kinds}
     pool = gen if gen else by
     dom = max(pool, key=lambda k: pool[k][1])
     fl, ms, n = pool[dom]
+    precision = dom.split()[1] if dom.startswith('conv ') else precision        # the dominant launch's own arithmetic
     peak = FP32_MFMA_PEAK_TF if precision == 'fp32' else F16_MFMA_PEAK_TF
     tf = fl / ms / 1e9
     g_fl, g_ms = sum(v[0] for v in gen.values()), sum(v[1] for v in gen.values())
@@ -274,6 +281,7 @@ EXTRA = [   # (name, gan, size, K, N, batch, precision or None = headline's, w_s
     ("cfg3 StyleGAN2-256 bf16x3", 'stylegan2', 256, 128, 32, 32, 'bf16x3', False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 mixed fp16", 'stylegan2', 256, 128, 32, 32, 'mixed', False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 W-space", 'stylegan2', 256, 128, 32, 32, None, True, 10, 'stylegan2-256'),
     ("cfg2 ProgGAN native 1024, K=64 N=16 B=32", 'proggan', 1024, 64, 16, 32, None, False, 4, 'proggan-1024'),
     ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32", 'proggan', 256, 64, 16, 32, None, False, 8, 'proggan-256'),

@@ -173,3 +173,24 @@ def test_f16_dynamic_operand_scale_range(dev):
         assert rel_err(y2 / mag, ref) < 1e-3
     tiny = C.conv2d(g0 * 1e-9, wp, 3, pad=1, precision=2, w_split=ws)     # no bound: below fp16's subnormals -> all zero
     assert float(tiny.abs().max()) == 0.0
+
+
+def test_f16_patch_kernel_is_stable_across_repeated_launches(dev):
+    """Regression (round 2): a counted s_waitcnt that left the patch loads in flight across the weight-stage barrier relied on
+    LDS-DMA and VGPR loads retiring in issue order; they do not, and the 128->128 @256x256 gradient conv (shortest K loop, two
+    workgroups per CU) read stale weight stages from its second launch on.  Every launch must reproduce the first one."""
+    torch.manual_seed(0)
+    for B, ci, co, h in [(2, 128, 128, 256), (8, 128, 128, 256), (2, 256, 256, 128)]:
+        w = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
+        wt = C.repack_w_t(w, co, 9, ci)
+        ws = C.split_weight(wt, 2)
+        g = torch.randn(B, h, h, co, device=dev) * 1e-5
+        am = g.abs().max().reshape(1)
+        ref = C.conv2d_dgrad(g, wt, (h, h), 3, pad=1, precision=1)
+        first = None
+        for rep in range(6):
+            d = C.conv2d_dgrad(g, wt, (h, h), 3, pad=1, precision=2, w_split=ws, a_amax=am)
+            assert rel_err(d, ref) < 1e-3, (B, ci, h, rep, rel_err(d, ref))
+            if first is None:
+                first = d
+            assert torch.equal(d, first), (B, ci, h, rep)

@@ -42,7 +42,7 @@ def test_image_and_shared_gate_gradient_per_scheme(dev, size, B):
     old = C.PRECISION
     rows = {}
     try:
-        for name in ('fp32', 'bf16x3', 'f16', 'f16x2'):
+        for name in ('fp32', 'bf16x3', 'f16', 'f16x2', 'mixed'):
             C.set_precision(name)
             res = {}
             for w_space in (True, False):
@@ -149,7 +149,7 @@ def test_fp16_image_error_distribution(dev, family):
         with torch.no_grad():
             C.set_precision('fp32')
             ref = G(z)
-            for name in ('bf16x3', 'f16', 'f16x2'):
+            for name in ('bf16x3', 'f16', 'f16x2', 'mixed'):
                 C.set_precision(name)
                 img = G(z)
                 e = ((img - ref).abs().flatten(1).max(1).values / ref.abs().flatten(1).max(1).values).cpu()

@@ -44,13 +44,28 @@ class WgradDesc(ctypes.Structure):
 # Set with set_precision() / train.py --precision / bench.py --precision, or WGS_CONV_PRECISION at import.
 #  -1 'auto'   per generator: the cheapest mode whose measured image error stays inside the north_star's 1e-3 gate for that
 #              architecture (tests/test_precision_schemes_gpu.py): see AUTO_TABLE
-PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3}
+#   4 'mixed'  StyleGAN2 only — per-layer arithmetic by an error budget: every fp16 layer adds an independent ~2.5e-4 (f16) or
+#              ~1.7e-4 (f16x2) to the image error, and 91 % of the generator's MACs sit in the six layers at >= 64x64, so
+#              those run in fp16 (f16 for the stride-1 convs, f16x2 for the up-convs, which are not MFMA-bound) and the seven
+#              low-resolution layers (9 % of the MACs, latency-bound) in bf16x3: the image error of f16x2 at ~the speed of f16.
+#              Other generators treat 'mixed' as f16x2.
+PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'mixed': 4}
 DEFAULT_PRECISION = 'auto'
 AUTO = -1
 # (generator family, output resolution) -> mode for 'auto'.  Error accumulates with depth (each fp16 layer adds ~2e-4):
 # StyleGAN2-256 (13 modulated 3x3 layers) measures 7e-4 .. 9e-4 in f16, StyleGAN2-1024 (17 layers) 1.5e-3 -> split-bf16 there.
-AUTO_TABLE = {('stylegan2', 256): 'f16', ('stylegan2', 128): 'f16', ('stylegan2', 64): 'f16', ('stylegan2', 32): 'f16',
-              ('proggan', 256): 'f16'}       # ProgGAN truncated to 256^2: 4e-4; BigGAN-128 measures 1.3e-3 .. 1.7e-3 in f16 -> fallback
+AUTO_TABLE = {('stylegan2', 256): 'mixed', ('stylegan2', 128): 'mixed', ('stylegan2', 64): 'mixed', ('stylegan2', 32): 'f16x2',
+              ('proggan', 256): 'f16x2'}
+MIXED = 4
+
+
+def layer_precision(code, out_res, is_up):
+    """Concrete arithmetic of one StyleGAN2 layer under mode `code` (see 'mixed' above)."""
+    if code != MIXED:
+        return code
+    if out_res < 64:
+        return 1
+    return 3 if is_up else 2
 AUTO_FALLBACK = 'bf16x3'
 
 
@@ -77,6 +92,8 @@ class resolved:
 
 
 def precision_code(name):
+    if isinstance(name, int) and name == -1:
+        return name
     if isinstance(name, int):
         if name not in PRECISION_NAMES.values():
             raise L.WgsError("unknown conv precision %r" % (name,))
@@ -207,6 +224,8 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     prec = PRECISION if precision is None else precision
     if prec == AUTO:           # a bare conv call outside a generator: the fp32-class mode
         prec = PRECISION_NAMES[AUTO_FALLBACK]
+    if prec == MIXED:          # per-layer policies are resolved by the generator (stylegan2.py); elsewhere: fp16 x2
+        prec = 3
     if (grad_operand or _GRAD_CTX) and prec >= 2 and a_amax is None:
         # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
         prec = 1

@@ -290,15 +290,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
             const bool last = (t + TPS >= p.ntaps);
             issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + TPS);
             if (PIPE) {
-                // The next chunk's patch loads go out BEHIND the first step's weight DMAs: vmcnt retires in order, so that
-                // step's barrier can wait for the DMAs only (vmcnt(NPL + 1)) and leave the HBM-latency loads in flight for
-                // a second step — with 48 single MFMAs per step (~1.6 us) one step does not cover an HBM miss under load.
+                // The next chunk's patch loads go out behind the first step's weight DMAs.  NOTE (measured, round 2): a COUNTED
+                // wait here — vmcnt(NPL + 1), "DMAs landed, patch loads still in flight" — is WRONG on gfx950: LDS-DMA loads
+                // (buffer_load ... lds) and VGPR-destination loads do not retire in issue order relative to each other, so the
+                // count does not prove that the older DMAs have landed (sporadic stale weight stages: errors of 0.2, NaNs; found
+                // by the shared-gate gradient test, reproduced in isolation on the 128->128 @256^2 dgrad).  Everything is drained.
                 if (t == 0) load_patch(c + 1);
                 mma_step(stage, t);
-                if (t == 0 && !last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL + 1) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 if (WGS_PABL != 6) __builtin_amdgcn_s_barrier();
+                // the bare s_barrier intrinsic does not order memory operations for the compiler (unlike __syncthreads(), whose
+                // fences would drain the patch loads): pin the next step's DMA issue and fragment reads behind it
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             } else {
 #pragma unroll
                 for (int u = 0; u < TPS; ++u) mma_tap(stage, u, g.tapoff[t + u]);

@@ -316,8 +316,9 @@ class Generator(nn.Module):
             s_view = S[:, ly['off']:]
             demod = demods[i]
             H = x.shape[1]
+            lp = C.layer_precision(C.PRECISION, 2 * H if ly['up'] else H, ly['up'])      # 'mixed': per-layer arithmetic
             if ly['up']:
-                t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'])
+                t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'], precision=lp)
                 y = torch.empty(B, 2 * H, 2 * H, Co, device=dev)
                 L.check(lib.wgs_sg2_blur_noise_bias_act(L.ptr(t), L.ptr(ly['blur']), L.ptr(ly['noise']),
                                                         L.ptr(ly['noise_w']), L.ptr(ly['bias']), L.ptr(y), B, 2 * H, 2 * H,
@@ -325,7 +326,7 @@ class Generator(nn.Module):
                 del t
             else:
                 y = C.conv2d(x, ly['wp'], 3, pad=1, a_scale=s_view, a_ld=sumC, col_scale=demod, noise=ly['noise'],
-                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'])
+                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'], precision=lp)
             outs.append(y)
             x = y
             if i % 2 == 0:
@@ -389,12 +390,13 @@ class Generator(nn.Module):
                     g = ops.upfirdn2d_mhwc(dskip.reshape(B * 3, Hc, Hc, 1), r['upk_f'], 1, 1, 2, 2, 1, 1, 1, 1)
                     dskip = g.reshape(B, 3, Hc // 2, Hc // 2)
             # input gradient of this layer (un-scaled by its own style: the producer applies it)
+            lp = C.layer_precision(C.PRECISION, Hc, ly['up'])
             if ly['up']:
                 dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)     # |dt| <= 4 max|dy|: the kernel sums to 4
-                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0)
+                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp)
                 del dt
             else:
-                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0)
+                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0, precision=lp)
             del dy
             sA_off, num_next = ly['off'], num
         # bottom layer: its input is the ConstantInput -> only the style gradient remains
