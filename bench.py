@@ -218,7 +218,7 @@ def hbm_subpaths(eng, dev, B):
     C_, H = 128, 256
     tin = torch.randn(B, H + 1, H + 1, C_, device=dev); y = torch.empty(B, H, H, C_, device=dev)
     k4 = torch.ones(4, 4, device=dev) / 16; nz = torch.randn(H * H, device=dev); nw = torch.ones(1, device=dev); bias = torch.zeros(C_, device=dev)
-    t = timed(lambda: L.check(lib.wgs_sg2_blur_noise_bias_act(L.ptr(tin), L.ptr(k4), L.ptr(nz), L.ptr(nw), L.ptr(bias), L.ptr(y),
+    t = timed(lambda: L.check(lib.wgs_sg2_blur_noise_bias_act(L.ptr(tin), L.ptr(k4), L.ptr(nz), L.ptr(nw), L.ptr(bias), L.ptr(y), None,
                                                               B, H, H, C_, st), 'blur'))
     by = (tin.numel() + y.numel()) * 4
     out['blur_noise_bias_act_256'] = {"bytes": by, "us": round(t * 1e6, 1), "GB/s": round(by / t / 1e9, 1)}

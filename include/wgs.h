@@ -164,6 +164,10 @@ typedef struct wgs_conv_desc {
                                 before rounding it to fp16 and multiply the accumulators by 2^-k: gradients (dgrad launches) of
                                 any magnitude keep 11 significant bits and cannot overflow.  NULL: no scaling (k = 0). */
     float a_bound;           /* bound of |a_scale| (and of any linear map the caller folded into x after measuring m); 0 = 1 */
+    const float* a_amax2;    /* optional second device scalar multiplied into the bound (forward launches: max |a_scale|) */
+    float* y_amax;           /* precision >= 1: optional device scalar (caller-zeroed) raised (atomic max) to max |y| of this launch
+                                — chained into the next layer's a_amax, so that a forward pass in the fp16 modes cannot overflow
+                                whatever the magnitude of a checkpoint's activations */
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
 /* n launches that share every operand and differ only in (Hg, Wg, oy0, ox0, taps) — the 4 sub-pixel phases of a
@@ -235,8 +239,9 @@ int wgs_linear_wgrad(const float* gy, const float* x, float* dw, float* db, int 
 
 /* Blur(4x4, pad (1,1)) after the transposed conv (:165,212) fused with NoiseInjection (:231-241) and
  * FusedLeakyReLU (:264): x [B,Ho+1,Wo+1,C] NHWC -> y [B,Ho,Wo,C]. */
+/* y_amax: optional device scalar (caller-zeroed) raised to max |y| — the next layer's wgs_conv_desc.a_amax. */
 int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const float* noise, const float* noise_w,
-                                const float* bias, float* y, int B, int Ho, int Wo, int C, wgs_stream_t stream);
+                                const float* bias, float* y, float* y_amax, int B, int Ho, int Wo, int C, wgs_stream_t stream);
 
 /* ToRGB (:270-282): img[b,o,p] = wscale * sum_c x[b,p,c] s[b,c] w[o,c] + bias[o] + (skip ? skip[b,o,p] : 0).
  * x NHWC [B,P,C]; img/skip NCHW [B,3,P]. C power of two. */

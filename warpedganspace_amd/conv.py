@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
                 ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
                 ('w_hi', ctypes.c_void_p), ('w_lo', ctypes.c_void_p),
                 ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64),
-                ('a_amax', ctypes.c_void_p), ('a_bound', ctypes.c_float)]
+                ('a_amax', ctypes.c_void_p), ('a_bound', ctypes.c_float), ('a_amax2', ctypes.c_void_p), ('y_amax', ctypes.c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -55,7 +55,7 @@ AUTO = -1
 # (generator family, output resolution) -> mode for 'auto'.  Error accumulates with depth (each fp16 layer adds ~2e-4):
 # StyleGAN2-256 (13 modulated 3x3 layers) measures 7e-4 .. 9e-4 in f16, StyleGAN2-1024 (17 layers) 1.5e-3 -> split-bf16 there.
 AUTO_TABLE = {('stylegan2', 256): 'mixed', ('stylegan2', 128): 'mixed', ('stylegan2', 64): 'mixed', ('stylegan2', 32): 'f16x2',
-              ('proggan', 256): 'f16x2'}
+              ('proggan', 256): 'f16'}       # ProgGAN-256 measures 4.1e-4 (max of 32 samples) in f16; BigGAN-128 1.3e-3 .. 1.7e-3 -> fallback
 MIXED = 4
 
 
@@ -206,7 +206,7 @@ def _timed(kind, flops, fn):
 def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None, w_split=None,
-          a_amax=None, a_bound=1.0, grad_operand=False):
+          a_amax=None, a_bound=1.0, grad_operand=False, a_amax2=None, y_amax=None):
     """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
         raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
@@ -230,7 +230,7 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
         # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
         prec = 1
     d.precision = prec
-    d.a_amax, d.a_bound = _p(a_amax), a_bound
+    d.a_amax, d.a_bound, d.a_amax2, d.y_amax = _p(a_amax), a_bound, _p(a_amax2), _p(y_amax)
     if isinstance(w_split, SplitCache):
         w_split = w_split.get(prec)
     d.w_tap_stride, d.w_row_stride = w_tap_stride, w_row_stride

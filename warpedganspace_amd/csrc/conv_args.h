@@ -32,6 +32,8 @@ struct ConvArgs {
     int sch;                        // operand scheme (conv_scheme.h): precision - 1
     const float* a_amax;            // fp16 schemes: device scalar bounding |x| (dynamic power-of-two operand scale), or null
     float a_bound;                  // ... times this factor (bound of |a_scale|, blur gain ...)
+    const float* a_amax2;           // ... times this optional second device scalar (bound of |a_scale| in forward launches)
+    float* y_amax;                  // optional device scalar raised (atomic max) to max |y| of this launch: the next layer's a_amax
     const unsigned short* a_hi;     // split (and style-modulated) activation planes: set by launch_bf16x3 (LDS-DMA path)
     const unsigned short* a_lo;
     float* ws;          // split-K workspace or null
@@ -86,7 +88,7 @@ void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, un
                 int C, hipStream_t st);
 // the same for the fp16 schemes: hi = f16(x * s * mult), lo = f16(residual) (lo may be null); mult from (a_amax, a_bound)
 void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
-               int C, const float* a_amax, float a_bound, hipStream_t st);
+               int C, const float* a_amax, const float* a_amax2, float a_bound, hipStream_t st);
 void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st);
 
 // patch form for stride-1 convs (conv_igemm_patch.hip); 0 = launch taken.  Needs x_bytes / w_bytes (fp32 extents) and the

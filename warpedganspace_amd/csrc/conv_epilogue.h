@@ -42,6 +42,7 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
             }
             const int rowbytes = p.Co * 4;
             const float slope = p.act_slope, gain = p.gain;
+            float vmax = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -56,13 +57,19 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
                         v *= cs[j];
                         v += nz + bs[j];
                         v = fmaxf(v, v * slope) * gain;           // == (v > 0 ? v : v * slope) * gain for slope in [0, 1]
+                        vmax = fmaxf(vmax, pix >= 0 ? fabsf(v) : 0.f);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)((unsigned)ro + (unsigned)noff[j]), 0, 0);
                     }
                 }
             }
+            if (p.y_amax) {      // magnitude bound for the next layer's fp16 operand scale: one atomic per wave
+                vmax = wave_max(vmax);
+                if (l31 == 0 && lh == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.y_amax), __float_as_uint(vmax));
+            }
             return;
         }
     }
+    float vmax_s = 0.f;
     const bool cs_fast = p.col_scale && (b_hi2 - b_lo <= 1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -86,11 +93,13 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
                     v += r_nz[row] + bias;
                     if (p.addend) v += p.addend[(size_t)r_add[row] * p.Co + n];
                     v = (p.act == 1) ? tanhf(v) : (v > 0.f ? v : v * p.act_slope) * p.gain;
+                    vmax_s = fmaxf(vmax_s, fabsf(v));
                     p.y[(size_t)pix * p.Co + n] = v;
                 }
             }
         }
     }
+    if (p.y_amax && vmax_s > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.y_amax), __float_as_uint(vmax_s));
 }
 
 template <int BM, int TM, int TN, int WM, int WN>

@@ -531,7 +531,7 @@ int wgs_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_st
 
 int wgs_split_f16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && hi && n > 0 && n % 4 == 0, "wgs_split_f16: bad arguments (n %% 4)");
-    wgsconv::split_f16(x, nullptr, 0, hi, lo, 1, (long)n, 4, nullptr, 1.f, (hipStream_t)stream);
+    wgsconv::split_f16(x, nullptr, 0, hi, lo, 1, (long)n, 4, nullptr, nullptr, 1.f, (hipStream_t)stream);
     WGS_CHECK_LAUNCH("modcvt_f16_kernel");
     return WGS_OK;
 }
@@ -574,6 +574,8 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     a.sch = d->precision > 0 ? d->precision - 1 : 0;
     a.a_amax = d->precision >= 2 ? d->a_amax : nullptr;
     a.a_bound = d->a_bound > 0.f ? d->a_bound : 1.f;
+    a.a_amax2 = d->precision >= 2 ? d->a_amax2 : nullptr;
+    a.y_amax = d->precision >= 1 ? d->y_amax : nullptr;
     wgsconv::fill_tap_tables(a);
     return WGS_OK;
 }

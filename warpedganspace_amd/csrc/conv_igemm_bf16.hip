@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4) ? 
     const int Hup = p.Hi << p.ups, Wup = p.Wi << p.ups;
     // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h); undone on the accumulators
     float op_mult = 1.f, op_inv = 1.f;
-    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_bound, op_mult, op_inv);
+    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);
 
     // K order: channel chunk OUTER, tap INNER — consecutive iterations re-read the same pixels' channel chunk shifted
     // by one tap, so a tile's activation working set per chunk (~17 KB) stays in L1/L2 across the taps, and the
@@ -371,6 +371,10 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArg
         o[k] = (p.act == 1) ? tanhf(u) : (u > 0.f ? u : u * p.act_slope) * p.gain;
     }
     *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + hw) * p.Co + n) = make_float4(o[0], o[1], o[2], o[3]);
+    if (p.y_amax) {     // magnitude bound for the next layer's fp16 operand scale
+        const float am = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        if (am > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.y_amax), __float_as_uint(am));
+    }
 }
 
 // fill ph[0] of a single-phase launch from the main fields (after the row padding decision)
@@ -463,7 +467,7 @@ static bool try_dma(ConvArgs& a, int bn, int nblocks, hipStream_t st) {
     unsigned short* hi = reinterpret_cast<unsigned short*>(a.ws);
     unsigned short* lo = hi + elems;
     if (a.sch == 0) split_bf16(a.x, a.a_scale, a.a_ld, hi, lo, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, st);
-    else split_f16(a.x, a.a_scale, a.a_ld, hi, nullptr, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, a.a_amax, a.a_bound, st);
+    else split_f16(a.x, a.a_scale, a.a_ld, hi, nullptr, a.B, (long)a.Hi * a.Wi * a.Ci, a.Ci, a.a_amax, a.a_amax2, a.a_bound, st);
     a.a_hi = hi; a.a_lo = lo;
     a.x_bytes /= 2; a.w_bytes /= 2;            // extents of the bf16 planes
     launch_dma_bf16x3(a, bn, nblocks, st);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(
     const int kc0 = ((0 + lh) ^ swz) * 16, kc1 = ((2 + lh) ^ swz) * 16;       // byte offset of this lane's 8 k-values, k-step 0 / 1
     const int a_rd = (wm * WM + l31) * ROW, b_rd = NA * A_BYTES + (wn * WN + l31) * ROW;
     float op_mult = 1.f, op_inv = 1.f;       // fp16 schemes: the pre-pass scaled the activations by op_mult (conv_scheme.h)
-    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_bound, op_mult, op_inv);
+    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);
 
     // Multiply stage `cur` while the DMA of the next chunk is issued into stage `nxt` between the first MFMA slots; the
     // operand fragments of slot s+1 are read from LDS before the MFMAs of slot s.
@@ -194,9 +194,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(
 // fp16 schemes: hi = f16_rn(v * mult), lo = f16_rn(residual) (lo may be null) of v = x * style; mult: conv_scheme.h
 __global__ __launch_bounds__(256) void modcvt_f16_kernel(const float* __restrict__ x, const float* __restrict__ s, int s_ld,
                                                          unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
-                                                         long per_sample4, int c4n, long total4, const float* a_amax, float a_bound) {
+                                                         long per_sample4, int c4n, long total4, const float* a_amax, const float* a_amax2,
+                                                         float a_bound) {
     float mult, inv;
-    wgsconv::operand_scale(a_amax, a_bound, mult, inv);
+    wgsconv::operand_scale(a_amax, a_amax2, a_bound, mult, inv);
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
         float4 v = reinterpret_cast<const float4*>(x)[e];
         if (s) {
@@ -262,11 +263,11 @@ void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, un
 }
 
 void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
-               int C, const float* a_amax, float a_bound, hipStream_t st) {
+               int C, const float* a_amax, const float* a_amax2, float a_bound, hipStream_t st) {
     const long total4 = nsamples * per_sample / 4;
     long grid = (total4 + 255) / 256;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(modcvt_f16_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4, a_amax, a_bound);
+    hipLaunchKernelGGL(modcvt_f16_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4, a_amax, a_amax2, a_bound);
 }
 
 // a: fully prepared arguments (phases filled, a_hi/a_lo/w_hi/w_lo and extents set); bn = 256 or 128

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void ige
     float4 pr_[NPL];
     // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h), folded into the style vector / undone in the epilogue
     float op_mult = 1.f, op_inv = 1.f;
-    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_bound, op_mult, op_inv);
+    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
     const int cpt = p.Ci / BK;
     auto load_patch = [&](int c) {

@@ -76,10 +76,12 @@ template <> struct Scheme<2> {
 // Power-of-two operand scale for the fp16 schemes.  `amax` bounds |A| (before the per-sample a_scale factor, which the
 // caller's bound must include).  Returns mult = 2^k with amax * mult in [2^11, 2^12) — four binades below the fp16 maximum
 // (2^16), 26 above its smallest normal number — and inv = 2^-k for the accumulator.  amax == 0 / NaN / inf: no scaling.
-__device__ __forceinline__ void operand_scale(const float* amax_ptr, float bound, float& mult, float& inv) {
+// amax2 (optional second device scalar) multiplies the bound: forward launches pass max|x| of the producing layer and
+// max|style| separately.
+__device__ __forceinline__ void operand_scale(const float* amax_ptr, const float* amax2_ptr, float bound, float& mult, float& inv) {
     mult = 1.f; inv = 1.f;
     if (!amax_ptr) return;
-    const float am = amax_ptr[0] * bound;
+    const float am = amax_ptr[0] * bound * (amax2_ptr ? amax2_ptr[0] : 1.f);
     const int e = (__float_as_int(am) >> 23) & 0xff;       // am in [2^(e-127), 2^(e-126))
     if (!(am > 0.f) || e == 0 || e == 255) return;
     int k = 127 + 12 - (e - 126);                         // biased exponent of 2^(12 - (e - 126))

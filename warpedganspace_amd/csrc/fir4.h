@@ -18,16 +18,19 @@ template <bool EPI>
 __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, const float* __restrict__ kern,
                                                    float* __restrict__ y, int B, int Hin, int Win, int Ho, int Wo, int C,
                                                    int py0, int px0, const float* __restrict__ noise,
-                                                   const float* __restrict__ noise_w, const float* __restrict__ bias) {
+                                                   const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                   float* __restrict__ y_amax) {
     float kf[16];
+    float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) kf[i] = kern[15 - i];
     const int c4n = C >> 2;
     const int strips = (Ho + TY - 1) / TY;
     const int wpairs = (Wo + 1) >> 1;                 // a thread owns TWO adjacent output columns: 5 loads per row for 2 outputs
     const long total = (long)B * strips * wpairs * c4n;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+    const long e0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e0 < total;         // threads past the end shadow the last element (no store): the wave stays converged
+    const long e = live ? e0 : total - 1; // for the amax reduction below
     long r = e;
     const int c = (int)(r % c4n) * 4; r /= c4n;
     const int ox = (int)(r % wpairs) * 2; r /= wpairs;
@@ -76,20 +79,26 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
                         acc.z = (acc.z > 0.f ? acc.z : 0.2f * acc.z) * 1.4142135623730951f;
                         acc.w = (acc.w > 0.f ? acc.w : 0.2f * acc.w) * 1.4142135623730951f;
                     }
-                    *reinterpret_cast<float4*>(yb + ((size_t)oy * Wo + ox + px) * C) = acc;
+                    if (EPI) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+                    if (live) *reinterpret_cast<float4*>(yb + ((size_t)oy * Wo + ox + px) * C) = acc;
                 }
             }
         }
+    }
+    // magnitude bound of the activation for the next layer's fp16 operand scale: one atomic per wave
+    if (EPI && y_amax) {
+        vmax = wave_max(vmax);
+        if ((threadIdx.x & 63) == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(y_amax), __float_as_uint(vmax));
     }
 }
 
 template <bool EPI>
 inline void launch_fir4(const float* x, const float* kern, float* y, int B, int Hin, int Win, int Ho, int Wo, int C, int py0,
-                        int px0, const float* noise, const float* noise_w, const float* bias, hipStream_t st) {
+                        int px0, const float* noise, const float* noise_w, const float* bias, hipStream_t st, float* y_amax = nullptr) {
     const int strips = (Ho + TY - 1) / TY;
     const long total = (long)B * strips * ((Wo + 1) / 2) * (C / 4);
     hipLaunchKernelGGL(fir4_kernel<EPI>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
-                       C, py0, px0, noise, noise_w, bias);
+                       C, py0, px0, noise, noise_w, bias, y_amax);
 }
 
 }  // namespace wgsfir

@@ -480,11 +480,11 @@ int wgs_linear_wgrad(const float* gy, const float* x, float* dw, float* db, int 
 }
 
 int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const float* noise, const float* noise_w,
-                                const float* bias, float* y, int B, int Ho, int Wo, int C, wgs_stream_t stream) {
+                                const float* bias, float* y, float* y_amax, int B, int Ho, int Wo, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && kernel4x4 && bias && y, "wgs_sg2_blur_noise_bias_act: null pointer");
     WGS_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "wgs_sg2_blur_noise_bias_act: bad sizes (C %% 4)");
     WGS_CHECK_ARG(!noise || noise_w, "wgs_sg2_blur_noise_bias_act: noise needs noise_w");
-    wgsfir::launch_fir4<true>(x, kernel4x4, y, B, Ho + 1, Wo + 1, Ho, Wo, C, 1, 1, noise, noise_w, bias, (hipStream_t)stream);
+    wgsfir::launch_fir4<true>(x, kernel4x4, y, B, Ho + 1, Wo + 1, Ho, Wo, C, 1, 1, noise, noise_w, bias, (hipStream_t)stream, y_amax);
     WGS_CHECK_LAUNCH("fir4_kernel<epilogue>");
     return WGS_OK;
 }

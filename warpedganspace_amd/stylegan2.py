@@ -241,6 +241,7 @@ class Generator(nn.Module):
             P['mod_scale'], P['sumC'] = mods[0].scale, off
             P['map'] = [(l.weight.contiguous(), l.bias.contiguous(), l.scale, l.lr_mul) for l in list(self.style)[1:]]
             P['const'] = self.input.input[0].permute(1, 2, 0).contiguous()       # [4,4,C] NHWC
+            P['const_amax'] = P['const'].abs().max().reshape(1).contiguous()     # magnitude bound of the first layer's input
         self._prep = P
         return P
 
@@ -294,6 +295,12 @@ class Generator(nn.Module):
         x = P['const'].unsqueeze(0).expand(B, -1, -1, -1).contiguous()
         outs = []
         skip = None
+        # fp16 modes: magnitude chain for the dynamic operand scale — every producer raises max|y| of its output (one atomic
+        # per wave in its epilogue), the consumer scales its operand x * style by a power of two taken from max|x| * max|style|
+        # before rounding it to fp16: a forward pass cannot overflow fp16 whatever the checkpoint's activation magnitudes
+        f16_chain = any(C.layer_precision(C.PRECISION, 4 << ((j + 1) // 2), ly_['up']) >= 2 for j, ly_ in enumerate(P['layers']))
+        xmax = [P['const_amax']] + list(torch.zeros(len(P['layers']), 1, device=dev).unbind(0)) if f16_chain else None
+        smax = S.abs().max().reshape(1) if f16_chain else None
         # every layer's demodulation vector scale * rsqrt(scale^2 * sum_i s^2 wsq + 1e-8) in one batched launch
         demods = [torch.empty(B, ly['Co'], device=dev) for ly in P['layers']]
         nl = len(P['layers'])
@@ -317,16 +324,20 @@ class Generator(nn.Module):
             demod = demods[i]
             H = x.shape[1]
             lp = C.layer_precision(C.PRECISION, 2 * H if ly['up'] else H, ly['up'])      # 'mixed': per-layer arithmetic
+            sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp >= 2) else {}
+            ymax = xmax[i + 1] if f16_chain else None
             if ly['up']:
-                t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'], precision=lp)
+                t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'], precision=lp,
+                                          **sc_kw)
                 y = torch.empty(B, 2 * H, 2 * H, Co, device=dev)
                 L.check(lib.wgs_sg2_blur_noise_bias_act(L.ptr(t), L.ptr(ly['blur']), L.ptr(ly['noise']),
-                                                        L.ptr(ly['noise_w']), L.ptr(ly['bias']), L.ptr(y), B, 2 * H, 2 * H,
-                                                        Co, st), 'blur_nba')
+                                                        L.ptr(ly['noise_w']), L.ptr(ly['bias']), L.ptr(y), L.ptr(ymax), B, 2 * H,
+                                                        2 * H, Co, st), 'blur_nba')
                 del t
             else:
                 y = C.conv2d(x, ly['wp'], 3, pad=1, a_scale=s_view, a_ld=sumC, col_scale=demod, noise=ly['noise'],
-                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'], precision=lp)
+                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'], precision=lp,
+                             y_amax=ymax, **sc_kw)
             outs.append(y)
             x = y
             if i % 2 == 0:
