@@ -1,0 +1,52 @@
+"""GPU: the fp16 arithmetic modes must not depend on the MAGNITUDE of a generator's activations (fp16 has 5 exponent bits).
+A StyleGAN2 whose constant input and first-layer weights are scaled so that activations reach 1e6 (far beyond fp16's 65504)
+must still produce, in every fp16 mode, the image the exact-fp32 kernels produce — the forward magnitude chain (producers
+raise max|y|, consumers scale x * style by a power of two before rounding) and the backward one (max|dy|) at work."""
+import pytest
+import torch
+
+from tests import golden_inputs as GI
+from tests.util import rel_err
+from warpedganspace_amd import conv as C
+from warpedganspace_amd.gan_load import StyleGAN2Wrapper
+from warpedganspace_amd.stylegan2 import Generator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('scale', [1e-6, 1.0, 3e5])
+def test_fp16_modes_are_scale_free(dev, scale):
+    size, B = 64, 3
+    G = Generator(size, 512, 8)
+    sd = GI.fill_state_dict(G.state_dict(), 8100)
+    for k in sd:
+        if k.startswith('style.') and k.endswith('weight'):
+            sd[k] = sd[k] * 100.0
+    sd['input.input'] = sd['input.input'] * scale          # every activation of the network scales with the constant input
+    sd['noises.noise_0'] = sd['noises.noise_0'] * 0         # (the demodulated convs are scale-equivariant; noise / bias are not:
+    for k in list(sd):                                       #  silence them so that the whole image scales by `scale`)
+        if k.endswith('noise.weight') or k.endswith('activate.bias') or k.endswith('to_rgb1.bias') or (k.startswith('to_rgbs') and k.endswith('.bias')):
+            sd[k] = sd[k] * 0
+    G.load_state_dict(sd)
+    G = G.to(dev)
+    z = GI.rt(8101, B, 512).to(dev)
+    outs = {}
+    old = C.PRECISION
+    try:
+        for name in ('fp32', 'f16', 'f16x2', 'mixed'):
+            C.set_precision(name)
+            sh = (GI.rt(8102, B, 512) * 0.05).to(dev).requires_grad_(True)
+            img = StyleGAN2Wrapper(G, True)(z, sh)
+            (img * GI.rt(8103, *img.shape).to(dev)).sum().backward()
+            outs[name] = (img.detach(), sh.grad.detach())
+    finally:
+        C.PRECISION = old
+    ref_i, ref_g = outs['fp32']
+    assert torch.isfinite(ref_i).all() and float(ref_i.abs().max()) > 0
+    for name in ('f16', 'f16x2', 'mixed'):
+        i, g = outs[name]
+        assert torch.isfinite(i).all() and torch.isfinite(g).all(), name
+        e_i, e_g = rel_err(i, ref_i), rel_err(g, ref_g)
+        print('scale %g %-6s image err %.2e, free-running gradient err %.2e' % (scale, name, e_i, e_g))
+        assert e_i < 2e-3, (name, scale, e_i)
+        assert e_g < 1e-1, (name, scale, e_g)       # free-running (gate flips); what matters here: finite and of the right size

@@ -114,3 +114,27 @@ def test_traverse_vs_golden_and_oracle(dev, golden):
         for t in range(1, 5):
             zc = zc + 0.15 * S.forward_idx(idx, zc)
             assert rel_err(path[:, k, 4 + t], zc) < 1e-5
+
+
+def test_latent_dimension_not_multiple_of_four(dev):
+    """BigGAN-256 / -512 truncate dim_z to 119 / 112-ish values (BigGAN.py:106-108): the 16-byte-vector kernels run on
+    zero-padded copies; forward, backward and the traversal agree with the C oracle at d = 119."""
+    from oracle import wgs_oracle as O
+    from tests import golden_inputs as GI
+    from warpedganspace_amd.support_sets import SupportSets
+    K, N, d, B = 6, 3, 119, 5
+    c = GI.support_sets_case(K, N, d, B, 4119, learn_gammas=True)
+    S = SupportSets(K, N, d, learn_gammas=True, gamma=c['gamma'])
+    S.load_state_dict(c['sd'])
+    S.to(dev)
+    y = S(GI.one_hot(c['idx'], K).to(dev), c['z'].to(dev))
+    (y * c['gout'].to(dev)).sum().backward()
+    out, _ = O.rbf_c_forward(c['sd'], c['idx'], c['z'], True, c['gamma'])
+    dtable, _, _, _ = O.rbf_c_backward(c['sd'], c['idx'], c['z'], c['gout'], True, c['gamma'])
+    assert y.shape == (B, d)
+    assert abs(y.detach().double().cpu().numpy() - out).max() < 1e-5
+    assert abs(S.SUPPORT_SETS.grad.double().cpu().numpy() - dtable).max() / abs(dtable).max() < 1e-4
+    path, shift = S.traverse(c['z'][:2].to(dev), 0.2, 3)
+    ref_path, _ = O.traverse_paths(c['sd'], c['z'][:2], 0.2, 3, True, c['gamma'])
+    assert path.shape == (2, K, 7, d)
+    assert float((path.cpu() - ref_path).abs().max()) < 1e-4

@@ -93,6 +93,14 @@ class SupportSets(nn.Module):
     def forward_idx(self, idx, z, scale=None):
         """Unit-norm gradient field of warping function idx[b] at z[b]; optional per-sample `scale`
         (the trainer's shift magnitude, lib/trainer.py:235) is fused into the kernel."""
+        d = self.support_vectors_dim
+        pad = (-d) % 4
+        if pad:     # the kernels stream 16-byte vectors: zero-pad the latent dimension (BigGAN-256: 119); autograd slices back
+            K, n2 = self.ALPHAS.shape
+            table = torch.nn.functional.pad(self.SUPPORT_SETS.view(K, n2, d), (0, pad)).reshape(K, -1)
+            out = _RbfField.apply(table, self.ALPHAS, self.LOGGAMMA, torch.nn.functional.pad(z, (0, pad)), idx, scale,
+                                  float(self.gamma), bool(self.learn_gammas))
+            return out[:, :d]
         return _RbfField.apply(self.SUPPORT_SETS, self.ALPHAS, self.LOGGAMMA, z, idx, scale, float(self.gamma),
                                bool(self.learn_gammas))
 
@@ -113,14 +121,22 @@ class SupportSets(nn.Module):
     def traverse(self, codes, eps, steps):
         """All-K walks of traverse_latent_space.py:361-438 in one launch.
         Returns (path [n,K,2*steps+1,d], shift [n,K,2*steps+1,d])."""
-        n, d = codes.shape
+        n, d0 = codes.shape
         K, n2 = self.ALPHAS.shape
+        pad = (-d0) % 4
+        d = d0 + pad
+        table = self.SUPPORT_SETS
+        if pad:     # 16-byte vectors in the kernel: zero-pad the latent dimension (see forward_idx)
+            table = torch.nn.functional.pad(table.view(K, n2, d0), (0, pad)).reshape(K, -1).contiguous()
+            codes = torch.nn.functional.pad(codes, (0, pad))
         path = torch.empty(n, K, 2 * steps + 1, d, device=codes.device)
         shift = torch.empty_like(path)
         lg = self.LOGGAMMA.reshape(-1) if self.learn_gammas else None
         codes = codes.contiguous()
-        L.check(L.lib().wgs_rbf_traverse(L.ptr(self.SUPPORT_SETS), L.ptr(self.ALPHAS), L.ptr(lg),
+        L.check(L.lib().wgs_rbf_traverse(L.ptr(table), L.ptr(self.ALPHAS), L.ptr(lg),
                                          L.c_float(float(self.gamma)), L.ptr(codes), L.c_float(eps),
                                          steps, L.ptr(path), L.ptr(shift), n, K, n2, d, L.stream()),
                 'wgs_rbf_traverse')
+        if pad:
+            path, shift = path[..., :d0].contiguous(), shift[..., :d0].contiguous()
         return path, shift

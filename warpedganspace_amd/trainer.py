@@ -126,7 +126,10 @@ class TrainStep:
                     dist.broadcast(b.data, 0)
         K, n2 = support_sets.ALPHAS.shape
         self.K, self.n2, self.d = K, n2, support_sets.support_vectors_dim
-        self.rbf_ws = rbf_workspace(local_batch, n2, self.d, device)
+        # the RBF kernels stream 16-byte vectors: a latent dimension that is not a multiple of 4 (BigGAN-256 / -512 truncate
+        # dim_z to 119 / 112) runs on zero-padded copies of the table, the codes and the gradients (a few MB per step)
+        self.dp = (self.d + 3) & ~3
+        self.rbf_ws = rbf_workspace(local_batch, n2, self.dp, device)
         self.stats = torch.zeros(4, device=device)        # (ce, l1, total, accuracy) of the last step
         self.stats_sum = torch.zeros(4, device=device)
         self.stats_n = 0
@@ -191,10 +194,18 @@ class TrainStep:
             code = G.get_w(z) if self.w_space else z                          # :236
         # shift = mag * S(mask, code)   (:235) — fused scale
         lg = S.LOGGAMMA.reshape(-1) if S.learn_gammas else None
-        shift = torch.empty(B, self.d, device=self.dev)
-        L.check(lib.wgs_rbf_fwd(L.ptr(S.SUPPORT_SETS), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
-                                L.ptr(idx, torch.int64), L.ptr(code), L.ptr(mag), L.ptr(shift), L.ptr(self.rbf_ws),
-                                B, self.K, self.n2, self.d, st), 'wgs_rbf_fwd')
+        pad = self.dp - self.d
+        if pad:
+            table = torch.nn.functional.pad(S.SUPPORT_SETS.detach().view(self.K, self.n2, self.d), (0, pad)).reshape(self.K, -1).contiguous()
+            code_k = torch.nn.functional.pad(code, (0, pad)).contiguous()
+        else:
+            table, code_k = S.SUPPORT_SETS, code
+        shift = torch.empty(B, self.dp, device=self.dev)
+        L.check(lib.wgs_rbf_fwd(L.ptr(table), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
+                                L.ptr(idx, torch.int64), L.ptr(code_k), L.ptr(mag), L.ptr(shift), L.ptr(self.rbf_ws),
+                                B, self.K, self.n2, self.dp, st), 'wgs_rbf_fwd')
+        if pad:
+            shift = shift[:, :self.d].contiguous()
         shift.requires_grad_(True)
         img_shifted = G(z, shift)                                             # :239, input-gradient only
         if side is not None:
@@ -232,9 +243,16 @@ class TrainStep:
         dlg = gb[id(S.LOGGAMMA)].reshape(-1) if (S.learn_gammas and id(S.LOGGAMMA) in gb) else None
         dal = gb[id(S.ALPHAS)] if (S.learn_alphas and id(S.ALPHAS) in gb) else None
         gshift = shift.grad.contiguous()
-        L.check(lib.wgs_rbf_bwd(L.ptr(S.SUPPORT_SETS), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
-                                L.ptr(idx, torch.int64), L.ptr(code), L.ptr(mag), L.ptr(gshift), L.ptr(self.rbf_ws),
-                                L.ptr(dtable), L.ptr(dlg), L.ptr(dal), None, B, self.K, self.n2, self.d, st), 'wgs_rbf_bwd')
+        if pad:
+            gshift = torch.nn.functional.pad(gshift, (0, pad)).contiguous()
+            dtable_k = torch.zeros(self.K, self.n2 * self.dp, device=self.dev)
+        else:
+            dtable_k = dtable
+        L.check(lib.wgs_rbf_bwd(L.ptr(table), L.ptr(S.ALPHAS), L.ptr(lg), L.c_float(float(S.gamma)),
+                                L.ptr(idx, torch.int64), L.ptr(code_k), L.ptr(mag), L.ptr(gshift), L.ptr(self.rbf_ws),
+                                L.ptr(dtable_k), L.ptr(dlg), L.ptr(dal), None, B, self.K, self.n2, self.dp, st), 'wgs_rbf_bwd')
+        if pad:
+            dtable.view(self.K, self.n2, self.d).copy_(dtable_k.view(self.K, self.n2, self.dp)[:, :, :self.d])
         if side is not None:
             cur.wait_stream(side)                                             # deferred weight gradients (and their all-reduce)
         if self.world > 1:
