@@ -63,9 +63,14 @@ def layer_precision(code, out_res, is_up):
     """Concrete arithmetic of one StyleGAN2 layer under mode `code` (see 'mixed' above)."""
     if code != MIXED:
         return code
-    if out_res < 64:
+    if out_res < _MIXED_MIN_RES:
         return 1
-    return 3 if is_up else 2
+    return _MIXED_UP if is_up else 2
+
+
+# development overrides of the 'mixed' policy (read once at import): resolution from which layers run in fp16, arithmetic of the up-convs
+_MIXED_MIN_RES = int(os.environ.get('WGS_MIXED_MIN_RES', '64'))
+_MIXED_UP = {'f16': 2, 'f16x2': 3, 'bf16x3': 1}[os.environ.get('WGS_MIXED_UP', 'f16x2')]
 AUTO_FALLBACK = 'bf16x3'
 
 

@@ -64,7 +64,7 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
             }
             if (p.y_amax) {      // magnitude bound for the next layer's fp16 operand scale: one atomic per wave
                 vmax = wave_max(vmax);
-                if (l31 == 0 && lh == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.y_amax), __float_as_uint(vmax));
+                if (l31 == 0 && lh == 0) raise_amax(p.y_amax, vmax);
             }
             return;
         }
@@ -99,7 +99,7 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
             }
         }
     }
-    if (p.y_amax && vmax_s > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.y_amax), __float_as_uint(vmax_s));
+    if (p.y_amax) raise_amax(p.y_amax, vmax_s);
 }
 
 template <int BM, int TM, int TN, int WM, int WN>

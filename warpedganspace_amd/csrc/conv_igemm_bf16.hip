@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArg
     *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + hw) * p.Co + n) = make_float4(o[0], o[1], o[2], o[3]);
     if (p.y_amax) {     // magnitude bound for the next layer's fp16 operand scale
         const float am = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
-        if (am > 0.f) atomicMax(reinterpret_cast<unsigned int*>(p.y_amax), __float_as_uint(am));
+        raise_amax(p.y_amax, am);
     }
 }
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
     // magnitude bound of the activation for the next layer's fp16 operand scale: one atomic per wave
     if (EPI && y_amax) {
         vmax = wave_max(vmax);
-        if ((threadIdx.x & 63) == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(y_amax), __float_as_uint(vmax));
+        if ((threadIdx.x & 63) == 0) raise_amax(y_amax, vmax);
     }
 }
 

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     }
     if (dy_amax) {      // non-negative floats order like their bit patterns
         amax = wave_max(amax);
-        if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(dy_amax), __float_as_uint(amax));
+        if ((threadIdx.x & 63) == 0) raise_amax(dy_amax, amax);
     }
 }
 

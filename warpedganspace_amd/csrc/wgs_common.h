@@ -48,6 +48,15 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+// Raise a device-resident non-negative fp32 maximum (bit patterns of non-negative floats order like unsigned ints).
+// Thousands of waves target ONE address: an L2 atomic costs ~12 ns when they queue (16 k of them = 0.2 ms per launch), so
+// a wave first looks at the current value — after the first few arrivals almost every wave sees a value >= its own and
+// skips the atomic (a stale L1 line only costs a redundant atomic, never a wrong result).
+__device__ __forceinline__ void raise_amax(float* addr, float v) {
+    if (v > 0.f && v > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
