@@ -243,6 +243,23 @@ int wgs_linear_wgrad(const float* gy, const float* x, float* dw, float* db, int 
 int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const float* noise, const float* noise_w,
                                 const float* bias, float* y, float* y_amax, int B, int Ho, int Wo, int C, wgs_stream_t stream);
 
+/* The whole up-sampling StyledConv in one launch (fp16 operand schemes): modulated stride-2 transposed 3x3 conv
+ * (ModulatedConv2d.forward upsample branch, models/StyleGAN2/model.py:201-212: F.conv_transpose2d + Blur(pad (1,1))),
+ * demodulation, NoiseInjection (:231-241), FusedLeakyReLU (:264) — the (2H+1)^2 intermediate never reaches HBM.
+ *   t[b,u,v,n]  = alpha * col_scale[b,n] * sum_{ky,kx,k} x[b,(u-ky)/2,(v-kx)/2,k] a_scale[b,k] w[n,ky*3+kx,k]     (u-ky, v-kx even)
+ *   y[b,oy,ox,n] = lrelu_0.2( sum_{i,j} flip(kernel4x4)[i][j] t[b,oy+i-1,ox+j-1,n] + noise_w[0]*noise[oy*2H+ox] + bias[n] ) * sqrt(2)
+ * x [B,H,H,Ci] NHWC fp32, y [B,2H,2H,Co]; w_hi (w_lo) = the fp16 planes of the [Co,9,Ci] weights from wgs_split_f16.
+ * precision 2 (fp16) or 3 (fp16 x2); Ci % 32 == 0, Co % 64 == 0; a_amax / a_amax2 / a_bound / y_amax as in wgs_conv_desc. */
+typedef struct wgs_upconv_desc {
+    const float* x; const void* w_hi; const void* w_lo; float* y;
+    const float* a_scale; const float* col_scale; const float* bias; const float* noise; const float* noise_w;
+    const float* kernel4x4;
+    const float* a_amax; const float* a_amax2; float* y_amax;
+    float a_bound, alpha;
+    int B, H, Ci, Co, a_ld, col_ld, precision;
+} wgs_upconv_desc;
+int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* desc, wgs_stream_t stream);
+
 /* ToRGB (:270-282): img[b,o,p] = wscale * sum_c x[b,p,c] s[b,c] w[o,c] + bias[o] + (skip ? skip[b,o,p] : 0).
  * x NHWC [B,P,C]; img/skip NCHW [B,3,P]. C power of two. */
 int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip, float* img,

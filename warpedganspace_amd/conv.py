@@ -332,6 +332,48 @@ def conv_transpose2d_s2(x, w_packed, k=3, out=None, **epi):
     return launch_multi(x, w_packed, y, phases, osy=2, w_tap_stride=Ci, w_row_stride=k * k * Ci, **epi)
 
 
+class UpconvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'w_hi', 'w_lo', 'y', 'a_scale', 'col_scale', 'bias', 'noise', 'noise_w',
+                                               'kernel4x4', 'a_amax', 'a_amax2', 'y_amax')] + \
+               [('a_bound', ctypes.c_float), ('alpha', ctypes.c_float)] + \
+               [(n, ctypes.c_int32) for n in ('B', 'H', 'Ci', 'Co', 'a_ld', 'col_ld', 'precision')]
+
+
+# The fused up-sampling layer (conv_upfused.hip) is taken where it beats the phase GEMMs + blur kernel (tools/bench_upfused.py,
+# B = 32): fp16 from 16 x 16 inputs up; fp16 x2 — whose second weight plane doubles the kernel's dominant LDS-DMA traffic —
+# only at 128 x 128 inputs, where the unfused path's 1 GB intermediate costs more.
+UPCONV_FUSED_MIN_H = {2: int(os.environ.get('WGS_UPFUSED_MIN_H_F16', '16')),       # development A/B; a huge value = never
+                      3: int(os.environ.get('WGS_UPFUSED_MIN_H_F16X2', '128'))}
+
+
+def upconv_fused_ok(H, Ci, Co, precision):
+    return precision in (2, 3) and H >= UPCONV_FUSED_MIN_H[precision] and Ci % 32 == 0 and Co % 64 == 0
+
+
+def upconv_blur_act(x, w_split, blur_kernel, a_scale, a_ld, col_scale, noise, noise_w, bias, precision,
+                    a_amax=None, a_amax2=None, y_amax=None, alpha=1.0):
+    """StyleGAN2's up-sampling StyledConv in one launch (wgs_sg2_upconv_blur_act): modulated conv_transpose2d(stride 2) +
+    Blur(pad (1,1)) + noise + bias + leaky-relu*sqrt(2) (models/StyleGAN2/model.py:201-212,231-241,264).
+    x [B,H,H,Ci] NHWC; w_split: SplitCache / (hi, lo) fp16 planes of the [Co,9,Ci] weights; returns y [B,2H,2H,Co]."""
+    B, H, W, Ci = x.shape
+    if isinstance(w_split, SplitCache):
+        w_split = w_split.get(precision)
+    Co = w_split[0].shape[0]
+    if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and H == W):
+        raise L.WgsError("upconv_blur_act needs a contiguous square fp32 GPU tensor (no CPU fallback)")
+    y = torch.empty(B, 2 * H, 2 * H, Co, device=x.device)
+    d = UpconvDesc()
+    d.x, d.w_hi, d.w_lo, d.y = x.data_ptr(), w_split[0].data_ptr(), _p(w_split[1]), y.data_ptr()
+    d.a_scale, d.col_scale, d.bias, d.noise, d.noise_w = _p(a_scale), _p(col_scale), _p(bias), _p(noise), _p(noise_w)
+    d.kernel4x4, d.a_amax, d.a_amax2, d.y_amax = _p(blur_kernel), _p(a_amax), _p(a_amax2), _p(y_amax)
+    d.a_bound, d.alpha = 1.0, alpha
+    d.B, d.H, d.Ci, d.Co, d.a_ld, d.col_ld, d.precision = B, H, Ci, Co, a_ld, Co, precision
+    kind = ('conv %s %d->%d @%dx%d up-conv + blur fused B%d' % (precision_name(precision), Ci, Co, H, H, B)) if PROFILE is not None else None
+    _timed(kind, 2.0 * B * H * H * 9 * Co * Ci,
+           lambda: L.check(L.lib().wgs_sg2_upconv_blur_act(ctypes.byref(d), L.stream()), 'wgs_sg2_upconv_blur_act'))
+    return y
+
+
 def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
     """Gradient of conv_transpose2d_s2 w.r.t. its input = stride-2 conv over dy. wt_packed [k*k, Ci, Co]."""
     B, Ho, Wo, Co = dy.shape

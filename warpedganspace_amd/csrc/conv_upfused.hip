@@ -1,0 +1,402 @@
+// StyleGAN2 up-sampling layer in ONE kernel (fp16 operand schemes): modulated stride-2 transposed 3x3 conv, demodulation,
+// 4x4 blur, noise, bias, leaky-relu*sqrt(2)   (models/StyleGAN2/model.py:201-212 conv_transpose2d + Blur, :231-241, :264).
+//
+// The unfused path runs the transposed conv as four sub-pixel phase GEMMs that write a (2H+1)^2 intermediate t (1.08 GB at
+// 128->256 px, B = 32), and a second kernel reads t back through the blur.  Here one workgroup owns a 14 x 14 block of INPUT
+// cells of one sample and 64 output channels:
+//
+//   * GEMM rows = the 16 x 16 grid g of cell positions (the block + a one-cell halo: the 4-tap blur of the 28 x 28 output
+//     block needs t on [2*y0 - 1, 2*y0 + 30]);  t[2g + p] for the four parities p = (py, px) are FOUR accumulator sets
+//     of the same rows:  t_p[g] = sum over the phase's taps (ky = py mod 2, kx = px mod 2) of x[g + (p - k)/2] * w[k]
+//   * the activation operand is staged ONCE per 32-channel chunk as the 17 x 17 input patch; the nine (phase, tap) products
+//     read it with four different row shifts, so one A fragment feeds up to four MFMAs (phases) and is read 4x, not 9x
+//   * epilogue: accumulators * demodulation -> LDS as the 32 x 32 x 32-channel t tile (fp32, 128 KB), then the blur +
+//     noise + bias + activation over the 28 x 28 outputs with a sliding row window, stored as 128-B channel runs.
+//
+// Rows of the 16 x 16 grid outside the image produce exact zeros (their patch pixels are out of range -> 0), which is
+// upfirdn2d's zero padding of t.  MFMA efficiency = 196 useful cells of 256 rows (x tile-edge waste); in exchange the layer
+// loses the intermediate's write + two reads and the blur kernel.
+//
+// LDS: two patch buffers + two weight stages of TS products each (one barrier per stage), re-used by the epilogue's t tile.
+#include "wgs_common.h"
+#include "conv_scheme.h"
+#include "../../include/wgs.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+#ifndef WGS_UABL
+#define WGS_UABL 0   // development ablations (tools/build_abl.sh uabl): 1 no epilogue, 2 no MFMA, 3 no patch global loads,
+                     // 4 no weight DMA, 5 no K loop, 6 no blur arithmetic, 7 no output stores
+#endif
+
+constexpr int BK = 32;
+constexpr int ROW = 64;                  // bytes per LDS row of a weight plane (DMA: unpadded, XOR-swizzled 16-B slots)
+constexpr int PROW = 80;                 // bytes per LDS row of the patch (padded, linear)
+constexpr int OOB = (int)0x80000000;
+constexpr int CELLS = 14, PW = 17;          // cell columns of a tile, patch width (tile + 1 halo left, 2 right)
+constexpr int BN = 64;
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+// (phase, tap) products in issue order, grouped by the patch row shift they read
+//   shift 0: (dy, dx) = (0, 0)   1: (0, -1)   2: (-1, 0)   3: (-1, -1);   phase = py * 2 + px;   weight tap = ky * 3 + kx
+__device__ constexpr int T_PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0};
+__device__ constexpr int T_SH[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
+constexpr int T_W_HOST[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8};
+__device__ constexpr int SH_OFF[4] = {(PW + 1) * PROW, PW * PROW, 1 * PROW, 0};
+
+struct UpArgs {
+    const float* x; const unsigned short* w_hi; const unsigned short* w_lo; float* y;
+    const float* a_scale; const float* col_scale; const float* bias; const float* noise; const float* noise_w; const float* kern;
+    const float* a_amax; const float* a_amax2; float* y_amax;
+    float a_bound, alpha;
+    int B, H, Ci, Co, a_ld, col_ld;
+    int x_bytes, w_bytes, s_bytes, y_bytes;
+    int tiles_x, tiles_per_img;
+    int w_row_stride;          // elements between output channels of a weight plane (9 * Ci)
+    int tap_w[9];              // element offset of issue-order product t's weight tap (T_W[t] * Ci)
+};
+
+// GH = height of the grid-row block: 16 (8 waves, 14 x 14 cells, one workgroup per CU) or 8 (4 waves, 14 x 6 cells, 75 KB of
+// LDS: TWO workgroups per CU, whose staging, barriers and blur epilogues overlap each other's MFMAs).
+template <int SCH, int GH>
+struct UpCfg {
+    typedef wgsconv::Scheme<SCH> SC;
+    static constexpr int NB = SC::NB;
+    static constexpr int NW = GH / 2, NT = 64 * NW;
+    static constexpr int CY = GH - 2;                                  // cell rows of a tile
+    static constexpr int PH = GH + 1, NPIX = PW * PH, PALLOC = (NPIX + 7) / 8 * 8;
+    static constexpr int TS = GH == 16 ? (NB == 1 ? 9 : 5) : (NB == 1 ? 5 : 3);   // products per weight stage
+    static constexpr int NSTEP = (9 + TS - 1) / TS;
+    static constexpr int P_BYTES = PALLOC * PROW;
+    static constexpr int B_BYTES = BN * ROW, B_TAP = NB * B_BYTES, B_STAGE = TS * B_TAP;
+    static constexpr int K_BYTES = 2 * P_BYTES + 2 * B_STAGE;
+    static constexpr int T_BYTES = 2 * GH * 32 * 32 * 4;               // t tile: (2 GH) x 32 positions x 32 channels fp32
+    static constexpr int MAIN = K_BYTES > T_BYTES ? K_BYTES : T_BYTES;
+    static constexpr int OR = 2 * GH - 4;                              // output rows of a tile (28 or 12); 28 output columns
+    static constexpr int AUX_FLOATS = OR * 28 + 2 * BN;                // noise of the output block | bias | demodulation
+    static constexpr int SMEM = MAIN + AUX_FLOATS * 4;
+};
+
+template <int SCH, int GH>
+__global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(const UpArgs p) {
+    typedef UpCfg<SCH, GH> CF;
+    typedef wgsconv::Scheme<SCH> SC;
+    typedef typename SC::frag frag;
+    constexpr int NB = SC::NB;
+    static_assert(SC::NA == 1, "fp16 activation plane only");
+    constexpr int NW = CF::NW, NT = CF::NT;
+    constexpr int WM = 32, TN = 2;              // a wave: 32 grid rows x all 64 channels x 4 phases = 128 accumulator registers
+    constexpr int TS = CF::TS, NSTEP = CF::NSTEP;
+    constexpr int P_BYTES = CF::P_BYTES, B_BYTES = CF::B_BYTES, B_TAP = CF::B_TAP, B_STAGE = CF::B_STAGE;
+    constexpr int PALLOC = CF::PALLOC, NPIX = CF::NPIX;
+    constexpr int NPL = (PALLOC * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (5)
+    constexpr int OR = CF::OR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* patch = smem_b;                      // two buffers
+    unsigned char* bst = smem_b + 2 * P_BYTES;          // two weight stages
+    float* aux_nz = reinterpret_cast<float*>(smem_b + CF::MAIN);
+    float* aux_bias = aux_nz + OR * 28;
+    float* aux_cs = aux_bias + BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int ntn = p.Co / BN;
+    int bid;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int qn = nb >> 3, rn = nb & 7;
+        bid = xcd * qn + min(xcd, rn) + slot;
+    }
+    const int tile = bid / ntn, n0 = (bid % ntn) * BN;
+    const int b = tile / p.tiles_per_img;
+    const int trem = tile - b * p.tiles_per_img;
+    const int y0 = (trem / p.tiles_x) * CF::CY, x0 = (trem % p.tiles_x) * CELLS;
+    const int Ho = 2 * p.H;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(NB == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_scale), 0, p.s_bytes, 0x00020000);
+
+    // ---- the epilogue's per-tile scalars go to LDS now (noise of the output block, bias, demodulation): fetched there, every
+    // one of them would expose a memory latency with nothing to overlap it
+    {
+        const float nw = p.noise ? p.noise_w[0] : 0.f;
+        for (int e = tid; e < OR * 28; e += NT) {
+            const int ly = e / 28, lx = e - ly * 28;
+            const int oy = 2 * y0 + ly, ox = 2 * x0 + lx;
+            aux_nz[e] = (p.noise && oy < Ho && ox < Ho) ? nw * p.noise[oy * Ho + ox] : 0.f;
+        }
+        if (tid < BN) {
+            aux_bias[tid] = p.bias[n0 + tid];
+            aux_cs[tid] = p.col_scale[(size_t)b * p.col_ld + n0 + tid];
+        }
+    }
+
+    // ---- patch staging: element e = tid + j*NT -> patch pixel e / 8, float4 q = e % 8
+    const int q = tid & 7;
+    int p_goff[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int pp = (tid + j * NT) >> 3;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int iy = y0 - 2 + pr, ix = x0 - 2 + pc;
+        const bool v = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.H;
+        p_goff[j] = v ? (((b * p.H + iy) * p.H + ix) * p.Ci + q * 4) * 4 : OOB;
+    }
+    const int p_lbase = (tid >> 3) * PROW + q * 8;
+    float op_mult, op_inv;
+    wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);
+    const int cpt = p.Ci / BK;
+    float4 pr_[NPL];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    auto load_patch = [&](int c) {
+        const int cbyte = c < cpt ? c * (BK * 4) : OOB;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (WGS_UABL != 3) v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
+            else asm volatile("" : "+v"(v));
+            pr_[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsc, c < cpt ? (b * p.a_ld + q * 4 + c * BK) * 4 : OOB, 0, 0);
+        if (c < cpt) sc = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto store_patch = [&](int buf) {
+        unsigned char* pb = patch + buf * P_BYTES;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            float4 v = pr_[j];
+            v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
+            v.x *= op_mult; v.y *= op_mult; v.z *= op_mult; v.w *= op_mult;      // power of two: exact
+            const f32x4 f = {v.x, v.y, v.z, v.w};
+            uint2 h, l;
+            SC::cvt4(f, h, l);
+            if (((tid + j * NT) >> 3) < PALLOC) *reinterpret_cast<uint2*>(pb + p_lbase + j * (NT / 8) * PROW) = h;
+        }
+    };
+
+    // ---- weight DMA: instruction k of a stage = (product u, plane pl, 16-row group grp); waves take k = wave, wave + NW, ...
+    const int lrow = lane >> 2, slot = lane & 3;
+    constexpr int NI = TS * NB * 4;                     // DMA instructions per stage
+    constexpr int IPW = (NI + NW - 1) / NW;
+    auto issue_b = [&](int stage, int c, int s) {       // weights of (chunk c, step s) -> stage; past the end: zeros
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int k = wave + i * NW;
+            if (k < NI) {
+                const int u = k / (NB * 4), pl = (k >> 2) % NB, grp = k & 3;
+                const int t = s * TS + u;
+                const int row = grp * 16 + lrow;
+                const int lc = slot ^ ((row >> 2) & 3);
+                const bool ok = c < cpt && t < 9;
+                const int off = ok ? ((n0 + row) * p.w_row_stride + p.tap_w[t < 9 ? t : 0] + c * BK + lc * 8) * 2 : OOB;
+                lds_byte* d = (lds_byte*)(bst + stage * B_STAGE + u * B_TAP + pl * B_BYTES + grp * 16 * ROW);
+                if (WGS_UABL == 4) { asm volatile("" :: "v"(off)); continue; }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? rbl : rbh, d, 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[4][TN];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][j][r] = 0.f;
+
+    // ---- operand fragment addressing
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m_a = wm * WM + l31;
+    const int pa0 = ((m_a >> 4) * PW + (m_a & 15)) * PROW + lh * 16;
+    const int bswz = (l31 >> 2) & 3;
+    const int b_rd = l31 * ROW;
+    const int bk0 = ((0 + lh) ^ bswz) << 4, bk1 = ((2 + lh) ^ bswz) << 4;
+
+    auto mma_step = [&](int buf, int stage, int s) {
+        const unsigned char* pb = patch + buf * P_BYTES;
+        const unsigned char* bb = bst + stage * B_STAGE + b_rd;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag af;
+#pragma unroll
+            for (int u = 0; u < TS; ++u) {
+                const int t = s * TS + u;       // s is a compile-time constant at every call site
+                if (t < 9) {
+                    if (u == 0 || T_SH[t] != T_SH[t - 1]) af = *reinterpret_cast<const frag*>(pb + pa0 + SH_OFF[T_SH[t]] + ks * 32);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        frag bf[NB];
+#pragma unroll
+                        for (int pl = 0; pl < NB; ++pl)
+                            bf[pl] = *reinterpret_cast<const frag*>(bb + u * B_TAP + pl * B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
+                        if (WGS_UABL == 2) { asm volatile("" :: "v"(af), "v"(bf[0])); continue; }
+                        acc[T_PH[t]][j] = SC::mma(&af, bf, acc[T_PH[t]][j]);
+                    }
+                }
+            }
+        }
+    };
+    auto step_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- main loop: one barrier per weight stage; patch buffers alternate per chunk
+    load_patch(0);
+    issue_b(0, 0, 0);
+    store_patch(0);
+    step_barrier();
+    int stage = 0;
+    for (int c = 0; c < (WGS_UABL == 5 ? 0 : cpt); ++c) {
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const bool last = (s + 1 == NSTEP);
+            issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : s + 1);
+            if (s == 0) load_patch(c + 1);
+            mma_step(c & 1, stage, s);
+            if (last && c + 1 < cpt) store_patch((c + 1) & 1);
+            step_barrier();
+            stage ^= 1;
+        }
+    }
+
+    if (WGS_UABL == 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[ph][j][r];
+        if (sacc == 12345.678f) p.y[tid] = sacc;
+        return;
+    }
+    // ---- epilogue: t tile -> LDS, blur + noise + bias + activation, 32 channels at a time
+    float* T = reinterpret_cast<float*>(smem_b);          // [(2 GH) * 32 positions][32 channels]
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = p.kern[15 - i];
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    constexpr int NSTRIP = GH / 8, RS = OR / NSTRIP;      // row strips of the blur stage, output rows per strip (14 / 12)
+    const int bslot = tid >> 3;                           // (strip, column) of the blur stage
+    const int lx = bslot % 28, strip = bslot / 28;
+    const bool bl_live = bslot < 28 * NSTRIP;
+    float vmax = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        {
+            const float cs = aux_cs[half * 32 + l31];
+            const float al = p.alpha * op_inv;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * WM + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int pos = (2 * (m >> 4) + (ph >> 1)) * 32 + 2 * (m & 15) + (ph & 1);
+                    T[pos * 32 + l31] = (half ? acc[ph][1][r] : acc[ph][0][r]) * al * cs;
+                }
+        }
+        __syncthreads();
+        if (bl_live) {
+            const int c = n0 + half * 32 + q * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(aux_bias + half * 32 + q * 4);
+            const int ox = 2 * x0 + lx;
+            float4 win[4][4];
+#pragma unroll
+            for (int rr = 0; rr < RS + 3; ++rr) {
+                const int uy = strip * RS + rr + 1;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) win[rr & 3][jx] = *reinterpret_cast<const float4*>(T + ((uy * 32 + lx + 1 + jx) * 32 + q * 4));
+                if (rr >= 3) {
+                    const int ly = strip * RS + rr - 3;
+                    const int oy = 2 * y0 + ly;
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (WGS_UABL == 6) a = win[rr & 3][0];
+#pragma unroll
+                    for (int ky = 0; ky < (WGS_UABL == 6 ? 0 : 4); ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            const float wv = kf[ky * 4 + kx];
+                            const float4 v = win[(rr - 3 + ky) & 3][kx];
+                            a.x = fmaf(v.x, wv, a.x); a.y = fmaf(v.y, wv, a.y); a.z = fmaf(v.z, wv, a.z); a.w = fmaf(v.w, wv, a.w);
+                        }
+                    const bool ok = oy < Ho && ox < Ho;
+                    const float nz = aux_nz[ly * 28 + lx];
+                    a.x += nz + bv.x; a.y += nz + bv.y; a.z += nz + bv.z; a.w += nz + bv.w;
+                    a.x = (a.x > 0.f ? a.x : 0.2f * a.x) * 1.4142135623730951f;
+                    a.y = (a.y > 0.f ? a.y : 0.2f * a.y) * 1.4142135623730951f;
+                    a.z = (a.z > 0.f ? a.z : 0.2f * a.z) * 1.4142135623730951f;
+                    a.w = (a.w > 0.f ? a.w : 0.2f * a.w) * 1.4142135623730951f;
+                    if (ok) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+                    const int off = ok ? (((b * Ho + oy) * Ho + ox) * p.Co + c) * 4 : OOB;
+                    const u32x4 sv = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)};
+                    if (WGS_UABL == 7) { asm volatile("" :: "v"(sv), "v"(off)); continue; }
+                    __builtin_amdgcn_raw_buffer_store_b128(sv, ry, off, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (p.y_amax) {
+        vmax = wave_max(vmax);
+        if (lane == 0) raise_amax(p.y_amax, vmax);
+    }
+}
+
+template <int SCH, int GH>
+void launch_up(const UpArgs& a0, hipStream_t st) {
+    typedef UpCfg<SCH, GH> CF;
+    UpArgs a = a0;
+    a.tiles_x = (a.H + CELLS - 1) / CELLS;
+    a.tiles_per_img = a.tiles_x * ((a.H + CF::CY - 1) / CF::CY);
+    const int nblocks = a.B * a.tiles_per_img * (a.Co / BN);
+    auto k = upconv_blur_kernel<SCH, GH>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(CF::NT), CF::SMEM, st, a);
+}
+
+}  // namespace
+
+extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t stream) {
+    WGS_CHECK_ARG(d && d->x && d->w_hi && d->y && d->a_scale && d->col_scale && d->bias && d->kernel4x4,
+                  "wgs_sg2_upconv_blur_act: null pointer");
+    WGS_CHECK_ARG(d->precision == 2 || d->precision == 3, "wgs_sg2_upconv_blur_act: precision %d (fp16 schemes 2 / 3 only)", d->precision);
+    WGS_CHECK_ARG(d->precision == 2 || d->w_lo, "wgs_sg2_upconv_blur_act: fp16 x2 needs the low weight plane");
+    WGS_CHECK_ARG(d->B > 0 && d->H >= 4 && d->Ci % 32 == 0 && d->Ci > 0 && d->Co % 64 == 0 && d->Co > 0,
+                  "wgs_sg2_upconv_blur_act: B=%d H=%d Ci=%d (%%32) Co=%d (%%64)", d->B, d->H, d->Ci, d->Co);
+    WGS_CHECK_ARG(!d->noise || d->noise_w, "wgs_sg2_upconv_blur_act: noise needs noise_w");
+    const long xb = (long)d->B * d->H * d->H * d->Ci * 4, yb = (long)d->B * 4 * d->H * d->H * d->Co * 4;
+    const long wb = (long)d->Co * 9 * d->Ci * 2, sb = ((long)(d->B - 1) * d->a_ld + d->Ci) * 4;
+    WGS_CHECK_ARG(xb < 0x7fffffffL && yb < 0x7fffffffL && wb < 0x7fffffffL && sb < 0x7fffffffL,
+                  "wgs_sg2_upconv_blur_act: tensor larger than 2 GB (32-bit buffer offsets)");
+    UpArgs a;
+    a.x = d->x; a.w_hi = (const unsigned short*)d->w_hi; a.w_lo = (const unsigned short*)d->w_lo; a.y = d->y;
+    a.a_scale = d->a_scale; a.col_scale = d->col_scale; a.bias = d->bias; a.noise = d->noise; a.noise_w = d->noise_w;
+    a.kern = d->kernel4x4; a.a_amax = d->a_amax; a.a_amax2 = d->a_amax2; a.y_amax = d->y_amax;
+    a.a_bound = d->a_bound > 0.f ? d->a_bound : 1.f; a.alpha = d->alpha;
+    a.B = d->B; a.H = d->H; a.Ci = d->Ci; a.Co = d->Co; a.a_ld = d->a_ld; a.col_ld = d->col_ld;
+    a.x_bytes = (int)xb; a.w_bytes = (int)wb; a.s_bytes = (int)sb; a.y_bytes = (int)yb;
+    a.tiles_x = a.tiles_per_img = 0;
+    a.w_row_stride = 9 * d->Ci;
+    for (int t = 0; t < 9; ++t) a.tap_w[t] = T_W_HOST[t] * d->Ci;
+    // 14 x 14-cell tiles (one 8-wave workgroup per CU) unless they would leave the chip short of workgroups: then 14 x 6-cell
+    // tiles, two 4-wave workgroups per CU (they re-fetch the weights twice as often, which is what bounds the large layers)
+    const int t14 = (d->H + CELLS - 1) / CELLS;
+    const bool gh16 = wgs_flags().up_gh16 || (long)d->B * t14 * t14 * (d->Co / BN) >= 2048;
+    if (d->precision == 2) { if (gh16) launch_up<1, 16>(a, (hipStream_t)stream); else launch_up<1, 8>(a, (hipStream_t)stream); }
+    else { if (gh16) launch_up<2, 16>(a, (hipStream_t)stream); else launch_up<2, 8>(a, (hipStream_t)stream); }
+    WGS_CHECK_LAUNCH("upconv_blur_kernel");
+    return WGS_OK;
+}

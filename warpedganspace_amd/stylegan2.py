@@ -326,7 +326,10 @@ class Generator(nn.Module):
             lp = C.layer_precision(C.PRECISION, 2 * H if ly['up'] else H, ly['up'])      # 'mixed': per-layer arithmetic
             sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp >= 2) else {}
             ymax = xmax[i + 1] if f16_chain else None
-            if ly['up']:
+            if ly['up'] and C.upconv_fused_ok(H, Ci, Co, lp):
+                y = C.upconv_blur_act(x, ly['wp_s'], ly['blur'], s_view, sumC, demod, ly['noise'], ly['noise_w'], ly['bias'], lp,
+                                      y_amax=ymax, **sc_kw)
+            elif ly['up']:
                 t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'], precision=lp,
                                           **sc_kw)
                 y = torch.empty(B, 2 * H, 2 * H, Co, device=dev)
