@@ -118,3 +118,28 @@ def test_sampler_distribution_matches_reference_quirk(dev):
         pos += int((mag > 0).sum())
         tot += 64
     assert 0.64 < pos / tot < 0.78
+
+
+def test_prefetched_unshifted_pass_same_trajectory(dev):
+    """The next step's un-shifted pass G(z) is drawn and generated one step ahead on a third stream (trainer.py): the
+    sampler's draws, the batches and the optimisation trajectory are those of the plain schedule."""
+    size, K, N, B = 32, 16, 4, 4
+    runs = []
+    for prefetch in (False, True):
+        eng, _, _ = make(dev, size, K, N, B)
+        eng.prefetch = prefetch
+        traj, batches = [], []
+        for it in range(5):
+            if eng._pre is not None:
+                batches.append(tuple(t.clone() for t in eng._pre[:3]))
+            st = eng.step().tolist()
+            traj.append(st)
+        torch.cuda.synchronize()
+        runs.append((traj, batches, eng.bucket.flat.detach().clone()))
+        assert (eng._pre is not None) == prefetch
+    (t0, _, p0), (t1, b1, p1) = runs
+    assert len(b1) == 3           # steps 3..5 consumed a batch generated one step ahead (the first step runs single-stream)
+    for a, b in zip(t0, t1):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), (t0, t1)
+    assert rel_err(p1, p0) < 1e-5

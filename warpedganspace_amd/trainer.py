@@ -34,6 +34,7 @@ from .support_sets import rbf_workspace
 # process-wide switches, read once at import (development A/B only; defaults are the measured-best path)
 _TWO_STREAMS = os.environ.get('WGS_TWO_STREAMS', '1') != '0'
 _DEFER_WGRAD = os.environ.get('WGS_DEFER_WGRAD', '1') != '0'
+_PREFETCH = os.environ.get('WGS_PREFETCH', '1') != '0'        # next step's un-shifted generator pass one step ahead
 
 
 def sampler_seed(seed, rank, world, start_iter, device):
@@ -110,7 +111,10 @@ class TrainStep:
         self.B, self.dev, self.world, self.rank = local_batch, device, world, rank
         self.gen = torch.Generator(device=device)
         self.side_stream = torch.cuda.Stream(device=device)
+        self.pre_stream = torch.cuda.Stream(device=device)
         self.two_streams = _TWO_STREAMS      # un-shifted generator pass on the side stream
+        self.prefetch = _PREFETCH            # ... of the NEXT step's batch, next to this step's Reconstructor / backward phases
+        self._pre = None                     # (z, idx, mag, img, precision) drawn and generated one step ahead
         self.steps_done = 0
         self.sampler_seed = sampler_seed(seed, rank, world, start_iter, device)
         self.gen.manual_seed(self.sampler_seed)
@@ -173,8 +177,16 @@ class TrainStep:
     def step(self, z=None, idx=None, mag=None):
         G, S, R, p, B = self.G, self.S, self.R, self.p, self.B
         lib, st = L.lib(), L.stream()
-        if z is None:
-            z, idx, mag = self.sample()
+        auto = z is None
+        img = None
+        if auto:
+            if self._pre is not None:
+                z, idx, mag, img, prec = self._pre
+                self._pre = None
+                if prec != C.PRECISION:
+                    img = None              # generated in another arithmetic mode: redo it below
+            else:
+                z, idx, mag = self.sample()
         self.bucket.zero_grad()
         # The un-shifted pass G(z) (nothing saved, :200) runs on a side stream next to the shifted pass: both are the same
         # network on independent inputs, and their 4x4 .. 16x16 layers each fill only part of the chip.
@@ -184,12 +196,16 @@ class TrainStep:
         # (the same after a change of the conv arithmetic: the 16-bit weight planes of a mode are built on first use)
         side = self.side_stream if (self.two_streams and self.steps_done > 0 and self._last_precision == C.PRECISION) else None
         self._last_precision = C.PRECISION
-        if side is not None:
+        pre_img = img is not None           # G(z) of this batch was generated during the previous step (see below)
+        if pre_img:
+            cur.wait_stream(self.pre_stream)
+            img.record_stream(cur)
+        elif side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
                 img = G(z)
         with torch.no_grad():
-            if side is None:
+            if img is None:
                 img = G(z)                                                    # :200, nothing saved
             code = G.get_w(z) if self.w_space else z                          # :236
         # shift = mag * S(mask, code)   (:235) — fused scale
@@ -208,9 +224,21 @@ class TrainStep:
             shift = shift[:, :self.d].contiguous()
         shift.requires_grad_(True)
         img_shifted = G(z, shift)                                             # :239, input-gradient only
-        if side is not None:
+        if side is not None and not pre_img:
             cur.wait_stream(side)
             img.record_stream(cur)
+        # G(z) has no trainable ancestor (:200), so the NEXT step's un-shifted pass does not depend on this step's update: its
+        # batch is drawn now (same order of draws from the sampler's generator as one draw per step) and generated on a third
+        # stream, gated behind this step's shifted forward — it fills the CUs that the Reconstructor's small layers, the loss
+        # and the generator's low-resolution backward layers leave idle, instead of competing with the shifted forward's
+        # chip-filling layers.  Same arithmetic, same values; one generated batch stays unused when training stops.
+        if auto and side is not None and self.prefetch:
+            zn, idxn, magn = self.sample()
+            self.pre_stream.wait_stream(cur)
+            with torch.cuda.stream(self.pre_stream), torch.no_grad():
+                imgn = G(zn)
+            zn.record_stream(self.pre_stream)
+            self._pre = (zn, idxn, magn, imgn, C.PRECISION)
         logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True)   # :242
         L.check(lib.wgs_ce_l1_loss(L.ptr(logits), L.ptr(idx, torch.int64), L.ptr(mag_hat.reshape(B)), L.ptr(mag),
                                    L.c_float(p.lambda_cls), L.c_float(p.lambda_reg), L.ptr(self.dlogits), L.ptr(self.dmag),
