@@ -57,7 +57,10 @@ DTYPE_TEXT = {
              "weights (2 MFMAs), the seven layers below 64x64 split-bf16 (3 MFMAs, fp32-class); fp32 accumulate / demodulation / epilogue "
              "everywhere; dynamic power-of-two scale on fp16 gradient operands",
 }
-R_TEXT = "; reconstructor: exact fp32 MFMA forward + weight gradients, split-bf16 input-gradient convs"
+R_TEXT = {0: "; reconstructor (trained): exact fp32 MFMA forward, split-bf16 x3 (fp32-class) input-gradient and >= 128-channel weight-gradient "
+             "convs, exact fp32 MFMA for the other weight gradients; BatchNorm statistics in fp64 partials",
+          1: "; reconstructor (trained): fp32-class only - split-bf16 x3 (3 MFMAs, ~2^-16 per product) forward, input-gradient and "
+             ">= 128-channel weight-gradient convs, exact fp32 MFMA for the other weight gradients; BatchNorm statistics in fp64 partials"}
 
 
 def make_params(w_space=False):
@@ -282,6 +285,7 @@ EXTRA = [   # (name, gan, size, K, N, batch, precision or None = headline's, w_s
     ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 mixed fp16", 'stylegan2', 256, 128, 32, 32, 'mixed', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256, headline arithmetic with the reconstructor's forward convs in split-bf16 x3 instead of exact fp32 [R bf16x3]", 'stylegan2', 256, 128, 32, 32, None, False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 W-space", 'stylegan2', 256, 128, 32, 32, None, True, 10, 'stylegan2-256'),
     ("cfg2 ProgGAN native 1024, K=64 N=16 B=32", 'proggan', 1024, 64, 16, 32, None, False, 4, 'proggan-1024'),
     ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32", 'proggan', 256, 64, 16, 32, None, False, 8, 'proggan-256'),
@@ -294,14 +298,18 @@ EXTRA = [   # (name, gan, size, K, N, batch, precision or None = headline's, w_s
 
 def run_extra(dev, headline_precision, skip_name=None):
     from warpedganspace_amd import conv as C
+    from warpedganspace_amd import reconstructor as RR
     out = []
+    r_old = RR.R_PRECISION
     for name, gan, size, K, N, B, prec, w_space, steps, gkey in EXTRA:
         prec = prec or headline_precision
         try:
             old = C.set_precision(prec)
             prec = C.precision_name(C.resolve_auto(gan, size))        # 'auto' -> the concrete mode of this architecture
-            if skip_name is not None and (gan, size, K, N, B, prec, w_space) == skip_name:
+            r_alt = '[R bf16x3]' in name
+            if skip_name is not None and (gan, size, K, N, B, prec, w_space) == skip_name and not r_alt:
                 continue
+            RR.R_PRECISION = 'bf16x3' if r_alt else r_old
             eng = build(dev, gan, K, N, B, w_space=w_space, size=size)
             dt = timed_steps(eng, steps, 3, 1, dev)
             by = conv_profile(eng, 1)
@@ -318,6 +326,7 @@ def run_extra(dev, headline_precision, skip_name=None):
             out.append({"config": name, "precision": prec, "error": repr(e)[:300]})
         finally:
             C.PRECISION = old
+            RR.R_PRECISION = r_old
     return out
 
 
@@ -348,7 +357,8 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--cpu-threads', type=int, default=32)
-    ap.add_argument('--r-precision', choices=['fp32', 'bf16x3'], default='fp32', help='arithmetic of the Reconstructor convs (default exact fp32)')
+    ap.add_argument('--r-precision', choices=['fp32', 'bf16x3', 'auto'], default='fp32',
+                    help="arithmetic of the Reconstructor's forward convs (default exact fp32; auto = split-bf16 x3 unless --precision fp32)")
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the short runs of the other arithmetic modes / configs')
     ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default=C.DEFAULT_PRECISION,
@@ -376,7 +386,7 @@ def main():
     C.set_precision(args.precision)
     precision = C.precision_name(C.resolve_auto(args.gan, args.size))      # 'auto' -> the concrete mode of this architecture
     from warpedganspace_amd import reconstructor as RR
-    RR.R_PRECISION = 1 if args.r_precision == 'bf16x3' else 0
+    RR.R_PRECISION = args.r_precision
     eng = build(dev, args.gan, args.K, args.N, args.batch, rank=rank, w_space=args.w_space, size=args.size)
     dt = timed_steps(eng, args.steps, args.warmup, world, dev)
     stats = eng.pop_stats()
@@ -427,7 +437,7 @@ def main():
         out = {"metric": "training images/sec (warp->G->R->loss) %s K=%d" % ({'stylegan2': 'StyleGAN2-%d' % args.size}.get(args.gan, arch), args.K),
                "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": DTYPE_TEXT[precision] + R_TEXT, "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
+               "dtype": DTYPE_TEXT[precision] + R_TEXT[RR.forward_precision()], "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
                "config": {"workload": "%s arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (arch, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": precision, "precision_requested": args.precision,

@@ -91,6 +91,27 @@ def test_resnet_larger_inputs_statistical(dev, B, K, S):
     assert l2_rel(x2d.grad, x2.grad) < 5e-2
 
 
+def test_resnet_split_bf16_forward_option(dev, monkeypatch):
+    """R_PRECISION = 'bf16x3' (an option, not the default): forward convs in split-bf16 x3.  The forward stays fp32-class
+    (outputs within 1e-4 of the oracle, argmax identical); the extra gate flips cost gradient agreement — per-parameter
+    max-norm errors of ~2e-2 instead of < 1e-3 — which is why the exact kernels are the default (reconstructor.py)."""
+    from warpedganspace_amd import conv as C
+    from warpedganspace_amd import reconstructor as RR
+    assert RR.forward_precision() == 0                      # the default is exact fp32
+    monkeypatch.setattr(RR, 'R_PRECISION', 'bf16x3')
+    assert RR.forward_precision() == 1
+    R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, 4, 128, 64)
+    assert rel_err(lg, lo.detach()) < 1e-4 and rel_err(mg, mo.detach()) < 1e-4
+    assert torch.equal(torch.argmax(lg, 1).cpu(), torch.argmax(lo, 1))
+    errs = sorted(rel_err(p.grad, sd[n].grad) for n, p in R.named_parameters() if p.grad is not None)
+    print('split-bf16 forward: median / max parameter-gradient rel err', errs[len(errs) // 2], errs[-1])
+    num = sum(float((p.grad.cpu() - sd[n].grad).pow(2).sum()) for n, p in R.named_parameters() if p.grad is not None)
+    den = sum(float(sd[n].grad.pow(2).sum()) for n, p in R.named_parameters() if p.grad is not None)
+    assert (num / den) ** 0.5 < 1e-1
+    monkeypatch.setattr(RR, 'R_PRECISION', 'auto')
+    assert RR.forward_precision() == (0 if C.PRECISION == 0 else 1)
+
+
 def test_resnet_eval_mode_uses_running_stats(dev):
     R = seeded_resnet(8, 4)
     sd = {k: v.detach().clone() for k, v in R.state_dict().items()}

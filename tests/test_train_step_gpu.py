@@ -142,4 +142,6 @@ def test_prefetched_unshifted_pass_same_trajectory(dev):
     for a, b in zip(t0, t1):
         for x, y in zip(a, b):
             assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), (t0, t1)
-    assert rel_err(p1, p0) < 1e-5
+    # Adam's first steps move an entry by lr * sign(g): entries whose gradient is numerically zero may go either way in two
+    # runs of the SAME schedule (atomic accumulation order), 5 steps * 2 * lr = 1e-3 absolute at most
+    assert rel_err(p1, p0) < 2e-4

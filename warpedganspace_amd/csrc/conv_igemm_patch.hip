@@ -54,10 +54,10 @@ struct PatchGeom {       // uniform per launch
     int tapoff[16];      // byte offset of tap t's rows in a patch plane: ((dy - dy_min) * PW + (dx - dx_min)) * PROW
 };
 
-// BM = 256 (8 waves, one workgroup per CU) or 128 (4 waves, 100 KB less LDS: two workgroups per CU, whose barriers,
+// BM = 256 (8 waves, one workgroup per CU) or 128 (4 waves, 100 KB less LDS: two or three workgroups per CU, whose barriers,
 // patch stores and epilogues overlap each other's MFMAs — the better shape when K is short, i.e. Cin = 128).
 template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? 2 : 1) void igemm_patch_kernel(const ConvArgs p, const PatchGeom g) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SCH == 1 ? 3 : 2) : 1) void igemm_patch_kernel(const ConvArgs p, const PatchGeom g) {
     typedef wgsconv::Scheme<SCH> SC;
     typedef typename SC::frag frag;
     constexpr int NA = SC::NA, NB = SC::NB;
@@ -351,7 +351,10 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_patch(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
     const bool tps3 = a.ntaps % 3 == 0 && !wgs_flags().patch_tps1;
     if (a.sch == 0) launch_patch_t<0, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st);
-    else if (a.sch == 1) { if (tps3) launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
+    // (128-row fp16 tiles: one tap per stage = 38 KB of LDS and 154 VGPRs -> THREE workgroups per CU; with K = 4 chunks the
+    // prologue / epilogue of a tile is a third of its life, and a third resident workgroup hides more of it than the longer
+    // steps save: 128->128 @256^2 0.95 -> 0.90 ms)
+    else if (a.sch == 1) { if (tps3 && BM != 128) launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<1, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
     else { if (tps3 && BN == 128 && BM == 256) launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 3>(a, g, nblocks, st); else launch_patch_t<2, BM, BN, WAVES_M, WAVES_N, 1>(a, g, nblocks, st); }
 }
 

@@ -13,10 +13,10 @@ checkpoint compatibility but never executed: the reference runs it and discards 
 
 Execution is an explicit kernel schedule on NHWC activations: implicit-GEMM MFMA convs (fwd / dgrad /
 wgrad), fused train-mode BatchNorm(+residual)(+ReLU), max/avg pooling, small dense heads.
-The trained network's FORWARD convs and weight gradients always use the EXACT fp32 MFMA kernels, whatever arithmetic the
-frozen generator is run in: ReLU gates and train-mode BatchNorm statistics are fixed by the forward, and the few gates
-that flip between two fp32-class evaluations move R's gradients by ~1e-2.  The input-gradient (dgrad) convs are linear in
-dy for fixed gates / statistics and run in split-bf16 (~1e-5 relative) by default (R_DGRAD_PRECISION below).
+The trained network's FORWARD convs use the EXACT fp32 MFMA kernels by default, whatever arithmetic the frozen generator
+runs in: ReLU gates and train-mode BatchNorm statistics are fixed by the forward, and the gates that flip between two
+fp32-class evaluations move single gradient entries by ~1e-2 (R_PRECISION below).  The input-gradient (dgrad) convs and the
+>= 128-channel weight gradients are linear in dy for fixed gates / statistics and run in split-bf16 (~1e-5 relative).
 """
 import os
 
@@ -27,9 +27,22 @@ from . import _lib as L
 from . import conv as C
 
 BN_EPS, BN_MOM = 1e-5, 0.1
-# Arithmetic of R's conv fwd/dgrad launches: 0 = exact fp32 MFMA (default, see the module docstring); 1 = split-bf16 x3
-# (experiments only: WGS_R_PRECISION=bf16x3 or bench.py --r-precision bf16x3).
-R_PRECISION = 1 if os.environ.get('WGS_R_PRECISION', 'fp32').lower() in ('bf16x3', '1') else 0
+# Arithmetic of R's FORWARD convs: 'fp32' (default) = exact fp32 MFMA; 'bf16x3' = split-bf16 x3 (fp32-class, ~2^-16 per
+# product: logits move by ~1e-5 relative, argmax unchanged, but the extra ReLU-gate / max-pool flips move single parameter
+# gradients by ~2e-2 — measured by tests/test_reconstructor_gpu.py — versus < 1e-3 for the exact kernels, so it is an
+# option, not the default: it would buy 1.0 ms of the 30 ms step, bench.py reports that line in `extra`);
+# 'auto' = exact when the generator runs in exact fp32, split-bf16 otherwise.  WGS_R_PRECISION / bench.py --r-precision.
+R_PRECISION = os.environ.get('WGS_R_PRECISION', 'fp32').lower()
+
+
+def forward_precision():
+    if R_PRECISION in ('fp32', '0', 0):
+        return 0
+    if R_PRECISION in ('bf16x3', '1', 1):
+        return 1
+    return 0 if C.PRECISION == 0 else 1
+
+
 # Arithmetic of R's input-gradient (dgrad) convs of the BasicBlocks.  The activation gates and BN statistics that make R's
 # gradients sensitive are fixed by the (exact fp32) forward; the backward is linear in dy, so split-bf16 (~1e-5 relative) is
 # a smooth perturbation there (this includes conv1's image gradient, which with only 6(+2) output channels runs 75 %-empty
@@ -206,7 +219,8 @@ class Reconstructor(nn.Module):
         L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
         # stem: conv1 weights padded from 2c to Cp input channels
         w1p = self._conv1_padded(c, Cp, dev)
-        c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=R_PRECISION)
+        fp = forward_precision()
+        c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=fp)
         a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
         Hp = (a1.shape[1] + 2 - 3) // 2 + 1
         p1 = torch.empty(B, Hp, Hp, 64, device=dev)
@@ -217,11 +231,11 @@ class Reconstructor(nn.Module):
         h = p1
         for blk in fe.blocks():
             xin = h
-            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=R_PRECISION)
+            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=fp)
             aa, sa = _BN.fwd(blk.bn1, ca, ws, relu=True, train=train)
-            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=R_PRECISION)
+            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=fp)
             if blk.downsample is not None:
-                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=R_PRECISION)
+                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=fp)
                 ad, sd = _BN.fwd(blk.downsample[1], cd, ws, relu=False, train=train)
                 ident = ad
             else:

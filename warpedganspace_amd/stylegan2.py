@@ -368,9 +368,20 @@ class Generator(nn.Module):
         dev = dimg.device
         sumC = P['sumC']
         layers, rgbs = P['layers'], P['rgbs']
-        dS = torch.zeros(B, sumC, device=dev)       # d loss / d modulation outputs, all layers
+        # every zero-initialised accumulator of the pass (style-gradient partial sums, magnitude scalars) in ONE memset
+        nz = B * sumC + 16 + B * layers[0]['Ci'] + sum(3 * B * ly['Co'] for ly in layers) + 4 * (3 * len(layers) + 3)
+        zbuf, zoff = torch.zeros(nz, device=dev), [0]
+
+        def zeros(*shape):
+            n = 1
+            for v in shape:
+                n *= v
+            t = zbuf[zoff[0]:zoff[0] + n].view(*shape)
+            zoff[0] += (n + 3) & ~3                  # 16-byte aligned pieces (the kernels use float4 accesses)
+            return t
+        dS = zeros(B, sumC)                          # d loss / d modulation outputs, all layers
         dskip = dimg
-        amax = torch.zeros(len(layers), device=dev)  # per layer: max |dy * demod| (magnitude bound of the fp16 dgrad operand)
+        amax = zeros(len(layers))                    # per layer: max |dy * demod| (magnitude bound of the fp16 dgrad operand)
         gA, sA_off, cons = None, None, None          # un-scaled dgrad of the consumer conv, its style slice
         num_next = None
         for i in range(len(layers) - 1, -1, -1):
@@ -382,9 +393,9 @@ class Generator(nn.Module):
             has_rgb = (i % 2 == 0)
             r = rgbs[i // 2] if has_rgb else None
             dy = torch.empty_like(out)
-            num = torch.zeros(B, Co, device=dev)
-            dsA = torch.zeros(B, Co, device=dev) if gA is not None else None
-            dsR = torch.zeros(B, Co, device=dev) if has_rgb else None
+            num = zeros(B, Co)
+            dsA = zeros(B, Co) if gA is not None else None
+            dsR = zeros(B, Co) if has_rgb else None
             sA = S[:, sA_off:sA_off + Co].contiguous() if gA is not None else None
             sR = S[:, r['off']:r['off'] + Co].contiguous() if has_rgb else None
             L.check(lib.wgs_sg2_act_bwd(L.ptr(out), L.ptr(gA), L.ptr(sA), L.ptr(dskip if has_rgb else None),
@@ -415,7 +426,7 @@ class Generator(nn.Module):
             sA_off, num_next = ly['off'], num
         # bottom layer: its input is the ConstantInput -> only the style gradient remains
         ly = layers[0]
-        ds0 = torch.zeros(B, ly['Ci'], device=dev)
+        ds0 = zeros(B, ly['Ci'])
         L.check(lib.wgs_xg_reduce(L.ptr(P['const']), 0, L.ptr(gA), L.ptr(ds0), B, 16, ly['Ci'], st), 'xg_reduce')
         self._style_grad(lib, st, num_next, demods[0], S, ly, ds0, dS, B, sumC)
         dw = torch.empty(B, self.style_dim, device=dev)
