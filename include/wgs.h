@@ -249,7 +249,9 @@ int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const fl
  *   t[b,u,v,n]  = alpha * col_scale[b,n] * sum_{ky,kx,k} x[b,(u-ky)/2,(v-kx)/2,k] a_scale[b,k] w[n,ky*3+kx,k]     (u-ky, v-kx even)
  *   y[b,oy,ox,n] = lrelu_0.2( sum_{i,j} flip(kernel4x4)[i][j] t[b,oy+i-1,ox+j-1,n] + noise_w[0]*noise[oy*2H+ox] + bias[n] ) * sqrt(2)
  * x [B,H,H,Ci] NHWC fp32, y [B,2H,2H,Co]; w_hi (w_lo) = the fp16 planes of the [Co,9,Ci] weights from wgs_split_f16.
- * precision 2 (fp16) or 3 (fp16 x2); Ci % 32 == 0, Co % 64 == 0; a_amax / a_amax2 / a_bound / y_amax as in wgs_conv_desc. */
+ * precision 2 (fp16) or 3 (fp16 x2: here the ACTIVATION operand is split hi + lo against the single plane w_hi — two MFMAs per
+ * product and the error class of wgs_conv_desc's weight split; w_lo is not read); Ci % 32 == 0, Co % 64 == 0;
+ * a_amax / a_amax2 / a_bound / y_amax as in wgs_conv_desc. */
 typedef struct wgs_upconv_desc {
     const float* x; const void* w_hi; const void* w_lo; float* y;
     const float* a_scale; const float* col_scale; const float* bias; const float* noise; const float* noise_w;

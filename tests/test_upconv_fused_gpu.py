@@ -4,7 +4,8 @@ stride 2 + Blur(pad (1,1)) + noise + bias + leaky-relu*sqrt(2) in one launch (mo
   * EXACTNESS: against float64 conv_transpose2d + upfirdn blur of the SAME fp16-rounded operands (only the fp32
     accumulation order and the fp32 blur remain): ~1e-6;
   * ACCURACY of the mode against the unrounded float64 layer: the fp16 operand rounding, ~3e-4;
-  * agreement with the unfused launches (phase GEMMs + wgs_sg2_blur_noise_bias_act) of the same arithmetic;
+  * agreement with the unfused launches (phase GEMMs + wgs_sg2_blur_noise_bias_act): bit-level for fp16; for fp16 x2 the
+    fused kernel splits the activation operand where the GEMM kernels split the weights (same error class);
   * sizes: tile interior / border / image smaller than a tile / image not a multiple of the 14-cell tile / both weight planes."""
 import pytest
 import torch
@@ -59,8 +60,9 @@ def test_upconv_fused_vs_float64(dev, prec, B, Ci, Co, H):
     bias = torch.randn(Co, dtype=torch.float64) * 0.2
     kern = blur_kernel()
     xs = (x.float() * sc.float()[:, :, None, None]).double()              # the kernel's rounded fp32 product
-    wq = r16(w) if prec == 2 else r16x2(w)
-    y_q = layer_f64(r16(xs), wq, demod.float().double(), kern.float().double(), noise.float().double(), nw, bias.float().double())
+    # precision 3 in THIS kernel: the activation operand carries the hi + lo split, the weights one fp16 plane (Scheme<3>)
+    xq = r16(xs) if prec == 2 else r16x2(xs)
+    y_q = layer_f64(xq, r16(w), demod.float().double(), kern.float().double(), noise.float().double(), nw, bias.float().double())
     y_x = layer_f64(xs, w, demod, kern, noise, nw, bias)
 
     xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
@@ -83,7 +85,8 @@ def test_upconv_fused_vs_float64(dev, prec, B, Ci, Co, H):
     y2 = torch.empty_like(y)
     L.check(L.lib().wgs_sg2_blur_noise_bias_act(L.ptr(t), L.ptr(k_d), L.ptr(nz_d), L.ptr(nw_d), L.ptr(b_d), L.ptr(y2), None,
                                                 B, 2 * H, 2 * H, Co, L.stream()), 'blur_nba')
-    assert rel_err(y, y2.cpu()) < 3e-6
+    # (fp16 x2: the unfused GEMMs split the WEIGHT operand instead — same error class, different rounding)
+    assert rel_err(y, y2.cpu()) < (3e-6 if prec == 2 else 1.2e-3)
 
 
 def test_upconv_fused_operand_scale(dev):

@@ -339,11 +339,10 @@ class UpconvDesc(ctypes.Structure):
                [(n, ctypes.c_int32) for n in ('B', 'H', 'Ci', 'Co', 'a_ld', 'col_ld', 'precision')]
 
 
-# The fused up-sampling layer (conv_upfused.hip) is taken where it beats the phase GEMMs + blur kernel (tools/bench_upfused.py,
-# B = 32): fp16 from 16 x 16 inputs up; fp16 x2 — whose second weight plane doubles the kernel's dominant LDS-DMA traffic —
-# only at 128 x 128 inputs, where the unfused path's 1 GB intermediate costs more.
-UPCONV_FUSED_MIN_H = {2: int(os.environ.get('WGS_UPFUSED_MIN_H_F16', '16')),       # development A/B; a huge value = never
-                      3: int(os.environ.get('WGS_UPFUSED_MIN_H_F16X2', '128'))}
+# The fused up-sampling layer (conv_upfused.hip) is taken for the fp16 modes from this input size up (below it a 14 x 14-cell
+# tile wastes most of its GEMM rows on the image border; tools/bench_upfused.py).  Development A/B: a huge value = never.
+UPCONV_FUSED_MIN_H = {2: int(os.environ.get('WGS_UPFUSED_MIN_H_F16', '16')),
+                      3: int(os.environ.get('WGS_UPFUSED_MIN_H_F16X2', '16'))}
 
 
 def upconv_fused_ok(H, Ci, Co, precision):

@@ -5,6 +5,7 @@
 //   SCH 0  split-bf16 x3 : A = {hi, lo}, B = {hi, lo} bf16;  lo*hi + hi*lo + hi*hi         ~2^-16 per product, 3 MFMAs
 //   SCH 1  fp16          : A = {hi},     B = {hi}     fp16;  hi*hi                          ~2^-11 per operand, 1 MFMA
 //   SCH 2  fp16 x2       : A = {hi},     B = {hi, lo} fp16;  hi*lo + hi*hi (weights ~2^-22) ~2^-11 on the activation only, 2 MFMAs
+//   SCH 3  fp16 x2 (A)   : A = {hi, lo}, B = {hi}     fp16;  lo*hi + hi*hi (activations ~2^-22) ~2^-11 on the weights only, 2 MFMAs
 //
 // fp16 has 5 exponent bits: the activation operand is multiplied by a power of two chosen from a device-resident bound of
 // its magnitude (wgs_conv_desc.a_amax) before it is rounded, and the accumulator is multiplied back in the epilogue, so
@@ -68,6 +69,20 @@ template <> struct Scheme<2> {
     }
     static __device__ __forceinline__ sch_f32x16 mma(const frag* a, const frag* b, sch_f32x16 c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// fp16 x2 with the ACTIVATION split instead of the weights: A = {hi, lo}, B = {hi}; lo*hi + hi*hi.  Same two MFMAs and the same
+// error class as SCH 2 (one operand to ~2^-22, the other rounded to 11 bits); used where the weight planes' LDS-DMA traffic,
+// not the MFMA rate, bounds the kernel (conv_upfused.hip): the second weight plane would double that traffic.
+template <> struct Scheme<3> {
+    static constexpr int NA = 2, NB = 1, NP = 2;
+    typedef sch_f16x8 frag;
+    static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) { Scheme<2>::cvt4(f, hi, lo); }
+    static __device__ __forceinline__ sch_f32x16 mma(const frag* a, const frag* b, sch_f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
         return c;
     }

@@ -66,15 +66,15 @@ struct UpArgs {
 template <int SCH, int GH>
 struct UpCfg {
     typedef wgsconv::Scheme<SCH> SC;
-    static constexpr int NB = SC::NB;
+    static constexpr int NA = SC::NA, NB = SC::NB;
     static constexpr int NW = GH / 2, NT = 64 * NW;
     static constexpr int CY = GH - 2;                                  // cell rows of a tile
     static constexpr int PH = GH + 1, NPIX = PW * PH, PALLOC = (NPIX + 7) / 8 * 8;
-    static constexpr int TS = GH == 16 ? (NB == 1 ? 9 : 5) : (NB == 1 ? 5 : 3);   // products per weight stage
+    static constexpr int TS = GH == 16 ? (NA * NB == 1 ? 9 : 5) : (NA * NB == 1 ? 5 : 3);   // products per weight stage
     static constexpr int NSTEP = (9 + TS - 1) / TS;
     static constexpr int P_BYTES = PALLOC * PROW;
     static constexpr int B_BYTES = BN * ROW, B_TAP = NB * B_BYTES, B_STAGE = TS * B_TAP;
-    static constexpr int K_BYTES = 2 * P_BYTES + 2 * B_STAGE;
+    static constexpr int K_BYTES = 2 * NA * P_BYTES + 2 * B_STAGE;
     static constexpr int T_BYTES = 2 * GH * 32 * 32 * 4;               // t tile: (2 GH) x 32 positions x 32 channels fp32
     static constexpr int MAIN = K_BYTES > T_BYTES ? K_BYTES : T_BYTES;
     static constexpr int OR = 2 * GH - 4;                              // output rows of a tile (28 or 12); 28 output columns
@@ -87,8 +87,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     typedef UpCfg<SCH, GH> CF;
     typedef wgsconv::Scheme<SCH> SC;
     typedef typename SC::frag frag;
-    constexpr int NB = SC::NB;
-    static_assert(SC::NA == 1, "fp16 activation plane only");
+    constexpr int NA = SC::NA, NB = SC::NB;
     constexpr int NW = CF::NW, NT = CF::NT;
     constexpr int WM = 32, TN = 2;              // a wave: 32 grid rows x all 64 channels x 4 phases = 128 accumulator registers
     constexpr int TS = CF::TS, NSTEP = CF::NSTEP;
@@ -97,8 +96,8 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     constexpr int NPL = (PALLOC * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (5)
     constexpr int OR = CF::OR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* patch = smem_b;                      // two buffers
-    unsigned char* bst = smem_b + 2 * P_BYTES;          // two weight stages
+    unsigned char* patch = smem_b;                      // two buffers of NA planes
+    unsigned char* bst = smem_b + 2 * NA * P_BYTES;     // two weight stages
     float* aux_nz = reinterpret_cast<float*>(smem_b + CF::MAIN);
     float* aux_bias = aux_nz + OR * 28;
     float* aux_cs = aux_bias + BN;
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_hi), 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(NB == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>((NB == 2 && p.w_lo) ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_scale), 0, p.s_bytes, 0x00020000);
 
     // ---- the epilogue's per-tile scalars go to LDS now (noise of the output block, bias, demodulation): fetched there, every
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         if (c < cpt) sc = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     auto store_patch = [&](int buf) {
-        unsigned char* pb = patch + buf * P_BYTES;
+        unsigned char* pb = patch + buf * NA * P_BYTES;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             float4 v = pr_[j];
@@ -178,7 +177,10 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             const f32x4 f = {v.x, v.y, v.z, v.w};
             uint2 h, l;
             SC::cvt4(f, h, l);
-            if (((tid + j * NT) >> 3) < PALLOC) *reinterpret_cast<uint2*>(pb + p_lbase + j * (NT / 8) * PROW) = h;
+            if (((tid + j * NT) >> 3) < PALLOC) {
+                *reinterpret_cast<uint2*>(pb + p_lbase + j * (NT / 8) * PROW) = h;
+                if (NA == 2) *reinterpret_cast<uint2*>(pb + P_BYTES + p_lbase + j * (NT / 8) * PROW) = l;
+            }
         }
     };
 
@@ -221,24 +223,27 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     const int bk0 = ((0 + lh) ^ bswz) << 4, bk1 = ((2 + lh) ^ bswz) << 4;
 
     auto mma_step = [&](int buf, int stage, int s) {
-        const unsigned char* pb = patch + buf * P_BYTES;
+        const unsigned char* pb = patch + buf * NA * P_BYTES;
         const unsigned char* bb = bst + stage * B_STAGE + b_rd;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            frag af;
+            frag af[NA];
 #pragma unroll
             for (int u = 0; u < TS; ++u) {
                 const int t = s * TS + u;       // s is a compile-time constant at every call site
                 if (t < 9) {
-                    if (u == 0 || T_SH[t] != T_SH[t - 1]) af = *reinterpret_cast<const frag*>(pb + pa0 + SH_OFF[T_SH[t]] + ks * 32);
+                    if (u == 0 || T_SH[t] != T_SH[t - 1]) {
+#pragma unroll
+                        for (int pl = 0; pl < NA; ++pl) af[pl] = *reinterpret_cast<const frag*>(pb + pl * P_BYTES + pa0 + SH_OFF[T_SH[t]] + ks * 32);
+                    }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         frag bf[NB];
 #pragma unroll
                         for (int pl = 0; pl < NB; ++pl)
                             bf[pl] = *reinterpret_cast<const frag*>(bb + u * B_TAP + pl * B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
-                        if (WGS_UABL == 2) { asm volatile("" :: "v"(af), "v"(bf[0])); continue; }
-                        acc[T_PH[t]][j] = SC::mma(&af, bf, acc[T_PH[t]][j]);
+                        if (WGS_UABL == 2) { asm volatile("" :: "v"(af[0]), "v"(bf[0])); continue; }
+                        acc[T_PH[t]][j] = SC::mma(af, bf, acc[T_PH[t]][j]);
                     }
                 }
             }
@@ -373,7 +378,6 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     WGS_CHECK_ARG(d && d->x && d->w_hi && d->y && d->a_scale && d->col_scale && d->bias && d->kernel4x4,
                   "wgs_sg2_upconv_blur_act: null pointer");
     WGS_CHECK_ARG(d->precision == 2 || d->precision == 3, "wgs_sg2_upconv_blur_act: precision %d (fp16 schemes 2 / 3 only)", d->precision);
-    WGS_CHECK_ARG(d->precision == 2 || d->w_lo, "wgs_sg2_upconv_blur_act: fp16 x2 needs the low weight plane");
     WGS_CHECK_ARG(d->B > 0 && d->H >= 4 && d->Ci % 32 == 0 && d->Ci > 0 && d->Co % 64 == 0 && d->Co > 0,
                   "wgs_sg2_upconv_blur_act: B=%d H=%d Ci=%d (%%32) Co=%d (%%64)", d->B, d->H, d->Ci, d->Co);
     WGS_CHECK_ARG(!d->noise || d->noise_w, "wgs_sg2_upconv_blur_act: noise needs noise_w");
@@ -395,8 +399,10 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     // tiles, two 4-wave workgroups per CU (they re-fetch the weights twice as often, which is what bounds the large layers)
     const int t14 = (d->H + CELLS - 1) / CELLS;
     const bool gh16 = wgs_flags().up_gh16 || (long)d->B * t14 * t14 * (d->Co / BN) >= 2048;
+    // precision 3 (fp16 x2) splits the ACTIVATION operand here (Scheme<3>: same two MFMAs, same error class as the weight split of
+    // the GEMM kernels): the second weight plane would double the LDS-DMA traffic that bounds this kernel.  w_lo is not read.
     if (d->precision == 2) { if (gh16) launch_up<1, 16>(a, (hipStream_t)stream); else launch_up<1, 8>(a, (hipStream_t)stream); }
-    else { if (gh16) launch_up<2, 16>(a, (hipStream_t)stream); else launch_up<2, 8>(a, (hipStream_t)stream); }
+    else { if (gh16) launch_up<3, 16>(a, (hipStream_t)stream); else launch_up<3, 8>(a, (hipStream_t)stream); }
     WGS_CHECK_LAUNCH("upconv_blur_kernel");
     return WGS_OK;
 }
