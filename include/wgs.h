@@ -266,6 +266,10 @@ int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* desc, wgs_stream_t stream);
  * x NHWC [B,P,C]; img/skip NCHW [B,3,P]. C power of two. */
 int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip, float* img,
                       int B, int P, int C, float wscale, wgs_stream_t stream);
+/* The same with the skip branch's Upsample (model.py:257-262,279-281: upfirdn2d(skip, kernel*4, up=2, pad=(2,1))) evaluated in
+ * place: skip_lo [B,3,H/2,W/2] is the previous resolution's image, img [B,3,H,W]. */
+int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip_lo,
+                         const float* up_kernel4x4, float* img, int B, int H, int W, int C, float wscale, wgs_stream_t stream);
 
 /* Backward through one StyledConv output `out` [B,P,C] (post-activation, saved by the forward):
  *   dOut = sA*gA + sR*(sum_o drgb[b,o,p]*wR[o,c]*rscale);  dy = dOut * lrelu'(out)*sqrt(2)  -> dy [B,P,C]

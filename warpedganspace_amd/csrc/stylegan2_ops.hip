@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ skip, float* __restrict__ img,
-                                                        int P, int C, float wscale, int ppb) {
+                                                        int P, int C, float wscale, int ppb,
+                                                        const float* __restrict__ skip_lo, const float* __restrict__ upk, int Wimg) {
     // ppb = pixels per block (64, 128 or 256): small maps use small blocks so that the launch still fills the chip
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wm = sm;               // [3][C] modulated weights W[o,c]*s[b,c]*wscale
@@ -242,6 +243,25 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
             const size_t off = ((size_t)b * 3 + o) * P + p;
             float v = res[o * 256 + threadIdx.x] + bias[o];
             if (skip) v += skip[off];
+            if (skip_lo) {
+                // Upsample(skip) of model.py:257-262,279-281 = upfirdn2d(skip, k*4, up=2, pad=(2,1)) evaluated in place: of the 4x4
+                // taps only the 2x2 that land on the zero-inserted grid's samples contribute
+                const int oy = p / Wimg, ox = p - oy * Wimg, Hl = (P / Wimg) >> 1, Wl = Wimg >> 1;
+                const float* sl = skip_lo + ((size_t)b * 3 + o) * Hl * Wl;
+                float up = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    const int Y = oy + ky - 2, i = Y >> 1;
+                    if ((Y & 1) || i < 0 || i >= Hl) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int X = ox + kx - 2, j = X >> 1;
+                        if ((X & 1) || j < 0 || j >= Wl) continue;
+                        up = fmaf(upk[(3 - ky) * 4 + (3 - kx)], sl[i * Wl + j], up);
+                    }
+                }
+                v += up;
+            }
             img[off] = v;
         }
     }
@@ -497,8 +517,25 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
     int ppb = 256;
     while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
     if (C < 32) ppb = 256;                // a wave iteration covers 64 / (C/4) pixels: needs ppb/4 >= that
-    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale, ppb);
+    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale, ppb,
+                       (const float*)nullptr, (const float*)nullptr, 0);
     WGS_CHECK_LAUNCH("torgb_fwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip_lo,
+                         const float* up_kernel4x4, float* img, int B, int H, int W, int C, float wscale, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && s && w && bias && img && skip_lo && up_kernel4x4, "wgs_sg2_torgb_up_fwd: null pointer");
+    WGS_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C >= 4 && (C & (C - 1)) == 0,
+                  "wgs_sg2_torgb_up_fwd: even H, W and a power-of-two C >= 4 (H=%d W=%d C=%d)", H, W, C);
+    const int P = H * W;
+    const size_t smem = (size_t)(3 * C + 3 * 256) * sizeof(float);
+    int ppb = 256;
+    while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
+    if (C < 32) ppb = 256;
+    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias,
+                       (const float*)nullptr, img, P, C, wscale, ppb, skip_lo, up_kernel4x4, W);
+    WGS_CHECK_LAUNCH("torgb_fwd_kernel<up>");
     return WGS_OK;
 }
 

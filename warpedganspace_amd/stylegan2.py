@@ -346,16 +346,15 @@ class Generator(nn.Module):
             if i % 2 == 0:
                 r = P['rgbs'][i // 2]
                 Hc = x.shape[1]
-                if skip is not None:
-                    up = ops.upfirdn2d_mhwc(skip.reshape(B * 3, Hc // 2, Hc // 2, 1), r['upk'], 2, 2, 1, 1, 2, 1, 2, 1)
-                    skip_up = up.reshape(B, 3, Hc, Hc)
-                else:
-                    skip_up = None
                 img = torch.empty(B, 3, Hc, Hc, device=dev)
                 # the ToRGB kernel reads its style with row stride C: hand it a compact copy of the slice
                 s_rgb = S[:, r['off']:r['off'] + r['C']].contiguous()
-                L.check(lib.wgs_sg2_torgb_fwd(L.ptr(x), L.ptr(s_rgb), L.ptr(r['w']), L.ptr(r['bias']), L.ptr(skip_up),
-                                              L.ptr(img), B, Hc * Hc, r['C'], L.c_float(r['scale']), st), 'torgb')
+                if skip is not None:    # + Upsample(skip) (model.py:279-281), evaluated inside the ToRGB kernel's epilogue
+                    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(x), L.ptr(s_rgb), L.ptr(r['w']), L.ptr(r['bias']), L.ptr(skip), L.ptr(r['upk']),
+                                                     L.ptr(img), B, Hc, Hc, r['C'], L.c_float(r['scale']), st), 'torgb_up')
+                else:
+                    L.check(lib.wgs_sg2_torgb_fwd(L.ptr(x), L.ptr(s_rgb), L.ptr(r['w']), L.ptr(r['bias']), None,
+                                                  L.ptr(img), B, Hc * Hc, r['C'], L.c_float(r['scale']), st), 'torgb')
                 skip = img
         saved = (S, outs, demods, B) if save else None
         return skip, saved
