@@ -89,6 +89,26 @@ def test_upconv_fused_vs_float64(dev, prec, B, Ci, Co, H):
     assert rel_err(y, y2.cpu()) < (3e-6 if prec == 2 else 1.2e-3)
 
 
+def test_upconv_fused_general_kernel(dev):
+    """A 4x4 FIR that is NOT an outer product takes the kernel's 16-tap path (the separable one is a uniform branch)."""
+    torch.manual_seed(11)
+    B, Ci, Co, H = 2, 64, 64, 19
+    kern = torch.rand(4, 4, dtype=torch.float64) + 0.1
+    x = torch.randn(B, Ci, H, H, dtype=torch.float64)
+    w = torch.randn(Co, Ci, 3, 3, dtype=torch.float64) / (Ci * 9) ** 0.5
+    sc = (torch.randn(B, Ci) + 1.0).double()
+    demod = (torch.rand(B, Co) + 0.5).double()
+    noise = torch.randn(2 * H, 2 * H, dtype=torch.float64)
+    bias = torch.randn(Co, dtype=torch.float64) * 0.2
+    xs = (x.float() * sc.float()[:, :, None, None]).double()
+    y_q = layer_f64(r16(xs), r16(w), demod.float().double(), kern.float().double(), noise.float().double(), 0.3, bias.float().double())
+    wp = C.pack_weight(w.float()).to(dev)
+    y = C.upconv_blur_act(x.float().permute(0, 2, 3, 1).contiguous().to(dev), C.split_weight(wp, 2), kern.float().to(dev),
+                          sc.float().to(dev), Ci, demod.float().to(dev), noise.float().reshape(-1).to(dev),
+                          torch.tensor([0.3], device=dev), bias.float().to(dev), 2)
+    assert rel_err(y.permute(0, 3, 1, 2), y_q) < 3e-6
+
+
 def test_upconv_fused_operand_scale(dev):
     """Activations far outside fp16's range: the magnitude chain (a_amax x a_amax2) keeps all 11 bits."""
     torch.manual_seed(5)
