@@ -5,15 +5,20 @@ d, mode, out = sys.argv[1], sys.argv[2], sys.argv[3]
 tab = collections.OrderedDict()
 for f in sorted(glob.glob(d + '/*/p_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        if 'igemm' not in r['Kernel_Name']:
+        kn = r['Kernel_Name']
+        if 'igemm' in kn:
+            name = 'igemm_' + kn.split('igemm_')[1].split('(')[0]
+        elif 'upconv_blur_kernel' in kn:
+            name = 'upconv_blur_kernel' + kn.split('upconv_blur_kernel')[1].split('(')[0]
+        else:
             continue
-        name = 'igemm_' + r['Kernel_Name'].split('igemm_')[1].split('(')[0]
         key = (int(r['Dispatch_Id']), name)
         tab.setdefault(key, collections.OrderedDict())
         tab[key][r['Counter_Name']] = tab[key].get(r['Counter_Name'], 0) + float(r['Counter_Value'])
 B = 32
 shapes = [(512, 512, 64, 'conv %s 512->512 @64x64 9 taps B32'), (256, 256, 128, 'conv %s 256->256 @128x128 9 taps B32'),
-          (128, 128, 256, 'conv %s 128->128 @256x256 9 taps B32'), (256, 128, 128, 'conv %s 256->128 @128x128 up-conv x4 phases B32')]
+          (128, 128, 256, 'conv %s 128->128 @256x256 9 taps B32'),
+          (256, 128, 128, 'conv f16 256->128 @128x128 up-conv + blur fused B32'), (256, 128, 128, 'conv f16x2 256->128 @128x128 up-conv + blur fused B32')]
 keys = list(tab)
 launches = []
 lines = ['| launch | kernel | algorithmic HBM bytes (read + write) | FETCH_SIZE x2 + WRITE_SIZE | L2 hit | MFMA-busy share of SIMD cycles | VALU / SALU / LDS instr per MFMA | SQ_WAIT_ANY / WAIT_INST_ANY / ACTIVE (of wave cycles) |', '|---|---|---|---|---|---|---|---|']
@@ -22,11 +27,11 @@ for i, (ci, co, h, lab) in enumerate(shapes):
         break
     c = tab[keys[2 * i + 1]]          # second launch of each shape
     up = 'up-conv' in lab
-    ho = 2 * h + 1 if up else h
+    ho = 2 * h if up else h
     rd = B * h * h * ci * 4 + co * 9 * ci * 2
     wr = B * ho * ho * co * 4
     fetch, write = c.get('FETCH_SIZE', 0) * 1024 * 2, c.get('WRITE_SIZE', 0) * 1024
-    rec = dict(label=lab % mode, kernel=keys[2 * i + 1][1], shape='%d->%d @%d B=%d' % (ci, co, h, B), fetch_bytes=fetch, write_bytes=write,
+    rec = dict(label=(lab % mode) if '%s' in lab else lab, kernel=keys[2 * i + 1][1], shape='%d->%d @%d B=%d' % (ci, co, h, B), fetch_bytes=fetch, write_bytes=write,
                algorithmic_read_bytes=rd, algorithmic_write_bytes=wr, counters=c)
     launches.append(rec)
     mf = c.get('SQ_INSTS_MFMA', 0) or 1

@@ -214,26 +214,48 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
     const int lpp = c4n < 64 ? c4n : 64;   // lanes per pixel (power of two: C in {32..512})
     const int ppw = 64 / lpp;              // pixels per wave iteration
     const int sub = lane / lpp, cl = lane % lpp;
-    for (int it = 0; it < ppwave; it += ppw) {
-        const int pl = wave * ppwave + it + sub;
-        const int p = p0 + pl;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        if (p < P) {
-            const float* xp = x + ((size_t)b * P + p) * C;
-            for (int c = cl * 4; c < C; c += lpp * 4) {
-                const float4 v = *reinterpret_cast<const float4*>(xp + c);
-                const float4 w0 = *reinterpret_cast<const float4*>(wm + c);
-                const float4 w1 = *reinterpret_cast<const float4*>(wm + C + c);
-                const float4 w2 = *reinterpret_cast<const float4*>(wm + 2 * C + c);
-                a0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
-                a1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
-                a2 += v.x * w2.x + v.y * w2.y + v.z * w2.z + v.w * w2.w;
+    // a lane owns the same one or two channel quads for every pixel: its modulated weights stay in registers, and four pixels'
+    // loads are issued before the first is reduced (one pixel at a time left the kernel latency-bound at 4.0 TB/s)
+    const int nc = C / (lpp * 4);          // 1 (C <= 256) or 2 (C = 512)
+    float4 W0[2], W1[2], W2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = (cl + j * lpp) * 4;
+        const bool ok = j < nc;
+        W0[j] = ok ? *reinterpret_cast<const float4*>(wm + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        W1[j] = ok ? *reinterpret_cast<const float4*>(wm + C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        W2[j] = ok ? *reinterpret_cast<const float4*>(wm + 2 * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    constexpr int U = 4;
+    for (int it = 0; it < ppwave; it += ppw * U) {
+        float4 v[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pl = wave * ppwave + it + u * ppw + sub;
+            const int p = p0 + pl;
+            const bool live = it + u * ppw < ppwave && p < P;
+            const float* xp = x + ((size_t)b * P + (live ? p : 0)) * C;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                v[u][j] = (live && j < nc) ? *reinterpret_cast<const float4*>(xp + (cl + j * lpp) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (it + u * ppw >= ppwave) break;
+            const int pl = wave * ppwave + it + u * ppw + sub;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 t = v[u][j];
+                a0 += t.x * W0[j].x + t.y * W0[j].y + t.z * W0[j].z + t.w * W0[j].w;
+                a1 += t.x * W1[j].x + t.y * W1[j].y + t.z * W1[j].z + t.w * W1[j].w;
+                a2 += t.x * W2[j].x + t.y * W2[j].y + t.z * W2[j].z + t.w * W2[j].w;
             }
+            for (int off = lpp >> 1; off > 0; off >>= 1) {
+                a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64);
+            }
+            if (cl == 0) { res[pl] = a0; res[256 + pl] = a1; res[512 + pl] = a2; }
         }
-        for (int off = lpp >> 1; off > 0; off >>= 1) {
-            a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64);
-        }
-        if (cl == 0) { res[pl] = a0; res[256 + pl] = a1; res[512 + pl] = a2; }
     }
     __syncthreads();
     const int p = p0 + threadIdx.x;
@@ -512,7 +534,7 @@ int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const fl
 int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip, float* img,
                       int B, int P, int C, float wscale, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && s && w && bias && img, "wgs_sg2_torgb_fwd: null pointer");
-    WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && (C & (C - 1)) == 0, "wgs_sg2_torgb_fwd: C=%d must be a power of two >= 4", C);
+    WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && C <= 512 && (C & (C - 1)) == 0, "wgs_sg2_torgb_fwd: C=%d must be a power of two in [4, 512]", C);
     const size_t smem = (size_t)(3 * C + 3 * 256) * sizeof(float);
     int ppb = 256;
     while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
@@ -526,7 +548,7 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
 int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip_lo,
                          const float* up_kernel4x4, float* img, int B, int H, int W, int C, float wscale, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && s && w && bias && img && skip_lo && up_kernel4x4, "wgs_sg2_torgb_up_fwd: null pointer");
-    WGS_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C >= 4 && (C & (C - 1)) == 0,
+    WGS_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C >= 4 && C <= 512 && (C & (C - 1)) == 0,
                   "wgs_sg2_torgb_up_fwd: even H, W and a power-of-two C >= 4 (H=%d W=%d C=%d)", H, W, C);
     const int P = H * W;
     const size_t smem = (size_t)(3 * C + 3 * 256) * sizeof(float);
