@@ -119,7 +119,9 @@ def conv_profile(eng, nprof=2):
     the steps run single-stream (with the un-shifted pass on the side stream, kernels of the other stream would run inside
     the event pairs and inflate the per-launch durations).  Returns {label: [flops, ms, launches]} per step."""
     from warpedganspace_amd import conv as C
-    C.PROFILE = []
+    torch.cuda.synchronize()
+    eng._pre = None            # a batch whose un-shifted pass was generated one step ahead would make the first profiled step one
+    C.PROFILE = []             # generator pass short: the profiled steps draw their own batches and run every launch themselves
     two, eng.two_streams = eng.two_streams, False
     for _ in range(nprof):
         eng.step()
