@@ -14,7 +14,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else 'mixed'
 nz = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 size = int(os.environ.get('SIZE', 256))
-allerr = []
+allerr, berr = [], []
 for sidx in range(seeds):
     torch.manual_seed(100 + sidx)
     G0 = Generator(size, 512, 8)
@@ -31,10 +31,13 @@ for sidx in range(seeds):
             C.set_precision('fp32'); ref = G(z)
             C.set_precision(mode); img = G(z)
         errs.append(((img - ref).abs().flatten(1).max(1).values / ref.abs().flatten(1).max(1).values).cpu())
+        berr.append(float((img - ref).abs().max() / ref.abs().max()))       # whole-tensor max-norm of the batch (tests.util.rel_err)
     e = torch.cat(errs)
     allerr.append(e)
     print('weights %d: n=%d median %.2e p90 %.2e p99 %.2e max %.2e  over-gate %d' % (
         sidx, e.numel(), float(e.median()), float(e.quantile(0.9)), float(e.quantile(0.99)), float(e.max()), int((e > 1e-3).sum())), flush=True)
 e = torch.cat(allerr)
+b = torch.tensor(berr)
+print('%s @%d per batch of 32 (whole-tensor max-norm, the parity tests\' metric): n=%d median %.2e max %.2e' % (mode, size, b.numel(), float(b.median()), float(b.max())))
 print('%s @%d all: n=%d median %.2e p90 %.2e p99 %.2e max %.2e  over-gate %d' % (
     mode, size, e.numel(), float(e.median()), float(e.quantile(0.9)), float(e.quantile(0.99)), float(e.max()), int((e > 1e-3).sum())))

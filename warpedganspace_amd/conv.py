@@ -63,14 +63,22 @@ def layer_precision(code, out_res, is_up):
     """Concrete arithmetic of one StyleGAN2 layer under mode `code` (see 'mixed' above)."""
     if code != MIXED:
         return code
+    if _MIXED_POLICY is not None:
+        s1, up = _MIXED_POLICY.get(out_res, (1, 1))
+        return up if is_up else s1
     if out_res < _MIXED_MIN_RES:
         return 1
     return _MIXED_UP if is_up else 2
 
 
-# development overrides of the 'mixed' policy (read once at import): resolution from which layers run in fp16, arithmetic of the up-convs
+# development overrides of the 'mixed' policy (read once at import): resolution from which layers run in fp16, arithmetic of the
+# up-convs, or a whole table "res:stride1,up;..." (e.g. WGS_MIXED_POLICY="64:f16x2,f16x2;128:f16,f16x2;256:f16,f16x2")
 _MIXED_MIN_RES = int(os.environ.get('WGS_MIXED_MIN_RES', '64'))
-_MIXED_UP = {'f16': 2, 'f16x2': 3, 'bf16x3': 1}[os.environ.get('WGS_MIXED_UP', 'f16x2')]
+_PN = {'f16': 2, 'f16x2': 3, 'bf16x3': 1, 'fp32': 0}
+_MIXED_UP = _PN[os.environ.get('WGS_MIXED_UP', 'f16x2')]
+_MIXED_POLICY = None
+if os.environ.get('WGS_MIXED_POLICY'):
+    _MIXED_POLICY = {int(e.split(':')[0]): tuple(_PN[m] for m in e.split(':')[1].split(',')) for e in os.environ['WGS_MIXED_POLICY'].split(';')}
 AUTO_FALLBACK = 'bf16x3'
 
 
