@@ -58,11 +58,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         wr[t] = (k < K) ? *reinterpret_cast<const float4*>(w + (size_t)n * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float b = bias ? bias[n] * bscale : 0.f;
-    // four batch rows per trip: their loads and shuffle reductions are independent, so the latencies overlap
-    for (int m0 = 0; m0 < M; m0 += 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // eight batch rows per trip: their loads and shuffle reductions are independent, so the latencies overlap
+    constexpr int U = 8;
+    for (int m0 = 0; m0 < M; m0 += U) {
+        float acc[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) acc[u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             const int m = m0 + u < M ? m0 + u : M - 1;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -76,9 +79,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
-        if (lane < 4 && m0 + lane < M) {
-            float v = fmaf(lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3], wscale, b);
+        for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane < U && m0 + lane < M) {
+            float sel = acc[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) sel = lane == u ? acc[u] : sel;
+            float v = fmaf(sel, wscale, b);
             if (epi == 1) v = (v > 0.f ? v : 0.2f * v) * SQRT2;
             else if (epi == 2) v = rsqrtf(v + eps);
             y[(size_t)(m0 + lane) * ldy + n] = v * out_gain;
