@@ -56,7 +56,10 @@ struct PatchGeom {       // uniform per launch
 
 // BM = 256 (8 waves, one workgroup per CU) or 128 (4 waves, 100 KB less LDS: two or three workgroups per CU, whose barriers,
 // patch stores and epilogues overlap each other's MFMAs — the better shape when K is short, i.e. Cin = 128).
-template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
+// NTF: number of taps when it is known at compile time (9: every 3x3 conv), else 0.  With it the tap loop is unrolled and the
+// per-tap table entries (LDS row offsets, weight slab offsets) become loop-invariant scalar loads hoisted out of the chunk loop:
+// a scalar load inside a step shares lgkmcnt with the step's ds_reads, so waiting for it drained the fragment reads in flight.
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SCH == 1 ? 3 : 2) : 1) void igemm_patch_kernel(const ConvArgs p, const PatchGeom g) {
     typedef wgsconv::Scheme<SCH> SC;
     typedef typename SC::frag frag;
@@ -286,8 +289,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
     int stage = 0;
     for (int c = 0; c < cpt; ++c) {
         if (!PIPE) load_patch(c + 1);            // waits in registers through the tap steps (OOB past the last chunk)
-        for (int t = 0; t < p.ntaps; t += TPS) {
-            const bool last = (t + TPS >= p.ntaps);
+        const int ntaps = NTF ? NTF : p.ntaps;
+#pragma unroll
+        for (int t = 0; t < ntaps; t += TPS) {
+            const bool last = (t + TPS >= ntaps);
             issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + TPS);
             if (PIPE) {
                 // The next chunk's patch loads go out behind the first step's weight DMAs.  NOTE (measured, round 2): a COUNTED
@@ -337,13 +342,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
     wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh, op_inv);
 }
 
-template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
-void launch_patch_t(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF>
+void launch_patch_n(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
     typedef wgsconv::Scheme<SCH> SC;
     const size_t sm = (size_t)SC::NA * pmax_of(BM) * PROW + (size_t)2 * TPS * SC::NB * BN * ROW;
-    auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS>;
+    auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS, NTF>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
+}
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
+void launch_patch_t(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
+    // (256-row tiles only: +2.5 %; the three-per-CU 128-row tiles lose 7 % to the registers the unrolled steps take)
+    if (a.ntaps == 9 && SCH != 0 && BM == 256 && !wgs_flags().patch_ntf0) launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 9>(a, g, nblocks, st);
+    else launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 0>(a, g, nblocks, st);
 }
 
 // tile shape x scheme dispatch; the fp16 schemes take a tap row per barrier when the tap count allows it

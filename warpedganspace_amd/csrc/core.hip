@@ -22,6 +22,7 @@ static WgsFlags read_flags() {
     g.patch_tps1 = getenv("WGS_PATCH_TPS1") != nullptr;
     g.no_fused_up = getenv("WGS_NO_FUSED_UP") != nullptr;
     g.up_gh16 = getenv("WGS_UP_GH16") != nullptr;
+    g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
     return g;
 }
 static WgsFlags& flags_storage() {
