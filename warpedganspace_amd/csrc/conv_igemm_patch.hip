@@ -290,8 +290,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
     for (int c = 0; c < cpt; ++c) {
         if (!PIPE) load_patch(c + 1);            // waits in registers through the tap steps (OOB past the last chunk)
         const int ntaps = NTF ? NTF : p.ntaps;
-#pragma unroll
-        for (int t = 0; t < ntaps; t += TPS) {
+        auto tap_step = [&](int t) {
             const bool last = (t + TPS >= ntaps);
             issue_b(stage ^ 1, last ? c + 1 : c, last ? 0 : t + TPS);
             if (PIPE) {
@@ -316,6 +315,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
                 if (WGS_PABL != 6) __syncthreads();  // weight stage swap; after the last tap also: patch no longer read
             }
             stage ^= 1;
+        };
+        if (NTF) {
+#pragma unroll
+            for (int t = 0; t < NTF; t += TPS) tap_step(t);
+        } else {
+            for (int t = 0; t < ntaps; t += TPS) tap_step(t);
         }
         if (c + 1 < cpt) {
             store_patch();
