@@ -210,6 +210,13 @@ int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stre
 int wgs_pixelnorm_fwd(const float* x, float* y, int rows, int d, float eps, wgs_stream_t stream);
 int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream);
 
+/* The whole mapping network (model.py:288-295: PixelNorm, then L x EqualLinear(d, d, lr_mul, activation='fused_lrelu')) in ONE
+ * launch.  w / bias: host arrays of L device pointers ([d,d] and [d] per layer); acts: device [(L+1), B, d] — acts[0] =
+ * PixelNorm(z), acts[l+1] = output of layer l (the last is the latent w; all of them are what the backward's gates need).
+ * Bit-identical to wgs_pixelnorm_fwd + L x wgs_linear_fwd(..., epilogue 1).  d must be 512 (the reference's style_dim). */
+int wgs_mapping_mlp_fwd(const float* z, const float* const* w, const float* const* bias, float* acts, int B, int d, int L,
+                        float wscale, float lr_mul, float eps, wgs_stream_t stream);
+
 /* EqualLinear (:110-136) and friends, M = batch rows:
  *   y[m*ldy + n] = out_gain * epi( wscale * sum_k f(x[m*ldx + k]) * w[n*K + k] + bscale * bias[n] )
  * f = square when in_square (demodulation sum, :194);  epilogue 0 none, 1 leaky-relu(0.2)*sqrt(2)

@@ -17,3 +17,17 @@ for M, N, K in [(32, 512, 512), (32, 5000, 512), (64, 512, 512)]:
     t1 = timeit(lambda: L.check(lib.wgs_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), M, N, K, K, N, L.c_float(1.0), L.c_float(1.0), 0, 1, L.c_float(0.0), L.c_float(1.0), st), 'f'))
     t2 = timeit(lambda: L.check(lib.wgs_linear_dgrad(L.ptr(g), L.ptr(w), L.ptr(y), L.ptr(gx), M, N, K, N, K, L.c_float(1.0), L.c_float(0.2), L.c_float(1.41), 0, st), 'd'))
     print('M=%d N=%d K=%d: fwd %.1f us, dgrad %.1f us' % (M, N, K, t1, t2))
+# the mapping network: 1 + 8 launches vs one launch
+import ctypes
+for B in (32, 64):
+    d, nl = 512, 8
+    z = torch.randn(B, d, device=dev); ws = [torch.randn(d, d, device=dev) for _ in range(nl)]; bs = [torch.zeros(d, device=dev) for _ in range(nl)]
+    acts = torch.empty(nl + 1, B, d, device=dev)
+    wp = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws]); bp = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in bs])
+    def per_layer():
+        L.check(lib.wgs_pixelnorm_fwd(L.ptr(z), L.ptr(acts[0]), B, d, L.c_float(1e-8), st), 'pn')
+        for l in range(nl):
+            L.check(lib.wgs_linear_fwd(L.ptr(acts[l]), L.ptr(ws[l]), L.ptr(bs[l]), L.ptr(acts[l + 1]), B, d, d, d, d, L.c_float(0.01), L.c_float(0.01), 0, 1, L.c_float(0.0), L.c_float(1.0), st), 'l')
+    t1 = timeit(per_layer)
+    t2 = timeit(lambda: L.check(lib.wgs_mapping_mlp_fwd(L.ptr(z), wp, bp, L.ptr(acts), B, d, nl, L.c_float(0.01), L.c_float(0.01), L.c_float(1e-8), st), 'm'))
+    print('mapping network B=%d: 9 launches %.1f us, one launch %.1f us' % (B, t1, t2))

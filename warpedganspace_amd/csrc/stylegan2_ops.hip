@@ -78,17 +78,107 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
-        if (lane < U && m0 + lane < M) {
-            float sel = acc[0];
-#pragma unroll
-            for (int u = 1; u < U; ++u) sel = lane == u ? acc[u] : sel;
-            float v = fmaf(sel, wscale, b);
+        const float tot = wave_sum8(acc, lane);          // lane 8*j: row m0 + j
+        if ((lane & 7) == 0 && m0 + (lane >> 3) < M) {
+            float v = fmaf(tot, wscale, b);
             if (epi == 1) v = (v > 0.f ? v : 0.2f * v) * SQRT2;
             else if (epi == 2) v = rsqrtf(v + eps);
-            y[(size_t)(m0 + lane) * ldy + n] = v * out_gain;
+            y[(size_t)(m0 + (lane >> 3)) * ldy + n] = v * out_gain;
         }
+    }
+}
+
+// ---- the whole mapping network in ONE launch: PixelNorm + L x (EqualLinear + fused leaky-relu) (model.py:288-295) --------
+// One workgroup (8 waves) carries MLP_RPB = 2 batch rows through all L layers: the rows' activations live in LDS (ping-pong),
+// a wave owns d/8 output columns per layer and streams their weight rows (coalesced 2 KB per row) against the two activation
+// rows it keeps in registers.  Every layer's output also goes to acts[l+1] (the backward's gates).  Arithmetic = the per-layer
+// kernels' (same k-to-lane assignment, same reduction), so results are bit-identical to L launches of linear_fwd_kernel<2>.
+// A workgroup streams all L*d*d weights: ~8 MB at the ~150 GB/s one CU sustains from L2 = ~55 us, against L+1 launches of
+// ~14 us each; splitting the columns of a layer over workgroups instead would need a grid barrier per layer (4-7 us each).
+struct MappingArgs {
+    const float* z; float* acts;            // acts: [(L+1)][B][d]
+    const float* w[16]; const float* b[16];
+    int B, d, L;
+    float wscale, lr_mul, eps;
+};
+constexpr int MLP_RPB = 2, MLP_D = 512;
+__global__ __launch_bounds__(512) void mapping_mlp_fwd_kernel(const MappingArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[2][MLP_RPB][MLP_D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * MLP_RPB;
+    const size_t plane = (size_t)a.B * MLP_D;
+    // PixelNorm of this workgroup's rows (wave r < MLP_RPB), the arithmetic of pixelnorm_fwd_kernel
+    if (wave < MLP_RPB) {
+        const int r = row0 + wave;
+        if (r < a.B) {
+            const float* xr = a.z + (size_t)r * MLP_D;
+            float s = 0.f;
+            for (int j = lane; j < MLP_D; j += 64) s = fmaf(xr[j], xr[j], s);
+            s = wave_sum(s);
+            const float f = rsqrtf(s / MLP_D + a.eps);
+            for (int j = lane; j < MLP_D; j += 64) {
+                const float v = xr[j] * f;
+                xs[0][wave][j] = v;
+                a.acts[(size_t)r * MLP_D + j] = v;
+            }
+        } else {
+            for (int j = lane; j < MLP_D; j += 64) xs[0][wave][j] = 0.f;
+        }
+    }
+    __syncthreads();
+    constexpr int NPW = MLP_D / 8;                  // output columns per wave and layer
+    for (int l = 0; l < a.L; ++l) {
+        const float* __restrict__ w = a.w[l];
+        const float* __restrict__ bias = a.b[l];
+        const float (*xin)[MLP_D] = xs[l & 1];
+        float (*xout)[MLP_D] = xs[(l + 1) & 1];
+        float4 xr[MLP_RPB][2];
+#pragma unroll
+        for (int r = 0; r < MLP_RPB; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) xr[r][t] = *reinterpret_cast<const float4*>(&xin[r][4 * lane + 256 * t]);
+        float* out = a.acts + (size_t)(l + 1) * plane;
+        // weight rows in flight per wave: two groups of G (the next group's 2*G loads are issued before the current group is
+        // multiplied and reduced; one row at a time is a memory round trip per output column)
+        constexpr int G = 8;
+        float4 wq[2][G][2];
+        auto load_group = [&](int buf, int i0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int n = wave * NPW + i0 + g;
+                wq[buf][g][0] = *reinterpret_cast<const float4*>(w + (size_t)n * MLP_D + 4 * lane);
+                wq[buf][g][1] = *reinterpret_cast<const float4*>(w + (size_t)n * MLP_D + 4 * lane + 256);
+            }
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int gi = 0; gi < NPW / G; ++gi) {
+            if (gi + 1 < NPW / G) load_group((gi + 1) & 1, (gi + 1) * G);
+            float part[MLP_RPB][G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float4 w0 = wq[gi & 1][g][0], w1 = wq[gi & 1][g][1];
+#pragma unroll
+                for (int r = 0; r < MLP_RPB; ++r) {
+                    float s = 0.f;
+                    s = fmaf(xr[r][0].x, w0.x, s); s = fmaf(xr[r][0].y, w0.y, s); s = fmaf(xr[r][0].z, w0.z, s); s = fmaf(xr[r][0].w, w0.w, s);
+                    s = fmaf(xr[r][1].x, w1.x, s); s = fmaf(xr[r][1].y, w1.y, s); s = fmaf(xr[r][1].z, w1.z, s); s = fmaf(xr[r][1].w, w1.w, s);
+                    part[r][g] = s;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < MLP_RPB; ++r) {
+                const float tot = wave_sum8(part[r], lane);          // lane 8*g: column gi*G + g of row r
+                if ((lane & 7) == 0) {
+                    const int n = wave * NPW + gi * G + (lane >> 3);
+                    float v = fmaf(tot, a.wscale, bias[n] * a.lr_mul);
+                    v = (v > 0.f ? v : 0.2f * v) * SQRT2;
+                    xout[r][n] = v;
+                    if (row0 + r < a.B) out[(size_t)(row0 + r) * MLP_D + n] = v;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -491,6 +581,19 @@ int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
     if (K <= 256) WGS_LIN(1); else if (K <= 512) WGS_LIN(2); else if (K <= 1024) WGS_LIN(4); else WGS_LIN(8);
 #undef WGS_LIN
     WGS_CHECK_LAUNCH("linear_fwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_mapping_mlp_fwd(const float* z, const float* const* w, const float* const* bias, float* acts, int B, int d, int L,
+                        float wscale, float lr_mul, float eps, wgs_stream_t stream) {
+    WGS_CHECK_ARG(z && w && bias && acts && B > 0, "wgs_mapping_mlp_fwd: bad arguments");
+    WGS_CHECK_ARG(d == MLP_D && L >= 1 && L <= 16, "wgs_mapping_mlp_fwd: d = %d (must be %d), L = %d (1..16)", d, MLP_D, L);
+    MappingArgs a;
+    a.z = z; a.acts = acts; a.B = B; a.d = d; a.L = L; a.wscale = wscale; a.lr_mul = lr_mul; a.eps = eps;
+    for (int l = 0; l < 16; ++l) { a.w[l] = l < L ? w[l] : nullptr; a.b[l] = l < L ? bias[l] : nullptr; }
+    for (int l = 0; l < L; ++l) WGS_CHECK_ARG(a.w[l] && a.b[l], "wgs_mapping_mlp_fwd: null layer %d", l);
+    hipLaunchKernelGGL(mapping_mlp_fwd_kernel, dim3(wgs_cdiv(B, MLP_RPB)), dim3(512), 0, (hipStream_t)stream, a);
+    WGS_CHECK_LAUNCH("mapping_mlp_fwd_kernel");
     return WGS_OK;
 }
 

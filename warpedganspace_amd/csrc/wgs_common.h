@@ -48,6 +48,23 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+// Sum EIGHT values over the 64 lanes with 10 shuffles instead of 8 x 6: at the xor-32 / 16 / 8 steps a lane keeps half of its
+// values and sends the other half, so the data halves while the partial sums double; the last three steps finish one value per
+// lane.  On return lane l holds the total of v[idx], idx = 4*bit5(l) + 2*bit4(l) + bit3(l) (lane 8*j holds v[j]); the additions
+// form the same tree for every idx, so a value's total does not depend on which other values were reduced with it.
+__device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
+    float t[4], u[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (b5 ? v[4 + i] : v[i]) + __shfl_xor(b5 ? v[i] : v[4 + i], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (b4 ? t[2 + i] : t[i]) + __shfl_xor(b4 ? t[i] : t[2 + i], 16, 64);
+    float s = (b3 ? u[1] : u[0]) + __shfl_xor(b3 ? u[0] : u[1], 8, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    return s;
+}
 // Raise a device-resident non-negative fp32 maximum (bit patterns of non-negative floats order like unsigned ints).
 // Thousands of waves target ONE address: an L2 atomic costs ~12 ns when they queue (16 k of them = 0.2 ms per launch), so
 // a wave first looks at the current value — after the first few arrivals almost every wave sees a value >= its own and

@@ -251,16 +251,28 @@ class Generator(nn.Module):
         z = z.contiguous()
         B, d = z.shape
         lib, st = L.lib(), L.stream()
-        x = torch.empty_like(z)
-        L.check(lib.wgs_pixelnorm_fwd(L.ptr(z), L.ptr(x), B, d, L.c_float(1e-8), st), 'pixelnorm')
-        acts = [x]
-        for (w, b, scale, lr_mul) in P['map']:
-            y = torch.empty(B, w.shape[0], device=z.device)
-            L.check(lib.wgs_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, w.shape[0], w.shape[1], d, w.shape[0],
-                                       L.c_float(scale), L.c_float(lr_mul), 0, 1, L.c_float(0.0), L.c_float(1.0), st),
-                    'linear_fwd')
-            acts.append(y)
-            x = y
+        mp = P['map']
+        if d == 512 and 1 <= len(mp) <= 16 and all(m[0].shape == (512, 512) and m[2] == mp[0][2] and m[3] == mp[0][3] for m in mp):
+            # the whole mapping network in one launch (wgs_mapping_mlp_fwd); acts[l] are views of one buffer
+            n = len(mp)
+            buf = torch.empty(n + 1, B, d, device=z.device)
+            wp = (ctypes.c_void_p * n)(*[m[0].data_ptr() for m in mp])
+            bp = (ctypes.c_void_p * n)(*[m[1].data_ptr() for m in mp])
+            L.check(lib.wgs_mapping_mlp_fwd(L.ptr(z), wp, bp, L.ptr(buf), B, d, n, L.c_float(mp[0][2]), L.c_float(mp[0][3]),
+                                            L.c_float(1e-8), st), 'mapping_mlp_fwd')
+            acts = list(buf.unbind(0))
+            x = acts[-1]
+        else:
+            x = torch.empty_like(z)
+            L.check(lib.wgs_pixelnorm_fwd(L.ptr(z), L.ptr(x), B, d, L.c_float(1e-8), st), 'pixelnorm')
+            acts = [x]
+            for (w, b, scale, lr_mul) in mp:
+                y = torch.empty(B, w.shape[0], device=z.device)
+                L.check(lib.wgs_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, w.shape[0], w.shape[1], d, w.shape[0],
+                                           L.c_float(scale), L.c_float(lr_mul), 0, 1, L.c_float(0.0), L.c_float(1.0), st),
+                        'linear_fwd')
+                acts.append(y)
+                x = y
         return x, ((z, acts) if save else None)
 
     def _mapping_bwd(self, saved, gw):
