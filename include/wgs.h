@@ -297,6 +297,15 @@ int wgs_xg_reduce(const float* x, int x_batched, const float* g, float* ds, int 
  * (demod == NULL: no demodulation, dstyle = dsdir). */
 int wgs_sg2_style_grad(const float* num, const float* demod, const float* s, const float* dsdir, const float* wsq,
                        float scale2, float* dstyle, int B, int Co, int Ci, int ld_s, int ld_out, wgs_stream_t stream);
+/* Up to 24 of them in one launch (every modulated conv and ToRGB of a synthesis backward pass; B, ld_s, ld_out shared). */
+typedef struct wgs_style_grad_batch {
+    int32_t n, B, ld_s, ld_out;
+    const float* num[24]; const float* demod[24]; const float* s[24]; const float* dsdir[24]; const float* wsq[24];
+    float* dstyle[24];
+    int32_t Co[24], Ci[24];
+    float scale2[24];
+} wgs_style_grad_batch;
+int wgs_sg2_style_grad_batch(const wgs_style_grad_batch* batch, wgs_stream_t stream);
 /* wsq[o,i] = sum_t w[o,t,i]^2 for packed [Co,T,Ci] weights. */
 int wgs_sg2_wsq(const float* w_packed, float* wsq, int Co, int T, int Ci, wgs_stream_t stream);
 

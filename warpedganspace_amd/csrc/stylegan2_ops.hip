@@ -542,6 +542,48 @@ __global__ __launch_bounds__(256) void sg2_style_grad_kernel(const float* __rest
     }
 }
 
+// The same for up to 24 layers in ONE launch (blockIdx.z = layer): the synthesis backward has one such reduction per modulated
+// conv and per ToRGB, each far too small to fill the chip; none of their results is needed before the pass's last kernel.
+struct StyleGradBatchArgs {
+    int n, ld_s, ld_out;
+    const float* num[24]; const float* demod[24]; const float* s[24]; const float* dsdir[24]; const float* wsq[24];
+    float* dstyle[24];
+    int Co[24], Ci[24];
+    float scale2[24];
+};
+__global__ __launch_bounds__(256) void sg2_style_grad_batch_kernel(const StyleGradBatchArgs a) {
+    __shared__ double red[4][64];
+    const int l = blockIdx.z;
+    const int Co = a.Co[l], Ci = a.Ci[l];
+    if ((int)blockIdx.x * 64 >= Ci) return;
+    const float* __restrict__ num = a.num[l];
+    const float* __restrict__ demod = a.demod[l];
+    const float* __restrict__ wsq = a.wsq[l];
+    const int il = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    const int b = blockIdx.y;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (demod && i < Ci) {
+        int o = part;
+        for (; o + 4 < Co; o += 8) {
+            const double d0 = demod[(size_t)b * Co + o], d1 = demod[(size_t)b * Co + o + 4];
+            acc0 = fma((double)num[(size_t)b * Co + o] * d0 * d0, (double)wsq[(size_t)o * Ci + i], acc0);
+            acc1 = fma((double)num[(size_t)b * Co + o + 4] * d1 * d1, (double)wsq[(size_t)(o + 4) * Ci + i], acc1);
+        }
+        for (; o < Co; o += 4) {
+            const double d0 = demod[(size_t)b * Co + o];
+            acc0 = fma((double)num[(size_t)b * Co + o] * d0 * d0, (double)wsq[(size_t)o * Ci + i], acc0);
+        }
+    }
+    red[part][il] = acc0 + acc1;
+    __syncthreads();
+    if (part == 0 && i < Ci) {
+        const double acc = red[0][il] + red[1][il] + red[2][il] + red[3][il];
+        a.dstyle[l][(size_t)b * a.ld_out + i] =
+            (float)((double)a.dsdir[l][(size_t)b * Ci + i] - (double)a.s[l][(size_t)b * a.ld_s + i] * a.scale2[l] * acc);
+    }
+}
+
 // wsq[o,i] = sum_t w[o,t,i]^2   (w packed [Co,T,Ci]; one-off for the frozen generator)
 __global__ __launch_bounds__(256) void wsq_kernel(const float* __restrict__ w, float* __restrict__ wsq, int Co, int T, int Ci) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -705,6 +747,23 @@ int wgs_sg2_style_grad(const float* num, const float* demod, const float* s, con
     hipLaunchKernelGGL(sg2_style_grad_kernel, dim3(wgs_cdiv(Ci, 64), B), dim3(256), 0, (hipStream_t)stream, num, demod, s,
                        dsdir, wsq, scale2, dstyle, Co, Ci, ld_s, ld_out);
     WGS_CHECK_LAUNCH("sg2_style_grad_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_style_grad_batch(const wgs_style_grad_batch* d, wgs_stream_t stream) {
+    WGS_CHECK_ARG(d && d->n > 0 && d->n <= 24 && d->B > 0, "wgs_sg2_style_grad_batch: 1..24 layers");
+    StyleGradBatchArgs a;
+    a.n = d->n; a.ld_s = d->ld_s; a.ld_out = d->ld_out;
+    int cimax = 0;
+    for (int l = 0; l < d->n; ++l) {
+        WGS_CHECK_ARG(d->s[l] && d->dsdir[l] && d->dstyle[l] && d->Co[l] > 0 && d->Ci[l] > 0, "wgs_sg2_style_grad_batch: bad layer %d", l);
+        WGS_CHECK_ARG(!d->demod[l] || (d->num[l] && d->wsq[l]), "wgs_sg2_style_grad_batch: layer %d: demod needs num and wsq", l);
+        a.num[l] = d->num[l]; a.demod[l] = d->demod[l]; a.s[l] = d->s[l]; a.dsdir[l] = d->dsdir[l]; a.wsq[l] = d->wsq[l];
+        a.dstyle[l] = d->dstyle[l]; a.Co[l] = d->Co[l]; a.Ci[l] = d->Ci[l]; a.scale2[l] = d->scale2[l];
+        cimax = d->Ci[l] > cimax ? d->Ci[l] : cimax;
+    }
+    hipLaunchKernelGGL(sg2_style_grad_batch_kernel, dim3(wgs_cdiv(cimax, 64), d->B, d->n), dim3(256), 0, (hipStream_t)stream, a);
+    WGS_CHECK_LAUNCH("sg2_style_grad_batch_kernel");
     return WGS_OK;
 }
 

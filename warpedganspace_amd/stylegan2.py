@@ -24,6 +24,13 @@ from . import conv as C
 from . import ops
 
 
+class StyleGradBatch(ctypes.Structure):
+    """ctypes mirror of wgs_style_grad_batch (include/wgs.h)."""
+    _fields_ = [('n', ctypes.c_int32), ('B', ctypes.c_int32), ('ld_s', ctypes.c_int32), ('ld_out', ctypes.c_int32)] + \
+               [(k, ctypes.c_void_p * 24) for k in ('num', 'demod', 's', 'dsdir', 'wsq', 'dstyle')] + \
+               [('Co', ctypes.c_int32 * 24), ('Ci', ctypes.c_int32 * 24), ('scale2', ctypes.c_float * 24)]
+
+
 class LinearBatch(ctypes.Structure):
     """ctypes mirror of wgs_linear_batch (include/wgs.h)."""
     _fields_ = [('n', ctypes.c_int32), ('M', ctypes.c_int32), ('in_square', ctypes.c_int32), ('epilogue', ctypes.c_int32),
@@ -32,6 +39,10 @@ class LinearBatch(ctypes.Structure):
                 ('wscale', ctypes.c_float * 16), ('eps', ctypes.c_float * 16), ('out_gain', ctypes.c_float * 16)]
 
 SQRT2 = 2 ** 0.5
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
 
 
 def make_kernel(k):
@@ -393,7 +404,8 @@ class Generator(nn.Module):
         dS = zeros(B, sumC)                          # d loss / d modulation outputs, all layers
         dskip = dimg
         amax = zeros(len(layers))                    # per layer: max |dy * demod| (magnitude bound of the fp16 dgrad operand)
-        gA, sA_off, cons = None, None, None          # un-scaled dgrad of the consumer conv, its style slice
+        gA, sA_off = None, None                      # un-scaled dgrad of the consumer conv, its style slice
+        sg = []                                      # style-gradient reductions of the pass, launched together at the end
         num_next = None
         for i in range(len(layers) - 1, -1, -1):
             ly = layers[i]
@@ -418,10 +430,9 @@ class Generator(nn.Module):
             # style gradient of the consumer conv (layer i+1) is now complete: direct term dsA + demod path
             if gA is not None:
                 c = layers[i + 1]
-                self._style_grad(lib, st, num_next, demods[i + 1], S, c, dsA, dS, B, sumC)
+                sg.append((num_next, demods[i + 1], S[:, c['off']:], dsA, c['wsq'], dS[:, c['off']:], c['Co'], c['Ci']))
             if has_rgb:
-                L.check(lib.wgs_sg2_style_grad(None, None, L.rawptr(S[:, r['off']:]), L.ptr(dsR), None, L.c_float(1.0),
-                                               L.rawptr(dS[:, r['off']:]), B, 3, Co, sumC, sumC, st), 'style_grad_rgb')
+                sg.append((None, None, S[:, r['off']:], dsR, None, dS[:, r['off']:], 3, Co))
                 if i > 0:   # gradient of the up-sampled skip w.r.t. the lower-resolution image (upfirdn2d.py:110-115)
                     g = ops.upfirdn2d_mhwc(dskip.reshape(B * 3, Hc, Hc, 1), r['upk_f'], 1, 1, 2, 2, 1, 1, 1, 1)
                     dskip = g.reshape(B, 3, Hc // 2, Hc // 2)
@@ -439,19 +450,22 @@ class Generator(nn.Module):
         ly = layers[0]
         ds0 = zeros(B, ly['Ci'])
         L.check(lib.wgs_xg_reduce(L.ptr(P['const']), 0, L.ptr(gA), L.ptr(ds0), B, 16, ly['Ci'], st), 'xg_reduce')
-        self._style_grad(lib, st, num_next, demods[0], S, ly, ds0, dS, B, sumC)
+        sg.append((num_next, demods[0], S[:, ly['off']:], ds0, ly['wsq'], dS[:, ly['off']:], ly['Co'], ly['Ci']))
+        # every style gradient of the pass (13 modulated convs + 7 ToRGBs at 256^2) in one launch: dS is only read below
+        for k0 in range(0, len(sg), 24):
+            part = sg[k0:k0 + 24]
+            sb = StyleGradBatch()
+            sb.n, sb.B, sb.ld_s, sb.ld_out = len(part), B, sumC, sumC
+            for k, (num_, dem_, s_, dsd_, wsq_, out_, co_, ci_) in enumerate(part):
+                sb.num[k], sb.demod[k], sb.wsq[k] = _dp(num_), _dp(dem_), _dp(wsq_)
+                sb.s[k], sb.dsdir[k], sb.dstyle[k] = s_.data_ptr(), dsd_.data_ptr(), out_.data_ptr()
+                sb.Co[k], sb.Ci[k], sb.scale2[k] = co_, ci_, 1.0      # the stored demod carries the conv's weight scale: scale2 = 1
+            L.check(lib.wgs_sg2_style_grad_batch(ctypes.byref(sb), st), 'style_grad_batch')
         dw = torch.empty(B, self.style_dim, device=dev)
         L.check(lib.wgs_linear_dgrad(L.ptr(dS), L.ptr(P['wmod']), None, L.ptr(dw), B, sumC, self.style_dim, sumC,
                                      self.style_dim, L.c_float(P['mod_scale']), L.c_float(1.0), L.c_float(1.0), 0, st),
                 'dlatent')
         return dw
-
-    @staticmethod
-    def _style_grad(lib, st, num, demod, S, ly, dsdir, dS, B, sumC):
-        # stored demod already carries the conv's weight scale, so scale2 = 1 here (see _synthesis_fwd)
-        L.check(lib.wgs_sg2_style_grad(L.ptr(num), L.ptr(demod), L.rawptr(S[:, ly['off']:]), L.ptr(dsdir), L.ptr(ly['wsq']),
-                                       L.c_float(1.0), L.rawptr(dS[:, ly['off']:]), B, ly['Co'], ly['Ci'], sumC, sumC, st),
-                'style_grad')
 
     # -- reference-facing API -------------------------------------------------------------------------------
     def get_latent(self, input):
