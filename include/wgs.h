@@ -274,8 +274,8 @@ int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* desc, wgs_stream_t stream);
 int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip, float* img,
                       int B, int P, int C, float wscale, wgs_stream_t stream);
 /* The same with the skip branch's Upsample (model.py:257-262,279-281: upfirdn2d(skip, kernel*4, up=2, pad=(2,1))) evaluated in
- * place: skip_lo [B,3,H/2,W/2] is the previous resolution's image, img [B,3,H,W]. */
-int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip_lo,
+ * place: skip_lo [B,3,H/2,W/2] is the previous resolution's image, img [B,3,H,W]; s_ld = row stride of s (0 = C: compact). */
+int wgs_sg2_torgb_up_fwd(const float* x, const float* s, int s_ld, const float* w, const float* bias, const float* skip_lo,
                          const float* up_kernel4x4, float* img, int B, int H, int W, int C, float wscale, wgs_stream_t stream);
 
 /* Backward through one StyledConv output `out` [B,P,C] (post-activation, saved by the forward):
@@ -286,11 +286,11 @@ int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const f
  * post_scale [B,C] or NULL: the STORED gradient is dy * post_scale[b,c] (this layer's demodulation vector, i.e. the
  *   A-operand factor of its dgrad conv, which then needs no a_scale); num / dsA / dsR use the un-scaled dy.
  * dy_amax: optional device scalar (caller-zeroed), raised to max |stored gradient| (atomic max) — the magnitude bound the
- *   fp16 dgrad launches take as wgs_conv_desc.a_amax. */
+ *   fp16 dgrad launches take as wgs_conv_desc.a_amax.   s_ld: row stride of sA and sR (0 = C: compact [B,C] arrays). */
 int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
                     const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
                     float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P,
-                    int C, wgs_stream_t stream);
+                    int C, int s_ld, wgs_stream_t stream);
 /* ds[b,c] += sum_p x[(x_batched ? b : 0), p, c] * g[b,p,c] */
 int wgs_xg_reduce(const float* x, int x_batched, const float* g, float* ds, int B, int P, int C, wgs_stream_t stream);
 /* dstyle[b*ld_out + i] = dsdir[b*Ci + i] - s[b*ld_s + i]*scale2 * sum_o num[b,o]*demod[b,o]^2*wsq[o,i]

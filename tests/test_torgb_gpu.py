@@ -32,7 +32,7 @@ def test_torgb_with_inplace_skip_upsample(dev, B, H, C):
     xd, sd, wd, bd, kd, skd = (t.to(dev).contiguous() for t in (x, s, w, bias, upk, skip))
     lib, st = L.lib(), L.stream()
     img = torch.empty(B, 3, H, H, device=dev)
-    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(xd), L.ptr(sd), L.ptr(wd), L.ptr(bd), L.ptr(skd), L.ptr(kd), L.ptr(img), B, H, H, C,
+    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(xd), L.ptr(sd), 0, L.ptr(wd), L.ptr(bd), L.ptr(skd), L.ptr(kd), L.ptr(img), B, H, H, C,
                                      L.c_float(wscale), st), 'torgb_up')
     assert rel_err(img, ref) < 2e-6
     up = ops.upfirdn2d_mhwc(skd.reshape(B * 3, H // 2, H // 2, 1), kd, 2, 2, 1, 1, 2, 1, 2, 1).reshape(B, 3, H, H)
@@ -40,3 +40,10 @@ def test_torgb_with_inplace_skip_upsample(dev, B, H, C):
     L.check(lib.wgs_sg2_torgb_fwd(L.ptr(xd), L.ptr(sd), L.ptr(wd), L.ptr(bd), L.ptr(up), L.ptr(img2), B, H * H, C,
                                   L.c_float(wscale), st), 'torgb')
     assert rel_err(img, img2.cpu()) < 1e-6
+    # the style vector as rows of a wider matrix (the generator's [B, sumC] modulation output): s_ld
+    wide = torch.randn(B, C + 24, device=dev)
+    wide[:, 8:8 + C] = sd
+    img3 = torch.empty_like(img)
+    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(xd), L.rawptr(wide[:, 8:]), C + 24, L.ptr(wd), L.ptr(bd), L.ptr(skd), L.ptr(kd), L.ptr(img3),
+                                     B, H, H, C, L.c_float(wscale), st), 'torgb_up strided')
+    assert torch.equal(img3, img)

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ skip, float* __restrict__ img,
                                                         int P, int C, float wscale, int ppb,
-                                                        const float* __restrict__ skip_lo, const float* __restrict__ upk, int Wimg) {
+                                                        const float* __restrict__ skip_lo, const float* __restrict__ upk, int Wimg, int s_ld) {
     // ppb = pixels per block (64, 128 or 256): small maps use small blocks so that the launch still fills the chip
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wm = sm;               // [3][C] modulated weights W[o,c]*s[b,c]*wscale
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * ppb;
     const int ppwave = ppb >> 2;
-    for (int i = threadIdx.x; i < 3 * C; i += 256) wm[i] = w[i] * s[(size_t)b * C + (i % C)] * wscale;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) wm[i] = w[i] * s[(size_t)b * s_ld + (i % C)] * wscale;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c4n = C >> 2;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     const float* __restrict__ drgb, const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
     const float* __restrict__ noise, const float* __restrict__ noise_w, const float* __restrict__ bias,
     float* __restrict__ dy, float* __restrict__ num, float* __restrict__ dsA, float* __restrict__ dsR,
-    const float* __restrict__ post_scale, float* __restrict__ dy_amax, int P, int C, int chunk) {
+    const float* __restrict__ post_scale, float* __restrict__ dy_amax, int P, int C, int chunk, int s_ld) {
     __shared__ double red[3][256][4];
     float amax = 0.f;          // max |stored dy| seen by this thread
     const int b = blockIdx.y;
@@ -412,10 +412,10 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     const int p_begin = blockIdx.x * chunk, p_end = min(P, p_begin + chunk);
     const float nw = noise ? noise_w[0] : 0.f;
     for (int c = cl * 4; c < C; c += tpp * 4) {
-        float4 sa = gA ? *reinterpret_cast<const float4*>(sA + (size_t)b * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sa = gA ? *reinterpret_cast<const float4*>(sA + (size_t)b * s_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 sr = make_float4(0.f, 0.f, 0.f, 0.f), w0 = sr, w1 = sr, w2 = sr;
         if (drgb) {
-            sr = *reinterpret_cast<const float4*>(sR + (size_t)b * C + c);
+            sr = *reinterpret_cast<const float4*>(sR + (size_t)b * s_ld + c);
             w0 = *reinterpret_cast<const float4*>(wR + c);
             w1 = *reinterpret_cast<const float4*>(wR + C + c);
             w2 = *reinterpret_cast<const float4*>(wR + 2 * C + c);
@@ -691,12 +691,12 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
     while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
     if (C < 32) ppb = 256;                // a wave iteration covers 64 / (C/4) pixels: needs ppb/4 >= that
     hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale, ppb,
-                       (const float*)nullptr, (const float*)nullptr, 0);
+                       (const float*)nullptr, (const float*)nullptr, 0, C);
     WGS_CHECK_LAUNCH("torgb_fwd_kernel");
     return WGS_OK;
 }
 
-int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip_lo,
+int wgs_sg2_torgb_up_fwd(const float* x, const float* s, int s_ld, const float* w, const float* bias, const float* skip_lo,
                          const float* up_kernel4x4, float* img, int B, int H, int W, int C, float wscale, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && s && w && bias && img && skip_lo && up_kernel4x4, "wgs_sg2_torgb_up_fwd: null pointer");
     WGS_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C >= 4 && C <= 512 && (C & (C - 1)) == 0,
@@ -707,7 +707,7 @@ int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const f
     while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
     if (C < 32) ppb = 256;
     hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias,
-                       (const float*)nullptr, img, P, C, wscale, ppb, skip_lo, up_kernel4x4, W);
+                       (const float*)nullptr, img, P, C, wscale, ppb, skip_lo, up_kernel4x4, W, s_ld > 0 ? s_ld : C);
     WGS_CHECK_LAUNCH("torgb_fwd_kernel<up>");
     return WGS_OK;
 }
@@ -715,7 +715,7 @@ int wgs_sg2_torgb_up_fwd(const float* x, const float* s, const float* w, const f
 int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
                     const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
                     float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P, int C,
-                    wgs_stream_t stream) {
+                    int s_ld, wgs_stream_t stream) {
     WGS_CHECK_ARG(out && bias && dy && num, "wgs_sg2_act_bwd: null pointer");
     WGS_CHECK_ARG(gA || drgb, "wgs_sg2_act_bwd: needs at least one gradient source");
     WGS_CHECK_ARG(!gA || (sA && dsA), "wgs_sg2_act_bwd: gA needs sA and dsA");
@@ -728,7 +728,7 @@ int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const fl
     if (chunk < 16) chunk = 16;
     chunks = wgs_cdiv(P, chunk);
     hipLaunchKernelGGL(sg2_act_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
-                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk);
+                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk, s_ld > 0 ? s_ld : C);
     WGS_CHECK_LAUNCH("sg2_act_bwd_kernel");
     return WGS_OK;
 }

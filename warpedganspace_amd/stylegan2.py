@@ -370,12 +370,12 @@ class Generator(nn.Module):
                 r = P['rgbs'][i // 2]
                 Hc = x.shape[1]
                 img = torch.empty(B, 3, Hc, Hc, device=dev)
-                # the ToRGB kernel reads its style with row stride C: hand it a compact copy of the slice
-                s_rgb = S[:, r['off']:r['off'] + r['C']].contiguous()
                 if skip is not None:    # + Upsample(skip) (model.py:279-281), evaluated inside the ToRGB kernel's epilogue
-                    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(x), L.ptr(s_rgb), L.ptr(r['w']), L.ptr(r['bias']), L.ptr(skip), L.ptr(r['upk']),
-                                                     L.ptr(img), B, Hc, Hc, r['C'], L.c_float(r['scale']), st), 'torgb_up')
+                    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(x), L.rawptr(S[:, r['off']:]), sumC, L.ptr(r['w']), L.ptr(r['bias']), L.ptr(skip),
+                                                     L.ptr(r['upk']), L.ptr(img), B, Hc, Hc, r['C'], L.c_float(r['scale']), st), 'torgb_up')
                 else:
+                    # the plain ToRGB kernel reads its style with row stride C: hand it a compact copy of the slice
+                    s_rgb = S[:, r['off']:r['off'] + r['C']].contiguous()
                     L.check(lib.wgs_sg2_torgb_fwd(L.ptr(x), L.ptr(s_rgb), L.ptr(r['w']), L.ptr(r['bias']), None,
                                                   L.ptr(img), B, Hc * Hc, r['C'], L.c_float(r['scale']), st), 'torgb')
                 skip = img
@@ -419,13 +419,13 @@ class Generator(nn.Module):
             num = zeros(B, Co)
             dsA = zeros(B, Co) if gA is not None else None
             dsR = zeros(B, Co) if has_rgb else None
-            sA = S[:, sA_off:sA_off + Co].contiguous() if gA is not None else None
-            sR = S[:, r['off']:r['off'] + Co].contiguous() if has_rgb else None
-            L.check(lib.wgs_sg2_act_bwd(L.ptr(out), L.ptr(gA), L.ptr(sA), L.ptr(dskip if has_rgb else None),
-                                        L.ptr(r['w']) if has_rgb else None, L.ptr(sR),
+            sA = S[:, sA_off:] if gA is not None else None           # rows of the style matrix S, stride sumC
+            sR = S[:, r['off']:] if has_rgb else None
+            L.check(lib.wgs_sg2_act_bwd(L.ptr(out), L.ptr(gA), L.rawptr(sA), L.ptr(dskip if has_rgb else None),
+                                        L.ptr(r['w']) if has_rgb else None, L.rawptr(sR),
                                         L.c_float(r['scale'] if has_rgb else 0.0), L.ptr(ly['noise']), L.ptr(ly['noise_w']),
                                         L.ptr(ly['bias']), L.ptr(dy), L.ptr(num), L.ptr(dsA), L.ptr(dsR), L.ptr(demods[i]),
-                                        L.rawptr(amax[i:]), B, Pn, Co, st),
+                                        L.rawptr(amax[i:]), B, Pn, Co, sumC, st),
                     'sg2_act_bwd')           # dy is stored already multiplied by this layer's demodulation vector
             # style gradient of the consumer conv (layer i+1) is now complete: direct term dsA + demod path
             if gA is not None:
