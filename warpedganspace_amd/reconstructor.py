@@ -54,6 +54,9 @@ R_DGRAD_PRECISION = 0 if os.environ.get('WGS_R_DGRAD_PRECISION', 'bf16x3').lower
 # costs more than the MFMAs save: 45-50 vs 63 TFLOP/s, so those layers and conv1 keep the exact kernel).
 # WGS_R_WGRAD_PRECISION=fp32 selects the exact kernel everywhere.
 R_WGRAD_PRECISION = 0 if os.environ.get('WGS_R_WGRAD_PRECISION', 'bf16x3').lower() in ('fp32', '0') else 1
+# conv1's image gradient (64 -> 6(+2) channels over B x 256^2 pixels): development A/B between the exact narrow kernel
+# (igemm_narrow_kernel, precision 0) and the 128 x 32 split-bf16 tiles
+R_CONV1_DGRAD_PRECISION = 0 if os.environ.get('WGS_R_CONV1_DGRAD', 'bf16x3').lower() in ('fp32', '0') else R_DGRAD_PRECISION
 
 
 def _conv(ci, co, k, stride, pad):
@@ -344,7 +347,7 @@ class Reconstructor(nn.Module):
         if need_x[0] or need_x[1]:
             w1p = self._conv1_padded(c, Cp, dev)        # same weights as in the forward of this step (Adam runs after the backward)
             w1t = C.repack_w_t(w1p, 64, 49, Cp, out=self._scratch('w1t', (49, Cp, 64), torch.float32, dev))
-            dx = C.conv2d_dgrad(dc1, w1t, (S["H"], S["W"]), 7, stride=2, pad=3, precision=R_DGRAD_PRECISION)
+            dx = C.conv2d_dgrad(dc1, w1t, (S["H"], S["W"]), 7, stride=2, pad=3, precision=R_CONV1_DGRAD_PRECISION)
             d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
             d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
             L.check(lib.wgs_unpack_pair_grad(L.ptr(dx), L.ptr(d1), L.ptr(d2), B, c, S['H'] * S['W'], Cp, st), 'unpack_pair')
