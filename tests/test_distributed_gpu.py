@@ -128,15 +128,26 @@ def _worker(rank, world, port, q):
 
 @pytest.mark.timeout(900)
 def test_trainstep_world2_matches_sum_of_rank_gradients(dev):
-    world, port = 2, _free_port()
+    world = 2
     ctx = mp.get_context('spawn')
-    q = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get() for _ in range(world)]
-    for p in procs:
-        p.join(120)
+    torch.cuda.empty_cache()                 # the two ranks share this device with the test process's cached blocks
+
+    def run():
+        port = _free_port()
+        q = ctx.SimpleQueue()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get() for _ in range(world)]
+        for p in procs:
+            p.join(120)
+        return res, procs
+    res, procs = run()
+    # one retry for rendezvous trouble only (a port taken between _free_port() and the bind, a gloo connect timeout):
+    # a failed comparison is reported by the asserts below, never retried
+    if any(r[-1] is not None and any(s in r[-1] for s in ('Address already in use', 'timed out', 'Connection', 'connect')) for r in res):
+        print('rendezvous failed, retrying once:', [r[-1].splitlines()[-1] for r in res if r[-1]])
+        res, procs = run()
     for r in res:
         assert r[-1] is None, r[-1]
     for rank, err_g, err_p, same, err_s, differs, n_ev, nbytes, _ in res:
