@@ -138,8 +138,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* __restr
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) nbt[0] += 1;
     if (c >= C) return;
-    const double m = ws[c] / (double)N;
-    double var = ws[C + c] / (double)N - m * m;
+    // sums the WS_REP replicas itself (same order as ws_collapse_kernel): one launch less per BatchNorm forward
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < WS_REP; ++r) { s1 += ws[(size_t)r * 2 * C + c]; s2 += ws[(size_t)r * 2 * C + C + c]; }
+    const double m = s1 / (double)N;
+    double var = s2 / (double)N - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -459,7 +463,6 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
         const int rpb = reduce_rows_per_block(N, C);
         hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                            nullptr, nullptr, ws, N, C, rpb);
-        hipLaunchKernelGGL(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(wgs_cdiv(C, 256)), dim3(256), 0, st, ws, save_mean, save_invstd,
                            running_mean, running_var, num_batches_tracked, N, C, eps, momentum);
     } else {
