@@ -20,7 +20,6 @@ static WgsFlags read_flags() {
     g.no_patch = getenv("WGS_NO_PATCH") != nullptr;
     g.patch_bm256 = getenv("WGS_PATCH_BM256") != nullptr;
     g.patch_tps1 = getenv("WGS_PATCH_TPS1") != nullptr;
-    g.no_fused_up = getenv("WGS_NO_FUSED_UP") != nullptr;
     g.up_gh16 = getenv("WGS_UP_GH16") != nullptr;
     g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
     return g;
