@@ -273,10 +273,12 @@ def test_conv_split_bf16_patch_form(dev, B, Ci, Co, H):
 
 
 @pytest.mark.parametrize('B,Ci,Co,H,k,s,p', [(4, 64, 64, 16, 3, 1, 1), (3, 64, 128, 17, 3, 2, 1), (2, 128, 128, 9, 3, 1, 1),
-                                             (2, 256, 512, 8, 1, 2, 0), (5, 128, 64, 7, 3, 1, 1), (32, 64, 64, 64, 3, 1, 1)])
+                                             (2, 256, 512, 8, 1, 2, 0), (5, 128, 64, 7, 3, 1, 1), (32, 64, 64, 64, 3, 1, 1),
+                                             (2, 512, 512, 8, 3, 1, 1), (3, 64, 128, 16, 3, 1, 1), (2, 128, 64, 24, 3, 1, 1)])
 def test_conv_wgrad_split_bf16(dev, B, Ci, Co, H, k, s, p):
     """wgs_wgrad_desc.precision = 1: operands transposed in registers into the [channel][pixel] LDS image and split into
-    bf16 hi / lo, 3 MFMAs per product — within ~2e-5 of float64 (the exact kernel: ~1e-6), any K split."""
+    bf16 hi / lo, 3 MFMAs per product — within ~2e-5 of float64 (the exact kernel: ~1e-6), any K split.  Covers the per-tap
+    kernel and the kernel-row form (stride-1 3x3, width % 8 == 0, 64 or >= 512 channels: three taps per workgroup)."""
     torch.manual_seed(Ci + Co + H)
     x = torch.randn(B, Ci, H, H, dtype=torch.float64)
     w = (torch.randn(Co, Ci, k, k, dtype=torch.float64) / (Ci * k * k) ** 0.5).requires_grad_(True)

@@ -28,4 +28,8 @@ for ci, co, h, k, s in [(64, 64, 64, 3, 1), (64, 128, 64, 3, 2), (128, 128, 32, 
     for prec in (0, 1):
         ms = timeit(lambda: C.conv2d_wgrad(x, dy, dw, k, stride=s, pad=k // 2, precision=prec))
         line += ' %s %7.3f ms %6.1f TF |' % ('fp32  ' if prec == 0 else 'bf16x3', ms, fl / ms / 1e9)
+    if prec == 1:      # agreement of the two kernels on this shape
+        d0 = torch.zeros_like(dw); d1 = torch.zeros_like(dw)
+        C.conv2d_wgrad(x, dy, d0, k, stride=s, pad=k // 2, precision=0); C.conv2d_wgrad(x, dy, d1, k, stride=s, pad=k // 2, precision=1)
+        line += ' diff %.1e' % ((d1 - d0).abs().max() / d0.abs().max()).item()
     print(line, flush=True)

@@ -173,6 +173,161 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args
     }
 }
 
+// ---- three taps of one kernel row per workgroup --------------------------------------------------------------------------
+// The per-tap kernel above moves 32 KB of operands per 96 MFMAs (333 B / MFMA) and sits at 62-90 TFLOP/s against the vector
+// memory path.  For a stride-1 conv the three taps (ky, kx = 0..2) of a kernel row read the SAME dy chunk and the same input
+// row shifted by one pixel: a workgroup that owns all three stages dy once and 10 input pixels per 8-pixel octet (instead of
+// 3 x 8), writes three shifted [channel][k] images of the input tile, and runs three accumulator sets: BM x 64 tiles, 26 KB per
+// 144 MFMAs at BM = 128 (180 B / MFMA).  grid = (co tiles x ci tiles, kernel rows, K splits).
+template <int BM>
+__global__ __launch_bounds__(256, 1) void igemm_wgrad16_row_kernel(const Wgrad16Args p) {
+    constexpr int BN = 64, NT = 3;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int STAGE = 2 * A_BYTES + NT * 2 * B_BYTES;       // A_hi | A_lo | tap 0: B_hi | B_lo | tap 1 ... | tap 2 ...
+    constexpr int UA = BM, UB = BN;                             // staging units (channel quad, pixel octet): one per thread
+    static_assert(UA + UB <= 256, "one staging unit per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = p.Ci / BN;
+    const int co0 = (blockIdx.x / ntn) * BM, ci0 = (blockIdx.x % ntn) * BN;
+    const int t0 = blockIdx.y * NT;                             // taps t0 .. t0+2: same dy, dx = dx0, dx0+1, dx0+2
+    const int dyt = p.dy_[t0], dx0 = p.dx_[t0];
+    const int nchunks = p.M / BK;                               // the host guarantees Wo % 8 == 0 (octets never straddle rows) and M % 32 == 0
+    const int per = (nchunks + p.ksplit - 1) / p.ksplit;
+    const int c_begin = blockIdx.z * per, c_end = min(nchunks, c_begin + per);
+    if (c_begin >= c_end) return;
+
+    const bool isA = tid < UA, isB = !isA && tid < UA + UB;
+    const int f = isA ? tid : tid - UA;
+    const int nq = (isA ? BM : BN) / 4;
+    const int u_cq = f % nq, u_po = f / nq;                     // channel quad, pixel octet (0..3)
+    float4 rg[10];
+    auto load_chunk = [&](int c) {
+        const int m = c * BK + u_po * 8;                        // first pixel of the octet
+        if (isA) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rg[j] = *reinterpret_cast<const float4*>(p.dy + (size_t)(m + j) * p.Co + co0 + u_cq * 4);
+        } else if (isB) {
+            const int ox = m % p.Wo;
+            const int tt = m / p.Wo;
+            const int oy = tt % p.Ho;
+            const int b = tt / p.Ho;
+            const int iy = oy + dyt;
+            const bool rowok = iy >= 0 && iy < p.Hi;
+            const float* row = p.x + ((size_t)(b * p.Hi + (rowok ? iy : 0)) * p.Wi) * p.Ci + ci0 + u_cq * 4;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int ix = ox + dx0 + j;
+                rg[j] = (rowok && ix >= 0 && ix < p.Wi) ? *reinterpret_cast<const float4*>(row + (size_t)ix * p.Ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char* base = smem_b + buf * STAGE;
+        if (isA) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = cc == 0 ? rg[j].x : (cc == 1 ? rg[j].y : (cc == 2 ? rg[j].z : rg[j].w));
+                uint2 h0, l0, h1, l1;
+                SC::cvt4(f32x4{e[0], e[1], e[2], e[3]}, h0, l0);
+                SC::cvt4(f32x4{e[4], e[5], e[6], e[7]}, h1, l1);
+                const int off = (u_cq * 4 + cc) * ROWB + u_po * 16;
+                *reinterpret_cast<uint4*>(base + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                *reinterpret_cast<uint4*>(base + A_BYTES + off) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+        } else if (isB) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float e[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) e[j] = cc == 0 ? rg[j].x : (cc == 1 ? rg[j].y : (cc == 2 ? rg[j].z : rg[j].w));
+                // split once, then three shifted windows of the 16-bit values
+                unsigned short hs[10], ls[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const __bf16 h = (__bf16)e[j];
+                    const __bf16 l = (__bf16)(e[j] - (float)h);
+                    hs[j] = __builtin_bit_cast(unsigned short, h);
+                    ls[j] = __builtin_bit_cast(unsigned short, l);
+                }
+                const int off = (u_cq * 4 + cc) * ROWB + u_po * 16;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    unsigned char* pl = base + 2 * A_BYTES + q * 2 * B_BYTES;
+                    *reinterpret_cast<uint4*>(pl + off) = make_uint4(hs[q] | (hs[q + 1] << 16), hs[q + 2] | (hs[q + 3] << 16),
+                                                                     hs[q + 4] | (hs[q + 5] << 16), hs[q + 6] | (hs[q + 7] << 16));
+                    *reinterpret_cast<uint4*>(pl + B_BYTES + off) = make_uint4(ls[q] | (ls[q + 1] << 16), ls[q + 2] | (ls[q + 3] << 16),
+                                                                               ls[q + 4] | (ls[q + 5] << 16), ls[q + 6] | (ls[q + 7] << 16));
+                }
+            }
+        }
+    };
+
+    f32x16 acc[NT][TM];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    load_chunk(c_begin);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        if (c + 1 < c_end) load_chunk(c + 1);
+        const unsigned char* base = smem_b + cur * STAGE;
+        const unsigned char* a_hi = base + (wm * WM + l31) * ROWB + lh * 16;
+        const unsigned char* b_hi = base + 2 * A_BYTES + (wn * WN + l31) * ROWB + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            frag af[TM][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                af[i][0] = *reinterpret_cast<const frag*>(a_hi + i * 32 * ROWB + ks * 32);
+                af[i][1] = *reinterpret_cast<const frag*>(a_hi + A_BYTES + i * 32 * ROWB + ks * 32);
+            }
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                frag bf[2];
+                bf[0] = *reinterpret_cast<const frag*>(b_hi + q * 2 * B_BYTES + ks * 32);
+                bf[1] = *reinterpret_cast<const frag*>(b_hi + q * 2 * B_BYTES + B_BYTES + ks * 32);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[q][i] = SC::mma(af[i], bf, acc[q][i]);
+            }
+        }
+        if (c + 1 < c_end) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        float* out = p.dw + (size_t)p.wt[t0 + q] * p.w_tap_stride;
+        const int ci = ci0 + wn * WN + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                unsafeAtomicAdd(out + (size_t)co * p.w_row_stride + ci, acc[q][i][r]);
+            }
+    }
+}
+
+template <int BM>
+void launch16_row(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
+    const size_t sm = (size_t)2 * (2 * BM + 3 * 2 * 64) * ROWB;
+    auto k = igemm_wgrad16_row_kernel<BM>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k, grid, dim3(256), sm, st, a);
+}
+
 template <int BM, int BN>
 void launch16(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
@@ -193,6 +348,30 @@ int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st) {
     a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
+    // stride-1 convs whose taps come as kernel rows (dy equal, dx consecutive within each group of three): the row kernel
+    bool rows = d->isx == 1 && d->isy == 1 && d->ntaps % 3 == 0 && d->Wo % 8 == 0 && a.M % BK == 0 && d->Hi == d->Ho && d->Wi == d->Wo &&
+                !wgs_flags().wgrad_per_tap &&
+                // measured (tools/bench_wgrad.py, B = 32): 64 channels 88 vs 51 TFLOP/s per-tap (and vs 65 exact fp32), 512 channels
+                // 92 vs 86; at 128 / 256 channels the per-tap tiles stay ahead (85 vs 79, 91 vs 90) — both forms end at ~90 TFLOP/s,
+                // where the K-split atomics of the [Co,9,Ci] result, not the operand traffic, set the pace
+                (d->Ci == 64 || d->Co == 64 || d->Ci >= 512);
+    for (int t = 0; rows && t < d->ntaps; t += 3)
+        rows = d->dy_t[t + 1] == d->dy_t[t] && d->dy_t[t + 2] == d->dy_t[t] && d->dx_t[t + 1] == d->dx_t[t] + 1 && d->dx_t[t + 2] == d->dx_t[t] + 2;
+    if (rows) {
+        const int bm = d->Co >= 128 ? 128 : 64;
+        const int tiles = (d->Co / bm) * (d->Ci / 64), nrow = d->ntaps / 3;
+        const int nchunks = a.M / BK;
+        int ks = d->ksplit;
+        if (ks <= 0) {
+            ks = (768 + tiles * nrow - 1) / (tiles * nrow);       // ~3 workgroups per CU (one resident at a time: 100 KB of LDS)
+            if (ks > nchunks / 4) ks = nchunks / 4;
+            if (ks < 1) ks = 1;
+        }
+        a.ksplit = ks;
+        dim3 grid((unsigned)tiles, (unsigned)nrow, (unsigned)ks);
+        if (bm == 128) launch16_row<128>(a, grid, st); else launch16_row<64>(a, grid, st);
+        return 0;
+    }
     const int BM = d->Co >= 128 ? 128 : 64, BN = d->Ci >= 128 ? 128 : 64;
     const int tiles = ((d->Co + BM - 1) / BM) * ((d->Ci + BN - 1) / BN);
     const int nchunks = (a.M + BK - 1) / BK;

@@ -22,6 +22,7 @@ static WgsFlags read_flags() {
     g.patch_tps1 = getenv("WGS_PATCH_TPS1") != nullptr;
     g.up_gh16 = getenv("WGS_UP_GH16") != nullptr;
     g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
+    g.wgrad_per_tap = getenv("WGS_WGRAD_PER_TAP") != nullptr;
     return g;
 }
 static WgsFlags& flags_storage() {

@@ -33,7 +33,7 @@ void wgs_set_error(const char* fmt, ...);
 // WGS_PATCH_NTF0): read from the
 // environment ONCE, when the first launch asks for them, and immutable afterwards — no getenv on launch paths, no mutable
 // global state.  All default to off = the measured-best path.
-struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0; };
+struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap; };
 const WgsFlags& wgs_flags();
 
 static inline int wgs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -276,7 +276,9 @@ class Reconstructor(nn.Module):
         # Weight gradients are not on the path to the image gradient.  With `deferred` (a list) they are queued as closures
         # and the caller runs them where it likes (TrainStep: on a side stream, next to the generator's backward).
         def wgrad(x, dy, dw, k, stride, pad):
-            prec = R_WGRAD_PRECISION if min(x.shape[-1], dy.shape[-1]) >= 128 else 0
+            # split-bf16 where it beats the exact kernel: >= 128 channels on both sides, and the stride-1 3x3 convs at 64
+            # channels through the kernel-row form (conv_wgrad16.hip: 88 vs 65 TFLOP/s)
+            prec = R_WGRAD_PRECISION if (min(x.shape[-1], dy.shape[-1]) >= 128 or (k == 3 and stride == 1 and x.shape[-1] % 64 == 0)) else 0
             if deferred is None:
                 C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad, precision=prec)
             else:
