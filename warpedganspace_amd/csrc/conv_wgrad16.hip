@@ -364,6 +364,10 @@ int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st) {
         int ks = d->ksplit;
         if (ks <= 0) {
             ks = (768 + tiles * nrow - 1) / (tiles * nrow);       // ~3 workgroups per CU (one resident at a time: 100 KB of LDS)
+            // every split adds Co*Ci*taps fp32 atomics: ~19 M of them cost ~100 us whatever the layer (K-split sweep in DESIGN.md),
+            // so wide layers take fewer, longer splits as long as the chip stays covered (512 channels @8x8: 8 -> 2 splits, 107 -> 86 us)
+            const int cap = (int)(5000000L / ((long)d->Co * d->Ci * d->ntaps));
+            if (cap >= 1 && ks > cap && tiles * nrow * cap >= 190) ks = cap;
             if (ks > nchunks / 4) ks = nchunks / 4;
             if (ks < 1) ks = 1;
         }
