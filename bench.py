@@ -53,9 +53,9 @@ DTYPE_TEXT = {
            "fp32 accumulate / demodulation / epilogue (image error vs the fp32 reference ~4e-4, gate 1e-3)",
     'f16x2': "f16x2: as f16 with the frozen weights as fp16 hi+lo, 2 fp16 MFMAs per product",
     'mixed': "mixed fp16: per-layer arithmetic of the generator by an image-error budget (gate 1e-3) - the stride-1 3x3 convs at >= 64x64 "
-             "(64 % of the MACs) round both operands to fp16 (1 MFMA per product), the up-convs at >= 64x64 use fp16 activations x fp16 hi+lo "
-             "weights (2 MFMAs), the seven layers below 64x64 split-bf16 (3 MFMAs, fp32-class); fp32 accumulate / demodulation / epilogue "
-             "everywhere; dynamic power-of-two scale on fp16 gradient operands",
+             "(64 % of the MACs) round both operands to fp16 (1 MFMA per product), the up-sampling layers at >= 64x64 split one operand into "
+             "fp16 hi+lo in the forward pass (2 MFMAs; their input-gradient convs: plain fp16), the seven layers below 64x64 split-bf16 "
+             "(3 MFMAs, fp32-class); fp32 accumulate / demodulation / epilogue everywhere; dynamic power-of-two scale on every fp16 operand",
 }
 R_TEXT = {0: "; reconstructor (trained): exact fp32 MFMA forward, split-bf16 x3 (fp32-class) input-gradient and >= 128-channel weight-gradient "
              "convs, exact fp32 MFMA for the other weight gradients; BatchNorm statistics in fp64 partials",

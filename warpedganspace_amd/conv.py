@@ -71,6 +71,17 @@ def layer_precision(code, out_res, is_up):
     return _MIXED_UP if is_up else 2
 
 
+def layer_precision_bwd(code, out_res, is_up):
+    """Arithmetic of a layer's INPUT-GRADIENT conv.  'mixed': the up-sampling layers' dgrads run in plain f16 — the two-MFMA
+    forms exist for the image-error budget of the forward pass; the gradient has its own gate (shared-gate gradient error,
+    tests/test_precision_schemes_gpu.py) and stays well inside it."""
+    lp = layer_precision(code, out_res, is_up)
+    if code == MIXED and is_up and lp == 3 and _MIXED_BWD_UP_F16:
+        return 2
+    return lp
+
+
+_MIXED_BWD_UP_F16 = os.environ.get('WGS_MIXED_BWD_UP', 'f16') == 'f16'      # development A/B: 'f16x2' = as the forward
 # development overrides of the 'mixed' policy (read once at import): resolution from which layers run in fp16, arithmetic of the
 # up-convs, or a whole table "res:stride1,up;..." (e.g. WGS_MIXED_POLICY="64:f16x2,f16x2;128:f16,f16x2;256:f16,f16x2")
 _MIXED_MIN_RES = int(os.environ.get('WGS_MIXED_MIN_RES', '64'))

@@ -437,7 +437,7 @@ class Generator(nn.Module):
                     g = ops.upfirdn2d_mhwc(dskip.reshape(B * 3, Hc, Hc, 1), r['upk_f'], 1, 1, 2, 2, 1, 1, 1, 1)
                     dskip = g.reshape(B, 3, Hc // 2, Hc // 2)
             # input gradient of this layer (un-scaled by its own style: the producer applies it)
-            lp = C.layer_precision(C.PRECISION, Hc, ly['up'])
+            lp = C.layer_precision_bwd(C.PRECISION, Hc, ly['up'])
             if ly['up']:
                 dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)     # |dt| <= 4 max|dy|: the kernel sums to 4
                 gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp)
