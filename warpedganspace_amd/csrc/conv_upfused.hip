@@ -124,21 +124,6 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>((NB == 2 && p.w_lo) ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_scale), 0, p.s_bytes, 0x00020000);
 
-    // ---- the epilogue's per-tile scalars go to LDS now (noise of the output block, bias, demodulation): fetched there, every
-    // one of them would expose a memory latency with nothing to overlap it
-    {
-        const float nw = p.noise ? p.noise_w[0] : 0.f;
-        for (int e = tid; e < OR * 28; e += NT) {
-            const int ly = e / 28, lx = e - ly * 28;
-            const int oy = 2 * y0 + ly, ox = 2 * x0 + lx;
-            aux_nz[e] = (p.noise && oy < Ho && ox < Ho) ? nw * p.noise[oy * Ho + ox] : 0.f;
-        }
-        if (tid < BN) {
-            aux_bias[tid] = p.bias[n0 + tid];
-            aux_cs[tid] = p.col_scale[(size_t)b * p.col_ld + n0 + tid];
-        }
-    }
-
     // ---- patch staging: element e = tid + j*NT -> patch pixel e / 8, float4 q = e % 8
     const int q = tid & 7;
     int p_goff[NPL];
@@ -259,9 +244,25 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- the epilogue's per-tile scalars go to LDS now (noise of the output block, bias, demodulation): fetched there, every
+    // one of them would expose a memory latency with nothing to overlap it
+    auto fill_aux = [&]() {
+        const float nw = p.noise ? p.noise_w[0] : 0.f;
+        for (int e = tid; e < OR * 28; e += NT) {
+            const int ly = e / 28, lx = e - ly * 28;
+            const int oy = 2 * y0 + ly, ox = 2 * x0 + lx;
+            aux_nz[e] = (p.noise && oy < Ho && ox < Ho) ? nw * p.noise[oy * Ho + ox] : 0.f;
+        }
+        if (tid < BN) {
+            aux_bias[tid] = p.bias[n0 + tid];
+            aux_cs[tid] = p.col_scale[(size_t)b * p.col_ld + n0 + tid];
+        }
+    };
+
     // ---- main loop: one barrier per weight stage; patch buffers alternate per chunk
     load_patch(0);
     issue_b(0, 0, 0);
+    fill_aux();                 // behind the first patch loads and weight DMAs: its own load latency overlaps theirs
     store_patch(0);
     step_barrier();
     int stage = 0;
