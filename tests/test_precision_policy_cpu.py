@@ -1,0 +1,50 @@
+"""CPU: host-side arithmetic policy of the generator's conv launches (warpedganspace_amd/conv.py) — which mode a layer runs in
+under 'auto' / 'mixed', forward and backward, and which launches take the fused up-sampling kernel.  No kernel runs here."""
+import pytest
+
+from warpedganspace_amd import conv as C
+
+
+def test_precision_names_round_trip():
+    for name, code in C.PRECISION_NAMES.items():
+        assert C.precision_code(name) == code
+        assert C.precision_name(code) == name
+    with pytest.raises(Exception):
+        C.precision_code('fp8')
+
+
+def test_auto_resolves_per_architecture():
+    old = C.set_precision('auto')
+    try:
+        assert C.precision_name(C.resolve_auto('stylegan2', 256)) == 'mixed'
+        assert C.precision_name(C.resolve_auto('stylegan2', 1024)) == 'bf16x3'        # f16 / f16x2 miss the gate at 1024^2
+        assert C.precision_name(C.resolve_auto('proggan', 256)) == 'f16'
+        assert C.precision_name(C.resolve_auto('biggan', 128)) == 'bf16x3'
+        assert C.precision_name(C.resolve_auto('sngan', 32)) == C.AUTO_FALLBACK
+        C.set_precision('fp32')
+        assert C.resolve_auto('stylegan2', 256) == 0                                    # an explicit mode wins everywhere
+    finally:
+        C.PRECISION = old
+
+
+def test_mixed_policy_per_layer():
+    M = C.MIXED
+    # forward: below 64 x 64 split-bf16, stride-1 convs fp16, up-sampling layers fp16 x2
+    assert C.layer_precision(M, 32, False) == 1 and C.layer_precision(M, 32, True) == 1
+    assert C.layer_precision(M, 64, False) == 2 and C.layer_precision(M, 256, False) == 2
+    assert C.layer_precision(M, 64, True) == 3 and C.layer_precision(M, 256, True) == 3
+    # backward: the up-sampling layers' input-gradient convs in plain fp16, everything else as the forward
+    assert C.layer_precision_bwd(M, 128, True) == 2
+    assert C.layer_precision_bwd(M, 128, False) == 2 and C.layer_precision_bwd(M, 16, True) == 1
+    # any fixed mode is the same for every layer, forward and backward
+    for code in (0, 1, 2, 3):
+        assert C.layer_precision(code, 8, True) == code and C.layer_precision_bwd(code, 256, True) == code
+
+
+def test_fused_upconv_selection():
+    assert C.upconv_fused_ok(128, 256, 128, 3) and C.upconv_fused_ok(32, 512, 512, 2)
+    assert not C.upconv_fused_ok(128, 256, 128, 1)          # split-bf16 keeps the phase GEMMs + blur kernel
+    assert not C.upconv_fused_ok(128, 256, 128, 0)
+    assert not C.upconv_fused_ok(8, 512, 512, 2)            # maps below 16 x 16
+    assert not C.upconv_fused_ok(512, 64, 32, 2)            # 32 output channels: not a multiple of the 64-column tile
+    assert not C.upconv_fused_ok(64, 24, 64, 2)
