@@ -350,11 +350,9 @@ int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st) {
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
     // stride-1 convs whose taps come as kernel rows (dy equal, dx consecutive within each group of three): the row kernel
     bool rows = d->isx == 1 && d->isy == 1 && d->ntaps % 3 == 0 && d->Wo % 8 == 0 && a.M % BK == 0 && d->Hi == d->Ho && d->Wi == d->Wo &&
-                !wgs_flags().wgrad_per_tap &&
-                // measured (tools/bench_wgrad.py, B = 32): 64 channels 88 vs 51 TFLOP/s per-tap (and vs 65 exact fp32), 512 channels
-                // 92 vs 86; at 128 / 256 channels the per-tap tiles stay ahead (85 vs 79, 91 vs 90) — both forms end at ~90 TFLOP/s,
-                // where the K-split atomics of the [Co,9,Ci] result, not the operand traffic, set the pace
-                (d->Ci == 64 || d->Co == 64 || d->Ci >= 512);
+                !wgs_flags().wgrad_per_tap;
+    // measured (tools/bench_wgrad.py, B = 32, with the split cap below): 64 / 128 / 256 / 512 channels 105 / 102 / 109 / 113 TFLOP/s
+    // against 51 / 86 / 90 / 86 for the per-tap tiles (and 65-70 for the exact fp32 kernel)
     for (int t = 0; rows && t < d->ntaps; t += 3)
         rows = d->dy_t[t + 1] == d->dy_t[t] && d->dy_t[t + 2] == d->dy_t[t] && d->dx_t[t + 1] == d->dx_t[t] + 1 && d->dx_t[t + 2] == d->dx_t[t] + 2;
     if (rows) {
