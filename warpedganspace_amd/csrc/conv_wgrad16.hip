@@ -380,6 +380,8 @@ int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st) {
     int ks = d->ksplit;
     if (ks <= 0) {
         ks = (1024 + tiles * d->ntaps - 1) / (tiles * d->ntaps);
+        const int cap = wgs_flags().wgrad_per_tap ? 0 : (int)(5000000L / ((long)d->Co * d->Ci * d->ntaps));      // as in the row form above
+        if (cap >= 1 && ks > cap && tiles * d->ntaps * cap >= 190) ks = cap;
         if (ks > nchunks / 4) ks = nchunks / 4;
         if (ks < 1) ks = 1;
     }
