@@ -2,19 +2,19 @@
 // 4x4 blur, noise, bias, leaky-relu*sqrt(2)   (models/StyleGAN2/model.py:201-212 conv_transpose2d + Blur, :231-241, :264).
 //
 // The unfused path runs the transposed conv as four sub-pixel phase GEMMs that write a (2H+1)^2 intermediate t (1.08 GB at
-// 128->256 px, B = 32), and a second kernel reads t back through the blur.  Here one workgroup owns a 14 x 14 block of INPUT
+// 128->256 px, B = 32), and a second kernel reads t back through the blur.  Here one workgroup owns a 16 x 12 block of INPUT
 // cells of one sample and 64 output channels:
 //
-//   * GEMM rows = the 16 x 16 grid g of cell positions (the block + a one-cell halo: the 4-tap blur of the 28 x 28 output
-//     block needs t on [2*y0 - 1, 2*y0 + 30]);  t[2g + p] for the four parities p = (py, px) are FOUR accumulator sets
+//   * GEMM rows = the 18 x 14 grid g of cell positions (the block + a one-cell halo: the 4-tap blur of the 32 x 24 output
+//     block needs t one position beyond it on every side; 252 of the tile's 256 rows);  t[2g + p] for the four parities p = (py, px) are FOUR accumulator sets
 //     of the same rows:  t_p[g] = sum over the phase's taps (ky = py mod 2, kx = px mod 2) of x[g + (p - k)/2] * w[k]
 //   * the activation operand is staged ONCE per 32-channel chunk as the 17 x 17 input patch; the nine (phase, tap) products
 //     read it with four different row shifts, so one A fragment feeds up to four MFMAs (phases) and is read 4x, not 9x
-//   * epilogue: accumulators * demodulation -> LDS as the 32 x 32 x 32-channel t tile (fp32, 128 KB), then the blur +
-//     noise + bias + activation over the 28 x 28 outputs with a sliding row window, stored as 128-B channel runs.
+//   * epilogue: accumulators * demodulation -> LDS as the 36 x 28 x 32-channel t tile (fp32, 126 KB), then the blur +
+//     noise + bias + activation over the 32 x 24 outputs with a sliding row window, stored as 128-B channel runs.
 //
-// Rows of the 16 x 16 grid outside the image produce exact zeros (their patch pixels are out of range -> 0), which is
-// upfirdn2d's zero padding of t.  MFMA efficiency = 196 useful cells of 256 rows (x tile-edge waste); in exchange the layer
+// Grid positions outside the image produce exact zeros (their patch pixels are out of range -> 0), which is
+// upfirdn2d's zero padding of t.  MFMA efficiency = 192 useful cells of 256 rows (x tile-edge waste: none in x for 32 / 64 / 128-wide maps); in exchange the layer
 // loses the intermediate's write + two reads and the blur kernel.
 //
 // LDS: two patch buffers + two weight stages of TS products each (one barrier per stage), re-used by the epilogue's t tile.
@@ -37,7 +37,6 @@ constexpr int BK = 32;
 constexpr int ROW = 64;                  // bytes per LDS row of a weight plane (DMA: unpadded, XOR-swizzled 16-B slots)
 constexpr int PROW = 80;                 // bytes per LDS row of the patch (padded, linear)
 constexpr int OOB = (int)0x80000000;
-constexpr int CELLS = 14, PW = 17;          // cell columns of a tile, patch width (tile + 1 halo left, 2 right)
 constexpr int BN = 64;
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -47,7 +46,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 __device__ constexpr int T_PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0};
 __device__ constexpr int T_SH[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
 constexpr int T_W_HOST[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8};
-__device__ constexpr int SH_OFF[4] = {(PW + 1) * PROW, PW * PROW, 1 * PROW, 0};
+// patch row shift of the four (dy, dx) groups, in patch pixels (PW = patch width of the tile shape)
+__device__ constexpr int sh_off(int sh, int PW) { return sh == 0 ? PW + 1 : (sh == 1 ? PW : (sh == 2 ? 1 : 0)); }
 
 struct UpArgs {
     const float* x; const unsigned short* w_hi; const unsigned short* w_lo; float* y;
@@ -61,24 +61,28 @@ struct UpArgs {
     int tap_w[9];              // element offset of issue-order product t's weight tap (T_W[t] * Ci)
 };
 
-// GH = height of the grid-row block: 16 (8 waves, 14 x 14 cells, one workgroup per CU) or 8 (4 waves, 14 x 6 cells, 75 KB of
+// GH selects the tile: 16 (8 waves, 16 x 12 cells, one workgroup per CU) or 8 (4 waves, 14 x 6 cells, 75 KB of
 // LDS: TWO workgroups per CU, whose staging, barriers and blur epilogues overlap each other's MFMAs).
 template <int SCH, int GH>
 struct UpCfg {
     typedef wgsconv::Scheme<SCH> SC;
     static constexpr int NA = SC::NA, NB = SC::NB;
     static constexpr int NW = GH / 2, NT = 64 * NW;
-    static constexpr int CY = GH - 2;                                  // cell rows of a tile
-    static constexpr int PH = GH + 1, NPIX = PW * PH, PALLOC = (NPIX + 7) / 8 * 8;
+    // grid of cell positions g: GH == 16 -> 18 x 14 (252 of the 256 GEMM rows; 16 x 12 cells: 128 / 64 / 32-wide maps divide by
+    // 16, so only the tile rows have an edge remainder), GH == 8 -> 16 x 8 (14 x 6 cells)
+    static constexpr int GX = GH == 16 ? 18 : 16, GY = GH == 16 ? 14 : 8;
+    static constexpr int CX = GX - 2, CY = GY - 2;                     // cells of a tile
+    static constexpr int PW = GX + 1, PH = GY + 1, NPIX = PW * PH, PALLOC = (NPIX + 7) / 8 * 8;
+    static constexpr int TW = 2 * GX, TH = 2 * GY;                     // t tile positions
+    static constexpr int OW = 2 * CX, OR = 2 * CY;                     // output block
     static constexpr int TS = GH == 16 ? (NA * NB == 1 ? 9 : 5) : (NA * NB == 1 ? 5 : 3);   // products per weight stage
     static constexpr int NSTEP = (9 + TS - 1) / TS;
     static constexpr int P_BYTES = PALLOC * PROW;
     static constexpr int B_BYTES = BN * ROW, B_TAP = NB * B_BYTES, B_STAGE = TS * B_TAP;
     static constexpr int K_BYTES = 2 * NA * P_BYTES + 2 * B_STAGE;
-    static constexpr int T_BYTES = 2 * GH * 32 * 32 * 4;               // t tile: (2 GH) x 32 positions x 32 channels fp32
+    static constexpr int T_BYTES = TW * TH * 32 * 4;                   // t tile: TH x TW positions x 32 channels fp32
     static constexpr int MAIN = K_BYTES > T_BYTES ? K_BYTES : T_BYTES;
-    static constexpr int OR = 2 * GH - 4;                              // output rows of a tile (28 or 12); 28 output columns
-    static constexpr int AUX_FLOATS = OR * 28 + 2 * BN;                // noise of the output block | bias | demodulation
+    static constexpr int AUX_FLOATS = OR * OW + 2 * BN;                // noise of the output block | bias | demodulation
     static constexpr int SMEM = MAIN + AUX_FLOATS * 4;
 };
 
@@ -95,12 +99,12 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     constexpr int P_BYTES = CF::P_BYTES, B_BYTES = CF::B_BYTES, B_TAP = CF::B_TAP, B_STAGE = CF::B_STAGE;
     constexpr int PALLOC = CF::PALLOC, NPIX = CF::NPIX;
     constexpr int NPL = (PALLOC * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (5)
-    constexpr int OR = CF::OR;
+    constexpr int OR = CF::OR, OW = CF::OW, GX = CF::GX, GY = CF::GY, PW = CF::PW, TW = CF::TW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* patch = smem_b;                      // two buffers of NA planes
     unsigned char* bst = smem_b + 2 * NA * P_BYTES;     // two weight stages
     float* aux_nz = reinterpret_cast<float*>(smem_b + CF::MAIN);
-    float* aux_bias = aux_nz + OR * 28;
+    float* aux_bias = aux_nz + OR * OW;
     float* aux_cs = aux_bias + BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     const int tile = bid / ntn, n0 = (bid % ntn) * BN;
     const int b = tile / p.tiles_per_img;
     const int trem = tile - b * p.tiles_per_img;
-    const int y0 = (trem / p.tiles_x) * CF::CY, x0 = (trem % p.tiles_x) * CELLS;
+    const int y0 = (trem / p.tiles_x) * CF::CY, x0 = (trem % p.tiles_x) * CF::CX;
     const int Ho = 2 * p.H;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -203,7 +207,8 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     // ---- operand fragment addressing
     const int l31 = lane & 31, lh = lane >> 5;
     const int m_a = wm * WM + l31;
-    const int pa0 = ((m_a >> 4) * PW + (m_a & 15)) * PROW + lh * 16;
+    const int m_c = m_a < GX * GY ? m_a : GX * GY - 1;       // GEMM rows past the grid (252..255) shadow its last position
+    const int pa0 = ((m_c / GX) * PW + (m_c % GX)) * PROW + lh * 16;
     const int bswz = (l31 >> 2) & 3;
     const int b_rd = l31 * ROW;
     const int bk0 = ((0 + lh) ^ bswz) << 4, bk1 = ((2 + lh) ^ bswz) << 4;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
                 if (t < 9) {
                     if (u == 0 || T_SH[t] != T_SH[t - 1]) {
 #pragma unroll
-                        for (int pl = 0; pl < NA; ++pl) af[pl] = *reinterpret_cast<const frag*>(pb + pl * P_BYTES + pa0 + SH_OFF[T_SH[t]] + ks * 32);
+                        for (int pl = 0; pl < NA; ++pl) af[pl] = *reinterpret_cast<const frag*>(pb + pl * P_BYTES + pa0 + sh_off(T_SH[t], PW) * PROW + ks * 32);
                     }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     // one of them would expose a memory latency with nothing to overlap it
     auto fill_aux = [&]() {
         const float nw = p.noise ? p.noise_w[0] : 0.f;
-        for (int e = tid; e < OR * 28; e += NT) {
-            const int ly = e / 28, lx = e - ly * 28;
+        for (int e = tid; e < OR * OW; e += NT) {
+            const int ly = e / OW, lx = e - ly * OW;
             const int oy = 2 * y0 + ly, ox = 2 * x0 + lx;
             aux_nz[e] = (p.noise && oy < Ho && ox < Ho) ? nw * p.noise[oy * Ho + ox] : 0.f;
         }
@@ -311,23 +316,31 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         sep = sep && dev <= 2e-7f * kmax;
     }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    constexpr int NSTRIP = GH / 8, RS = OR / NSTRIP;      // row strips of the blur stage, output rows per strip (14 / 12)
+    constexpr int NSTRIP = (NT / 8) / OW, RS = OR / NSTRIP;  // row strips of the blur stage (2 x 12 rows / 1 x 12 rows)
+    static_assert(NSTRIP >= 1 && RS * NSTRIP == OR, "blur strips");
     const int bslot = tid >> 3;                           // (strip, column) of the blur stage
-    const int lx = bslot % 28, strip = bslot / 28;
-    const bool bl_live = bslot < 28 * NSTRIP;
+    const int lx = bslot % OW, strip = bslot / OW;
+    const bool bl_live = bslot < OW * NSTRIP;
     float vmax = 0.f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         {
             const float cs = aux_cs[half * 32 + l31];
             const float al = p.alpha * op_inv;
+            const int mb = wm * WM + 4 * lh;                 // this lane's first grid row; its 16 rows are mb + (r & 3) + 8 * (r >> 2)
+            const int mbq = mb / GX, mbr = mb - mbq * GX;
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = wm * WM + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int pos = (2 * (m >> 4) + (ph >> 1)) * 32 + 2 * (m & 15) + (ph & 1);
-                    T[pos * 32 + l31] = (half ? acc[ph][1][r] : acc[ph][0][r]) * al * cs;
+                    const int cr = (r & 3) + 8 * (r >> 2);       // compile-time row offset (<= 27)
+                    int gx = mbr + cr, gy = mbq;
+                    if (gx >= GX) { gx -= GX; ++gy; }
+                    if (gx >= GX) { gx -= GX; ++gy; }
+                    if (gy < GY) {
+                        const int pos = (2 * gy + (ph >> 1)) * TW + 2 * gx + (ph & 1);
+                        T[pos * 32 + l31] = (half ? acc[ph][1][r] : acc[ph][0][r]) * al * cs;
+                    }
                 }
         }
         __syncthreads();
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             auto emit = [&](float4 a, int ly) {
                 const int oy = 2 * y0 + ly;
                 const bool ok = oy < Ho && ox < Ho;
-                const float nz = aux_nz[ly * 28 + lx];
+                const float nz = aux_nz[ly * OW + lx];
                 a.x += nz + bv.x; a.y += nz + bv.y; a.z += nz + bv.z; a.w += nz + bv.w;
                 a.x = (a.x > 0.f ? a.x : 0.2f * a.x) * 1.4142135623730951f;
                 a.y = (a.y > 0.f ? a.y : 0.2f * a.y) * 1.4142135623730951f;
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
                     float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx) {
-                        const float4 v = *reinterpret_cast<const float4*>(T + ((uy * 32 + lx + 1 + jx) * 32 + q * 4));
+                        const float4 v = *reinterpret_cast<const float4*>(T + ((uy * TW + lx + 1 + jx) * 32 + q * 4));
                         h.x = fmaf(v.x, kh[jx], h.x); h.y = fmaf(v.y, kh[jx], h.y); h.z = fmaf(v.z, kh[jx], h.z); h.w = fmaf(v.w, kh[jx], h.w);
                     }
                     hwin[rr & 3] = h;
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
                 for (int rr = 0; rr < RS + 3; ++rr) {
                     const int uy = strip * RS + rr + 1;
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx) win[rr & 3][jx] = *reinterpret_cast<const float4*>(T + ((uy * 32 + lx + 1 + jx) * 32 + q * 4));
+                    for (int jx = 0; jx < 4; ++jx) win[rr & 3][jx] = *reinterpret_cast<const float4*>(T + ((uy * TW + lx + 1 + jx) * 32 + q * 4));
                     if (rr >= 3) {
                         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -409,7 +422,7 @@ template <int SCH, int GH>
 void launch_up(const UpArgs& a0, hipStream_t st) {
     typedef UpCfg<SCH, GH> CF;
     UpArgs a = a0;
-    a.tiles_x = (a.H + CELLS - 1) / CELLS;
+    a.tiles_x = (a.H + CF::CX - 1) / CF::CX;
     a.tiles_per_img = a.tiles_x * ((a.H + CF::CY - 1) / CF::CY);
     const int nblocks = a.B * a.tiles_per_img * (a.Co / BN);
     auto k = upconv_blur_kernel<SCH, GH>;
@@ -440,10 +453,10 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     a.tiles_x = a.tiles_per_img = 0;
     a.w_row_stride = 9 * d->Ci;
     for (int t = 0; t < 9; ++t) a.tap_w[t] = T_W_HOST[t] * d->Ci;
-    // 14 x 14-cell tiles (one 8-wave workgroup per CU) unless they would leave the chip short of workgroups: then 14 x 6-cell
+    // 16 x 12-cell tiles (one 8-wave workgroup per CU) unless they would leave the chip short of workgroups: then 14 x 6-cell
     // tiles, two 4-wave workgroups per CU (they re-fetch the weights twice as often, which is what bounds the large layers)
-    const int t14 = (d->H + CELLS - 1) / CELLS;
-    const bool gh16 = wgs_flags().up_gh16 || (long)d->B * t14 * t14 * (d->Co / BN) >= 2048;
+    const long big_tiles = (long)((d->H + 15) / 16) * ((d->H + 11) / 12);        // 16 x 12-cell tiles of the 8-wave form
+    const bool gh16 = wgs_flags().up_gh16 || (long)d->B * big_tiles * (d->Co / BN) >= 1536;
     // precision 3 (fp16 x2) splits the ACTIVATION operand here (Scheme<3>: same two MFMAs, same error class as the weight split of
     // the GEMM kernels): the second weight plane would double the LDS-DMA traffic that bounds this kernel.  w_lo is not read.
     if (d->precision == 2) { if (gh16) launch_up<1, 16>(a, (hipStream_t)stream); else launch_up<1, 8>(a, (hipStream_t)stream); }
