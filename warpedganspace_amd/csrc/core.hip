@@ -23,6 +23,7 @@ static WgsFlags read_flags() {
     g.up_gh16 = getenv("WGS_UP_GH16") != nullptr;
     g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
     g.wgrad_per_tap = getenv("WGS_WGRAD_PER_TAP") != nullptr;
+    g.patch_wide = getenv("WGS_PATCH_WIDE") != nullptr;
     return g;
 }
 static WgsFlags& flags_storage() {

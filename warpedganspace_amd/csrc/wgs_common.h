@@ -30,13 +30,17 @@ void wgs_set_error(const char* fmt, ...);
     } while (0)
 
 // Development A/B switches (WGS_DMA_ALWAYS, WGS_PHASE_PATCH, WGS_NO_PATCH, WGS_PATCH_BM256, WGS_PATCH_TPS1, WGS_UP_GH16,
-// WGS_PATCH_NTF0): read from the
+// WGS_PATCH_NTF0, WGS_WGRAD_PER_TAP, WGS_PATCH_WIDE): read from the
 // environment ONCE, when the first launch asks for them, and immutable afterwards — no getenv on launch paths, no mutable
 // global state.  All default to off = the measured-best path.
-struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap; };
+struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap, patch_wide; };
 const WgsFlags& wgs_flags();
 
 static inline int wgs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// n / d for a launch-uniform divisor d >= 2 as one multiply-high: magic = ceil(2^32 / d), exact for n * d < 2^32
+// (a 32-bit integer division is ~35 VALU instructions on gfx950; the short-K conv tiles do a dozen of them per lane).
+static inline unsigned wgs_div_magic(int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+__device__ __forceinline__ int wgs_div_fast(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
 
 // ---- wave64 reductions (gfx950: wavefront = 64 lanes) -------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
