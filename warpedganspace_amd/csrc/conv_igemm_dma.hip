@@ -13,6 +13,15 @@
 // the DMA (lane -> row = lane/4, slot = lane%4 fetches logical chunk slot ^ swz) and on the ds_read address.
 //
 // Template parameter SCH: the same kernel for the fp16 schemes (conv_scheme.h) — one activation plane, one or two weight planes.
+//
+// Pipeline: a ring of NS stages (as many as fit in LDS: 4 for the fp16 forms, 3 / 2 for the two-plane forms).  EVERY vector
+// memory operation of the main loop is an LDS-DMA, so — unlike the kernels that mix DMAs with VGPR loads (conv_igemm_patch.hip)
+// — a COUNTED wait is legal: at the top of step k a wave waits until all but its newest NS - 2 chunks have landed
+// (s_waitcnt vmcnt((NS - 2) * NPIECE)), the barrier then publishes chunk k of all waves and retires stage (k - 1) % NS, whose
+// refill with chunk k + NS - 1 is issued between the first MFMA slots.  A chunk has NS - 1 steps of flight instead of one.
+#ifndef WGS_DABL
+#define WGS_DABL 0   // development ablation (tools/build_abl.sh dabl 1): 1 = two stages, everything drained at every barrier
+#endif
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
@@ -33,6 +42,8 @@ constexpr int OOB = (int)0x80000000;   // byte offset beyond any buffer this ker
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
+constexpr int dma_stages(int stage_bytes) { return 160 * 1024 / stage_bytes >= 4 ? 4 : (160 * 1024 / stage_bytes >= 3 ? 3 : 2); }
+
 template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(const ConvArgs p) {
     typedef wgsconv::Scheme<SCH> SC;
@@ -42,6 +53,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW;
     constexpr int STAGE = NA * A_BYTES + NB * B_BYTES;
+    constexpr int NS = WGS_DABL == 1 ? 2 : dma_stages(STAGE);
     constexpr int AI = BM / 16 / NW, BI = BN / 16 / NW;     // 16-row DMA instructions per wave and plane
     static_assert(AI >= 1 && BI >= 1 && AI * 16 * NW == BM && BI * 16 * NW == BN, "tile / wave count mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -181,13 +193,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(
         }
     };
 
-    issue(0);
-    __syncthreads();                  // drains the DMA (vmcnt(0)) and publishes stage 0
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue(st);      // chunks 0 .. NS-2 (past the end: zeros)
+    int cur = 0, nxt = NS - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        mma_tile(cur, cur ^ 1);       // chunk kt+1 lands while chunk kt is multiplied
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * NPIECE) : "memory");   // this wave's pieces of chunk kt have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();     // ... and everybody's; stage `nxt` (chunk kt-1) is no longer read
+        asm volatile("" ::: "memory");    // (the bare s_barrier does not order memory operations for the compiler)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tile(cur, nxt);               // chunk kt+NS-1 is issued into `nxt` while chunk kt is multiplied
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-fill DMAs past the last chunk: the epilogue re-uses the LDS
+    __syncthreads();
     wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh, op_inv);
 }
 
@@ -238,7 +259,8 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float* __restrict__
 
 template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_dma_s(const ConvArgs& a, hipStream_t st, int nblocks) {
-    const size_t sm = (size_t)2 * (wgsconv::Scheme<SCH>::NA * BM + wgsconv::Scheme<SCH>::NB * BN) * ROW;
+    const size_t stage = (size_t)(wgsconv::Scheme<SCH>::NA * BM + wgsconv::Scheme<SCH>::NB * BN) * ROW;
+    const size_t sm = (WGS_DABL == 1 ? 2 : dma_stages((int)stage)) * stage;
     auto k = igemm_dma16_kernel<SCH, BM, BN, WAVES_M, WAVES_N>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a);
