@@ -32,4 +32,5 @@ for _ in range(8):
     C.conv2d(x, w, 3, pad=1, out=y, **kw)
 e_.record(); torch.cuda.synchronize()
 ms = s_.elapsed_time(e_) / 8
-print('dma form %d->%d @%d %s: pre-pass + conv %.3f ms (%.1f TF incl. pre-pass)' % (ci, co, h, C.precision_name(m), ms, 2.0 * B * h * h * co * ci * 9 / ms / 1e9), flush=True)
+import hashlib
+print('dma form %d->%d @%d %s: pre-pass + conv %.3f ms (%.1f TF incl. pre-pass)  sha %s' % (ci, co, h, C.precision_name(m), ms, 2.0 * B * h * h * co * ci * 9 / ms / 1e9, hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:12]), flush=True)
