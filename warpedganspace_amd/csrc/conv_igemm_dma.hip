@@ -20,8 +20,15 @@
 // (s_waitcnt vmcnt((NS - 2) * NPIECE)), the barrier then publishes chunk k of all waves and retires stage (k - 1) % NS, whose
 // refill with chunk k + NS - 1 is issued between the first MFMA slots.  A chunk has NS - 1 steps of flight instead of one.
 #ifndef WGS_DABL
-#define WGS_DABL 0   // development ablation (tools/build_abl.sh dabl 1): 1 = two stages, everything drained at every barrier
+#define WGS_DABL 0   // development ablations (tools/build_abl.sh dabl 1 2): 1 = two stages, everything drained at every
+                     // barrier; 2 = ring without the ping-pong schedule
 #endif
+//
+// Schedule of the single-plane fp16 form (8 waves = two per SIMD): PING-PONG.  A wave alternates a memory phase (all 12
+// operand fragments of a chunk LDS -> registers, the DMAs of a later chunk) with a compute phase (the chunk's 16 MFMAs from
+// registers), one barrier after each; waves 4-7 run one phase behind waves 0-3, so on every SIMD one wave multiplies while
+// the other fetches, and the matrix pipe goes from one wave's MFMA block straight into the other's.  (With all eight waves in
+// phase, every barrier was followed by eight waves waiting on their first fragment reads.)
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
@@ -196,16 +203,64 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st) issue(st);      // chunks 0 .. NS-2 (past the end: zeros)
     int cur = 0, nxt = NS - 1;
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * NPIECE) : "memory");   // this wave's pieces of chunk kt have landed
+    auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();     // ... and everybody's; stage `nxt` (chunk kt-1) is no longer read
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");    // (the bare s_barrier does not order memory operations for the compiler)
         __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr bool PP = SCH == 1 && NW == 8 && NS >= 3 && WGS_DABL == 0;
+    if (PP) {
+        const int grp = wave >> 2;
+        frag af[2][TM][NA], bf[2][TN][NB];
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * NPIECE) : "memory");   // own pieces of chunk 0
+        bar();                                   // chunk 0 of all waves
+        if (grp == 1) bar();                     // waves 4-7: one phase behind
+        for (int kt = 0; kt < nk; ++kt) {
+            // memory phase: fragments of chunk kt, DMAs of chunk kt+NS-1 into the stage chunk kt-1 was read from (by waves 0-3 two
+            // phases ago, by waves 4-7 one phase ago: both behind a barrier)
+            const unsigned char* base = smem_b + cur * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int kc = ks ? kc1 : kc0;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < NB; ++pl) bf[ks][j][pl] = *reinterpret_cast<const frag*>(base + b_rd + pl * B_BYTES + j * 32 * ROW + kc);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < NA; ++pl) af[ks][i][pl] = *reinterpret_cast<const frag*>(base + a_rd + pl * A_BYTES + i * 32 * ROW + kc);
+            }
+            begin_chunk();
+#pragma unroll
+            for (int idx = 0; idx < NPIECE; ++idx) issue_piece(nxt, idx);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * NPIECE) : "memory");   // own pieces of chunk kt+1 have landed
+            bar();
+            // compute phase
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(af[ks][i], bf[ks][j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            nxt = nxt + 1 == NS ? 0 : nxt + 1;
+        }
+        if (grp == 0) bar();
+    } else {
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * NPIECE) : "memory");   // this wave's pieces of chunk kt have landed
+        bar();                            // ... and everybody's; stage `nxt` (chunk kt-1) is no longer read
         mma_tile(cur, nxt);               // chunk kt+NS-1 is issued into `nxt` while chunk kt is multiplied
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cur = cur + 1 == NS ? 0 : cur + 1;
         nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-fill DMAs past the last chunk: the epilogue re-uses the LDS
     __syncthreads();
