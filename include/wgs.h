@@ -168,6 +168,11 @@ typedef struct wgs_conv_desc {
     float* y_amax;           /* precision >= 1: optional device scalar (caller-zeroed) raised (atomic max) to max |y| of this launch
                                 — chained into the next layer's a_amax, so that a forward pass in the fp16 modes cannot overflow
                                 whatever the magnitude of a checkpoint's activations */
+    const uint16_t* x_f16;   /* optional: the activation operand ALREADY as its fp16 plane, hi = f16_rn(x * 2^k) in the layout of x
+                                with k from (a_amax, a_bound, a_amax2) as above — written by the producing kernel
+                                (wgs_sg2_blur_bwd_f16) instead of the fp32 tensor.  Then x may be NULL; precision must be 2,
+                                a_scale NULL, ups 0, w_hi given, Ci % 32 == 0, Co % 128 == 0: the launch runs the LDS-DMA
+                                kernel without its pre-pass (same bits as the fp32 route) or fails with WGS_EINVAL. */
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
 /* n launches that share every operand and differ only in (Hg, Wg, oy0, ox0, taps) — the 4 sub-pixel phases of a
@@ -249,6 +254,13 @@ int wgs_linear_wgrad(const float* gy, const float* x, float* dw, float* db, int 
 /* y_amax: optional device scalar (caller-zeroed) raised to max |y| — the next layer's wgs_conv_desc.a_amax. */
 int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const float* noise, const float* noise_w,
                                 const float* bias, float* y, float* y_amax, int B, int Ho, int Wo, int C, wgs_stream_t stream);
+
+/* Backward of that Blur for a fp16 consumer: dt = upfirdn2d(dy, flip(kernel), pad (2,2)) (upfirdn2d.py:110-115 with the g_pad of
+ * the forward's pad (1,1)), dy [B,H,W,C] fp32 -> dt_hi [B,H+1,W+1,C] as the fp16 operand plane f16_rn(dt * 2^k) of the stride-2
+ * gradient conv that consumes it (wgs_conv_desc.x_f16; k from the device scalar a_amax >= max|dy| and a_bound = sum|kernel|).
+ * kernel4x4: the 16 taps as wgs_upfirdn2d takes them for that call. */
+int wgs_sg2_blur_bwd_f16(const float* dy, const float* kernel4x4, uint16_t* dt_hi, const float* a_amax, float a_bound,
+                         int B, int H, int W, int C, wgs_stream_t stream);
 
 /* The whole up-sampling StyledConv in one launch (fp16 operand schemes): modulated stride-2 transposed 3x3 conv
  * (ModulatedConv2d.forward upsample branch, models/StyleGAN2/model.py:201-212: F.conv_transpose2d + Blur(pad (1,1))),

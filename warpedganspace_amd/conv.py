@@ -24,7 +24,8 @@ class ConvDesc(ctypes.Structure):
                 ('dy', ctypes.c_int8 * 64), ('dx', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
                 ('w_hi', ctypes.c_void_p), ('w_lo', ctypes.c_void_p),
                 ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64),
-                ('a_amax', ctypes.c_void_p), ('a_bound', ctypes.c_float), ('a_amax2', ctypes.c_void_p), ('y_amax', ctypes.c_void_p)]
+                ('a_amax', ctypes.c_void_p), ('a_bound', ctypes.c_float), ('a_amax2', ctypes.c_void_p), ('y_amax', ctypes.c_void_p),
+                ('x_f16', ctypes.c_void_p)]
 
 
 class WgradDesc(ctypes.Structure):
@@ -230,12 +231,14 @@ def _timed(kind, flops, fn):
 def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None, w_split=None,
-          a_amax=None, a_bound=1.0, grad_operand=False, a_amax2=None, y_amax=None):
-    """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous)."""
-    if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32):
+          a_amax=None, a_bound=1.0, grad_operand=False, a_amax2=None, y_amax=None, x_f16=False):
+    """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous).
+    x_f16: x is the int16 tensor holding the operand's fp16 plane (wgs_conv_desc.x_f16), written by the producing kernel."""
+    if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == (torch.int16 if x_f16 else torch.float32)):
         raise L.WgsError("conv launch needs contiguous fp32 GPU tensors (no CPU fallback)")
     d = ConvDesc() if into is None else into
-    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.x, d.w, d.y = (None if x_f16 else x.data_ptr()), w.data_ptr(), y.data_ptr()
+    d.x_f16 = x.data_ptr() if x_f16 else None
     d.a_scale, d.col_scale, d.bias = _p(a_scale), _p(col_scale), _p(bias)
     d.noise, d.noise_w = _p(noise), _p(noise_w)
     d.B, d.Hi, d.Wi, d.Ci = x.shape
@@ -397,9 +400,30 @@ def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
     B, Ho, Wo, Co = dy.shape
     Ci = wt_packed.shape[1]
     Hi, Wi = (Ho - k) // 2 + 1, (Wo - k) // 2 + 1
-    dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=dy.dtype)
+    dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=torch.float32)
     taps = [(ky, kx, ky * k + kx) for ky in range(k) for kx in range(k)]
     return launch(dy, wt_packed, dx, taps, Hi, Wi, isy=2, w_tap_stride=Ci * Co, w_row_stride=Co, grad_operand=True, **epi)
+
+
+# The transposed blur in front of an up-sampling layer's gradient conv can store its result as that conv's fp16 operand plane
+# (wgs_sg2_blur_bwd_f16 -> wgs_conv_desc.x_f16): the (2H+1)^2 fp32 tensor is never written and the conv runs the LDS-DMA kernel
+# without a pre-pass, bit-identical to the fp32 route.  Taken for plain-fp16 gradient launches that fill the chip with 256-row tiles.
+BLUR_BWD_F16 = os.environ.get('WGS_BLUR_BWD_F16', '1') != '0'
+
+
+def blur_bwd_f16_ok(B, Hc, Ci_dgrad, Co_dgrad, precision):
+    """dy [B,Hc,Hc,Ci_dgrad] -> gradient conv to [B,Hc/2,Hc/2,Co_dgrad]"""
+    if not BLUR_BWD_F16 or precision != 2 or Ci_dgrad % 32 or Co_dgrad % 128:
+        return False
+    return (B * (Hc // 2) ** 2 // 256) * (Co_dgrad // 128) >= 256
+
+
+def blur_bwd_f16(dy, blur_f, a_amax, a_bound):
+    B, H, W, Cc = dy.shape
+    dt = torch.empty(B, H + 1, W + 1, Cc, device=dy.device, dtype=torch.int16)
+    L.check(L.lib().wgs_sg2_blur_bwd_f16(L.ptr(dy), L.ptr(blur_f), L.ptr(dt, torch.int16), L.rawptr(a_amax), L.c_float(a_bound),
+                                         B, H, W, Cc, L.stream()), 'wgs_sg2_blur_bwd_f16')
+    return dt
 
 
 def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0, precision=0):

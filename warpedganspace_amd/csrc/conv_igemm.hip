@@ -545,7 +545,9 @@ int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stre
 }
 
 static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
-    WGS_CHECK_ARG(d && d->x && d->w && d->y, "wgs_conv_igemm: null pointer");
+    WGS_CHECK_ARG(d && (d->x || d->x_f16) && d->w && d->y, "wgs_conv_igemm: null pointer");
+    WGS_CHECK_ARG(!d->x_f16 || (d->precision == 2 && !d->a_scale && !d->ups && d->w_hi && d->Ci % 32 == 0 && d->Co % 128 == 0 && d->ntaps <= 16),
+                  "wgs_conv_igemm: x_f16 needs precision 2, no a_scale / ups, pre-split weights, Ci %% 32 == 0, Co %% 128 == 0, <= 16 taps");
     WGS_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hg > 0 && d->Wg > 0 && d->Ho > 0 && d->Wo > 0,
                   "wgs_conv_igemm: bad spatial sizes");
     WGS_CHECK_ARG(d->Ci > 0 && d->Ci % 8 == 0, "wgs_conv_igemm: Ci=%d must be a multiple of 8", d->Ci);
@@ -569,7 +571,7 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     WGS_CHECK_ARG(d->ups >= 0 && d->ups <= 3 && d->add_ups >= 0 && d->add_ups <= 3, "wgs_conv_igemm: bad upsample shift");
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
-    a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = nullptr; a.a_lo = nullptr;
+    a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = d->x_f16; a.a_lo = nullptr;
     WGS_CHECK_ARG(d->precision >= 0 && d->precision <= 3, "wgs_conv_igemm: precision=%d (0 fp32, 1 bf16x3, 2 f16, 3 f16x2)", d->precision);
     a.sch = d->precision > 0 ? d->precision - 1 : 0;
     a.a_amax = d->precision >= 2 ? d->a_amax : nullptr;
@@ -585,6 +587,11 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     const int rc = build_conv_args(d, a);
     if (rc != WGS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (d->x_f16) {
+        WGS_CHECK_ARG(wgsconv::launch_bf16x3(a, st) == 0, "wgs_conv_igemm: x_f16 launch not covered by the LDS-DMA kernel (operand extents)");
+        WGS_CHECK_LAUNCH("igemm_dma16_kernel<x_f16>");
+        return WGS_OK;
+    }
     if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && d->ntaps <= 16 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&
         d->act == 0 && d->act_slope == 1.f && d->gain == 1.f) {
         const long waves = ((long)a.M + 15) / 16;

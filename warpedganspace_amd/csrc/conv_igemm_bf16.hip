@@ -527,6 +527,15 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     for (int t = 0; t < a.ntaps; ++t) wt_max = a.wt[t] > wt_max ? a.wt[t] : wt_max;
     if (!set_extents(a, wt_max)) return 1;
     fill_tap_tables(a);
+    if (a.a_hi) {
+        // the caller's producer wrote the fp16 operand plane itself (wgs_conv_desc.x_f16): LDS-DMA kernel, no pre-pass
+        const int ntm = (a.M + 255) / 256;
+        const int bn = a.Co % 256 == 0 && ntm * (a.Co / 256) >= 200 ? 256 : 128;
+        single_phase(a);
+        a.x_bytes /= 2; a.w_bytes /= 2;            // extents of the 16-bit planes
+        launch_dma_bf16x3(a, bn, ntm * (a.Co / bn), st);
+        return 0;
+    }
     // stride-1 3x3 convs with pre-split weights: the patch form stages the activation halo patch once per channel chunk
     if (WGS_ABL != 16 && !wgs_flags().no_patch && launch_patch_bf16x3(a, st) == 0) return 0;
     // Styled launches want every tile inside one sample (one style vector per tile, and the only form the 8-wave

@@ -34,6 +34,6 @@ const WgsFlags& wgs_flags() { return flags_storage(); }
 
 extern "C" {
 const char* wgs_last_error(void) { return g_err; }
-int wgs_abi_version(void) { return 2; }
+int wgs_abi_version(void) { return 3; }
 void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
 }

@@ -7,19 +7,26 @@
 // (4x5 float4: two adjacent output columns per thread) in registers: ~3 loads per output instead of 16, every load a
 // fully coalesced row segment.
 // EPI adds the StyleGAN2 noise + bias + leaky-relu*sqrt(2) epilogue (model.py:303-310, fused_act.py:91-99).
+// F16 (without EPI): the result is stored as the fp16 operand plane of the consuming conv, hi = f16_rn(out * 2^k) with the
+// power of two of conv_scheme.h's operand_scale(a_amax, a_bound) — exactly what that conv's own staging (or the LDS-DMA
+// pre-pass) would make of the fp32 tensor, which is then never written: half the store bytes, no pre-pass.
 #pragma once
 #include "wgs_common.h"
+#include "conv_scheme.h"
 
 namespace wgsfir {
 
 constexpr int TY = 16;
 
-template <bool EPI>
+template <bool EPI, bool F16 = false>
 __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, const float* __restrict__ kern,
                                                    float* __restrict__ y, int B, int Hin, int Win, int Ho, int Wo, int C,
                                                    int py0, int px0, const float* __restrict__ noise,
                                                    const float* __restrict__ noise_w, const float* __restrict__ bias,
-                                                   float* __restrict__ y_amax) {
+                                                   float* __restrict__ y_amax, const float* __restrict__ a_amax, float a_bound) {
+    static_assert(!(EPI && F16), "the fp16 plane is the operand of a gradient conv: no epilogue");
+    float op_mult = 1.f, op_inv = 1.f;
+    if (F16) wgsconv::operand_scale(a_amax, nullptr, a_bound, op_mult, op_inv);
     float kf[16];
     float vmax = 0.f;
 #pragma unroll
@@ -80,7 +87,13 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
                         acc.w = (acc.w > 0.f ? acc.w : 0.2f * acc.w) * 1.4142135623730951f;
                     }
                     if (EPI) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-                    if (live) *reinterpret_cast<float4*>(yb + ((size_t)oy * Wo + ox + px) * C) = acc;
+                    if (F16) {
+                        const wgsconv::sch_f32x4 f = {acc.x * op_mult, acc.y * op_mult, acc.z * op_mult, acc.w * op_mult};
+                        uint2 h, l;
+                        wgsconv::Scheme<1>::cvt4(f, h, l);
+                        unsigned short* yh = reinterpret_cast<unsigned short*>(y) + (size_t)b * Ho * Wo * C + c;
+                        if (live) *reinterpret_cast<uint2*>(yh + ((size_t)oy * Wo + ox + px) * C) = h;
+                    } else if (live) *reinterpret_cast<float4*>(yb + ((size_t)oy * Wo + ox + px) * C) = acc;
                 }
             }
         }
@@ -92,13 +105,14 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
     }
 }
 
-template <bool EPI>
+template <bool EPI, bool F16 = false>
 inline void launch_fir4(const float* x, const float* kern, float* y, int B, int Hin, int Win, int Ho, int Wo, int C, int py0,
-                        int px0, const float* noise, const float* noise_w, const float* bias, hipStream_t st, float* y_amax = nullptr) {
+                        int px0, const float* noise, const float* noise_w, const float* bias, hipStream_t st, float* y_amax = nullptr,
+                        const float* a_amax = nullptr, float a_bound = 1.f) {
     const int strips = (Ho + TY - 1) / TY;
     const long total = (long)B * strips * ((Wo + 1) / 2) * (C / 4);
-    hipLaunchKernelGGL(fir4_kernel<EPI>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
-                       C, py0, px0, noise, noise_w, bias, y_amax);
+    hipLaunchKernelGGL((fir4_kernel<EPI, F16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
+                       C, py0, px0, noise, noise_w, bias, y_amax, a_amax, a_bound);
 }
 
 }  // namespace wgsfir

@@ -439,8 +439,13 @@ class Generator(nn.Module):
             # input gradient of this layer (un-scaled by its own style: the producer applies it)
             lp = C.layer_precision_bwd(C.PRECISION, Hc, ly['up'])
             if ly['up']:
-                dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)     # |dt| <= 4 max|dy|: the kernel sums to 4
-                gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp)
+                # |dt| <= 4 max|dy|: the kernel sums to 4
+                if C.blur_bwd_f16_ok(B, Hc, Co, ly['Ci'], lp):     # dt only as the gradient conv's fp16 operand plane
+                    dt = C.blur_bwd_f16(dy, ly['blur_f'], amax[i:], 4.0)
+                    gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp, x_f16=True)
+                else:
+                    dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)
+                    gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp)
                 del dt
             else:
                 gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0, precision=lp)
