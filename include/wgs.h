@@ -303,6 +303,20 @@ int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const fl
                     const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
                     float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P,
                     int C, int s_ld, wgs_stream_t stream);
+/* The same, storing the gradient ONLY as the fp16 operand plane of the dgrad conv that consumes it (wgs_conv_desc.x_f16 with
+ * a_amax = dy_bound, a_bound = 1): dy_hi [B,P,C] = f16_rn(dy * post_scale * 2^k), k from the device scalar dy_bound >= max |dy *
+ * post_scale| (any over-estimate up to ~2^7; wgs_sg2_dy_bound computes one from the operands' magnitudes).  The fp32 tensor
+ * is not written: 2 bytes instead of 4 per element here, 2 instead of 4 read by the conv, and no conversion in the conv. */
+int wgs_sg2_act_bwd_f16(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
+                        const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
+                        uint16_t* dy_hi, const float* dy_bound, float* num, float* dsA, float* dsR, const float* post_scale,
+                        float* dy_amax, int B, int P, int C, int s_ld, wgs_stream_t stream);
+/* bound[0] = sqrt(2) * max_{b,c} post_scale[b,c] * (|sA[b,c]| * gA_amax + |sR[b,c]| * rscale * drgb_amax * drgb_factor *
+ * sum_o |wR[o,c]|): an upper bound of |dy * post_scale| of the wgs_sg2_act_bwd launch with these operands, from the device
+ * scalars gA_amax >= max|gA| (the producing conv's y_amax) and drgb_amax * drgb_factor >= max|drgb|; either source may be NULL. */
+int wgs_sg2_dy_bound(const float* gA_amax, const float* sA, const float* drgb_amax, float drgb_factor, const float* wR,
+                     const float* sR, float rscale, const float* post_scale, float* bound, int B, int C, int s_ld,
+                     wgs_stream_t stream);
 /* ds[b,c] += sum_p x[(x_batched ? b : 0), p, c] * g[b,p,c] */
 int wgs_xg_reduce(const float* x, int x_batched, const float* g, float* ds, int B, int P, int C, wgs_stream_t stream);
 /* dstyle[b*ld_out + i] = dsdir[b*Ci + i] - s[b*ld_s + i]*scale2 * sum_o num[b,o]*demod[b,o]^2*wsq[o,i]

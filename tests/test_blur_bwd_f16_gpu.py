@@ -85,3 +85,77 @@ def test_generator_backward_same_gradient(dev, monkeypatch):
     assert torch.isfinite(outs[0]).all()
     # (the style-gradient reductions behind z use fp32 atomics: two runs of the SAME route differ in the last bits)
     assert (outs[0] - outs[1]).abs().max() <= 1e-5 * outs[1].abs().max()
+
+
+@pytest.mark.parametrize('with_gA,with_rgb', [(True, True), (True, False), (False, True)])
+def test_act_bwd_plane_and_bound(dev, with_gA, with_rgb):
+    """wgs_sg2_act_bwd_f16 stores f16_rn(dy * 2^k) of wgs_sg2_act_bwd's dy (k from the a-priori bound), the same reductions, and
+    wgs_sg2_dy_bound is an upper bound of max|dy| that is not absurdly loose."""
+    torch.manual_seed(7 + with_gA * 2 + with_rgb)
+    lib = L.lib()
+    B, H, Cc, sumC = 3, 24, 64, 200
+    P = H * H
+    out = torch.randn(B, P, Cc, device=dev)
+    gA = torch.randn(B, P, Cc, device=dev) * 3e-4 if with_gA else None
+    S = torch.randn(B, sumC, device=dev) + 1.0
+    sA, sR = S[:, 10:], S[:, 100:]
+    drgb = torch.randn(B, 3, P, device=dev) * 2e-3 if with_rgb else None
+    wR = torch.randn(3, Cc, device=dev)
+    noise, nw, bias = torch.randn(P, device=dev), torch.full((1,), 0.3, device=dev), torch.randn(Cc, device=dev) * 0.1
+    demod = torch.rand(B, Cc, device=dev) + 0.5
+    rscale = 0.125
+
+    def run(f16, bound=None):
+        num, dsA, dsR = (torch.zeros(B, Cc, device=dev) for _ in range(3))
+        am = torch.zeros(1, device=dev)
+        common = (L.ptr(out), L.ptr(gA), L.rawptr(sA if with_gA else None), L.ptr(drgb), L.ptr(wR) if with_rgb else None,
+                  L.rawptr(sR if with_rgb else None), L.c_float(rscale if with_rgb else 0.0), L.ptr(noise), L.ptr(nw), L.ptr(bias))
+        tail = (L.ptr(num), L.ptr(dsA) if with_gA else None, L.ptr(dsR) if with_rgb else None, L.ptr(demod), L.ptr(am), B, P, Cc, sumC, L.stream())
+        if f16:
+            dy = torch.empty(B, P, Cc, device=dev, dtype=torch.int16)
+            L.check(lib.wgs_sg2_act_bwd_f16(*common, L.ptr(dy, torch.int16), L.ptr(bound), *tail), 'act_bwd_f16')
+        else:
+            dy = torch.empty(B, P, Cc, device=dev)
+            L.check(lib.wgs_sg2_act_bwd(*common, L.ptr(dy), *tail), 'act_bwd')
+        return dy, num, dsA, dsR, am
+
+    dy, num, dsA, dsR, am = run(False)
+    bound = torch.zeros(1, device=dev)
+    gmax = gA.abs().amax().reshape(1) if with_gA else None
+    dmax = (drgb.abs().amax().reshape(1) / 4.0) if with_rgb else None           # given as max/4 with factor 4
+    L.check(lib.wgs_sg2_dy_bound(L.ptr(gmax), L.rawptr(sA if with_gA else None), L.ptr(dmax), L.c_float(4.0), L.ptr(wR) if with_rgb else None,
+                                 L.rawptr(sR if with_rgb else None), L.c_float(rscale if with_rgb else 0.0), L.ptr(demod), L.ptr(bound),
+                                 B, Cc, sumC, L.stream()), 'dy_bound')
+    assert am.item() <= bound.item() <= 300.0 * am.item(), (am.item(), bound.item())
+    plane, num2, dsA2, dsR2, am2 = run(True, bound)
+    a, k = bound.item(), 0
+    while a * 2.0 ** k < 2048.0:
+        k += 1
+    while a * 2.0 ** k >= 4096.0:
+        k -= 1
+    assert torch.equal(plane, (dy * 2.0 ** k).half().view(torch.int16))
+    assert am2.item() == am.item()
+    for u, v in ((num, num2), (dsA, dsA2), (dsR, dsR2)):
+        assert (u - v).abs().max() <= 1e-5 * (u.abs().max() + 1e-30)
+
+
+def test_generator_backward_dy_plane_same_gradient(dev, monkeypatch):
+    from tests import golden_inputs as GI
+    from warpedganspace_amd.stylegan2 import Generator
+    torch.manual_seed(0)
+    G = Generator(128, 512, 8)
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 977))
+    G = G.to(dev).eval()
+    z = torch.randn(32, 512, device=dev)
+    outs = []
+    with C.resolved(C.precision_code('f16')):
+        for on in (True, False):
+            monkeypatch.setattr(C, 'DY_PLANE', on)
+            zz = z.clone().requires_grad_(True)
+            img = G([zz])[0]
+            gi = torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)
+            img.backward(gi)
+            outs.append(zz.grad.clone())
+    assert torch.isfinite(outs[0]).all()
+    # same fp16 roundings unless a value falls below the (looser) scale's normal range: < 2^-19 of the tensor's maximum
+    assert (outs[0] - outs[1]).abs().max() <= 2e-5 * outs[1].abs().max()

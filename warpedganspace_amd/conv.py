@@ -316,7 +316,7 @@ def conv2d_dgrad(dy, wt_packed, in_hw, k, stride=1, pad=0, **epi):
     Hi, Wi = in_hw
     Ci = wt_packed.shape[1]
     if stride == 1:
-        dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=dy.dtype)
+        dx = torch.empty(B, Hi, Wi, Ci, device=dy.device, dtype=torch.float32)
         taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
         return launch(dy, wt_packed, dx, taps, Hi, Wi, w_tap_stride=Ci * Co, w_row_stride=Co, grad_operand=True, **epi)
     if stride != 2:
@@ -409,6 +409,10 @@ def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
 # (wgs_sg2_blur_bwd_f16 -> wgs_conv_desc.x_f16): the (2H+1)^2 fp32 tensor is never written and the conv runs the LDS-DMA kernel
 # without a pre-pass, bit-identical to the fp32 route.  Taken for plain-fp16 gradient launches that fill the chip with 256-row tiles.
 BLUR_BWD_F16 = os.environ.get('WGS_BLUR_BWD_F16', '1') != '0'
+# The same for the stride-1 layers: sg2_act_bwd stores dy only as the fp16 plane of the gradient conv (wgs_sg2_act_bwd_f16), scaled
+# from an a-priori magnitude bound (wgs_sg2_dy_bound) since its own maximum is not known before it has run.
+DY_PLANE = os.environ.get('WGS_DY_PLANE', '1') != '0'
+DY_PLANE_MIN_CO = int(os.environ.get('WGS_DY_PLANE_MIN_CO', '256'))
 
 
 def blur_bwd_f16_ok(B, Hc, Ci_dgrad, Co_dgrad, precision):
@@ -416,6 +420,13 @@ def blur_bwd_f16_ok(B, Hc, Ci_dgrad, Co_dgrad, precision):
     if not BLUR_BWD_F16 or precision != 2 or Ci_dgrad % 32 or Co_dgrad % 128:
         return False
     return (B * (Hc // 2) ** 2 // 256) * (Co_dgrad // 128) >= 256
+
+
+def dy_plane_ok(B, Hc, Ci_dgrad, Co_dgrad, precision):
+    """sg2_act_bwd may store dy [B,Hc,Hc,Ci_dgrad] only as the fp16 plane of the stride-1 gradient conv to Co_dgrad channels"""
+    if not DY_PLANE or precision != 2 or Ci_dgrad % 32 or Co_dgrad % 128 or Co_dgrad < DY_PLANE_MIN_CO:
+        return False
+    return (B * Hc * Hc // 256) * (Co_dgrad // 128) >= 256
 
 
 def blur_bwd_f16(dy, blur_f, a_amax, a_bound):

@@ -401,8 +401,13 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     const float* __restrict__ drgb, const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
     const float* __restrict__ noise, const float* __restrict__ noise_w, const float* __restrict__ bias,
     float* __restrict__ dy, float* __restrict__ num, float* __restrict__ dsA, float* __restrict__ dsR,
-    const float* __restrict__ post_scale, float* __restrict__ dy_amax, int P, int C, int chunk, int s_ld) {
+    const float* __restrict__ post_scale, float* __restrict__ dy_amax, int P, int C, int chunk, int s_ld,
+    unsigned short* __restrict__ dy_h, const float* __restrict__ dy_bound) {
     __shared__ double red[3][256][4];
+    // dy_h: store the gradient ONLY as the fp16 operand plane of the dgrad conv that consumes it (f16_rn(dy * 2^k), k from the
+    // a-priori bound dy_bound >= max |stored dy|, conv_scheme.h) instead of the fp32 tensor
+    float h_mult = 1.f, h_inv = 1.f;
+    if (dy_h) wgsconv::operand_scale(dy_bound, nullptr, 1.f, h_mult, h_inv);
     float amax = 0.f;          // max |stored dy| seen by this thread
     const int b = blockIdx.y;
     const int c4n = C >> 2;
@@ -455,7 +460,12 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
             // conv kernels' A-operand prologue computes when it is handed dy and the factor separately)
             d.x = __fmul_rn(d.x, ps.x); d.y = __fmul_rn(d.y, ps.y); d.z = __fmul_rn(d.z, ps.z); d.w = __fmul_rn(d.w, ps.w);
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
-            *reinterpret_cast<float4*>(dy + off) = d;
+            if (dy_h) {
+                const wgsconv::sch_f32x4 f = {d.x * h_mult, d.y * h_mult, d.z * h_mult, d.w * h_mult};
+                uint2 h, l;
+                wgsconv::Scheme<1>::cvt4(f, h, l);
+                *reinterpret_cast<uint2*>(dy_h + off) = h;
+            } else *reinterpret_cast<float4*>(dy + off) = d;
         }
         // combine the `ppi` pixel sub-streams that share this channel group
         __syncthreads();
@@ -723,24 +733,81 @@ int wgs_sg2_torgb_up_fwd(const float* x, const float* s, int s_ld, const float* 
     return WGS_OK;
 }
 
-int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
-                    const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
-                    float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P, int C,
-                    int s_ld, wgs_stream_t stream) {
-    WGS_CHECK_ARG(out && bias && dy && num, "wgs_sg2_act_bwd: null pointer");
-    WGS_CHECK_ARG(gA || drgb, "wgs_sg2_act_bwd: needs at least one gradient source");
-    WGS_CHECK_ARG(!gA || (sA && dsA), "wgs_sg2_act_bwd: gA needs sA and dsA");
-    WGS_CHECK_ARG(!drgb || (wR && sR && dsR), "wgs_sg2_act_bwd: drgb needs wR, sR, dsR");
-    WGS_CHECK_ARG(!noise || noise_w, "wgs_sg2_act_bwd: noise needs noise_w");
-    WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && (C & (C - 1)) == 0, "wgs_sg2_act_bwd: C=%d must be a power of two >= 4", C);
+static int sg2_act_bwd_launch(const char* name, const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
+                              const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
+                              float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P, int C,
+                              int s_ld, uint16_t* dy_h, const float* dy_bound, wgs_stream_t stream) {
+    WGS_CHECK_ARG(out && bias && (dy || dy_h) && num, "%s: null pointer", name);
+    WGS_CHECK_ARG(gA || drgb, "%s: needs at least one gradient source", name);
+    WGS_CHECK_ARG(!gA || (sA && dsA), "%s: gA needs sA and dsA", name);
+    WGS_CHECK_ARG(!drgb || (wR && sR && dsR), "%s: drgb needs wR, sR, dsR", name);
+    WGS_CHECK_ARG(!noise || noise_w, "%s: noise needs noise_w", name);
+    WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && (C & (C - 1)) == 0, "%s: C=%d must be a power of two >= 4", name, C);
     // ~2048 blocks in total; each block owns `chunk` pixels of one sample
     int chunks = wgs_cdiv(2048, B);
     int chunk = wgs_cdiv(P, chunks);
     if (chunk < 16) chunk = 16;
     chunks = wgs_cdiv(P, chunk);
     hipLaunchKernelGGL(sg2_act_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
-                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk, s_ld > 0 ? s_ld : C);
+                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk, s_ld > 0 ? s_ld : C,
+                       reinterpret_cast<unsigned short*>(dy_h), dy_bound);
     WGS_CHECK_LAUNCH("sg2_act_bwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_sg2_act_bwd(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
+                    const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
+                    float* dy, float* num, float* dsA, float* dsR, const float* post_scale, float* dy_amax, int B, int P, int C,
+                    int s_ld, wgs_stream_t stream) {
+    WGS_CHECK_ARG(dy, "wgs_sg2_act_bwd: null pointer");
+    return sg2_act_bwd_launch("wgs_sg2_act_bwd", out, gA, sA, drgb, wR, sR, rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale,
+                              dy_amax, B, P, C, s_ld, nullptr, nullptr, stream);
+}
+
+int wgs_sg2_act_bwd_f16(const float* out, const float* gA, const float* sA, const float* drgb, const float* wR,
+                        const float* sR, float rscale, const float* noise, const float* noise_w, const float* bias,
+                        uint16_t* dy_hi, const float* dy_bound, float* num, float* dsA, float* dsR, const float* post_scale,
+                        float* dy_amax, int B, int P, int C, int s_ld, wgs_stream_t stream) {
+    WGS_CHECK_ARG(dy_hi && dy_bound, "wgs_sg2_act_bwd_f16: null pointer");
+    return sg2_act_bwd_launch("wgs_sg2_act_bwd_f16", out, gA, sA, drgb, wR, sR, rscale, noise, noise_w, bias, nullptr, num, dsA, dsR,
+                              post_scale, dy_amax, B, P, C, s_ld, dy_hi, dy_bound, stream);
+}
+
+// bound[0] = sqrt(2) * max_{b,c} post_scale[b,c] * ( |sA[b,c]| * gA_amax + |sR[b,c]| * rscale * drgb_amax * drgb_factor * sum_o |wR[o,c]| )
+// >= max |dy * post_scale| of the sg2_act_bwd launch with the same operands (|lrelu'| * sqrt(2) <= sqrt(2)): one workgroup.
+__global__ __launch_bounds__(256) void sg2_dy_bound_kernel(const float* __restrict__ gA_amax, const float* __restrict__ sA,
+                                                           const float* __restrict__ drgb_amax, float drgb_factor,
+                                                           const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
+                                                           const float* __restrict__ post_scale, float* __restrict__ bound,
+                                                           int B, int C, int s_ld) {
+    __shared__ float red[4];
+    const float a = gA_amax ? gA_amax[0] : 0.f;
+    const float r = drgb_amax ? drgb_amax[0] * drgb_factor * rscale : 0.f;
+    float m = 0.f;
+    for (int e = threadIdx.x; e < B * C; e += 256) {
+        const int b = e / C, c = e - b * C;
+        float v = 0.f;
+        if (gA_amax) v += fabsf(sA[(size_t)b * s_ld + c]) * a;
+        if (drgb_amax) v += fabsf(sR[(size_t)b * s_ld + c]) * r * (fabsf(wR[c]) + fabsf(wR[C + c]) + fabsf(wR[2 * C + c]));
+        if (post_scale) v *= fabsf(post_scale[(size_t)b * C + c]);
+        m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) bound[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * SQRT2;
+}
+
+int wgs_sg2_dy_bound(const float* gA_amax, const float* sA, const float* drgb_amax, float drgb_factor, const float* wR,
+                     const float* sR, float rscale, const float* post_scale, float* bound, int B, int C, int s_ld,
+                     wgs_stream_t stream) {
+    WGS_CHECK_ARG(bound && (gA_amax || drgb_amax), "wgs_sg2_dy_bound: null pointer");
+    WGS_CHECK_ARG(!gA_amax || sA, "wgs_sg2_dy_bound: gA_amax needs sA");
+    WGS_CHECK_ARG(!drgb_amax || (wR && sR), "wgs_sg2_dy_bound: drgb_amax needs wR and sR");
+    WGS_CHECK_ARG(B > 0 && C > 0, "wgs_sg2_dy_bound: bad sizes");
+    hipLaunchKernelGGL(sg2_dy_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gA_amax, sA, drgb_amax, drgb_factor, wR, sR,
+                       rscale, post_scale, bound, B, C, s_ld > 0 ? s_ld : C);
+    WGS_CHECK_LAUNCH("sg2_dy_bound_kernel");
     return WGS_OK;
 }
 

@@ -404,6 +404,8 @@ class Generator(nn.Module):
         dS = zeros(B, sumC)                          # d loss / d modulation outputs, all layers
         dskip = dimg
         amax = zeros(len(layers))                    # per layer: max |dy * demod| (magnitude bound of the fp16 dgrad operand)
+        gam = zeros(len(layers))                     # per layer: max |gA| of its gradient conv (16-bit kernels' epilogue)
+        gA_amax, dimg_amax, skip_level = None, None, 0
         gA, sA_off = None, None                      # un-scaled dgrad of the consumer conv, its style slice
         sg = []                                      # style-gradient reductions of the pass, launched together at the end
         num_next = None
@@ -415,18 +417,34 @@ class Generator(nn.Module):
             Pn = Hc * Hc
             has_rgb = (i % 2 == 0)
             r = rgbs[i // 2] if has_rgb else None
-            dy = torch.empty_like(out)
             num = zeros(B, Co)
             dsA = zeros(B, Co) if gA is not None else None
             dsR = zeros(B, Co) if has_rgb else None
             sA = S[:, sA_off:] if gA is not None else None           # rows of the style matrix S, stride sumC
             sR = S[:, r['off']:] if has_rgb else None
-            L.check(lib.wgs_sg2_act_bwd(L.ptr(out), L.ptr(gA), L.rawptr(sA), L.ptr(dskip if has_rgb else None),
-                                        L.ptr(r['w']) if has_rgb else None, L.rawptr(sR),
-                                        L.c_float(r['scale'] if has_rgb else 0.0), L.ptr(ly['noise']), L.ptr(ly['noise_w']),
-                                        L.ptr(ly['bias']), L.ptr(dy), L.ptr(num), L.ptr(dsA), L.ptr(dsR), L.ptr(demods[i]),
-                                        L.rawptr(amax[i:]), B, Pn, Co, sumC, st),
-                    'sg2_act_bwd')           # dy is stored already multiplied by this layer's demodulation vector
+            lp = C.layer_precision_bwd(C.PRECISION, Hc, ly['up'])
+            # a stride-1 layer's dy has ONE consumer, its gradient conv: in the plain-fp16 launches that fill the chip it is stored
+            # only as that conv's fp16 operand plane, scaled from an a-priori bound of its magnitude (its own maximum is not known
+            # before the kernel has run): max|gA| from the producing conv's epilogue, max|drgb| <= 4^levels * max|dimg|
+            plane = (not ly['up']) and C.dy_plane_ok(B, Hc, Co, ly['Ci'], lp) and (gA is None or gA_amax is not None)
+            rgb_args = (L.ptr(dskip if has_rgb else None), L.ptr(r['w']) if has_rgb else None, L.rawptr(sR),
+                        L.c_float(r['scale'] if has_rgb else 0.0))
+            if plane:
+                if has_rgb and dimg_amax is None:
+                    dimg_amax = dimg.abs().amax().reshape(1)
+                L.check(lib.wgs_sg2_dy_bound(L.rawptr(gA_amax), L.rawptr(sA), L.rawptr(dimg_amax if has_rgb else None),
+                                             L.c_float(4.0 ** skip_level), rgb_args[1], rgb_args[2], rgb_args[3], L.ptr(demods[i]),
+                                             L.rawptr(amax[i:]), B, Co, sumC, st), 'sg2_dy_bound')
+                dy = torch.empty(out.shape, device=dev, dtype=torch.int16)
+                L.check(lib.wgs_sg2_act_bwd_f16(L.ptr(out), L.ptr(gA), L.rawptr(sA), *rgb_args, L.ptr(ly['noise']), L.ptr(ly['noise_w']),
+                                                L.ptr(ly['bias']), L.ptr(dy, torch.int16), L.rawptr(amax[i:]), L.ptr(num), L.ptr(dsA),
+                                                L.ptr(dsR), L.ptr(demods[i]), None, B, Pn, Co, sumC, st), 'sg2_act_bwd_f16')
+            else:
+                dy = torch.empty_like(out)
+                L.check(lib.wgs_sg2_act_bwd(L.ptr(out), L.ptr(gA), L.rawptr(sA), *rgb_args, L.ptr(ly['noise']), L.ptr(ly['noise_w']),
+                                            L.ptr(ly['bias']), L.ptr(dy), L.ptr(num), L.ptr(dsA), L.ptr(dsR), L.ptr(demods[i]),
+                                            L.rawptr(amax[i:]), B, Pn, Co, sumC, st),
+                        'sg2_act_bwd')           # dy is stored already multiplied by this layer's demodulation vector
             # style gradient of the consumer conv (layer i+1) is now complete: direct term dsA + demod path
             if gA is not None:
                 c = layers[i + 1]
@@ -436,19 +454,27 @@ class Generator(nn.Module):
                 if i > 0:   # gradient of the up-sampled skip w.r.t. the lower-resolution image (upfirdn2d.py:110-115)
                     g = ops.upfirdn2d_mhwc(dskip.reshape(B * 3, Hc, Hc, 1), r['upk_f'], 1, 1, 2, 2, 1, 1, 1, 1)
                     dskip = g.reshape(B, 3, Hc // 2, Hc // 2)
-            # input gradient of this layer (un-scaled by its own style: the producer applies it)
-            lp = C.layer_precision_bwd(C.PRECISION, Hc, ly['up'])
+                    skip_level += 1                  # |dskip| <= 4 x the level above: the kernel sums to 4
+            # input gradient of this layer (un-scaled by its own style: the producer applies it); its maximum feeds the next bound
+            gA_amax = gam[i:]
             if ly['up']:
                 # |dt| <= 4 max|dy|: the kernel sums to 4
                 if C.blur_bwd_f16_ok(B, Hc, Co, ly['Ci'], lp):     # dt only as the gradient conv's fp16 operand plane
                     dt = C.blur_bwd_f16(dy, ly['blur_f'], amax[i:], 4.0)
-                    gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp, x_f16=True)
+                    gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp, x_f16=True,
+                                                     y_amax=gA_amax)
                 else:
                     dt = ops.upfirdn2d_mhwc(dy, ly['blur_f'], 1, 1, 1, 1, 2, 2, 2, 2)
-                    gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp)
+                    gA = C.conv_transpose2d_s2_dgrad(dt, ly['wt'], w_split=ly['wt_s'], a_amax=amax[i:], a_bound=4.0, precision=lp,
+                                                     y_amax=gA_amax if lp >= 1 else None)
+                    if lp < 1:
+                        gA_amax = None
                 del dt
             else:
-                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0, precision=lp)
+                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0, precision=lp,
+                                    x_f16=plane, y_amax=gA_amax if lp >= 1 else None)
+                if lp < 1:
+                    gA_amax = None
             del dy
             sA_off, num_next = ly['off'], num
         # bottom layer: its input is the ConstantInput -> only the style gradient remains
