@@ -287,7 +287,7 @@ EXTRA = [   # (name, gan, size, K, N, batch, precision or None = headline's, w_s
     ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', False, 10, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 mixed fp16", 'stylegan2', 256, 128, 32, 32, 'mixed', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256, headline arithmetic with the reconstructor's forward convs in split-bf16 x3 instead of exact fp32 [R bf16x3]", 'stylegan2', 256, 128, 32, 32, None, False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256, headline arithmetic with the reconstructor's forward convs in exact fp32 instead of split-bf16 x3 [R fp32]", 'stylegan2', 256, 128, 32, 32, None, False, 30, 'stylegan2-256'),
     ("cfg3 StyleGAN2-256 W-space", 'stylegan2', 256, 128, 32, 32, None, True, 10, 'stylegan2-256'),
     ("cfg2 ProgGAN native 1024, K=64 N=16 B=32", 'proggan', 1024, 64, 16, 32, None, False, 4, 'proggan-1024'),
     ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32", 'proggan', 256, 64, 16, 32, None, False, 8, 'proggan-256'),
@@ -308,12 +308,12 @@ def run_extra(dev, headline_precision, skip_name=None):
         try:
             old = C.set_precision(prec)
             prec = C.precision_name(C.resolve_auto(gan, size))        # 'auto' -> the concrete mode of this architecture
-            r_alt = '[R bf16x3]' in name
+            r_alt = '[R fp32]' in name
             if skip_name is not None and (gan, size, K, N, B, prec, w_space) == skip_name and not r_alt:
                 continue
-            RR.R_PRECISION = 'bf16x3' if r_alt else r_old
+            RR.R_PRECISION = 'fp32' if r_alt else r_old
             eng = build(dev, gan, K, N, B, w_space=w_space, size=size)
-            dt = timed_steps(eng, steps, 3, 1, dev)
+            dt = timed_steps(eng, steps, 6, 1, dev)
             by = conv_profile(eng, 1)
             a_fl, a_ms = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
             rec = {"config": name, "precision": prec, "value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
@@ -359,8 +359,8 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--cpu-threads', type=int, default=32)
-    ap.add_argument('--r-precision', choices=['fp32', 'bf16x3', 'auto'], default='fp32',
-                    help="arithmetic of the Reconstructor's forward convs (default exact fp32; auto = split-bf16 x3 unless --precision fp32)")
+    ap.add_argument('--r-precision', choices=['fp32', 'bf16x3', 'auto'], default='auto',
+                    help="arithmetic of the Reconstructor's forward convs (auto = split-bf16 x3 when the generator runs in a 16-bit mode, exact fp32 otherwise)")
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the short runs of the other arithmetic modes / configs')
     ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default=C.DEFAULT_PRECISION,
@@ -439,7 +439,7 @@ def main():
         out = {"metric": "training images/sec (warp->G->R->loss) %s K=%d" % ({'stylegan2': 'StyleGAN2-%d' % args.size}.get(args.gan, arch), args.K),
                "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": DTYPE_TEXT[precision] + R_TEXT[RR.forward_precision()], "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
+               "dtype": DTYPE_TEXT[precision] + R_TEXT[RR.forward_precision(C.precision_code(precision))], "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
                "config": {"workload": "%s arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (arch, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": precision, "precision_requested": args.precision,

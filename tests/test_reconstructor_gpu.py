@@ -92,12 +92,16 @@ def test_resnet_larger_inputs_statistical(dev, B, K, S):
 
 
 def test_resnet_split_bf16_forward_option(dev, monkeypatch):
-    """R_PRECISION = 'bf16x3' (an option, not the default): forward convs in split-bf16 x3.  The forward stays fp32-class
-    (outputs within 1e-4 of the oracle, argmax identical); the extra gate flips cost gradient agreement — per-parameter
-    max-norm errors of ~2e-2 instead of < 1e-3 — which is why the exact kernels are the default (reconstructor.py)."""
-    from warpedganspace_amd import conv as C
+    """R_PRECISION = 'bf16x3': forward convs in split-bf16 x3 (what 'auto' selects inside a training step whose generator runs in a
+    16-bit mode).  The forward stays fp32-class (outputs within 1e-4 of the oracle, argmax identical); on IDENTICAL inputs the
+    extra gate flips cost gradient agreement — per-parameter max-norm errors of ~2e-2 instead of < 1e-3 — which is why a
+    Reconstructor on its own, and every step with an exact-fp32 generator, keeps the exact kernels (reconstructor.py)."""
     from warpedganspace_amd import reconstructor as RR
-    assert RR.forward_precision() == 0                      # the default is exact fp32
+    assert RR.R_PRECISION == 'auto'
+    assert RR.forward_precision() == 0 and RR.forward_precision(0) == 0       # on its own / fp32 generator: exact fp32
+    assert RR.forward_precision(1) == 1 and RR.forward_precision(2) == 1 and RR.forward_precision(4) == 1
+    monkeypatch.setattr(RR, 'R_PRECISION', 'fp32')
+    assert RR.forward_precision(2) == 0
     monkeypatch.setattr(RR, 'R_PRECISION', 'bf16x3')
     assert RR.forward_precision() == 1
     R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, 4, 128, 64)
@@ -108,8 +112,6 @@ def test_resnet_split_bf16_forward_option(dev, monkeypatch):
     num = sum(float((p.grad.cpu() - sd[n].grad).pow(2).sum()) for n, p in R.named_parameters() if p.grad is not None)
     den = sum(float(sd[n].grad.pow(2).sum()) for n, p in R.named_parameters() if p.grad is not None)
     assert (num / den) ** 0.5 < 1e-1
-    monkeypatch.setattr(RR, 'R_PRECISION', 'auto')
-    assert RR.forward_precision() == (0 if C.PRECISION == 0 else 1)
 
 
 def test_resnet_eval_mode_uses_running_stats(dev):

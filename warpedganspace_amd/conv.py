@@ -101,6 +101,15 @@ def resolve_auto(family, resolution):
     return PRECISION_NAMES[AUTO_TABLE.get((family, resolution), AUTO_FALLBACK)]
 
 
+_LAST_RESOLVED = None
+
+
+def last_resolved():
+    """Concrete precision code of the most recent generator forward / backward of this process (None: none yet).  The training step
+    reads it right after its generator forward to choose the Reconstructor's 'auto' arithmetic."""
+    return _LAST_RESOLVED
+
+
 class resolved:
     """Context manager: run the enclosed launches with the concrete precision `code` (a generator's forward / backward)."""
 
@@ -108,8 +117,9 @@ class resolved:
         self.code = code
 
     def __enter__(self):
-        global PRECISION
+        global PRECISION, _LAST_RESOLVED
         self.old, PRECISION = PRECISION, self.code
+        _LAST_RESOLVED = self.code
 
     def __exit__(self, *exc):
         global PRECISION

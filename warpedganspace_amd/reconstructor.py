@@ -27,20 +27,24 @@ from . import _lib as L
 from . import conv as C
 
 BN_EPS, BN_MOM = 1e-5, 0.1
-# Arithmetic of R's FORWARD convs: 'fp32' (default) = exact fp32 MFMA; 'bf16x3' = split-bf16 x3 (fp32-class, ~2^-16 per
-# product: logits move by ~1e-5 relative, argmax unchanged, but the extra ReLU-gate / max-pool flips move single parameter
-# gradients by ~2e-2 — measured by tests/test_reconstructor_gpu.py — versus < 1e-3 for the exact kernels, so it is an
-# option, not the default: it would buy 1.0 ms of the 30 ms step, bench.py reports that line in `extra`);
-# 'auto' = exact when the generator runs in exact fp32, split-bf16 otherwise.  WGS_R_PRECISION / bench.py --r-precision.
-R_PRECISION = os.environ.get('WGS_R_PRECISION', 'fp32').lower()
+# Arithmetic of R's FORWARD convs.  'fp32' = exact fp32 MFMA; 'bf16x3' = split-bf16 x3 (fp32-class, ~2^-16 per product: logits
+# move by ~1e-5 relative, argmax unchanged, 1.05 ms less per 27.6 ms step); 'auto' (default) = split-bf16 when the training step's
+# GENERATOR runs in a 16-bit mode, exact otherwise — and exact for a Reconstructor used on its own (no generator_precision set).
+# Why not simply exact: with an fp16-operand generator the images R sees differ from the fp32 ones by ~7e-4, which flips far more of
+# R's ReLU gates / max-pool winners than a 1e-5 perturbation of its own convs; and the reference's own convs run in TF32 (2^-11) on
+# the GPUs it targets (torch.backends.cudnn.allow_tf32 defaults to True).  Why not always: on identical inputs the extra gate
+# flips of split-bf16 move single parameter-gradient entries by ~2e-2 of the tensor maximum against < 1e-3 for the exact kernels
+# (tests/test_reconstructor_gpu.py), so the exact path stays the reference point of the unit tests and of --precision fp32 runs.
+# WGS_R_PRECISION / bench.py --r-precision.
+R_PRECISION = os.environ.get('WGS_R_PRECISION', 'auto').lower()
 
 
-def forward_precision():
+def forward_precision(generator_precision=None):
     if R_PRECISION in ('fp32', '0', 0):
         return 0
     if R_PRECISION in ('bf16x3', '1', 1):
         return 1
-    return 0 if C.PRECISION == 0 else 1
+    return 1 if (generator_precision is not None and generator_precision >= 1) else 0
 
 
 # Arithmetic of R's input-gradient (dgrad) convs of the BasicBlocks.  The activation gates and BN statistics that make R's
@@ -222,7 +226,7 @@ class Reconstructor(nn.Module):
         L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
         # stem: conv1 weights padded from 2c to Cp input channels
         w1p = self._conv1_padded(c, Cp, dev)
-        fp = forward_precision()
+        fp = forward_precision(getattr(self, 'generator_precision', None))
         c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=fp)
         a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
         Hp = (a1.shape[1] + 2 - 3) // 2 + 1

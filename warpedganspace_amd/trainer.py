@@ -239,6 +239,7 @@ class TrainStep:
                 imgn = G(zn)
             zn.record_stream(self.pre_stream)
             self._pre = (zn, idxn, magn, imgn, C.PRECISION)
+        R.generator_precision = C.last_resolved()       # the arithmetic G just ran in: R's 'auto' forward mode follows it
         logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True)   # :242
         L.check(lib.wgs_ce_l1_loss(L.ptr(logits), L.ptr(idx, torch.int64), L.ptr(mag_hat.reshape(B)), L.ptr(mag),
                                    L.c_float(p.lambda_cls), L.c_float(p.lambda_reg), L.ptr(self.dlogits), L.ptr(self.dmag),
