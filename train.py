@@ -53,7 +53,7 @@ def parse(argv=None):
     ext.add_argument('--seed', type=int, default=None)
     ext.add_argument('--precision', choices=('fp32', 'bf16x3', 'f16', 'f16x2'), default=None,
                      help="arithmetic of the frozen generator's convs (default: warpedganspace_amd.conv.DEFAULT_PRECISION); "
-                          "the reconstructor's forward always runs in exact fp32")
+                          "the reconstructor stays fp32-class (split-bf16 x3 forward with a 16-bit generator, exact fp32 otherwise; WGS_R_PRECISION)")
     return p.parse_args(argv)
 
 
