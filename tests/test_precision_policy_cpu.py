@@ -48,3 +48,38 @@ def test_fused_upconv_selection():
     assert not C.upconv_fused_ok(8, 512, 512, 2)            # maps below 16 x 16
     assert not C.upconv_fused_ok(512, 64, 32, 2)            # 32 output channels: not a multiple of the 64-column tile
     assert not C.upconv_fused_ok(64, 24, 64, 2)
+
+
+def test_reconstructor_auto_forward_mode_follows_the_generator(monkeypatch):
+    """R_PRECISION 'auto': split-bf16 forward convs inside a step whose generator ran in a 16-bit mode, exact fp32 for an fp32
+    generator and for a Reconstructor used on its own; 'fp32' / 'bf16x3' pin it."""
+    from warpedganspace_amd import reconstructor as RR
+    monkeypatch.setattr(RR, 'R_PRECISION', 'auto')
+    assert RR.forward_precision() == 0 and RR.forward_precision(None) == 0 and RR.forward_precision(0) == 0
+    for code in (1, 2, 3, 4):
+        assert RR.forward_precision(code) == 1
+    monkeypatch.setattr(RR, 'R_PRECISION', 'fp32')
+    assert all(RR.forward_precision(c) == 0 for c in (None, 0, 1, 2, 3, 4))
+    monkeypatch.setattr(RR, 'R_PRECISION', 'bf16x3')
+    assert all(RR.forward_precision(c) == 1 for c in (None, 0, 1, 2, 3, 4))
+
+
+def test_last_resolved_tracks_the_generator_context():
+    old = C.last_resolved()
+    with C.resolved(3):
+        assert C.PRECISION == 3
+    assert C.last_resolved() == 3
+    with C.resolved(0):
+        pass
+    assert C.last_resolved() == 0
+    C._LAST_RESOLVED = old
+
+
+def test_plane_route_gates():
+    # transposed-blur plane: plain fp16 gradient launches that fill the chip with 256-row tiles
+    assert C.blur_bwd_f16_ok(32, 256, 128, 256, 2) and C.blur_bwd_f16_ok(32, 64, 512, 512, 2)
+    assert not C.blur_bwd_f16_ok(32, 256, 128, 256, 3) and not C.blur_bwd_f16_ok(32, 256, 128, 256, 1)
+    assert not C.blur_bwd_f16_ok(2, 32, 512, 512, 2) and not C.blur_bwd_f16_ok(32, 256, 24, 256, 2)
+    # dy plane of the stride-1 layers: from 256 channels up (the 128-column DMA tile loses to the patch form)
+    assert C.dy_plane_ok(32, 128, 256, 256, 2) and C.dy_plane_ok(32, 64, 512, 512, 2)
+    assert not C.dy_plane_ok(32, 256, 128, 128, 2) and not C.dy_plane_ok(32, 128, 256, 256, 1)
