@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wm = sm;               // [3][C] modulated weights W[o,c]*s[b,c]*wscale
     float* res = sm + 3 * C;      // [3][256]
+    float* upk_s = res + 3 * 256; // [16] flipped up-sampling taps (fetched here: in the epilogue each would be a dependent global load)
+    if (skip_lo && threadIdx.x < 16) upk_s[threadIdx.x] = upk[15 - threadIdx.x];
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * ppb;
     const int ppwave = ppb >> 2;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
                     for (int kx = 0; kx < 4; ++kx) {
                         const int X = ox + kx - 2, j = X >> 1;
                         if ((X & 1) || j < 0 || j >= Wl) continue;
-                        up = fmaf(upk[(3 - ky) * 4 + (3 - kx)], sl[i * Wl + j], up);
+                        up = fmaf(upk_s[ky * 4 + kx], sl[i * Wl + j], up);
                     }
                 }
                 v += up;
@@ -707,9 +709,10 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
                       int B, int P, int C, float wscale, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && s && w && bias && img, "wgs_sg2_torgb_fwd: null pointer");
     WGS_CHECK_ARG(B > 0 && P > 0 && C >= 4 && C <= 512 && (C & (C - 1)) == 0, "wgs_sg2_torgb_fwd: C=%d must be a power of two in [4, 512]", C);
-    const size_t smem = (size_t)(3 * C + 3 * 256) * sizeof(float);
+    const size_t smem = (size_t)(3 * C + 3 * 256 + 16) * sizeof(float);
     int ppb = 256;
-    while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
+    while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 8192) ppb >>= 1;      // >= 4 rounds of ~8 workgroups per CU: prologue / epilogue
+                                                                          // of one round under the streaming of the next
     if (C < 32) ppb = 256;                // a wave iteration covers 64 / (C/4) pixels: needs ppb/4 >= that
     hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale, ppb,
                        (const float*)nullptr, (const float*)nullptr, 0, C);
@@ -723,9 +726,10 @@ int wgs_sg2_torgb_up_fwd(const float* x, const float* s, int s_ld, const float* 
     WGS_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C >= 4 && C <= 512 && (C & (C - 1)) == 0,
                   "wgs_sg2_torgb_up_fwd: even H, W and a power-of-two C >= 4 (H=%d W=%d C=%d)", H, W, C);
     const int P = H * W;
-    const size_t smem = (size_t)(3 * C + 3 * 256) * sizeof(float);
+    const size_t smem = (size_t)(3 * C + 3 * 256 + 16) * sizeof(float);
     int ppb = 256;
-    while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 1024) ppb >>= 1;
+    while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 8192) ppb >>= 1;      // >= 4 rounds of ~8 workgroups per CU: prologue / epilogue
+                                                                          // of one round under the streaming of the next
     if (C < 32) ppb = 256;
     hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias,
                        (const float*)nullptr, img, P, C, wscale, ppb, skip_lo, up_kernel4x4, W, s_ld > 0 ? s_ld : C);
