@@ -622,6 +622,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
 
 int wgs_conv_igemm_multi(const wgs_conv_desc* descs, int n, wgs_stream_t stream) {
     WGS_CHECK_ARG(descs && n > 0, "wgs_conv_igemm_multi: bad arguments");
+    for (int i = 0; i < n; ++i) WGS_CHECK_ARG(!descs[i].x_f16, "wgs_conv_igemm_multi: x_f16 operands are single-launch only (wgs_conv_igemm)");
     if (n >= 2 && n <= 4 && descs[0].precision >= 1) {
         ConvArgs as[4];
         bool ok = true;
