@@ -213,31 +213,54 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     const int b_rd = l31 * ROW;
     const int bk0 = ((0 + lh) ^ bswz) << 4, bk1 = ((2 + lh) ^ bswz) << 4;
 
+    // A step's products in issue order (k-step outer, product inner), software-pipelined by hand: the two weight fragments of
+    // product q+1 — and its activation fragments when the row shift or the k-step changes — are read from LDS BEFORE the MFMAs of
+    // product q (two register sets each, pinned with sched_barrier).  The compiler's own schedule was {ds_read B; wait; 4 MFMAs}
+    // per product: the fragment-read latency in front of every MFMA group, with only the partner wave to cover it.
     auto mma_step = [&](int buf, int stage, int s) {
         const unsigned char* pb = patch + buf * NA * P_BYTES;
         const unsigned char* bb = bst + stage * B_STAGE + b_rd;
+        constexpr int Q = 2 * TS;                    // (k-step, product) slots; s is a compile-time constant at every call site
+        frag af[2][NA], bf[2][TN][NB];
+        auto ld_a = [&](int q, frag* a) {
+            const int ks = q / TS, t = s * TS + q % TS;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            frag af[NA];
+            for (int pl = 0; pl < NA; ++pl) a[pl] = *reinterpret_cast<const frag*>(pb + pl * P_BYTES + pa0 + sh_off(T_SH[t], PW) * PROW + ks * 32);
+        };
+        auto ld_b = [&](int q, frag (*b)[NB]) {
+            const int ks = q / TS, u = q % TS;
 #pragma unroll
-            for (int u = 0; u < TS; ++u) {
-                const int t = s * TS + u;       // s is a compile-time constant at every call site
-                if (t < 9) {
-                    if (u == 0 || T_SH[t] != T_SH[t - 1]) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int pl = 0; pl < NA; ++pl) af[pl] = *reinterpret_cast<const frag*>(pb + pl * P_BYTES + pa0 + sh_off(T_SH[t], PW) * PROW + ks * 32);
-                    }
+                for (int pl = 0; pl < NB; ++pl)
+                    b[j][pl] = *reinterpret_cast<const frag*>(bb + u * B_TAP + pl * B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
+        };
+        int qa = 0, qb = 0;                          // register set holding the current product's A / B fragments
+        ld_a(0, af[0]);
+        ld_b(0, bf[0]);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        frag bf[NB];
-#pragma unroll
-                        for (int pl = 0; pl < NB; ++pl)
-                            bf[pl] = *reinterpret_cast<const frag*>(bb + u * B_TAP + pl * B_BYTES + j * 32 * ROW + (ks ? bk1 : bk0));
-                        if (WGS_UABL == 2) { asm volatile("" :: "v"(af[0]), "v"(bf[0])); continue; }
-                        acc[T_PH[t]][j] = SC::mma(af, bf, acc[T_PH[t]][j]);
-                    }
+        for (int q = 0; q < Q; ++q) {
+            const int t = s * TS + q % TS;
+            if (t >= 9) continue;                    // (the last step of a chunk may be short)
+            int nq = q + 1;
+            while (nq < Q && s * TS + nq % TS >= 9) ++nq;
+            int qa_next = qa;
+            if (nq < Q) {
+                ld_b(nq, bf[qb ^ 1]);
+                if (nq / TS != q / TS || T_SH[s * TS + nq % TS] != T_SH[t]) {
+                    qa_next = qa ^ 1;
+                    ld_a(nq, af[qa_next]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);       // (without it hipcc sinks the reads behind three of the product's four MFMAs)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (WGS_UABL == 2) { asm volatile("" :: "v"(af[qa][0]), "v"(bf[qb][j][0])); continue; }
+                acc[T_PH[t]][j] = SC::mma(af[qa], bf[qb][j], acc[T_PH[t]][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            qa = qa_next;
+            qb ^= 1;
         }
     };
     auto step_barrier = [&]() {
