@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
     const int p_lbase = (tid >> 3) * PROW + q * 8;
     auto p_loff_of = [&](int j) { return ((tid + j * NT) >> 3) < PMAX ? p_lbase + j * (NT / 8) * PROW : -1; };
     const float* sc_ptr = p.a_scale ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
-    constexpr bool PIPE = (NA == 1 && NB == 1);       // single-plane (fp16) form: hand-pipelined steps, counted waits
+    constexpr bool PIPE = (NA == 1 && NB == 1);       // single-plane (fp16) form: hand-pipelined steps, explicit waits
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_scale ? p.a_scale : p.x), 0, p.a_scale ? p.s_bytes : 0, 0x00020000);
     float4 pr_[NPL];
     const int npl = g.npl;      // staging slots past the patch's own size are skipped (uniform branch), not loaded-as-zero
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
         }
         // (no use of the loaded style vector here: touching it would make the compiler wait for it — and, vmcnt being in-order,
         // for the nine patch loads in front of it — at the top of every chunk; the operand scale is applied in store_patch)
-        if (PIPE) {      // always exactly one VMEM operation (the step barrier below counts them); range-checked past the end
+        if (PIPE) {      // the style vector through the same buffer path as the patch (range-checked past the end)
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsc, (sc_ptr && c < cpt) ? (b * p.a_ld + q * 4 + c * BK) * 4 : OOB, 0, 0);
             if (sc_ptr && c < cpt) sc = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         } else if (sc_ptr && c < cpt) sc = *reinterpret_cast<const float4*>(sc_ptr + c * BK);

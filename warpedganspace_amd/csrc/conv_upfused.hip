@@ -8,7 +8,7 @@
 //   * GEMM rows = the 18 x 14 grid g of cell positions (the block + a one-cell halo: the 4-tap blur of the 32 x 24 output
 //     block needs t one position beyond it on every side; 252 of the tile's 256 rows);  t[2g + p] for the four parities p = (py, px) are FOUR accumulator sets
 //     of the same rows:  t_p[g] = sum over the phase's taps (ky = py mod 2, kx = px mod 2) of x[g + (p - k)/2] * w[k]
-//   * the activation operand is staged ONCE per 32-channel chunk as the 17 x 17 input patch; the nine (phase, tap) products
+//   * the activation operand is staged ONCE per 32-channel chunk as the 19 x 15 input patch; the nine (phase, tap) products
 //     read it with four different row shifts, so one A fragment feeds up to four MFMAs (phases) and is read 4x, not 9x
 //   * epilogue: accumulators * demodulation -> LDS as the 36 x 28 x 32-channel t tile (fp32, 126 KB), then the blur +
 //     noise + bias + activation over the 32 x 24 outputs with a sliding row window, stored as 128-B channel runs.
