@@ -6,20 +6,26 @@ as the reference constructors do; no checkpoints offline), K=128 warping functio
 reconstructor, batch 32 per GPU, Z-space shifts, --learn-gammas, synthetic z ~ N(0, I) sampled in HBM.
 
   python bench.py --gpus N --steps K --warmup W
+The headline (`value`, `dtype`, `roofline`) is the REFERENCE's arithmetic: exact fp32 everywhere (f32-input MFMA, fp32
+accumulate; the reference computes in fp32).  `extra[0]` is the same workload with the same K / W in
+the product's default arithmetic (`auto` = the mixed fp16 / split-bf16 per-layer policy of DESIGN.md section 3.2), with
+its own `roofline`; it runs at every N.  The remaining `extra` entries (other modes / BASELINE configs, short runs) are N=1 only.
+
 With N > 1 and no torch.distributed environment, bench.py starts the N ranks ITSELF (torch.distributed.run, one rank per
 GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line; under an external launcher (RANK / WORLD_SIZE set) it runs
 as one rank of that job and checks that WORLD_SIZE == --gpus.  Gradients of R and S are all-reduced over RCCL once per
-step; per-GPU batch is fixed (weak scaling); the generator is never communicated.
+step; per-GPU batch is fixed (weak scaling); the generator is never communicated.  `--dist-backend gloo` (or
+WGS_DIST_BACKEND=gloo) swaps RCCL for gloo and lets the ranks share one device: the N > 1 code path end to end on a 1-GPU box.
 
 Prints ONE JSON line on rank 0:
   value / ms_per_step  whole-job images/sec over exactly --steps timed steps (barrier + device sync on both sides, max over ranks)
-  roofline             the DOMINANT conv kernel shape (largest share of the step): its algorithmic FLOPs / its own HIP-event
-                       durations (2 extra single-stream steps), against the dense MFMA peak of the operand dtype; the family
-                       average and the whole-step rate are reported next to it
-  comm                 (N > 1) RCCL world size, all-reduce payload per step, exposed wait of the main stream per step
+  roofline             the DOMINANT KERNEL of the step by kernel symbol (largest summed HIP-event time over all its launch
+                       shapes, 2 extra single-stream steps): its summed algorithmic FLOPs / its summed duration against the
+                       dense MFMA peak of its operand dtype; the per-symbol and per-shape lists are reported beside it
+  host                 kernel launches per step issued by the library and host enqueue time per step (queue empty at start)
+  comm                 (N > 1) backend, world size, all-reduce payload per step, exposed wait of the main stream per step
   hbm_subpaths         achieved GB/s of the HBM-bound sub-kernels (RBF fwd/bwd, Adam, blur, ToRGB, BN) on their cfg3 operands
-  extra                short runs of the other arithmetic modes and BASELINE configs (exact fp32, bf16x3, f16x2, W space,
-                       ProgGAN cfg2 native + 256^2 truncation, BigGAN cfg4, StyleGAN2-1024 cfg5): img/s and conv TFLOP/s each
+  extra                see above
   cpu_baseline         the oracle's replay of the reference step as written on this box's host cores (bounded sample)
 """
 import argparse
@@ -46,21 +52,22 @@ GFLOP_PER_IMG = {'stylegan2-256': 285.8, 'stylegan2-1024': 687.8, 'proggan-1024'
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf16,f16}, dense (no sparsity)
 MFMA_PER_PRODUCT = {'fp32': 1.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}        # per launch label (a 'mixed' run has all three 16-bit kinds)
+DTYPE = {'fp32': 'fp32', 'bf16x3': 'bf16x3 (split-bf16, fp32-class)', 'f16': 'fp16 operands, fp32 accumulate',
+         'f16x2': 'fp16 x2 operands, fp32 accumulate', 'mixed': 'mixed fp16 / split-bf16 per layer, fp32 accumulate'}
 DTYPE_TEXT = {
-    'fp32': "fp32 (f32-input MFMA, f32 accumulate) everywhere",
+    'fp32': "fp32 everywhere (the reference's arithmetic): every conv of G and R, forward and backward, is f32-input MFMA "
+            "(v_mfma_f32_32x32x2_f32) with fp32 accumulate; everything else fp32 VALU",
     'bf16x3': "bf16x3: generator convs split every fp32 operand into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (~2^-16)",
-    'f16': "f16: generator convs round operands to fp16 (dynamic power-of-two scale on gradient operands), 1 fp16 MFMA per product, "
-           "fp32 accumulate / demodulation / epilogue (image error vs the fp32 reference ~4e-4, gate 1e-3)",
+    'f16': "f16: generator convs round operands to fp16 (dynamic power-of-two scale on every operand), 1 fp16 MFMA per product, "
+           "fp32 accumulate / demodulation / epilogue (image error vs the fp32 kernels ~8e-4 at 256^2: on the 1e-3 gate, reported only)",
     'f16x2': "f16x2: as f16 with the frozen weights as fp16 hi+lo, 2 fp16 MFMAs per product",
-    'mixed': "mixed fp16: per-layer arithmetic of the generator by an image-error budget (gate 1e-3) - the stride-1 3x3 convs at >= 64x64 "
-             "(64 % of the MACs) round both operands to fp16 (1 MFMA per product), the up-sampling layers at >= 64x64 split one operand into "
-             "fp16 hi+lo in the forward pass (2 MFMAs; their input-gradient convs: plain fp16), the seven layers below 64x64 split-bf16 "
-             "(3 MFMAs, fp32-class); fp32 accumulate / demodulation / epilogue everywhere; dynamic power-of-two scale on every fp16 operand",
+    'mixed': "mixed fp16: per-layer arithmetic of the generator by an image-error budget (gate 1e-3; conv.MixedPolicy, DESIGN.md section "
+             "3.2): fp16 operands (1 or 2 MFMAs per product) in the layers at >= 64x64, split-bf16 x3 (fp32-class) below; fp32 accumulate / "
+             "demodulation / epilogue everywhere; dynamic power-of-two scale on every fp16 operand",
 }
-R_TEXT = {0: "; reconstructor (trained): exact fp32 MFMA forward, split-bf16 x3 (fp32-class) input-gradient and >= 128-channel weight-gradient "
-             "convs, exact fp32 MFMA for the other weight gradients; BatchNorm statistics in fp64 partials",
-          1: "; reconstructor (trained): fp32-class only - split-bf16 x3 (3 MFMAs, ~2^-16 per product) forward, input-gradient and "
-             ">= 128-channel weight-gradient convs, exact fp32 MFMA for the other weight gradients; BatchNorm statistics in fp64 partials"}
+R_TEXT = {(0, 0, 0): "; reconstructor (trained): exact fp32 MFMA forward, input-gradient and weight-gradient convs; BatchNorm statistics in fp64 partials",
+          (1, 1, 1): "; reconstructor (trained): fp32-class only - split-bf16 x3 (3 MFMAs, ~2^-16 per product) forward, input-gradient and "
+                     "the wide weight-gradient convs, exact fp32 MFMA for the other weight gradients; BatchNorm statistics in fp64 partials"}
 
 
 def make_params(w_space=False):
@@ -69,7 +76,10 @@ def make_params(w_space=False):
                                  shift_in_w_space=w_space)
 
 
-def build(dev, gan, K, N, B, rank=0, w_space=False, size=256):
+ENGINE_KW = {}      # --single-stream: TrainStep(two_streams=False), so that a rocprofv3 kernel table adds up to the step
+
+
+def build(dev, gan, K, N, B, rank=0, w_space=False, size=256, precision='fp32', r_precision='auto'):
     """gan: 'stylegan2' (size 256 / 1024), 'proggan' (size 1024 native or 256 = first 14 blocks), 'biggan' (size 128 / 256)."""
     from warpedganspace_amd.reconstructor import Reconstructor
     from warpedganspace_amd.support_sets import SupportSets
@@ -91,7 +101,7 @@ def build(dev, gan, K, N, B, rank=0, w_space=False, size=256):
     R = Reconstructor('ResNet', K, channels=3)
     world = dist.get_world_size() if dist.is_initialized() else 1
     return TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), make_params(w_space), B, dev, world=world, seed=0,
-                     rank=rank)
+                     rank=rank, precision=precision, r_precision=r_precision, **ENGINE_KW)
 
 
 def timed_steps(eng, steps, warmup, world, dev):
@@ -117,61 +127,105 @@ def timed_steps(eng, steps, warmup, world, dev):
 def conv_profile(eng, nprof=2):
     """HIP events around every implicit-GEMM launch of `nprof` extra steps.  torch's current stream IS the launch stream, and
     the steps run single-stream (with the un-shifted pass on the side stream, kernels of the other stream would run inside
-    the event pairs and inflate the per-launch durations).  Returns {label: [flops, ms, launches]} per step."""
+    the event pairs and inflate the per-launch durations).  Returns a list of (shape label, kernel symbol, FLOPs, ms, launches)
+    per step, one entry per (label, symbol)."""
+    from warpedganspace_amd import _lib as L
     from warpedganspace_amd import conv as C
     torch.cuda.synchronize()
     eng._pre = None            # a batch whose un-shifted pass was generated one step ahead would make the first profiled step one
     C.PROFILE = []             # generator pass short: the profiled steps draw their own batches and run every launch themselves
+    L.lib().wgs_dev_trace_kernels(1)
     two, eng.two_streams = eng.two_streams, False
-    for _ in range(nprof):
-        eng.step()
-    torch.cuda.synchronize()
-    eng.two_streams = two
-    recs, C.PROFILE = C.PROFILE, None
+    try:
+        for _ in range(nprof):
+            eng.step()
+        torch.cuda.synchronize()
+    finally:
+        eng.two_streams = two
+        L.lib().wgs_dev_trace_kernels(0)
+        recs, C.PROFILE = C.PROFILE, None
     by = {}
-    for kind, fl, s, e in recs:
-        k = by.setdefault(kind, [0.0, 0.0, 0])
+    for kind, fl, s, e, sym in recs:
+        k = by.setdefault((kind, sym), [0.0, 0.0, 0.0])
         k[0] += fl / nprof; k[1] += s.elapsed_time(e) / nprof; k[2] += 1.0 / nprof
-    return by
+    return [(kind, sym, v[0], v[1], v[2]) for (kind, sym), v in by.items()]
 
 
-def roofline_of(by, precision, img_per_s_per_gpu, gflop_per_img):
-    # the generator's conv family: the launches in the run's arithmetic ('mixed': every 16-bit kind)
-    kinds = ('f16', 'f16x2', 'bf16x3') if precision == 'mixed' else (precision,)
-    gen = {k: v for k, v in by.items() if k.startswith('conv ') and k.split()[1] in kinds}
-    pool = gen if gen else by
-    dom = max(pool, key=lambda k: pool[k][1])
-    fl, ms, n = pool[dom]
-    precision = dom.split()[1] if dom.startswith('conv ') else precision        # the dominant launch's own arithmetic
-    peak = FP32_MFMA_PEAK_TF if precision == 'fp32' else F16_MFMA_PEAK_TF
-    tf = fl / ms / 1e9
-    g_fl, g_ms = sum(v[0] for v in gen.values()), sum(v[1] for v in gen.values())
-    a_fl, a_ms = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
-    top = sorted(by.items(), key=lambda kv: -kv[1][1])[:8]
-    pmc = os.path.join(REPO, 'profiles', 'r2_conv_pmc.json')
+def _label_precision(label):
+    parts = label.split()
+    return parts[1] if len(parts) > 1 and parts[1] in MFMA_PER_PRODUCT else 'fp32'
+
+
+def roofline_of(recs, img_per_s_per_gpu, gflop_per_img):
+    """Per-kernel-symbol accounting of the conv launches of a step.  The dominant kernel = the symbol with the largest summed
+    time; achieved = its summed algorithmic FLOPs / its summed HIP-event time."""
+    sym = {}
+    for label, s, fl, ms, n in recs:
+        d = sym.setdefault(s or '?', {'fl': 0.0, 'ms': 0.0, 'n': 0.0, 'mfma_fl': 0.0, 'prec': set(), 'shapes': []})
+        prec = _label_precision(label)
+        d['fl'] += fl; d['ms'] += ms; d['n'] += n; d['mfma_fl'] += MFMA_PER_PRODUCT[prec] * fl
+        d['prec'].add(prec)
+        d['shapes'].append({"shape": label, "gflop_per_step": round(fl / 1e9, 1), "ms_per_step": round(ms, 3),
+                            "TFLOP/s": round(fl / ms / 1e9, 1), "launches": round(n, 1)})
+
+    def peak_of(d):
+        return FP32_MFMA_PEAK_TF if d['prec'] == {'fp32'} else F16_MFMA_PEAK_TF
+    dom = max(sym, key=lambda k: sym[k]['ms'])
+    d = sym[dom]
+    peak = peak_of(d)
+    tf = d['fl'] / d['ms'] / 1e9
+    a_fl, a_ms = sum(v['fl'] for v in sym.values()), sum(v['ms'] for v in sym.values())
+    pmc = os.path.join(REPO, 'profiles', 'r3_conv_pmc.json')
     traffic, note = None, "not measured in this run (PMC counters need separate rocprofv3 --pmc passes: profiles/)"
     if os.path.exists(pmc):
         try:
-            rec = [r for r in json.load(open(pmc))['launches'] if r.get('label') == dom]
+            rec = [r for r in json.load(open(pmc))['kernels'] if r.get('symbol') == dom]
             if rec:
-                traffic = round((rec[0]['fetch_bytes'] + rec[0]['write_bytes']) / 1e9, 3)
-                note = ("STATIC: GB per launch from the committed rocprofv3 --pmc passes profiles/r2_conv_pmc.json (FETCH_SIZE x2 on gfx950 "
-                        "+ WRITE_SIZE), same kernel and shape; algorithmic %.3f GB" % ((rec[0]['algorithmic_read_bytes'] + rec[0]['algorithmic_write_bytes']) / 1e9))
+                traffic = round(rec[0]['hbm_bytes_per_launch'] / 1e9, 3)
+                note = ("STATIC: mean GB per launch of this kernel symbol from the committed rocprofv3 --pmc passes profiles/r3_conv_pmc.json "
+                        "(FETCH_SIZE x2 on gfx950 + WRITE_SIZE); algorithmic %.3f GB" % (rec[0]['algorithmic_bytes_per_launch'] / 1e9))
         except Exception:  # noqa: BLE001
             pass
+    by_symbol = [{"symbol": k, "ms_per_step": round(v['ms'], 3), "share_of_conv_time": round(v['ms'] / a_ms, 4), "launches": round(v['n'], 1),
+                  "gflop_per_step": round(v['fl'] / 1e9, 1), "TFLOP/s": round(v['fl'] / v['ms'] / 1e9, 1), "peak": peak_of(v),
+                  "frac": round(v['fl'] / v['ms'] / 1e9 / peak_of(v), 4)}
+                 for k, v in sorted(sym.items(), key=lambda kv: -kv[1]['ms'])]
     out = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
            "traffic": traffic, "traffic_note": note,
-           "executed_mfma_frac": round(MFMA_PER_PRODUCT[precision] * tf / peak, 4),
-           "kernel_launches_per_step": round(n, 1), "kernel_ms_per_step": round(ms, 3), "kernel_avg_launch_ms": round(ms / n, 4),
-           "kernel_gflop_per_step": round(fl / 1e9, 1),
-           "generator_conv_family": {"TFLOP/s": round(g_fl / g_ms / 1e9, 2) if g_ms else None, "ms_per_step": round(g_ms, 3),
-                                     "frac": round(g_fl / g_ms / 1e9 / peak, 4) if g_ms else None},
+           "executed_mfma_frac": round(d['mfma_fl'] / d['ms'] / 1e9 / peak, 4),
+           "kernel_launches_per_step": round(d['n'], 1), "kernel_ms_per_step": round(d['ms'], 3),
+           "kernel_avg_launch_ms": round(d['ms'] / d['n'], 4), "kernel_gflop_per_step": round(d['fl'] / 1e9, 1),
+           "kernel_shapes": sorted(d['shapes'], key=lambda r: -r['ms_per_step']),
            "all_conv_launches": {"TFLOP/s": round(a_fl / a_ms / 1e9, 2), "ms_per_step": round(a_ms, 3), "gflop_per_step": round(a_fl / 1e9, 1)},
-           "top_shapes": [{"shape": k, "ms_per_step": round(v[1], 3), "TFLOP/s": round(v[0] / v[1] / 1e9, 1), "launches": round(v[2], 1)} for k, v in top]}
+           "by_symbol": by_symbol[:10],
+           "method": "HIP events on the launch stream around every conv launch of 2 extra single-stream steps; per symbol: sum of the "
+                     "launches' algorithmic FLOPs (2 * pixels * Cout * Cin * taps) / sum of their durations; rocprofv3 tables of the same "
+                     "build: profiles/r3_step_*_kernel_stats.md"}
     if gflop_per_img:
         out["step_achieved_TFLOPs"] = round(img_per_s_per_gpu * gflop_per_img / 1e3, 2)
         out["step_frac"] = round(img_per_s_per_gpu * gflop_per_img / 1e3 / peak, 4)
     return out
+
+
+def host_overheads(eng, n=3):
+    """Kernel launches per step issued by libwgs_hip.so (its own counter; torch's sampler / memset launches come on top: the
+    rocprofv3 tables in profiles/ count everything) and the host time to ENQUEUE one step (queue drained before each)."""
+    from warpedganspace_amd import _lib as L
+    lib = L.lib()
+    torch.cuda.synchronize()
+    c0 = lib.wgs_dev_launch_count()
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.step()
+        ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    c1 = lib.wgs_dev_launch_count()
+    return {"library_launches_per_step": round((c1 - c0) / n, 1), "host_enqueue_ms_per_step": round(min(ts) * 1e3, 3),
+            "host_enqueue_ms_per_step_mean": round(sum(ts) / n * 1e3, 3),
+            "note": "enqueue = wall time of TrainStep.step() returning with the device queue empty at its start (Python + ctypes + HIP "
+                    "launch calls of one step; the device runs behind it)"}
 
 
 def hbm_subpaths(eng, dev, B):
@@ -278,69 +332,86 @@ def cpu_baseline(size, K, N, b, steps, threads):
     dt = sum(times) / len(times)
     return {"value": round(b / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "%d step(s) of batch %d (after a 32x32 warm-up step), StyleGAN2-%d K=%d N=%d ResNet-18, reference step as written "
-                      "(lib/trainer.py:190-254) replayed by oracle/wgs_oracle.py on PyTorch-CPU" % (steps, b, size, K, N)}
+                      "(lib/trainer.py:190-254) replayed by oracle/wgs_oracle.py on PyTorch-CPU; per-step seconds %s"
+                      % (steps, b, size, K, N, [round(t, 2) for t in times])}
 
 
-EXTRA = [   # (name, gan, size, K, N, batch, precision or None = headline's, w_space, steps, GFLOP-per-image key or None)
-    ("cfg3 StyleGAN2-256 exact fp32", 'stylegan2', 256, 128, 32, 32, 'fp32', False, 6, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 bf16x3", 'stylegan2', 256, 128, 32, 32, 'bf16x3', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 mixed fp16", 'stylegan2', 256, 128, 32, 32, 'mixed', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256, headline arithmetic with the reconstructor's forward convs in exact fp32 instead of split-bf16 x3 [R fp32]", 'stylegan2', 256, 128, 32, 32, None, False, 30, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 W-space", 'stylegan2', 256, 128, 32, 32, None, True, 10, 'stylegan2-256'),
-    ("cfg2 ProgGAN native 1024, K=64 N=16 B=32", 'proggan', 1024, 64, 16, 32, None, False, 4, 'proggan-1024'),
-    ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32", 'proggan', 256, 64, 16, 32, None, False, 8, 'proggan-256'),
-    ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16", 'biggan', 128, 128, 32, 16, None, False, 8, 'biggan-128'),
-    ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16", 'biggan', 256, 128, 32, 16, None, False, 6, None),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path", 'stylegan2', 1024, 200, 64, 8, 'f16', False, 6, 'stylegan2-1024'),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, default arithmetic of this architecture", 'stylegan2', 1024, 200, 64, 8, 'auto', False, 6, 'stylegan2-1024'),
+# Short runs of the other arithmetic modes and BASELINE configs (N = 1 only).
+# (name, gan, size, K, N, batch, generator precision, reconstructor precision, w_space, steps, GFLOP-per-image key or None)
+EXTRA = [
+    ("cfg3 StyleGAN2-256 bf16x3", 'stylegan2', 256, 128, 32, 32, 'bf16x3', 'auto', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', 'auto', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', 'auto', False, 10, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 auto, reconstructor convs in exact fp32 [R fp32]", 'stylegan2', 256, 128, 32, 32, 'auto', 'fp32', False, 20, 'stylegan2-256'),
+    ("cfg3 StyleGAN2-256 auto, W-space", 'stylegan2', 256, 128, 32, 32, 'auto', 'auto', True, 10, 'stylegan2-256'),
+    ("cfg2 ProgGAN native 1024, K=64 N=16 B=32, auto", 'proggan', 1024, 64, 16, 32, 'auto', 'auto', False, 4, 'proggan-1024'),
+    ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32, auto", 'proggan', 256, 64, 16, 32, 'auto', 'auto', False, 8, 'proggan-256'),
+    ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16, auto", 'biggan', 128, 128, 32, 16, 'auto', 'auto', False, 8, 'biggan-128'),
+    ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16, auto", 'biggan', 256, 128, 32, 16, 'auto', 'auto', False, 6, None),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, exact fp32", 'stylegan2', 1024, 200, 64, 8, 'fp32', 'auto', False, 3, 'stylegan2-1024'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path (mixed policy of this architecture)", 'stylegan2', 1024, 200, 64, 8, 'mixed', 'auto', False, 6, 'stylegan2-1024'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, auto", 'stylegan2', 1024, 200, 64, 8, 'auto', 'auto', False, 6, 'stylegan2-1024'),
 ]
 
 
-def run_extra(dev, headline_precision, skip_name=None):
+def run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, warmup, gkey, world=1, rank=0, full=False):
+    """Build an engine, time `steps` steps after `warmup`, profile the conv launches; `full` adds the roofline and host sections."""
     from warpedganspace_amd import conv as C
-    from warpedganspace_amd import reconstructor as RR
+    eng = build(dev, gan, K, N, B, rank=rank, w_space=w_space, size=size, precision=prec, r_precision=r_prec)
+    name = C.precision_name(eng.precision)
+    dt = timed_steps(eng, steps, warmup, world, dev)
+    recs = conv_profile(eng, 2 if full else 1)
+    a_fl, a_ms = sum(r[2] for r in recs), sum(r[3] for r in recs)
+    rec = {"precision": name, "r_arith": list(eng.r_arith), "dtype": DTYPE[name], "value": round(B * world * steps / dt, 2), "unit": "images/sec",
+           "n_gpus": world, "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+           "conv_TFLOP/s": round(a_fl / a_ms / 1e9, 1), "conv_ms_per_step": round(a_ms, 2), "conv_gflop_per_step": round(a_fl / 1e9, 1)}
+    if gkey:
+        rec["step_achieved_TFLOPs"] = round(B * steps / dt * GFLOP_PER_IMG[gkey] / 1e3, 1)
+    if full:
+        rec["dtype_detail"] = DTYPE_TEXT[name] + R_TEXT.get(tuple(eng.r_arith), "; reconstructor arithmetic (forward, dgrad, wgrad; 0 exact fp32, 1 split-bf16 x3): %s" % (tuple(eng.r_arith),))
+        rec["roofline"] = roofline_of(recs, B * steps / dt, GFLOP_PER_IMG.get(gkey) if gkey else None)
+        rec["host"] = host_overheads(eng)
+    return rec, eng
+
+
+def run_extra(dev):
     out = []
-    r_old = RR.R_PRECISION
-    for name, gan, size, K, N, B, prec, w_space, steps, gkey in EXTRA:
-        prec = prec or headline_precision
+    for name, gan, size, K, N, B, prec, r_prec, w_space, steps, gkey in EXTRA:
         try:
-            old = C.set_precision(prec)
-            prec = C.precision_name(C.resolve_auto(gan, size))        # 'auto' -> the concrete mode of this architecture
-            r_alt = '[R fp32]' in name
-            if skip_name is not None and (gan, size, K, N, B, prec, w_space) == skip_name and not r_alt:
-                continue
-            RR.R_PRECISION = 'fp32' if r_alt else r_old
-            eng = build(dev, gan, K, N, B, w_space=w_space, size=size)
-            dt = timed_steps(eng, steps, 6, 1, dev)
-            by = conv_profile(eng, 1)
-            a_fl, a_ms = sum(v[0] for v in by.values()), sum(v[1] for v in by.values())
-            rec = {"config": name, "precision": prec, "value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
-                   "steps": steps, "conv_TFLOP/s": round(a_fl / a_ms / 1e9, 1), "conv_ms_per_step": round(a_ms, 2),
-                   "conv_gflop_per_step": round(a_fl / 1e9, 1)}
-            if gkey:
-                rec["step_achieved_TFLOPs"] = round(B * steps / dt * GFLOP_PER_IMG[gkey] / 1e3, 1)
-            out.append(rec)
+            rec, eng = run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, 6, gkey)
+            out.append(dict({"config": name}, **rec))
             del eng
-            torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             out.append({"config": name, "precision": prec, "error": repr(e)[:300]})
-        finally:
-            C.PRECISION = old
-            RR.R_PRECISION = r_old
+        torch.cuda.empty_cache()
     return out
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, backend):
     """--gpus N without a launcher: start N ranks of this script (one per GPU) and relay their output."""
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    if have < n and backend != 'gloo':
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, have))
+    if have < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + argv
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+
+
+def comm_section(eng, backend):
+    eng.comm_events = []
+    for _ in range(5):
+        eng.step()
+    torch.cuda.synchronize()
+    waits = [a.elapsed_time(b) for a, b in eng.comm_events]
+    eng.comm_events = None
+    return {"backend": "RCCL (torch.distributed 'nccl')" if backend == 'nccl' else "gloo (development switch: ranks may share one device)",
+            "world_size_observed": dist.get_world_size(), "allreduce_bytes_per_step": eng.allreduce_bytes, "collectives_per_step": 2,
+            "exposed_wait_ms_per_step": round(sum(waits) / len(waits), 3),
+            "note": "main-stream time between reaching the wait for the two all-reduces (R group, queued behind R's weight gradients on "
+                    "the side stream; S group, after the RBF backward) and their completion, mean of 5 extra steps on rank 0"}
 
 
 def main():
@@ -357,19 +428,27 @@ def main():
     ap.add_argument('--w-space', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=4)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default='fp32',
+                    help="arithmetic of the HEADLINE run's generator convs (default: fp32 = the reference's arithmetic)")
     ap.add_argument('--r-precision', choices=['fp32', 'bf16x3', 'auto'], default='auto',
-                    help="arithmetic of the Reconstructor's forward convs (auto = split-bf16 x3 when the generator runs in a 16-bit mode, exact fp32 otherwise)")
+                    help="arithmetic of the Reconstructor's convs (auto = exact fp32 beside an fp32 generator, split-bf16 x3 beside a 16-bit one)")
+    ap.add_argument('--product-precision', choices=tuple(C.PRECISION_NAMES), default=C.DEFAULT_PRECISION,
+                    help="arithmetic of the extra[0] run (same workload, same steps / warmup): the product's default")
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--single-stream', action='store_true', help='no side streams (profiling: kernel times then add up to the step)')
+    ap.add_argument('--no-product-run', action='store_true', help='skip extra[0] (the default-arithmetic run with the same steps / warmup)')
     ap.add_argument('--no-extra', action='store_true', help='skip the short runs of the other arithmetic modes / configs')
-    ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default=C.DEFAULT_PRECISION,
-                    help="arithmetic of the generator's implicit-GEMM convs (warpedganspace_amd/conv.py)")
+    ap.add_argument('--dist-backend', choices=('nccl', 'gloo'), default=os.environ.get('WGS_DIST_BACKEND', 'nccl'),
+                    help="nccl = RCCL (one rank per GPU); gloo = development switch, ranks share the visible device(s)")
     args = ap.parse_args()
+    if args.single_stream:
+        ENGINE_KW['two_streams'] = False
 
     in_job = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
     if args.gpus > 1 and not in_job:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.dist_backend))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -377,45 +456,25 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == 'gloo':
+        local_rank %= ndev
+    if ndev <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
-    C.set_precision(args.precision)
-    precision = C.precision_name(C.resolve_auto(args.gan, args.size))      # 'auto' -> the concrete mode of this architecture
-    from warpedganspace_amd import reconstructor as RR
-    RR.R_PRECISION = args.r_precision
-    eng = build(dev, args.gan, args.K, args.N, args.batch, rank=rank, w_space=args.w_space, size=args.size)
-    dt = timed_steps(eng, args.steps, args.warmup, world, dev)
-    stats = eng.pop_stats()
-    ms_per_step = dt / args.steps * 1e3
-    value = args.batch * world * args.steps / dt
     gkey = '%s-%d' % (args.gan, args.size)
-
-    comm = None
-    if world > 1:
-        eng.comm_events = []
-        for _ in range(5):
-            eng.step()
-        torch.cuda.synchronize()
-        waits = [a.elapsed_time(b) for a, b in eng.comm_events]
-        eng.comm_events = None
-        comm = {"backend": "RCCL (torch.distributed 'nccl')", "world_size_observed": dist.get_world_size(),
-                "allreduce_bytes_per_step": eng.allreduce_bytes, "collectives_per_step": 2,
-                "exposed_wait_ms_per_step": round(sum(waits) / len(waits), 3),
-                "note": "main-stream time between reaching the wait for the two all-reduces (R group, queued behind R's weight gradients on "
-                        "the side stream; S group, after the RBF backward) and their completion, mean of 5 extra steps on rank 0"}
-
-    roofline = None
-    if not args.no_roofline:
-        roofline = roofline_of(conv_profile(eng, 2), precision, value / world, GFLOP_PER_IMG.get(gkey))
-
+    full = not args.no_roofline
+    head, eng = run_one(dev, args.gan, args.size, args.K, args.N, args.batch, args.precision, args.r_precision, args.w_space,
+                        args.steps, args.warmup, gkey, world=world, rank=rank, full=full)
+    stats = eng.pop_stats()
+    comm = comm_section(eng, args.dist_backend) if world > 1 else None
     hbm = None
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and world == 1 and full:
         try:
             hbm = hbm_subpaths(eng, dev, args.batch)
         except Exception as e:  # noqa: BLE001
@@ -423,9 +482,20 @@ def main():
     del eng
     torch.cuda.empty_cache()
 
-    extra = None
+    extra = []
+    if not args.no_product_run:
+        # the same workload, steps and warm-up in the product's default arithmetic, with its own roofline (every rank takes part)
+        prod, eng = run_one(dev, args.gan, args.size, args.K, args.N, args.batch, args.product_precision, 'auto', args.w_space,
+                            args.steps, args.warmup, gkey, world=world, rank=rank, full=full)
+        prod["last_stats"] = eng.pop_stats()
+        if world > 1:
+            prod["comm"] = comm_section(eng, args.dist_backend)
+        extra.append(dict({"config": "headline workload in the product's default arithmetic (--precision %s), same steps / warmup"
+                                     % args.product_precision}, **prod))
+        del eng
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extra:
-        extra = run_extra(dev, args.precision, skip_name=(args.gan, args.size, args.K, args.N, args.batch, precision, args.w_space))
+        extra += run_extra(dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.gan == 'stylegan2':
@@ -437,14 +507,17 @@ def main():
     if rank == 0:
         arch = {'stylegan2': 'StyleGAN2-FFHQ-%d' % args.size, 'proggan': 'ProgGAN (%d)' % args.size, 'biggan': 'BigGAN-%d' % args.size}[args.gan]
         out = {"metric": "training images/sec (warp->G->R->loss) %s K=%d" % ({'stylegan2': 'StyleGAN2-%d' % args.size}.get(args.gan, arch), args.K),
-               "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": DTYPE_TEXT[precision] + R_TEXT[RR.forward_precision(C.precision_code(precision))], "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
+               "value": head["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": head["dtype"], "dtype_detail": head.get("dtype_detail"),
+               "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
                "config": {"workload": "%s arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
                                       % (arch, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
-                          "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": precision, "precision_requested": args.precision,
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": head["precision"],
+                          "precision_requested": args.precision, "r_arith": head["r_arith"],
                           "algorithmic_gflop_per_image": GFLOP_PER_IMG.get(gkey)},
-               "last_stats": stats, "roofline": roofline, "comm": comm, "hbm_subpaths": hbm, "extra": extra, "cpu_baseline": cpu}
+               "last_stats": stats, "roofline": head.get("roofline"), "host": head.get("host"), "comm": comm, "hbm_subpaths": hbm,
+               "extra": extra or None, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

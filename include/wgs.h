@@ -30,6 +30,12 @@ int wgs_abi_version(void);
  * launch that consults them, and never change afterwards — except through this test hook, which re-reads them (call it
  * with no launch in flight on another thread).  All default to off. */
 void wgs_dev_reload_flags(void);
+/* Launch accounting for bench.py (statistics; no launch path reads them): the number of kernels this library has launched in
+ * the process so far, and — after wgs_dev_trace_kernels(1) — the symbol of the last implicit-GEMM kernel launched on the calling
+ * thread, spelled as rocprofv3 prints it (e.g. "igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0>"; "" before the first one). */
+int64_t wgs_dev_launch_count(void);
+void wgs_dev_trace_kernels(int on);
+const char* wgs_dev_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------
  * RBF warping field  —  replaces SupportSets.forward + its autograd backward

@@ -23,7 +23,8 @@ import torch
 
 from warpedganspace_amd.aux import sample_z, update_progress
 from warpedganspace_amd.config import GAN_RESOLUTIONS, GAN_WEIGHTS
-from warpedganspace_amd.gan_load import build_gan
+from warpedganspace_amd import conv as C
+from warpedganspace_amd.gan_load import build_gan, set_generator_precision
 
 
 def tensor2image(t):
@@ -52,7 +53,8 @@ def parse(argv=None):
     ext.add_argument('--random-init-generator', action='store_true')
     ext.add_argument('--seed', type=int, default=None, help="seed of the latent-code sampler")
     ext.add_argument('--batch-size', type=int, default=32, help="codes rendered per generator call")
-    ext.add_argument('--precision', choices=('fp32', 'bf16x3', 'f16', 'f16x2'), default=None)
+    ext.add_argument('--precision', choices=('auto', 'fp32', 'bf16x3', 'f16', 'f16x2', 'mixed'), default=None,
+                     help="arithmetic of the generator's convs (default: the fp32-class bf16x3; fp32 = the reference's)")
     ext.add_argument('--root', type=str, default='experiments', help="root of the experiments tree")
     return p, p.parse_args(argv)
 
@@ -76,9 +78,6 @@ def main(argv=None):
     if not (args.cuda and torch.cuda.is_available()):
         raise SystemExit("sample_gan.py renders with the HIP generators and needs an MI355X (--cuda)")
     dev = torch.device('cuda')
-    if ext['precision'] is not None:
-        from warpedganspace_amd import conv as C
-        C.set_precision(ext['precision'])
     res = args.stylegan2_resolution if args.gan_type == 'StyleGAN2' else GAN_RESOLUTIONS[args.gan_type]
     weights = GAN_WEIGHTS[args.gan_type]['weights'][res]
     if args.verbose:
@@ -89,6 +88,7 @@ def main(argv=None):
         print("  \\__Pre-trained weights: {}".format('<random init>' if ext['random_init_generator'] else weights))
     G = build_gan(args.gan_type, args.biggan_target_classes, args.stylegan2_resolution, args.shift_in_w_space, weights,
                   random_init=ext['random_init_generator']).to(dev).eval()
+    set_generator_precision(G, ext['precision'] or C.IMAGE_DEFAULT_PRECISION)
     if args.verbose:
         print("#. Sample {} {}-dimensional latent codes...".format(args.num_samples, G.dim_z))
         if args.z_truncation:

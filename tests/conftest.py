@@ -35,16 +35,6 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(autouse=True)
-def exact_fp32_unless_set():
-    """Every test starts from the exact-fp32 conv arithmetic (the reference's), whatever the product default
-    (conv.DEFAULT_PRECISION) is; tests of the other modes select them explicitly (precision= / conv.set_precision)."""
-    from warpedganspace_amd import conv as C
-    old, C.PRECISION = C.PRECISION, 0
-    yield
-    C.PRECISION = old
-
-
 @pytest.fixture()
 def dev_flags(monkeypatch):
     """Set development switches of libwgs_hip.so (read once from the environment) for one test: dev_flags(WGS_DMA_ALWAYS='1')."""

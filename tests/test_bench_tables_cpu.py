@@ -23,9 +23,10 @@ def test_dtype_text_covers_every_concrete_mode(bench):
     for name, code in C.PRECISION_NAMES.items():
         if code >= 0:
             assert name in bench.DTYPE_TEXT and bench.DTYPE_TEXT[name]
-    assert set(bench.R_TEXT) == {0, 1}
+            assert name in bench.DTYPE and bench.DTYPE[name]
+    assert bench.DTYPE['fp32'] == 'fp32'                      # the headline's dtype field: the reference's arithmetic, verbatim
     for code in (None, 0, 1, 2, 3, 4):
-        assert RR.forward_precision(code) in bench.R_TEXT
+        assert tuple(RR.r_arith('auto', code)) in bench.R_TEXT
 
 
 def test_flop_table_matches_the_survey(bench):
@@ -36,13 +37,29 @@ def test_flop_table_matches_the_survey(bench):
 
 def test_extra_runs_are_well_formed(bench):
     names = set()
-    for name, gan, size, K, N, B, prec, w_space, steps, gkey in bench.EXTRA:
+    for name, gan, size, K, N, B, prec, r_prec, w_space, steps, gkey in bench.EXTRA:
         assert name not in names
         names.add(name)
         assert gan in ('stylegan2', 'proggan', 'biggan') and size in (128, 256, 1024) and K > 0 and N > 0 and B > 0 and steps >= 3
-        assert prec is None or prec in C.PRECISION_NAMES
+        assert prec in C.PRECISION_NAMES and r_prec in ('auto', 'fp32', 'bf16x3')
         assert gkey is None or gkey in bench.GFLOP_PER_IMG
     assert sum('[R fp32]' in n for n in names) == 1
+
+
+def test_roofline_groups_by_kernel_symbol(bench):
+    """The dominant kernel is chosen by SYMBOL (summed over its launch shapes), and its rate is summed FLOPs / summed time."""
+    recs = [('conv f16x2 256->128 @128x128 up-conv + blur fused B32', 'upconv_blur_kernel<3, 16>', 618.5e9, 2.2, 2.0),
+            ('conv f16x2 512->256 @64x64 up-conv + blur fused B32', 'upconv_blur_kernel<3, 16>', 618.5e9, 2.0, 2.0),
+            ('conv f16 128->128 @256x256 9 taps B32', 'igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0>', 1855.4e9, 2.7, 3.0),
+            ('wgrad fp32 64->64 @64x64 9 taps B32', 'igemm_wgrad_kernel<64, 64, 2, 2, false>', 19.3e9, 0.3, 4.0)]
+    r = bench.roofline_of(recs, 1000.0, 285.8)
+    assert r['kernel'] == 'upconv_blur_kernel<3, 16>'                       # 4.2 ms summed beats the heaviest single shape (2.7 ms)
+    assert abs(r['achieved'] - 2 * 618.5 / 4.2) < 0.5 and r['peak'] == bench.F16_MFMA_PEAK_TF
+    assert abs(r['frac'] - r['achieved'] / 2500.0) < 1e-3
+    assert abs(r['executed_mfma_frac'] - 2 * r['frac']) < 1e-3             # f16x2: two MFMAs per product
+    assert [s['symbol'] for s in r['by_symbol']][:2] == ['upconv_blur_kernel<3, 16>', 'igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0>']
+    fp = bench.roofline_of([('conv fp32 128->128 @256x256 9 taps B32', 'igemm_nt_kernel<128, 128, 32, 2, 2, true>', 1855.4e9, 17.0, 3.0)], 340.0, 285.8)
+    assert fp['peak'] == bench.FP32_MFMA_PEAK_TF and abs(fp['achieved'] - 1855.4 / 17.0) < 0.1
 
 
 def test_no_gpu_means_a_loud_failure(bench, monkeypatch):

@@ -74,14 +74,13 @@ def test_generator_backward_same_gradient(dev, monkeypatch):
     G = G.to(dev).eval()
     z = torch.randn(32, 512, device=dev)
     outs = []
-    with C.resolved(C.precision_code('f16')):
-        for on in (True, False):
-            monkeypatch.setattr(C, 'BLUR_BWD_F16', on)
-            zz = z.clone().requires_grad_(True)
-            img = G([zz])[0]
-            gi = torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)
-            img.backward(gi)
-            outs.append(zz.grad.clone())
+    for on in (True, False):
+        monkeypatch.setattr(C, 'BLUR_BWD_F16', on)
+        zz = z.clone().requires_grad_(True)
+        img = G([zz], precision='f16')[0]
+        gi = torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)
+        img.backward(gi)
+        outs.append(zz.grad.clone())
     assert torch.isfinite(outs[0]).all()
     # (the style-gradient reductions behind z use fp32 atomics: two runs of the SAME route differ in the last bits)
     assert (outs[0] - outs[1]).abs().max() <= 1e-5 * outs[1].abs().max()
@@ -148,14 +147,13 @@ def test_generator_backward_dy_plane_same_gradient(dev, monkeypatch):
     G = G.to(dev).eval()
     z = torch.randn(32, 512, device=dev)
     outs = []
-    with C.resolved(C.precision_code('f16')):
-        for on in (True, False):
-            monkeypatch.setattr(C, 'DY_PLANE', on)
-            zz = z.clone().requires_grad_(True)
-            img = G([zz])[0]
-            gi = torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)
-            img.backward(gi)
-            outs.append(zz.grad.clone())
+    for on in (True, False):
+        monkeypatch.setattr(C, 'DY_PLANE', on)
+        zz = z.clone().requires_grad_(True)
+        img = G([zz], precision='f16')[0]
+        gi = torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)
+        img.backward(gi)
+        outs.append(zz.grad.clone())
     assert torch.isfinite(outs[0]).all()
     # same fp16 roundings unless a value falls below the (looser) scale's normal range: < 2^-19 of the tensor's maximum
     assert (outs[0] - outs[1]).abs().max() <= 2e-5 * outs[1].abs().max()

@@ -73,9 +73,11 @@ def test_train_checkpoint_traverse_roundtrip(tmp_path):
     common = ['--gan-type', 'StyleGAN2', '--stylegan2-resolution', '256', '-K', '4', '-D', '2', '--learn-gammas', '--batch-size', '2',
               '--log-freq', '2', '--ckp-freq', '2', '--random-init-generator', '--seed', '0']
     out1 = run([osp.join(REPO, 'train.py')] + common + ['--max-iter', '6'], cwd)
-    assert 'Restored Adam moments (step 4)' in out1 and 'Start training from iteration 4' in out1
+    # with the moments in the checkpoint the state is the one AFTER iteration 4: the run continues at 5 and the Adam step count
+    # stays equal to the iteration number (a reference-layout checkpoint re-runs `iter` with fresh optimizers, as the reference does)
+    assert 'Restored Adam moments (step 4)' in out1 and 'Start training from iteration 5' in out1
     ck6 = torch.load(osp.join(wip, 'models', 'checkpoint.pt'), map_location='cpu')
-    assert ck6['iter'] == 6 and ck6['optim']['step'] == 4 + 3          # iterations 4, 5, 6 ran (the reference re-runs `iter` too)
+    assert ck6['iter'] == 6 and ck6['optim']['step'] == 6
     torch.save(dict(ref_like, iter=6), osp.join(wip, 'models', 'checkpoint.pt'))
     out2 = run([osp.join(REPO, 'train.py')] + common + ['--max-iter', '8'], cwd)
     assert 'Restored Adam moments' not in out2 and 'Start training from iteration 6' in out2

@@ -89,17 +89,14 @@ def test_step_at_256x256_images_vs_oracle_replay(dev, sg2_256_case, mode):
     S.load_state_dict(t['c']['sd'])
     R = Reconstructor('ResNet', t['K'])
     R.load_state_dict(t['sd_r'])
-    old = C.set_precision(mode)
-    try:
-        eng = TrainStep(StyleGAN2Wrapper(G, False).to(dev).eval(), S.to(dev).train(), R.to(dev).train(), _params(), t['B'], dev, seed=1)
-        st = eng.step(t['z'].to(dev), t['idx'].to(dev), t['mag'].to(dev)).tolist()
-    finally:
-        C.PRECISION = old
+    eng = TrainStep(StyleGAN2Wrapper(G, False).to(dev).eval(), S.to(dev).train(), R.to(dev).train(), _params(), t['B'], dev, seed=1,
+                    precision=mode)
+    st = eng.step(t['z'].to(dev), t['idx'].to(dev), t['mag'].to(dev)).tolist()
     o, gr = t['o'], t['grads']
     gb = eng.bucket.gview
     e_s = rel_err(gb[id(eng.S.SUPPORT_SETS)], gr['S'])
     worst = max(rel_err(prm.grad, gr['R'][n]) for n, prm in eng.R.named_parameters() if n in gr['R'] and not n.startswith('features_extractor.fc'))
-    name = C.precision_name(C.PRECISION_NAMES[C.AUTO_TABLE[('stylegan2', 256)]]) if mode == 'auto' else mode
+    name = C.precision_name(eng.precision)
     print('StyleGAN2-256 step, %s: loss %.6f (oracle %.6f), dS err %.2e, worst dR err %.2e' % (name, st[2], o['loss'], e_s, worst))
     tight = mode in ('fp32', 'bf16x3')
     assert abs(st[2] - o['loss']) < (1e-4 if tight else 2e-3) * max(1.0, abs(o['loss']))
@@ -170,14 +167,10 @@ def test_biggan256_class_conditional_batch16(dev):
     outs, grads = {}, {}
     probe = GI.rt(643, 16, 3, 256, 256).to(dev)
     for mode in ('fp32', 'bf16x3'):
-        old = C.set_precision(mode)
-        try:
-            sh = (GI.rt(642, 16, 119) * 0.1).to(dev).requires_grad_(True)
-            img = G(z.to(dev) + sh, G.shared(cls.to(dev)))
-            (img * probe).sum().backward()
-            outs[mode], grads[mode] = img.detach(), sh.grad.detach()
-        finally:
-            C.PRECISION = old
+        sh = (GI.rt(642, 16, 119) * 0.1).to(dev).requires_grad_(True)
+        img = G(z.to(dev) + sh, G.shared(cls.to(dev)), precision=mode)
+        (img * probe).sum().backward()
+        outs[mode], grads[mode] = img.detach(), sh.grad.detach()
     with torch.no_grad():
         img2 = G(z[:2].to(dev), G.shared(cls[:2].to(dev)))
     e_or = rel_err(img2, ref2)
@@ -207,14 +200,10 @@ def test_cfg5_full_size_step_fp16_path(dev):
         G.G.load_state_dict(sd)
         S = SupportSets(K, N, 512, learn_gammas=True, gamma=1.0 / 512)
         R = Reconstructor('ResNet', K)
-        old = C.set_precision(mode)
-        try:
-            eng = TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), _params(), B, dev, seed=4)
-            z, idx, mag = _samples(B, 512, K, 650)
-            st = eng.step(z.to(dev), idx.to(dev), mag.to(dev)).tolist()
-            res[mode] = (st, eng.argmax.cpu().clone(), eng.bucket.gview[id(eng.S.SUPPORT_SETS)].double().cpu().reshape(-1).clone())
-        finally:
-            C.PRECISION = old
+        eng = TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), _params(), B, dev, seed=4, precision=mode)
+        z, idx, mag = _samples(B, 512, K, 650)
+        st = eng.step(z.to(dev), idx.to(dev), mag.to(dev)).tolist()
+        res[mode] = (st, eng.argmax.cpu().clone(), eng.bucket.gview[id(eng.S.SUPPORT_SETS)].double().cpu().reshape(-1).clone())
         del eng, G, S, R
         torch.cuda.empty_cache()
     (s0, a0, g0), (s1, a1, g1) = res['fp32'], res['f16']

@@ -31,16 +31,11 @@ def test_fp16_modes_are_scale_free(dev, scale):
     G = G.to(dev)
     z = GI.rt(8101, B, 512).to(dev)
     outs = {}
-    old = C.PRECISION
-    try:
-        for name in ('fp32', 'f16', 'f16x2', 'mixed'):
-            C.set_precision(name)
-            sh = (GI.rt(8102, B, 512) * 0.05).to(dev).requires_grad_(True)
-            img = StyleGAN2Wrapper(G, True)(z, sh)
-            (img * GI.rt(8103, *img.shape).to(dev)).sum().backward()
-            outs[name] = (img.detach(), sh.grad.detach())
-    finally:
-        C.PRECISION = old
+    for name in ('fp32', 'f16', 'f16x2', 'mixed'):
+        sh = (GI.rt(8102, B, 512) * 0.05).to(dev).requires_grad_(True)
+        img = StyleGAN2Wrapper(G, True)(z, sh, precision=name)
+        (img * GI.rt(8103, *img.shape).to(dev)).sum().backward()
+        outs[name] = (img.detach(), sh.grad.detach())
     ref_i, ref_g = outs['fp32']
     assert torch.isfinite(ref_i).all() and float(ref_i.abs().max()) > 0
     for name in ('f16', 'f16x2', 'mixed'):

@@ -14,17 +14,29 @@ def test_precision_names_round_trip():
 
 
 def test_auto_resolves_per_architecture():
-    old = C.set_precision('auto')
-    try:
-        assert C.precision_name(C.resolve_auto('stylegan2', 256)) == 'mixed'
-        assert C.precision_name(C.resolve_auto('stylegan2', 1024)) == 'bf16x3'        # f16 / f16x2 miss the gate at 1024^2
-        assert C.precision_name(C.resolve_auto('proggan', 256)) == 'f16'
-        assert C.precision_name(C.resolve_auto('biggan', 128)) == 'bf16x3'
-        assert C.precision_name(C.resolve_auto('sngan', 32)) == C.AUTO_FALLBACK
-        C.set_precision('fp32')
-        assert C.resolve_auto('stylegan2', 256) == 0                                    # an explicit mode wins everywhere
-    finally:
-        C.PRECISION = old
+    assert C.precision_name(C.resolve('auto', 'stylegan2', 256)) == 'mixed'
+    assert C.precision_name(C.resolve(None, 'stylegan2', 256)) == 'mixed'                # None = auto
+    assert C.precision_name(C.resolve('auto', 'proggan', 256)) == 'f16'
+    assert C.precision_name(C.resolve('auto', 'biggan', 128)) == 'bf16x3'
+    assert C.precision_name(C.resolve('auto', 'sngan', 32)) == C.AUTO_FALLBACK
+    assert C.precision_name(C.resolve('auto', 'stylegan2', 64)) == C.AUTO_FALLBACK      # no measurement behind it: fp32-class
+    assert C.resolve('fp32', 'stylegan2', 256) == 0 and C.resolve(3, 'proggan', 256) == 3   # an explicit mode wins everywhere
+    for key, name in C.AUTO_TABLE.items():
+        assert name in C.PRECISION_NAMES and name != 'auto', key
+
+
+def test_no_process_wide_arithmetic_state():
+    """The arithmetic is an attribute / argument of generators and step engines: the module holds no mutable mode."""
+    for gone in ('PRECISION', 'set_precision', 'resolved', 'last_resolved', '_LAST_RESOLVED', 'grad_operands', '_GRAD_CTX'):
+        assert not hasattr(C, gone), gone
+    from warpedganspace_amd import reconstructor as RR
+    for gone in ('R_PRECISION', 'R_DGRAD_PRECISION', 'R_WGRAD_PRECISION', 'forward_precision'):
+        assert not hasattr(RR, gone), gone
+    from warpedganspace_amd.stylegan2 import Generator
+    a, b = Generator(32, 512, 2), Generator(32, 512, 2)
+    a.precision = 'f16'
+    assert a.resolve_precision() == 2 and b.resolve_precision() == 0 and b.resolve_precision('mixed') == 4
+    assert Generator(256, 512, 2).resolve_precision('auto') == C.MIXED
 
 
 def test_mixed_policy_per_layer():
@@ -50,29 +62,20 @@ def test_fused_upconv_selection():
     assert not C.upconv_fused_ok(64, 24, 64, 2)
 
 
-def test_reconstructor_auto_forward_mode_follows_the_generator(monkeypatch):
-    """R_PRECISION 'auto': split-bf16 forward convs inside a step whose generator ran in a 16-bit mode, exact fp32 for an fp32
-    generator and for a Reconstructor used on its own; 'fp32' / 'bf16x3' pin it."""
+def test_reconstructor_arithmetic_follows_the_generator():
+    """r_precision 'auto': fp32-class (split-bf16 x3) convs inside a step whose generator runs in a 16-bit mode, the reference's
+    exact fp32 for an fp32 generator and for a Reconstructor used on its own; 'fp32' / 'bf16x3' pin it; an RArith passes through."""
     from warpedganspace_amd import reconstructor as RR
-    monkeypatch.setattr(RR, 'R_PRECISION', 'auto')
-    assert RR.forward_precision() == 0 and RR.forward_precision(None) == 0 and RR.forward_precision(0) == 0
+    assert RR.r_arith('auto') == RR.R_EXACT and RR.r_arith('auto', None) == RR.R_EXACT and RR.r_arith('auto', 0) == RR.R_EXACT
     for code in (1, 2, 3, 4):
-        assert RR.forward_precision(code) == 1
-    monkeypatch.setattr(RR, 'R_PRECISION', 'fp32')
-    assert all(RR.forward_precision(c) == 0 for c in (None, 0, 1, 2, 3, 4))
-    monkeypatch.setattr(RR, 'R_PRECISION', 'bf16x3')
-    assert all(RR.forward_precision(c) == 1 for c in (None, 0, 1, 2, 3, 4))
-
-
-def test_last_resolved_tracks_the_generator_context():
-    old = C.last_resolved()
-    with C.resolved(3):
-        assert C.PRECISION == 3
-    assert C.last_resolved() == 3
-    with C.resolved(0):
-        pass
-    assert C.last_resolved() == 0
-    C._LAST_RESOLVED = old
+        assert RR.r_arith('auto', code) == RR.R_FP32_CLASS
+    assert all(RR.r_arith('fp32', c) == RR.R_EXACT for c in (None, 0, 1, 2, 3, 4))
+    assert all(RR.r_arith('bf16x3', c) == RR.R_FP32_CLASS for c in (None, 0, 1, 2, 3, 4))
+    hybrid = RR.RArith(forward=0, dgrad=1, wgrad=1)
+    assert RR.r_arith(hybrid, 2) is hybrid
+    with pytest.raises(Exception):
+        RR.r_arith('fp8')
+    assert RR.Reconstructor('LeNet', 4, channels=1).arith == RR.R_EXACT
 
 
 def test_plane_route_gates():
@@ -83,3 +86,7 @@ def test_plane_route_gates():
     # dy plane of the stride-1 layers: from 256 channels up (the 128-column DMA tile loses to the patch form)
     assert C.dy_plane_ok(32, 128, 256, 256, 2) and C.dy_plane_ok(32, 64, 512, 512, 2)
     assert not C.dy_plane_ok(32, 256, 128, 128, 2) and not C.dy_plane_ok(32, 128, 256, 256, 1)
+    # a plane must stay addressable through one buffer descriptor (< 2^31 bytes at 2 bytes per element, which is how the library
+    # sizes it): per-GPU batch 64 at 256^2 is fine ([64, 257, 257, 128] fp16 = 1.08e9 bytes), batch 128 keeps the fp32 route
+    assert C.blur_bwd_f16_ok(64, 256, 128, 256, 2) and not C.blur_bwd_f16_ok(128, 256, 128, 256, 2)
+    assert C.dy_plane_ok(64, 128, 256, 256, 2) and not C.dy_plane_ok(512, 128, 256, 256, 2)

@@ -39,16 +39,14 @@ def test_image_and_shared_gate_gradient_per_scheme(dev, size, B):
     G, sd = build(size, 4000 + size, dev)
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     z = GI.rt(11 + size, B, 512)
-    old = C.PRECISION
     rows = {}
-    try:
+    if True:
         for name in ('fp32', 'bf16x3', 'f16', 'f16x2', 'mixed'):
-            C.set_precision(name)
             res = {}
             for w_space in (True, False):
                 G.debug_keep = {}
                 sh = (GI.rt(12 + size, B, 512) * 0.1).to(dev).requires_grad_(True)
-                img = StyleGAN2Wrapper(G, w_space)(z.to(dev), sh)
+                img = StyleGAN2Wrapper(G, w_space)(z.to(dev), sh, precision=name)
                 probe = GI.rt(13 + size, *img.shape)
                 (img * probe.to(dev)).sum().backward()
                 gates = ([] if w_space else [g.cpu() for g in G.debug_keep['mapping']]) + [g.cpu() for g in G.debug_keep['synthesis']]
@@ -70,8 +68,6 @@ def test_image_and_shared_gate_gradient_per_scheme(dev, size, B):
             rows[name] = res
             print('StyleGAN2-%d %-7s image err W %.2e Z %.2e | shared-gate gradient err W %.2e Z %.2e' % (
                 size, name, res['img_W'], res['img_Z'], res['grad_W'], res['grad_Z']))
-    finally:
-        C.PRECISION = old
     _record('stylegan2_%d' % size, rows)
     for name, res in rows.items():
         ok = res['img_W'] < GATE and res['img_Z'] < GATE and res['grad_W'] < GATE
@@ -92,9 +88,8 @@ def test_step_loss_and_argmax_fp16_schemes(dev, name):
     """One training step (StyleGAN2-32, K=16, ResNet-18 R) in the fp16 modes against the oracle's replay: loss within 1e-3,
     path-index argmax bit-exact, S / R gradients within a few 1e-3 (fp16 operand rounding: 2^-11)."""
     from tests.test_train_step_gpu import make
-    old = C.set_precision(name)
-    try:
-        eng, ref, c = make(dev, 32, 16, 4, 4, False)
+    if True:
+        eng, ref, c = make(dev, 32, 16, 4, 4, False, precision=name)
         g = torch.Generator().manual_seed(7)
         z = torch.randn(4, 512, generator=g)
         idx = torch.randint(0, 16, (4,), generator=g)
@@ -114,8 +109,6 @@ def test_step_loss_and_argmax_fp16_schemes(dev, name):
         assert abs(st[2] - o['loss']) < 3e-3 * max(1.0, abs(o['loss']))
         assert torch.equal(eng.argmax.cpu(), o['argmax'])
         assert cos > 0.9
-    finally:
-        C.PRECISION = old
 
 
 @pytest.mark.parametrize('family', ['stylegan2-256', 'proggan-256', 'biggan-128'])
@@ -145,17 +138,14 @@ def test_fp16_image_error_distribution(dev, family):
         fam, res = 'biggan', 128
     NB = 6                                             # batches of 32 latent codes (the training batch of cfg3)
     zs = [torch.randn(32, G.dim_z, device=dev) for _ in range(NB)]
-    old = C.PRECISION
     out = {}
-    try:
+    if True:
         with torch.no_grad():
-            C.set_precision('fp32')
-            refs = [G(z) for z in zs]
+            refs = [G(z, precision='fp32') for z in zs]
             for name in ('bf16x3', 'f16', 'f16x2', 'mixed'):
-                C.set_precision(name)
                 per_sample, per_batch = [], []
                 for z, ref in zip(zs, refs):
-                    img = G(z)
+                    img = G(z, precision=name)
                     per_sample.append(((img - ref).abs().flatten(1).max(1).values / ref.abs().flatten(1).max(1).values).cpu())
                     per_batch.append(float((img - ref).abs().max() / ref.abs().max()))      # tests.util.rel_err of the batch tensor
                 e = torch.cat(per_sample)
@@ -165,8 +155,6 @@ def test_fp16_image_error_distribution(dev, family):
                 print('%s %-6s image error vs exact fp32: batch tensor (B=32) median %.2e max %.2e | per sample median %.2e  p90 %.2e  max %.2e  (%.1f %% over 1e-3)' % (
                     family, name, out[name]['batch_median'], out[name]['batch_max'], out[name]['median'], out[name]['p90'], out[name]['max'],
                     100 * out[name]['over_gate_fraction']))
-    finally:
-        C.PRECISION = old
     _record('distribution_' + family, out)
     assert out['bf16x3']['max'] < 1e-4
     default = C.AUTO_TABLE.get((fam, res), C.AUTO_FALLBACK)

@@ -28,8 +28,10 @@ def seeded_resnet(K, seed):
     return R
 
 
-def _run_pair(dev, B, K, S):
+def _run_pair(dev, B, K, S, arith=None):
     R = seeded_resnet(K, 3)
+    if arith is not None:
+        R.arith = arith
     sd = {k: v.detach().clone().contiguous() for k, v in R.state_dict().items()}
     for k in list(sd):
         if sd[k].is_floating_point() and not (k.endswith('running_mean') or k.endswith('running_var')):
@@ -91,20 +93,13 @@ def test_resnet_larger_inputs_statistical(dev, B, K, S):
     assert l2_rel(x2d.grad, x2.grad) < 5e-2
 
 
-def test_resnet_split_bf16_forward_option(dev, monkeypatch):
-    """R_PRECISION = 'bf16x3': forward convs in split-bf16 x3 (what 'auto' selects inside a training step whose generator runs in a
+def test_resnet_split_bf16_option(dev):
+    """arith = R_FP32_CLASS: convs in split-bf16 x3 (what 'auto' selects inside a training step whose generator runs in a
     16-bit mode).  The forward stays fp32-class (outputs within 1e-4 of the oracle, argmax identical); on IDENTICAL inputs the
     extra gate flips cost gradient agreement — per-parameter max-norm errors of ~2e-2 instead of < 1e-3 — which is why a
     Reconstructor on its own, and every step with an exact-fp32 generator, keeps the exact kernels (reconstructor.py)."""
     from warpedganspace_amd import reconstructor as RR
-    assert RR.R_PRECISION == 'auto'
-    assert RR.forward_precision() == 0 and RR.forward_precision(0) == 0       # on its own / fp32 generator: exact fp32
-    assert RR.forward_precision(1) == 1 and RR.forward_precision(2) == 1 and RR.forward_precision(4) == 1
-    monkeypatch.setattr(RR, 'R_PRECISION', 'fp32')
-    assert RR.forward_precision(2) == 0
-    monkeypatch.setattr(RR, 'R_PRECISION', 'bf16x3')
-    assert RR.forward_precision() == 1
-    R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, 4, 128, 64)
+    R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, 4, 128, 64, arith=RR.R_FP32_CLASS)
     assert rel_err(lg, lo.detach()) < 1e-4 and rel_err(mg, mo.detach()) < 1e-4
     assert torch.equal(torch.argmax(lg, 1).cpu(), torch.argmax(lo, 1))
     errs = sorted(rel_err(p.grad, sd[n].grad) for n, p in R.named_parameters() if p.grad is not None)

@@ -13,21 +13,13 @@ from warpedganspace_amd.gan_load import StyleGAN2Wrapper
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def split_bf16():
-    old = C.PRECISION
-    C.PRECISION = 1
-    yield
-    C.PRECISION = old
-
-
-def test_stylegan2_256_forward_and_gradient(dev, golden, split_bf16):
+def test_stylegan2_256_forward_and_gradient(dev, golden):
     from tests.test_stylegan2_gpu import build
     g = golden('stylegan2')
     G, sd = build(256, 400 + 256, dev)
     z = GI.rt(410 + 256, 2, 512).to(dev)
     shift = (GI.rt(411 + 256, 2, 512) * 0.02).to(dev).requires_grad_(True)
-    img = StyleGAN2Wrapper(G, False)(z, shift)
+    img = StyleGAN2Wrapper(G, False)(z, shift, precision='bf16x3')
     probe = GI.rt(412 + 256, *img.shape).to(dev)
     (img * probe).sum().backward()
     e = max(rel_err(F.avg_pool2d(img.detach(), 8), g['g256_img_pool8']), rel_err(img.detach()[:, :, 100:116, 60:76], g['g256_img_crop']))
@@ -37,8 +29,8 @@ def test_stylegan2_256_forward_and_gradient(dev, golden, split_bf16):
     assert eg < 1e-2     # Z-space gradient through ~1e8 leaky-relu gates + random mapping net (see test_stylegan2_gpu)
 
 
-def test_reconstructor_stays_exact_fp32(dev, split_bf16):
-    """The trained network R ignores the global arithmetic switch (its convs pass precision=0)."""
+def test_reconstructor_stays_exact_fp32(dev):
+    """A Reconstructor on its own runs the reference's arithmetic (exact fp32 convs), whatever generators run in."""
     from tests.test_reconstructor_gpu import _run_pair
     R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, 4, 128, 64)
     assert rel_err(lg, lo.detach()) < 1e-4 and rel_err(mg, mo.detach()) < 1e-4
@@ -46,9 +38,9 @@ def test_reconstructor_stays_exact_fp32(dev, split_bf16):
     assert max(rel_err(p.grad, sd[n].grad) for n, p in R.named_parameters() if p.grad is not None) < 1e-3
 
 
-def test_training_step_loss_and_argmax(dev, split_bf16):
+def test_training_step_loss_and_argmax(dev):
     from tests.test_train_step_gpu import make
-    eng, ref, c = make(dev, 32, 16, 4, 4, False)
+    eng, ref, c = make(dev, 32, 16, 4, 4, False, precision='bf16x3')
     g = torch.Generator().manual_seed(7)
     z = torch.randn(4, 512, generator=g)
     idx = torch.randint(0, 16, (4,), generator=g)

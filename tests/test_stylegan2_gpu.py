@@ -174,24 +174,18 @@ def test_high_resolution_architectures(dev, size, B):
     """The 512 / 1024 architectures (cfg5: channels down to 64 / 32 — the narrow-Cout tiles, Cin = 32 chunks, ToRGB on 32
     channels): forward image against the CPU oracle, split-bf16 against the exact-fp32 kernels, and the input gradient of
     the two arithmetic modes against each other."""
-    from warpedganspace_amd import conv as C
     G, sd = build(size, 4242 + size, dev)
     z = GI.rt(11 + size, B, 512)
     shift = GI.rt(12 + size, B, 512) * 0.3
     with torch.no_grad():
         ref = O.sg2_generate(sd, z, size, shift)
     outs, grads = {}, {}
-    old = C.PRECISION
-    try:
-        for prec in (0, 1):
-            C.PRECISION = prec
-            sh = shift.to(dev).requires_grad_(True)
-            img = StyleGAN2Wrapper(G, False)(z.to(dev), sh)
-            probe = GI.rt(13 + size, *img.shape).to(dev)
-            (img * probe).sum().backward()
-            outs[prec], grads[prec] = img.detach(), sh.grad.detach()
-    finally:
-        C.PRECISION = old
+    for prec in (0, 1):
+        sh = shift.to(dev).requires_grad_(True)
+        img = StyleGAN2Wrapper(G, False)(z.to(dev), sh, precision=prec)
+        probe = GI.rt(13 + size, *img.shape).to(dev)
+        (img * probe).sum().backward()
+        outs[prec], grads[prec] = img.detach(), sh.grad.detach()
     e0, e1 = rel_err(outs[0], ref), rel_err(outs[1], ref)
     print('StyleGAN2-%d: image vs oracle: exact fp32 %.2e, split-bf16 %.2e; grad split vs exact %.2e' % (size, e0, e1, rel_err(grads[1], grads[0])))
     assert e0 < 1e-4 and e1 < 1e-4                      # gate of the north_star: 1e-3
@@ -203,26 +197,20 @@ def test_full_size_batch_consistency(dev):
     """BASELINE-size property (256x256, batch 32, both arithmetic modes): a sample's image and input gradient do not depend on
     what else is in the batch.  The batch-32 run takes the large-tile / merged-phase / patch / LDS-DMA kernels, the batch-2
     run mostly the 128-row and split-K ones, so this also cross-checks the kernel families against each other."""
-    from warpedganspace_amd import conv as C
     G, _ = build(256, 909, dev)
     z = GI.rt(910, 32, 512).to(dev)
     shift = (GI.rt(911, 32, 512) * 0.3).to(dev)
     probe = GI.rt(912, 32, 3, 256, 256).to(dev)
     wrap = StyleGAN2Wrapper(G, False)
-    old = C.PRECISION
-    try:
-        for prec, tol in ((1, 2e-5), (0, 2e-5)):
-            C.PRECISION = prec
-            sh = shift.clone().requires_grad_(True)
-            img = wrap(z, sh)
-            (img * probe).sum().backward()
-            for sl in (slice(0, 2), slice(30, 32)):
-                sh2 = shift[sl].clone().requires_grad_(True)
-                img2 = wrap(z[sl], sh2)
-                (img2 * probe[sl]).sum().backward()
-                e_img, e_g = rel_err(img2, img[sl]), rel_err(sh2.grad, sh.grad[sl])
-                print('precision %d rows %s: image %.2e grad %.2e' % (prec, sl, e_img, e_g))
-                assert e_img < tol
-                assert e_g < 5e-2              # free-running gradient: gate flips between two fp32-class evaluations
-    finally:
-        C.PRECISION = old
+    for prec, tol in ((1, 2e-5), (0, 2e-5)):
+        sh = shift.clone().requires_grad_(True)
+        img = wrap(z, sh, precision=prec)
+        (img * probe).sum().backward()
+        for sl in (slice(0, 2), slice(30, 32)):
+            sh2 = shift[sl].clone().requires_grad_(True)
+            img2 = wrap(z[sl], sh2, precision=prec)
+            (img2 * probe[sl]).sum().backward()
+            e_img, e_g = rel_err(img2, img[sl]), rel_err(sh2.grad, sh.grad[sl])
+            print('precision %d rows %s: image %.2e grad %.2e' % (prec, sl, e_img, e_g))
+            assert e_img < tol
+            assert e_g < 5e-2              # free-running gradient: gate flips between two fp32-class evaluations

@@ -17,7 +17,7 @@ from warpedganspace_amd.trainer import TrainStep
 pytestmark = pytest.mark.gpu
 
 
-def make(dev, size, K, N, B, w_space=False):
+def make(dev, size, K, N, B, w_space=False, precision='fp32', r_precision='auto'):
     torch.manual_seed(0)
     G = Generator(size, 512, 8)
     sd_g = GI.fill_state_dict(G.state_dict(), 900 + size)
@@ -37,7 +37,7 @@ def make(dev, size, K, N, B, w_space=False):
     ref = O.ReferenceStep(sd_g, c['sd'], sd_r, size, learn_gammas=True, gamma=c['gamma'], shift_in_w_space=w_space,
                           g_requires_grad=False)
     wrap = StyleGAN2Wrapper(G, w_space).to(dev).eval()
-    eng = TrainStep(wrap, S.to(dev).train(), R.to(dev).train(), params, B, dev, seed=1)
+    eng = TrainStep(wrap, S.to(dev).train(), R.to(dev).train(), params, B, dev, seed=1, precision=precision, r_precision=r_precision)
     return eng, ref, c
 
 

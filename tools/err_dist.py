@@ -28,8 +28,8 @@ for sidx in range(seeds):
     for i in range(0, nz, 32):
         z = torch.randn(min(32, nz - i), 512, device=dev)
         with torch.no_grad():
-            C.set_precision('fp32'); ref = G(z)
-            C.set_precision(mode); img = G(z)
+            ref = G(z, precision='fp32')
+            img = G(z, precision=mode)
         errs.append(((img - ref).abs().flatten(1).max(1).values / ref.abs().flatten(1).max(1).values).cpu())
         berr.append(float((img - ref).abs().max() / ref.abs().max()))       # whole-tensor max-norm of the batch (tests.util.rel_err)
     e = torch.cat(errs)

@@ -51,15 +51,23 @@ def parse(argv=None):
     ext = p.add_argument_group('extensions (not stored in args.json)')
     ext.add_argument('--random-init-generator', action='store_true')
     ext.add_argument('--seed', type=int, default=None)
-    ext.add_argument('--precision', choices=('fp32', 'bf16x3', 'f16', 'f16x2'), default=None,
-                     help="arithmetic of the frozen generator's convs (default: warpedganspace_amd.conv.DEFAULT_PRECISION); "
-                          "the reconstructor stays fp32-class (split-bf16 x3 forward with a 16-bit generator, exact fp32 otherwise; WGS_R_PRECISION)")
+    ext.add_argument('--precision', choices=('auto', 'fp32', 'bf16x3', 'f16', 'f16x2', 'mixed'), default=None,
+                     help="arithmetic of the frozen generator's convs (default: warpedganspace_amd.conv.DEFAULT_PRECISION = auto: the "
+                          "cheapest mode measured inside the 1e-3 image-error gate for the architecture, else the fp32-class bf16x3; "
+                          "fp32 = the reference's arithmetic everywhere)")
+    ext.add_argument('--r-precision', choices=('auto', 'fp32', 'bf16x3'), default='auto',
+                     help="arithmetic of the trained reconstructor's convs: auto = exact fp32 with an fp32 generator, the fp32-class "
+                          "split-bf16 x3 with a 16-bit one")
+    ext.add_argument('--check-precision', type=int, default=0, metavar='N',
+                     help="every N iterations regenerate the batch's images with the exact-fp32 kernels and report / check the "
+                          "16-bit mode's image error against the 1e-3 gate (0 = off)")
     return p.parse_args(argv)
 
 
 def main(argv=None):
     args = parse(argv)
-    ext = {'random_init_generator': args.random_init_generator, 'seed': args.seed, 'precision': args.precision}
+    ext = {'random_init_generator': args.random_init_generator, 'seed': args.seed, 'precision': args.precision,
+           'r_precision': args.r_precision, 'check_precision': args.check_precision}
     for k in ext:
         delattr(args, k)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -92,10 +100,11 @@ def main(argv=None):
             args.num_support_sets, args.num_support_dipoles, G.dim_z, sum(p.numel() for p in S.parameters() if p.requires_grad)))
         print("#. Reconstructor trainable parameters: {:,}".format(sum(p.numel() for p in R.parameters() if p.requires_grad)))
         print("#. Experiment: {}".format(exp_dir))
+    from warpedganspace_amd import conv as C
     args.seed = ext['seed']
-    if ext['precision'] is not None:
-        from warpedganspace_amd import conv as C
-        C.set_precision(ext['precision'])
+    args.precision = ext['precision'] or C.DEFAULT_PRECISION
+    args.r_precision = ext['r_precision']
+    args.check_precision = ext['check_precision']
     trn = Trainer(params=args, exp_dir=exp_dir, use_cuda=use_cuda, multi_gpu=world > 1)
     trn.train(generator=G, support_sets=S, reconstructor=R)
     if world > 1:

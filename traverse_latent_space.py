@@ -19,7 +19,8 @@ import torch
 from PIL import Image
 
 from warpedganspace_amd.config import GAN_RESOLUTIONS, GAN_WEIGHTS
-from warpedganspace_amd.gan_load import build_gan
+from warpedganspace_amd import conv as C
+from warpedganspace_amd.gan_load import build_gan, set_generator_precision
 from warpedganspace_amd.support_sets import SupportSets
 
 
@@ -50,6 +51,8 @@ def main(argv=None):
     p.add_argument('--no-cuda', dest='cuda', action='store_false')
     p.add_argument('--random-init-generator', action='store_true', help="extension: no pre-trained generator file")
     p.add_argument('--pool-root', type=str, default=osp.join('experiments', 'latent_codes'))
+    p.add_argument('--precision', choices=('auto', 'fp32', 'bf16x3', 'f16', 'f16x2', 'mixed'), default=None,
+                   help="extension: arithmetic of the generator's convs (default: the fp32-class bf16x3; fp32 = the reference's)")
     p.set_defaults(cuda=True)
     args = p.parse_args(argv)
 
@@ -84,6 +87,7 @@ def main(argv=None):
     res = cfg["stylegan2_resolution"] if gan_type == 'StyleGAN2' else GAN_RESOLUTIONS[gan_type]
     G = build_gan(gan_type, cfg.get("biggan_target_classes"), cfg["stylegan2_resolution"], cfg["shift_in_w_space"],
                   GAN_WEIGHTS[gan_type]['weights'][res], random_init=args.random_init_generator).to(dev).eval()
+    set_generator_precision(G, args.precision or C.IMAGE_DEFAULT_PRECISION)
     S = SupportSets(num_support_sets=cfg["num_support_sets"], num_support_dipoles=cfg["num_support_dipoles"],
                     support_vectors_dim=G.dim_z, learn_alphas=cfg["learn_alphas"], learn_gammas=cfg["learn_gammas"],
                     gamma=1.0 / G.dim_z if cfg["gamma"] is None else cfg["gamma"])

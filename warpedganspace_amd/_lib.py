@@ -38,6 +38,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.wgs_last_error.restype = ctypes.c_char_p
         _lib.wgs_rbf_ws_floats.restype = ctypes.c_int64
+        _lib.wgs_dev_launch_count.restype = ctypes.c_int64
+        _lib.wgs_dev_last_kernel.restype = ctypes.c_char_p
         for name in ("wgs_conv_ws_bytes",):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = ctypes.c_int64

@@ -105,10 +105,9 @@ class GBlock(nn.Module):
 
 class _BG(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, G, z, y):
-        ctx.prec = C.resolve_auto('biggan', G.resolution)
-        with C.resolved(ctx.prec):
-            img, saved = G._fwd(z, y, save=ctx.needs_input_grad[1])
+    def forward(ctx, G, z, y, prec):
+        ctx.prec = prec
+        img, saved = G._fwd(z, y, ctx.needs_input_grad[1], prec)
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:     # ReLU gates in execution order, NCHW (tests)
             gates = []
@@ -119,8 +118,7 @@ class _BG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        with C.resolved(ctx.prec), C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
-            return None, ctx.G._bwd(ctx.saved, gimg.contiguous()), None
+        return None, ctx.G._bwd(ctx.saved, gimg.contiguous(), ctx.prec), None, None
 
 
 class Generator(nn.Module):
@@ -155,6 +153,7 @@ class Generator(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self.debug_keep = None
+        self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
 
     def _apply(self, fn, *a, **k):
         self._prep = None
@@ -212,24 +211,23 @@ class Generator(nn.Module):
         return P
 
     # -- small helpers ------------------------------------------------------------------------------------
-    _PADDED = {}     # frozen weights whose K is not a multiple of 4 (the 256 / 512 architectures: z chunks of 17 / 15), zero-padded once
-
-    @classmethod
-    def _pad_k(cls, w):
+    def _pad_k(self, w):
+        """Frozen weights whose K is not a multiple of 4 (the 256 / 512 architectures: z chunks of 17 / 15), zero-padded once per
+        _prepare() — the cache lives in the per-instance `_prep` dict, which load_state_dict / .to() rebuild."""
         K = w.shape[1]
         Kp = (K + 3) & ~3
-        key = (w.data_ptr(), tuple(w.shape), str(w.device))
-        if key not in cls._PADDED:
+        cache = self._prepare().setdefault('padded', {})
+        key = (w.data_ptr(), tuple(w.shape))
+        if key not in cache:
             wp = torch.zeros(w.shape[0], Kp, device=w.device)
             wp[:, :K] = w
-            cls._PADDED[key] = wp
-        return cls._PADDED[key], Kp
+            cache[key] = (wp, w)          # keeps `w` alive: its address cannot be reused while the entry exists
+        return cache[key][0], Kp
 
-    @classmethod
-    def _lin(cls, x, w, inv, bias=None, bscale=1.0):
+    def _lin(self, x, w, inv, bias=None, bscale=1.0):
         B, K = x.shape
         if K % 4:
-            w, Kp = cls._pad_k(w)
+            w, Kp = self._pad_k(w)
             x = torch.nn.functional.pad(x, (0, Kp - K))
             K = Kp
         N = w.shape[0]
@@ -238,14 +236,13 @@ class Generator(nn.Module):
                                        0, 0, L.c_float(0.0), L.c_float(1.0), L.stream()), 'biggan_linear')
         return y
 
-    @classmethod
-    def _lin_dgrad(cls, g, w, inv, out, accumulate):
+    def _lin_dgrad(self, g, w, inv, out, accumulate):
         B, N = g.shape
         K = w.shape[1]
         if K % 4:
-            wp, Kp = cls._pad_k(w)
+            wp, Kp = self._pad_k(w)
             tmp = torch.empty(B, Kp, device=g.device)
-            cls._lin_dgrad(g, wp, inv, tmp, accumulate=False)
+            self._lin_dgrad(g, wp, inv, tmp, accumulate=False)
             if accumulate:
                 out += tmp[:, :K]
             else:
@@ -279,25 +276,26 @@ class Generator(nn.Module):
         return dx, dscale, dshift
 
     @staticmethod
-    def _conv(x, c, ups=0, addend=None, act=0, out_hw=None):
+    def _conv(x, c, prec, ups=0, addend=None, act=0, out_hw=None):
         B, H = x.shape[0], x.shape[1] << ups
         k = c['k']
         pad = k // 2
         y = torch.empty(B, H, H, c['co'], device=x.device)
         taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
         C.launch(x, c['wp'], y, taps, H, H, w_tap_stride=c['ci'], w_row_stride=k * k * c['ci'], ups=ups, alpha=c['inv'], bias=c['b'],
-                 addend=addend, act=act)
+                 addend=addend, act=act, precision=prec)
         return y
 
     @staticmethod
-    def _conv_dgrad(g, c):
-        """d/d(input of the conv on the up-sampled grid): [B,H,H,ci]."""
+    def _conv_dgrad(g, c, prec):
+        """d/d(input of the conv on the up-sampled grid): [B,H,H,ci].  (fp16 modes: a gradient operand without a magnitude
+        bound runs in split-bf16: grad_operand=True)"""
         B, H = g.shape[0], g.shape[1]
         k = c['k']
         pad = k // 2
         dx = torch.empty(B, H, H, c['ci'], device=g.device)
         taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
-        C.launch(g, c['wt'], dx, taps, H, H, w_tap_stride=c['ci'] * c['co'], w_row_stride=c['co'], alpha=c['inv'])
+        C.launch(g, c['wt'], dx, taps, H, H, w_tap_stride=c['ci'] * c['co'], w_row_stride=c['co'], alpha=c['inv'], precision=prec, grad_operand=True)
         return dx
 
     @staticmethod
@@ -308,12 +306,12 @@ class Generator(nn.Module):
         return dx
 
     # -- self-attention (layers.py:153-166) ---------------------------------------------------------------
-    def _att_fwd(self, a, x, save):
+    def _att_fwd(self, a, x, save, prec):
         lib, st = L.lib(), L.stream()
         B, H, _, ch = x.shape
         Pq, Pk = H * H, H * H // 4
-        theta = self._conv(x, a['theta'])                                     # [B,H,H,ch/8]
-        phi_f, g_f = self._conv(x, a['phi']), self._conv(x, a['g'])
+        theta = self._conv(x, a['theta'], prec)                                     # [B,H,H,ch/8]
+        phi_f, g_f = self._conv(x, a['phi'], prec), self._conv(x, a['g'], prec)
 
         def pool(t):
             Cn = t.shape[3]
@@ -327,7 +325,7 @@ class Generator(nn.Module):
         scores = torch.empty(B, Pq, Pk, device=x.device)
         for b in range(B):      # scores[b] = theta[b] (Pq x c8) . phi[b]^T : phi[b] plays the weight operand [Pk, 1, c8]
             C.launch(theta[b].reshape(1, Pq, 1, c8), phi[b], scores[b].reshape(1, Pq, 1, Pk), [(0, 0, 0)], Pq, 1,
-                     w_tap_stride=c8, w_row_stride=c8)
+                     w_tap_stride=c8, w_row_stride=c8, precision=prec)
         beta = torch.empty_like(scores)
         L.check(lib.wgs_softmax_rows_fwd(L.ptr(scores), L.ptr(beta), L.c_int64(B * Pq), Pk, st), 'att_softmax')
         del scores
@@ -335,26 +333,26 @@ class Generator(nn.Module):
         for b in range(B):      # o_pre[b] = beta[b] (Pq x Pk) . g[b] (Pk x c2): weight operand = g[b]^T [c2, 1, Pk]
             gt = C.repack_w_t(g[b].reshape(Pk, 1, c2), Pk, 1, c2)            # [1, c2, Pk]
             C.launch(beta[b].reshape(1, Pq, 1, Pk), gt, o_pre[b].reshape(1, Pq, 1, c2), [(0, 0, 0)], Pq, 1, w_tap_stride=Pk * c2,
-                     w_row_stride=Pk)
+                     w_row_stride=Pk, precision=prec)
         o = a['o']
         y = torch.empty_like(x)
-        C.launch(o_pre, o['wp'], y, [(0, 0, 0)], H, H, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['inv'] * a['gamma'], addend=x)
+        C.launch(o_pre, o['wp'], y, [(0, 0, 0)], H, H, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['inv'] * a['gamma'], addend=x, precision=prec)
         return y, ((x, theta, phi, iphi, g, ig, beta, o_pre) if save else None)
 
-    def _att_bwd(self, a, sv, gy):
+    def _att_bwd(self, a, sv, gy, prec):
         lib, st = L.lib(), L.stream()
         x, theta, phi, iphi, g, ig, beta, o_pre = sv
         B, H, _, ch = x.shape
         Pq, Pk, c8, c2 = H * H, H * H // 4, ch // 8, ch // 2
         o = a['o']
         do_pre = torch.empty_like(o_pre)
-        C.launch(gy, o['wt'], do_pre, [(0, 0, 0)], H, H, w_tap_stride=o['ci'] * o['co'], w_row_stride=o['co'], alpha=o['inv'] * a['gamma'])
+        C.launch(gy, o['wt'], do_pre, [(0, 0, 0)], H, H, w_tap_stride=o['ci'] * o['co'], w_row_stride=o['co'], alpha=o['inv'] * a['gamma'], precision=prec, grad_operand=True)
         dbeta = torch.empty_like(beta)
         dg = torch.zeros_like(g)
         for b in range(B):
             # dbeta[b] = do_pre[b] (Pq x c2) . g[b]^T ;  dg[b][k,c] = sum_q beta[b][q,k] do_pre[b][q,c]  (wgrad form)
             C.launch(do_pre[b].reshape(1, Pq, 1, c2), g[b], dbeta[b].reshape(1, Pq, 1, Pk), [(0, 0, 0)], Pq, 1, w_tap_stride=c2,
-                     w_row_stride=c2)
+                     w_row_stride=c2, precision=prec, grad_operand=True)
             C.conv2d_wgrad(do_pre[b].reshape(1, Pq, 1, c2), beta[b].reshape(1, Pq, 1, Pk), dg[b].reshape(Pk, 1, c2), 1)
         ds = torch.empty_like(beta)
         L.check(lib.wgs_softmax_rows_bwd(L.ptr(beta), L.ptr(dbeta), L.ptr(ds), L.c_int64(B * Pq), Pk, st), 'att_softmax_bwd')
@@ -364,7 +362,7 @@ class Generator(nn.Module):
         for b in range(B):
             pt = C.repack_w_t(phi[b].reshape(Pk, 1, c8), Pk, 1, c8)          # [1, c8, Pk]
             C.launch(ds[b].reshape(1, Pq, 1, Pk), pt, dtheta[b].reshape(1, Pq, 1, c8), [(0, 0, 0)], Pq, 1, w_tap_stride=Pk * c8,
-                     w_row_stride=Pk)
+                     w_row_stride=Pk, precision=prec, grad_operand=True)
             C.conv2d_wgrad(theta[b].reshape(1, Pq, 1, c8), ds[b].reshape(1, Pq, 1, Pk), dphi[b].reshape(Pk, 1, c8), 1)
 
         def unpool(d, idx):
@@ -372,13 +370,13 @@ class Generator(nn.Module):
             dx = torch.empty(B, H, H, Cn, device=x.device)
             L.check(lib.wgs_maxpool_bwd(L.ptr(d), L.rawptr(idx), L.ptr(dx), B, H, H, Cn, 2, 2, 0, st), 'att_pool_bwd')
             return dx
-        gx = gy + self._conv_dgrad(dtheta, a['theta'])
-        gx = gx + self._conv_dgrad(unpool(dphi, iphi), a['phi'])
-        gx = gx + self._conv_dgrad(unpool(dg, ig), a['g'])
+        gx = gy + self._conv_dgrad(dtheta, a['theta'], prec)
+        gx = gx + self._conv_dgrad(unpool(dphi, iphi), a['phi'], prec)
+        gx = gx + self._conv_dgrad(unpool(dg, ig), a['g'], prec)
         return gx
 
     # -- forward / backward ----------------------------------------------------------------------------------
-    def _fwd(self, z, y, save):
+    def _fwd(self, z, y, save, prec):
         P = self._prepare()
         z, y = z.contiguous(), y.contiguous()
         B = z.shape[0]
@@ -391,15 +389,15 @@ class Generator(nn.Module):
         for d, yb in zip(P['blocks'], ys):
             s1, t1 = self._ccbn_affine(d['bn1'], yb)
             a1 = self._affine_relu(h, s1, t1)
-            h1 = self._conv(a1, d['c1'], ups=1)
+            h1 = self._conv(a1, d['c1'], prec, ups=1)
             s2, t2 = self._ccbn_affine(d['bn2'], yb)
             a2 = self._affine_relu(h1, s2, t2)
-            sc = self._conv(h, d['sc'], ups=1)
-            out = self._conv(a2, d['c2'], addend=sc)
+            sc = self._conv(h, d['sc'], prec, ups=1)
+            out = self._conv(a2, d['c2'], prec, addend=sc)
             att_saved = None
             pre_att = out
             if d['att'] is not None:
-                out, att_saved = self._att_fwd(d['att'], out, save)
+                out, att_saved = self._att_fwd(d['att'], out, save, prec)
             if save:
                 saved.append((h, s1, a1, h1, s2, a2, yb, att_saved))
             del pre_att
@@ -407,11 +405,11 @@ class Generator(nn.Module):
         so = P['out_scale'].unsqueeze(0).expand(B, -1).contiguous()
         to = P['out_shift'].unsqueeze(0).expand(B, -1).contiguous()
         af = self._affine_relu(h, so, to)
-        y8 = self._conv(af, P['out'], act=1)
+        y8 = self._conv(af, P['out'], prec, act=1)
         img = y8[..., :3].permute(0, 3, 1, 2).contiguous()
         return img, ((saved, h, af, so, y8, zs, B) if save else None)
 
-    def _bwd(self, saved_all, gimg):
+    def _bwd(self, saved_all, gimg, prec):
         P = self._prepare()
         lib, st = L.lib(), L.stream()
         saved, h_last, af, so, y8, zs, B = saved_all
@@ -422,7 +420,7 @@ class Generator(nn.Module):
         dpre = torch.empty_like(g8)
         L.check(lib.wgs_bias_act(L.ptr(g8), None, L.ptr(y8), L.ptr(dpre), 9, 1, L.c_float(0.0), L.c_float(1.0), L.c_int64(g8.numel()),
                                  1, 1, st), 'tanh_bwd')
-        gaf = self._conv_dgrad(dpre, P['out'])
+        gaf = self._conv_dgrad(dpre, P['out'], prec)
         g, _, _ = self._affine_relu_bwd(h_last, af, gaf, so)
         cs = self.z_chunk_size
         dz = torch.zeros(B, self.dim_z, device=dev)
@@ -430,16 +428,16 @@ class Generator(nn.Module):
             d = P['blocks'][i]
             h, s1, a1, h1, s2, a2, yb, att_saved = saved[i]
             if d['att'] is not None:
-                g = self._att_bwd(d['att'], att_saved, g)
+                g = self._att_bwd(d['att'], att_saved, g, prec)
             dyb = torch.zeros(B, yb.shape[1], device=dev)
             # out = conv2(a2) + conv_sc(up(h))
-            ga2 = self._conv_dgrad(g, d['c2'])
+            ga2 = self._conv_dgrad(g, d['c2'], prec)
             gh1, ds2, dt2 = self._affine_relu_bwd(h1, a2, ga2, s2)
             self._ccbn_grad(d['bn2'], ds2, dt2, dyb)
-            ga1 = self._up_bwd(self._conv_dgrad(gh1, d['c1']))
+            ga1 = self._up_bwd(self._conv_dgrad(gh1, d['c1'], prec))
             gh, ds1, dt1 = self._affine_relu_bwd(h, a1, ga1, s1)
             self._ccbn_grad(d['bn1'], ds1, dt1, dyb)
-            gsc = self._up_bwd(self._conv_dgrad(g, d['sc']))
+            gsc = self._up_bwd(self._conv_dgrad(g, d['sc'], prec))
             g = gh + gsc
             dz[:, (i + 1) * cs:(i + 2) * cs] = dyb[:, self.shared_dim:]              # ys[i] = cat(y, zs[i+1])
         dz0 = torch.empty(B, cs, device=dev)
@@ -453,9 +451,13 @@ class Generator(nn.Module):
         self._lin_dgrad(dgain, c['wg'], c['ig'], dyb, accumulate=True)
         self._lin_dgrad(dshift.contiguous(), c['wb'], c['ib'], dyb, accumulate=True)
 
-    def forward(self, z, y):
-        """z [B, dim_z], y = self.shared(class ids) [B, shared_dim] (BigGAN.py:222-243)."""
-        return _BG.apply(self, z, y)
+    def resolve_precision(self, requested=None):
+        return C.resolve(self.precision if requested is None else requested, 'biggan', self.resolution)
+
+    def forward(self, z, y, precision=None):
+        """z [B, dim_z], y = self.shared(class ids) [B, shared_dim] (BigGAN.py:222-243).  precision (extension): arithmetic of
+        this call's convs (conv.PRECISION_NAMES; default self.precision)."""
+        return _BG.apply(self, z, y, self.resolve_precision(precision))
 
 
 class BigGANWrapper(nn.Module):
@@ -472,9 +474,12 @@ class BigGANWrapper(nn.Module):
             return self.target_classes.repeat(batch_size)
         return torch.from_numpy(np.random.choice(self.target_classes.cpu().numpy(), [batch_size]))
 
-    def forward(self, z, shift=None):
+    def forward(self, z, shift=None, precision=None):
         target_classes = self.mixed_classes(z.shape[0]).to(z.device)
-        return self.G(z if shift is None else z + shift, self.G.shared(target_classes))
+        return self.G(z if shift is None else z + shift, self.G.shared(target_classes), precision=precision)
+
+    def resolve_precision(self, requested=None):
+        return self.G.resolve_precision(requested)
 
 
 def build_biggan(pretrained_gan_weights=None, target_classes=(239,), config_file=None):

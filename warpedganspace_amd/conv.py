@@ -4,7 +4,6 @@ weights are "packed" as [Cout, T, Cin] (T = kh*kw taps; this is the memory of a 
 [Cout, Cin, kh, kw] tensor in channels_last format) or, for dgrad contractions, [T, Cin, Cout].
 """
 import ctypes
-import os
 
 import torch
 
@@ -37,126 +36,102 @@ class WgradDesc(ctypes.Structure):
                 ('precision', ctypes.c_int32)]
 
 
-# Arithmetic of the (frozen) generator's implicit-GEMM launches (wgs_conv_desc.precision, include/wgs.h):
-#   0 'fp32'   exact fp32 MFMA                                   (reference arithmetic, 157 TF ceiling)
+# Arithmetic of a generator's implicit-GEMM launches (wgs_conv_desc.precision, include/wgs.h):
+#   0 'fp32'   exact fp32 MFMA                                   (the reference's arithmetic, 157 TF ceiling)
 #   1 'bf16x3' split-bf16, 3 MFMAs per product, ~2^-16           (fp32-class: image error ~1e-5)
-#   2 'f16'    fp16 operands, 1 MFMA per product, fp32 accumulate (image error ~4e-4 at 256^2 — inside the 1e-3 gate)
-#   3 'f16x2'  fp16 activations x (hi + lo) fp16 weights, 2 MFMAs (image error ~3e-4)
-# Set with set_precision() / train.py --precision / bench.py --precision, or WGS_CONV_PRECISION at import.
+#   2 'f16'    fp16 operands, 1 MFMA per product, fp32 accumulate (image error ~8e-4 at 256^2: ON the 1e-3 gate, reported only)
+#   3 'f16x2'  fp16 activations x (hi + lo) fp16 weights, 2 MFMAs (image error ~5e-4)
+#   4 'mixed'  StyleGAN2 only: per-layer arithmetic from an error budget, see MixedPolicy
 #  -1 'auto'   per generator: the cheapest mode whose measured image error stays inside the north_star's 1e-3 gate for that
-#              architecture (tests/test_precision_schemes_gpu.py): see AUTO_TABLE
-#   4 'mixed'  StyleGAN2 only — per-layer arithmetic by an error budget: every fp16 layer adds an independent ~2.5e-4 (f16) or
-#              ~1.7e-4 (f16x2) to the image error, and 91 % of the generator's MACs sit in the six layers at >= 64x64, so
-#              those run in fp16 (f16 for the stride-1 convs, f16x2 for the up-convs, which are not MFMA-bound) and the seven
-#              low-resolution layers (9 % of the MACs, latency-bound) in bf16x3: the image error of f16x2 at ~the speed of f16.
-#              Other generators treat 'mixed' as f16x2.
+#              architecture with margin (tests/test_precision_schemes_gpu.py): see AUTO_TABLE
+# There is NO process-wide arithmetic state: a mode is an attribute of a generator instance (`G.precision`), an argument of
+# its forward (`G(z, shift, precision=...)`) and of the step engine (`TrainStep(..., precision=..., r_precision=...)`); bare
+# conv calls without `precision=` run the reference's arithmetic (exact fp32).
 PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'mixed': 4}
+AUTO, MIXED = -1, 4
+# default of the TRAINING CLIs (train.py, bench.py extra runs); the image-producing CLIs (traverse_latent_space.py,
+# sample_gan.py) default to IMAGE_DEFAULT_PRECISION, the fp32-class mode
 DEFAULT_PRECISION = 'auto'
-AUTO = -1
-# (generator family, output resolution) -> mode for 'auto'.  Error accumulates with depth (each fp16 layer adds ~2e-4):
-# StyleGAN2-256 (13 modulated 3x3 layers) measures 7e-4 .. 9e-4 in f16, StyleGAN2-1024 (17 layers) 1.5e-3 -> split-bf16 there.
-AUTO_TABLE = {('stylegan2', 256): 'mixed', ('stylegan2', 128): 'mixed', ('stylegan2', 64): 'mixed', ('stylegan2', 32): 'f16x2',
-              ('proggan', 256): 'f16'}       # ProgGAN-256 measures 4.1e-4 (max of 32 samples) in f16; BigGAN-128 1.3e-3 .. 1.7e-3 -> fallback
-MIXED = 4
-
-
-def layer_precision(code, out_res, is_up):
-    """Concrete arithmetic of one StyleGAN2 layer under mode `code` (see 'mixed' above)."""
-    if code != MIXED:
-        return code
-    if _MIXED_POLICY is not None:
-        s1, up = _MIXED_POLICY.get(out_res, (1, 1))
-        return up if is_up else s1
-    if out_res < _MIXED_MIN_RES:
-        return 1
-    return _MIXED_UP if is_up else 2
-
-
-def layer_precision_bwd(code, out_res, is_up):
-    """Arithmetic of a layer's INPUT-GRADIENT conv.  'mixed': the up-sampling layers' dgrads run in plain f16 — the two-MFMA
-    forms exist for the image-error budget of the forward pass; the gradient has its own gate (shared-gate gradient error,
-    tests/test_precision_schemes_gpu.py) and stays well inside it."""
-    lp = layer_precision(code, out_res, is_up)
-    if code == MIXED and is_up and lp == 3 and _MIXED_BWD_UP_F16:
-        return 2
-    return lp
-
-
-_MIXED_BWD_UP_F16 = os.environ.get('WGS_MIXED_BWD_UP', 'f16') == 'f16'      # development A/B: 'f16x2' = as the forward
-# development overrides of the 'mixed' policy (read once at import): resolution from which layers run in fp16, arithmetic of the
-# up-convs, or a whole table "res:stride1,up;..." (e.g. WGS_MIXED_POLICY="64:f16x2,f16x2;128:f16,f16x2;256:f16,f16x2")
-_MIXED_MIN_RES = int(os.environ.get('WGS_MIXED_MIN_RES', '64'))
-_PN = {'f16': 2, 'f16x2': 3, 'bf16x3': 1, 'fp32': 0}
-_MIXED_UP = _PN[os.environ.get('WGS_MIXED_UP', 'f16x2')]
-_MIXED_POLICY = None
-if os.environ.get('WGS_MIXED_POLICY'):
-    _MIXED_POLICY = {int(e.split(':')[0]): tuple(_PN[m] for m in e.split(':')[1].split(',')) for e in os.environ['WGS_MIXED_POLICY'].split(';')}
+IMAGE_DEFAULT_PRECISION = 'bf16x3'
+# (generator family, output resolution) -> mode for 'auto'; only entries with a measurement behind them
+# (profiles/r3_precision_schemes.json); everything else falls back to the fp32-class mode.
+AUTO_TABLE = {('stylegan2', 256): 'mixed', ('proggan', 256): 'f16'}
 AUTO_FALLBACK = 'bf16x3'
 
 
-def resolve_auto(family, resolution):
-    """Concrete precision code for generator `family` at `resolution` under the current setting."""
-    if PRECISION != AUTO:
-        return PRECISION
-    return PRECISION_NAMES[AUTO_TABLE.get((family, resolution), AUTO_FALLBACK)]
+class MixedPolicy:
+    """Per-layer arithmetic of a StyleGAN2 generator under 'mixed': every fp16-rounded layer adds an independent ~2.5e-4 (both
+    operands rounded, 'f16') or ~1.7e-4 (one operand, 'f16x2') to the image error, and the generator's MACs sit in the layers
+    at >= 64x64; so those run in fp16 and the low-resolution layers (latency-bound) in split-bf16.
+    table: {output resolution: (stride-1 conv code, up-conv code)}; resolutions not listed run `below` (bf16x3).
+    bwd_up_f16: the up-sampling layers' INPUT-GRADIENT convs run in plain f16 when their forward is f16x2 (the two-MFMA form
+    exists for the image-error budget; the gradient has its own gate, the shared-gate gradient error)."""
+
+    def __init__(self, table, below=1, bwd_up_f16=True):
+        self.table, self.below, self.bwd_up_f16 = dict(table), below, bwd_up_f16
+
+    def fwd(self, out_res, is_up):
+        s1, up = self.table.get(out_res, (self.below, self.below))
+        return up if is_up else s1
+
+    def bwd(self, out_res, is_up):
+        lp = self.fwd(out_res, is_up)
+        return 2 if (is_up and lp == 3 and self.bwd_up_f16) else lp
 
 
-_LAST_RESOLVED = None
+# StyleGAN2-256 (13 modulated layers; DESIGN.md section 3.2 has the measured error of every candidate)
+MIXED_256 = MixedPolicy({64: (2, 3), 128: (2, 3), 256: (2, 3)})
+# StyleGAN2-1024 (17 layers): the 512^2 / 1024^2 layers are HBM-bound, so the two-MFMA form is free there
+MIXED_1024 = MixedPolicy({64: (3, 3), 128: (3, 3), 256: (3, 3), 512: (3, 3), 1024: (3, 3)})
+MIXED_POLICIES = {256: MIXED_256, 1024: MIXED_1024}
 
 
-def last_resolved():
-    """Concrete precision code of the most recent generator forward / backward of this process (None: none yet).  The training step
-    reads it right after its generator forward to choose the Reconstructor's 'auto' arithmetic."""
-    return _LAST_RESOLVED
+def mixed_policy(size):
+    return MIXED_POLICIES.get(size, MIXED_256)
 
 
-class resolved:
-    """Context manager: run the enclosed launches with the concrete precision `code` (a generator's forward / backward)."""
+def layer_precision(code, out_res, is_up, policy=None):
+    """Concrete arithmetic of one StyleGAN2 layer's forward conv under mode `code`."""
+    if code != MIXED:
+        return code
+    return (policy or MIXED_256).fwd(out_res, is_up)
 
-    def __init__(self, code):
-        self.code = code
 
-    def __enter__(self):
-        global PRECISION, _LAST_RESOLVED
-        self.old, PRECISION = PRECISION, self.code
-        _LAST_RESOLVED = self.code
-
-    def __exit__(self, *exc):
-        global PRECISION
-        PRECISION = self.old
+def layer_precision_bwd(code, out_res, is_up, policy=None):
+    """Arithmetic of a layer's INPUT-GRADIENT conv under mode `code`."""
+    if code != MIXED:
+        return code
+    return (policy or MIXED_256).bwd(out_res, is_up)
 
 
 def precision_code(name):
-    if isinstance(name, int) and name == -1:
-        return name
-    if isinstance(name, int):
+    if isinstance(name, int) and not isinstance(name, bool):
         if name not in PRECISION_NAMES.values():
             raise L.WgsError("unknown conv precision %r" % (name,))
         return name
     key = str(name).lower()
     if key in PRECISION_NAMES:
         return PRECISION_NAMES[key]
-    if key.isdigit() and int(key) in PRECISION_NAMES.values():
+    if key.lstrip('-').isdigit() and int(key) in PRECISION_NAMES.values():
         return int(key)
     raise L.WgsError("unknown conv precision %r (choose from %s)" % (name, ', '.join(PRECISION_NAMES)))
 
 
-PRECISION = precision_code(os.environ.get('WGS_CONV_PRECISION', DEFAULT_PRECISION))
-
-
-def set_precision(name):
-    """Select the arithmetic of the generator convs for subsequent launches; returns the previous code."""
-    global PRECISION
-    old, PRECISION = PRECISION, precision_code(name)
-    return old
-
-
-def precision_name(code=None):
-    code = PRECISION if code is None else code
+def precision_name(code):
     return [k for k, v in PRECISION_NAMES.items() if v == code][0]
 
-# bench.py sets this to a list to collect (kind, algorithmic FLOPs, start event, end event) per launch;
-# the events are recorded on torch's current stream, which is the stream the kernels are launched on.
+
+def resolve(requested, family, resolution):
+    """Concrete precision code (0..4) of generator `family` at `resolution` for the requested mode (name or code; None = 'auto')."""
+    code = AUTO if requested is None else precision_code(requested)
+    if code != AUTO:
+        return code
+    return PRECISION_NAMES[AUTO_TABLE.get((family, resolution), AUTO_FALLBACK)]
+
+
+# Profiling hook (bench.py): set to a list to collect (shape label, algorithmic FLOPs, start event, end event, kernel symbol) per
+# launch; the events are recorded on torch's current stream, which is the stream the kernels are launched on, and the symbol is
+# the library's own record of the kernel it dispatched to (wgs_dev_last_kernel, needs wgs_dev_trace_kernels(1)).
 PROFILE = None
 
 
@@ -211,22 +186,6 @@ class SplitCache:
         return self.planes[precision]
 
 
-_GRAD_CTX = False
-
-
-class grad_operands:
-    """Context manager for a generator's backward pass: every conv launch inside has a GRADIENT as its activation operand.
-    In the fp16 modes such a launch needs a magnitude bound (a_amax); launches that do not provide one run in split-bf16."""
-
-    def __enter__(self):
-        global _GRAD_CTX
-        self.old, _GRAD_CTX = _GRAD_CTX, True
-
-    def __exit__(self, *exc):
-        global _GRAD_CTX
-        _GRAD_CTX = self.old
-
-
 def _timed(kind, flops, fn):
     if PROFILE is None:
         return fn()
@@ -234,7 +193,7 @@ def _timed(kind, flops, fn):
     s.record()
     r = fn()
     e.record()
-    PROFILE.append((kind, flops, s, e))
+    PROFILE.append((kind, flops, s, e, (L.lib().wgs_dev_last_kernel() or b'').decode()))
     return r
 
 
@@ -258,12 +217,12 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     d.ntaps = len(taps)
     d.a_ld, d.col_ld = a_ld, col_ld
     d.ups, d.add_ups, d.act, d.alpha, d.addend = ups, add_ups, act, alpha, _p(addend)
-    prec = PRECISION if precision is None else precision
+    prec = 0 if precision is None else precision      # a bare conv call: the reference's arithmetic
     if prec == AUTO:           # a bare conv call outside a generator: the fp32-class mode
         prec = PRECISION_NAMES[AUTO_FALLBACK]
     if prec == MIXED:          # per-layer policies are resolved by the generator (stylegan2.py); elsewhere: fp16 x2
         prec = 3
-    if (grad_operand or _GRAD_CTX) and prec >= 2 and a_amax is None:
+    if grad_operand and prec >= 2 and a_amax is None:
         # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
         prec = 1
     d.precision = prec
@@ -372,9 +331,8 @@ class UpconvDesc(ctypes.Structure):
 
 
 # The fused up-sampling layer (conv_upfused.hip) is taken for the fp16 modes from this input size up (below it a 14 x 14-cell
-# tile wastes most of its GEMM rows on the image border; tools/bench_upfused.py).  Development A/B: a huge value = never.
-UPCONV_FUSED_MIN_H = {2: int(os.environ.get('WGS_UPFUSED_MIN_H_F16', '16')),
-                      3: int(os.environ.get('WGS_UPFUSED_MIN_H_F16X2', '16'))}
+# tile wastes most of its GEMM rows on the image border; tools/bench_upfused.py).
+UPCONV_FUSED_MIN_H = {2: 16, 3: 16}
 
 
 def upconv_fused_ok(H, Ci, Co, precision):
@@ -418,23 +376,30 @@ def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
 # The transposed blur in front of an up-sampling layer's gradient conv can store its result as that conv's fp16 operand plane
 # (wgs_sg2_blur_bwd_f16 -> wgs_conv_desc.x_f16): the (2H+1)^2 fp32 tensor is never written and the conv runs the LDS-DMA kernel
 # without a pre-pass, bit-identical to the fp32 route.  Taken for plain-fp16 gradient launches that fill the chip with 256-row tiles.
-BLUR_BWD_F16 = os.environ.get('WGS_BLUR_BWD_F16', '1') != '0'
+BLUR_BWD_F16 = True
 # The same for the stride-1 layers: sg2_act_bwd stores dy only as the fp16 plane of the gradient conv (wgs_sg2_act_bwd_f16), scaled
 # from an a-priori magnitude bound (wgs_sg2_dy_bound) since its own maximum is not known before it has run.
-DY_PLANE = os.environ.get('WGS_DY_PLANE', '1') != '0'
-DY_PLANE_MIN_CO = int(os.environ.get('WGS_DY_PLANE_MIN_CO', '256'))
+DY_PLANE = True
+DY_PLANE_MIN_CO = 256       # below: the DMA form re-reads every activation row nine times from L2 (128 -> 128 @256^2: 0.98 vs 0.83 ms)
+# The LDS-DMA kernel addresses an fp16 operand plane through one buffer descriptor: its extent (2 bytes per element) must stay
+# below 2^31 bytes; larger planes (StyleGAN2-256 at a per-GPU batch >= 64: dt [64,257,257,128]) take the fp32 route.
+PLANE_MAX_BYTES = (1 << 31) - 1
+
+
+def _plane_fits(B, H, W, C):
+    return B * H * W * C * 2 <= PLANE_MAX_BYTES
 
 
 def blur_bwd_f16_ok(B, Hc, Ci_dgrad, Co_dgrad, precision):
     """dy [B,Hc,Hc,Ci_dgrad] -> gradient conv to [B,Hc/2,Hc/2,Co_dgrad]"""
-    if not BLUR_BWD_F16 or precision != 2 or Ci_dgrad % 32 or Co_dgrad % 128:
+    if not BLUR_BWD_F16 or precision != 2 or Ci_dgrad % 32 or Co_dgrad % 128 or not _plane_fits(B, Hc + 1, Hc + 1, Ci_dgrad):
         return False
     return (B * (Hc // 2) ** 2 // 256) * (Co_dgrad // 128) >= 256
 
 
 def dy_plane_ok(B, Hc, Ci_dgrad, Co_dgrad, precision):
     """sg2_act_bwd may store dy [B,Hc,Hc,Ci_dgrad] only as the fp16 plane of the stride-1 gradient conv to Co_dgrad channels"""
-    if not DY_PLANE or precision != 2 or Ci_dgrad % 32 or Co_dgrad % 128 or Co_dgrad < DY_PLANE_MIN_CO:
+    if not DY_PLANE or precision != 2 or Ci_dgrad % 32 or Co_dgrad % 128 or Co_dgrad < DY_PLANE_MIN_CO or not _plane_fits(B, Hc, Hc, Ci_dgrad):
         return False
     return (B * Hc * Hc // 256) * (Co_dgrad // 128) >= 256
 

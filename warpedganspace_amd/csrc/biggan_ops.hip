@@ -111,7 +111,7 @@ int wgs_affine_relu_fwd(const float* x, const float* scale, const float* shift, 
     WGS_CHECK_ARG(x && scale && shift && y && B > 0 && P > 0 && C >= 4 && C % 4 == 0, "wgs_affine_relu_fwd: bad arguments (C %% 4)");
     int grid = wgs_cdiv((int64_t)B * P * (C / 4), 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(affine_relu_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, B, P, C, relu);
+    WGS_LAUNCH(affine_relu_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, B, P, C, relu);
     WGS_CHECK_LAUNCH("affine_relu_fwd_kernel");
     return WGS_OK;
 }
@@ -124,7 +124,7 @@ int wgs_affine_relu_bwd(const float* x, const float* y, const float* g, const fl
     int chunk = wgs_cdiv(P, chunks);
     if (chunk < 16) chunk = 16;
     chunks = wgs_cdiv(P, chunk);
-    hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, x, y, g, scale, dx, dscale,
+    WGS_LAUNCH(affine_relu_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, x, y, g, scale, dx, dscale,
                        dshift, P, C, chunk, relu);
     WGS_CHECK_LAUNCH("affine_relu_bwd_kernel");
     return WGS_OK;
@@ -132,13 +132,13 @@ int wgs_affine_relu_bwd(const float* x, const float* y, const float* g, const fl
 
 int wgs_softmax_rows_fwd(const float* x, float* y, int64_t rows, int n, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && y && rows > 0 && rows < (1LL << 31) && n > 0, "wgs_softmax_rows_fwd: bad arguments");
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, y, rows, n);
+    WGS_LAUNCH(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, y, rows, n);
     WGS_CHECK_LAUNCH("softmax_fwd_kernel");
     return WGS_OK;
 }
 int wgs_softmax_rows_bwd(const float* y, const float* dy, float* dx, int64_t rows, int n, wgs_stream_t stream) {
     WGS_CHECK_ARG(y && dy && dx && rows > 0 && rows < (1LL << 31) && n > 0, "wgs_softmax_rows_bwd: bad arguments");
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, y, dy, dx, rows, n);
+    WGS_LAUNCH(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, y, dy, dx, rows, n);
     WGS_CHECK_LAUNCH("softmax_bwd_kernel");
     return WGS_OK;
 }

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
     const int m_last = min(m0 + BM, p.M) - 1;
     const int b_hi = (m_last / p.Wg) / p.Hg;
     const bool cs_fast = p.col_scale && (b_hi - b_lo <= 1);
+    float vmax = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
@@ -230,9 +231,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const ConvArgs p) {
                     if (p.addend) v += p.addend[(size_t)r_add[row] * p.Co + n];
                     v = (p.act == 1) ? tanhf(v) : (v > 0.f ? v : v * p.act_slope) * p.gain;
                     p.y[(size_t)pix * p.Co + n] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
                 }
             }
         }
+    }
+    if (p.y_amax) {      // magnitude bound for a consumer's fp16 operand scale (a 16-bit launch that fell back to this kernel)
+        vmax = wave_max(vmax);
+        if (lane == 0) raise_amax(p.y_amax, vmax);
     }
 }
 
@@ -487,14 +493,15 @@ int launch_nt(const ConvArgs& a, hipStream_t st) {
     const size_t smem_epi = (size_t)4 * BM * sizeof(int);
     const size_t sm = smem > smem_epi ? smem : smem_epi;
     dim3 grid((unsigned)(ntm * ntn), (unsigned)a.ksplit), block(256);
+    wgs_note_kernel("igemm_nt_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, BK, WAVES_M, WAVES_N, a.a_scale ? "true" : "false");
     if (a.a_scale) {
         auto k = igemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>;
         if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+        WGS_LAUNCH(k, grid, block, sm, st, a);
     } else {
         auto k = igemm_nt_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>;
         if (sm > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+        WGS_LAUNCH(k, grid, block, sm, st, a);
     }
     return 0;
 }
@@ -539,7 +546,7 @@ int wgs_split_f16(const float* x, uint16_t* hi, uint16_t* lo, int64_t n, wgs_str
 int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stream_t stream) {
     WGS_CHECK_ARG(src && dst && Co > 0 && T > 0 && Ci > 0, "wgs_repack_w_t: bad arguments");
     dim3 grid((Ci + 31) / 32, (Co + 31) / 32, T);
-    hipLaunchKernelGGL(repack_w_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, Co, T, Ci);
+    WGS_LAUNCH(repack_w_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, Co, T, Ci);
     WGS_CHECK_LAUNCH("repack_w_t_kernel");
     return WGS_OK;
 }
@@ -577,7 +584,7 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     a.a_amax = d->precision >= 2 ? d->a_amax : nullptr;
     a.a_bound = d->a_bound > 0.f ? d->a_bound : 1.f;
     a.a_amax2 = d->precision >= 2 ? d->a_amax2 : nullptr;
-    a.y_amax = d->precision >= 1 ? d->y_amax : nullptr;
+    a.y_amax = d->y_amax;
     wgsconv::fill_tap_tables(a);
     return WGS_OK;
 }
@@ -595,7 +602,8 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && d->ntaps <= 16 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&
         d->act == 0 && d->act_slope == 1.f && d->gain == 1.f) {
         const long waves = ((long)a.M + 15) / 16;
-        hipLaunchKernelGGL(igemm_narrow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+        wgs_note_kernel("igemm_narrow_kernel");
+        WGS_LAUNCH(igemm_narrow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
         WGS_CHECK_LAUNCH("igemm_narrow_kernel");
         return WGS_OK;
     }
@@ -664,7 +672,8 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
         int ks = d->ksplit;
         if (ks <= 0) { ks = (1024 + tiles - 1) / tiles; if (ks > nchunks / 4) ks = nchunks / 4; if (ks < 1) ks = 1; }
         a.ksplit = ks;
-        hipLaunchKernelGGL((igemm_wgrad_kernel<64, 128, 2, 2, true>), dim3((unsigned)tiles, 1, (unsigned)ks), dim3(256), 0, st, a);
+        wgs_note_kernel("igemm_wgrad_kernel<64, 128, 2, 2, true>");
+        WGS_LAUNCH((igemm_wgrad_kernel<64, 128, 2, 2, true>), dim3((unsigned)tiles, 1, (unsigned)ks), dim3(256), 0, st, a);
         WGS_CHECK_LAUNCH("igemm_wgrad_kernel<flat>");
         return WGS_OK;
     }
@@ -680,12 +689,13 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
     }
     a.ksplit = ks;
     dim3 grid((unsigned)tiles, (unsigned)d->ntaps, (unsigned)ks), block(256);
-    if (BM == 128 && BN == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, block, 0, st, a);
-    else if (BM == 128 && BN == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, block, 0, st, a);
-    else if (BM == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, block, 0, st, a);
-    else if (BN == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 128, 2, 2>), grid, block, 0, st, a);
-    else if (BN == 64) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 32, 2, 1>), grid, block, 0, st, a);
+    wgs_note_kernel("igemm_wgrad_kernel<%d, %d, %d, %d, false>", BM, BN, (BM == 128 && BN == 32) ? 4 : 2, (BN == 32) ? 1 : 2);
+    if (BM == 128 && BN == 128) WGS_LAUNCH((igemm_wgrad_kernel<128, 128, 2, 2>), grid, block, 0, st, a);
+    else if (BM == 128 && BN == 64) WGS_LAUNCH((igemm_wgrad_kernel<128, 64, 2, 2>), grid, block, 0, st, a);
+    else if (BM == 128) WGS_LAUNCH((igemm_wgrad_kernel<128, 32, 4, 1>), grid, block, 0, st, a);
+    else if (BN == 128) WGS_LAUNCH((igemm_wgrad_kernel<64, 128, 2, 2>), grid, block, 0, st, a);
+    else if (BN == 64) WGS_LAUNCH((igemm_wgrad_kernel<64, 64, 2, 2>), grid, block, 0, st, a);
+    else WGS_LAUNCH((igemm_wgrad_kernel<64, 32, 2, 1>), grid, block, 0, st, a);
     WGS_CHECK_LAUNCH("igemm_wgrad_kernel");
     return WGS_OK;
 }

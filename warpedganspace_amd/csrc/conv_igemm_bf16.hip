@@ -395,8 +395,9 @@ void launch_s(ConvArgs& a, hipStream_t st) {
 #define WGS_BF16_LAUNCH(AS, UP)                                                                             \
     {                                                                                                       \
         auto k = igemm_nt16_kernel<SCH, BM, BN, WAVES_M, WAVES_N, AS, UP>;                                  \
+        wgs_note_kernel("igemm_nt16_kernel<%d, %d, %d, %d, %d, %d, %s>", SCH, BM, BN, WAVES_M, WAVES_N, AS, UP ? "true" : "false"); \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);     \
-        hipLaunchKernelGGL(k, grid, block, sm, st, a);                                                      \
+        WGS_LAUNCH(k, grid, block, sm, st, a);                                                      \
     }
     if (a.ups) {
         if (mode == 0) WGS_BF16_LAUNCH(0, true) else if (mode == 1) WGS_BF16_LAUNCH(1, true) else WGS_BF16_LAUNCH(2, true)
@@ -421,12 +422,14 @@ void launch_big_s(ConvArgs& a, hipStream_t st, int nblocks) {
     dim3 grid((unsigned)(nblocks ? nblocks : ntm * ntn)), block(64 * WAVES_M * WAVES_N);
     if (!a.a_scale) {
         auto k = igemm_nt16_kernel<SCH, BM, BN, WAVES_M, WAVES_N, 0, false>;
+        wgs_note_kernel("igemm_nt16_kernel<%d, %d, %d, %d, %d, 0, false>", SCH, BM, BN, WAVES_M, WAVES_N);
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+        WGS_LAUNCH(k, grid, block, sm, st, a);
     } else {
         auto k = igemm_nt16_kernel<SCH, BM, BN, WAVES_M, WAVES_N, 2, false>;
+        wgs_note_kernel("igemm_nt16_kernel<%d, %d, %d, %d, %d, 2, false>", SCH, BM, BN, WAVES_M, WAVES_N);
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(k, grid, block, sm, st, a);
+        WGS_LAUNCH(k, grid, block, sm, st, a);
     }
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -442,12 +445,13 @@ namespace wgsconv {
 
 void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st) {
     const long work = (long)a.M * (a.Co / 4);
-    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    WGS_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
 }
 
 // operand extents for the buffer descriptors; every stream must be addressable with a 31-bit byte offset
 static bool set_extents(ConvArgs& a, int wt_max) {
-    const long xb = (long)a.B * a.Hi * a.Wi * a.Ci * 4;
+    // a producer-written fp16 plane (a_hi, wgs_conv_desc.x_f16) is addressed as such: 2 bytes per element
+    const long xb = (long)a.B * a.Hi * a.Wi * a.Ci * (a.a_hi ? 2 : 4);
     const long wb = ((long)wt_max * a.w_tap_stride + (long)(a.Co - 1) * a.w_row_stride + a.Ci) * 4;
     const long sb = a.a_scale ? ((long)(a.B - 1) * a.a_ld + a.Ci) * 4 : 0;
     const long lim = 0x7fffffffL;
@@ -532,7 +536,7 @@ int launch_bf16x3(const ConvArgs& a0, hipStream_t st) {
         const int ntm = (a.M + 255) / 256;
         const int bn = a.Co % 256 == 0 && ntm * (a.Co / 256) >= 200 ? 256 : 128;
         single_phase(a);
-        a.x_bytes /= 2; a.w_bytes /= 2;            // extents of the 16-bit planes
+        a.w_bytes /= 2;                            // extent of the 16-bit weight planes (x_bytes is the fp16 plane's already)
         launch_dma_bf16x3(a, bn, ntm * (a.Co / bn), st);
         return 0;
     }

@@ -317,8 +317,9 @@ void launch_dma_s(const ConvArgs& a, hipStream_t st, int nblocks) {
     const size_t stage = (size_t)(wgsconv::Scheme<SCH>::NA * BM + wgsconv::Scheme<SCH>::NB * BN) * ROW;
     const size_t sm = (WGS_DABL == 1 ? 2 : dma_stages((int)stage)) * stage;
     auto k = igemm_dma16_kernel<SCH, BM, BN, WAVES_M, WAVES_N>;
+    wgs_note_kernel("igemm_dma16_kernel<%d, %d, %d, %d, %d>", SCH, BM, BN, WAVES_M, WAVES_N);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a);
+    WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a);
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_dma(const ConvArgs& a, hipStream_t st, int nblocks) {
@@ -336,7 +337,7 @@ void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, un
     const long total4 = nsamples * per_sample / 4;
     long grid = (total4 + 255) / 256;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(modsplit_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4);
+    WGS_LAUNCH(modsplit_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4);
 }
 
 void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
@@ -344,7 +345,7 @@ void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, uns
     const long total4 = nsamples * per_sample / 4;
     long grid = (total4 + 255) / 256;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(modcvt_f16_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4, a_amax, a_amax2, a_bound);
+    WGS_LAUNCH(modcvt_f16_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, s, s_ld, hi, lo, per_sample / 4, C / 4, total4, a_amax, a_amax2, a_bound);
 }
 
 // a: fully prepared arguments (phases filled, a_hi/a_lo/w_hi/w_lo and extents set); bn = 256 or 128

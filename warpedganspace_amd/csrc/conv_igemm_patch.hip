@@ -358,8 +358,9 @@ void launch_patch_n(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStrea
     typedef wgsconv::Scheme<SCH> SC;
     const size_t sm = (size_t)SC::NA * pmax_of(BM) * PROW + (size_t)2 * TPS * SC::NB * BN * ROW;
     auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS, NTF>;
+    wgs_note_kernel("igemm_patch_kernel<%d, %d, %d, %d, %d, %d, %d>", SCH, BM, BN, WAVES_M, WAVES_N, TPS, NTF);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
+    WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
 }
 template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
 void launch_patch_t(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {

@@ -449,8 +449,9 @@ void launch_up(const UpArgs& a0, hipStream_t st) {
     a.tiles_per_img = a.tiles_x * ((a.H + CF::CY - 1) / CF::CY);
     const int nblocks = a.B * a.tiles_per_img * (a.Co / BN);
     auto k = upconv_blur_kernel<SCH, GH>;
+    wgs_note_kernel("upconv_blur_kernel<%d, %d>", SCH, GH);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(CF::NT), CF::SMEM, st, a);
+    WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(CF::NT), CF::SMEM, st, a);
 }
 
 }  // namespace

@@ -324,16 +324,18 @@ template <int BM>
 void launch16_row(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
     const size_t sm = (size_t)2 * (2 * BM + 3 * 2 * 64) * ROWB;
     auto k = igemm_wgrad16_row_kernel<BM>;
+    wgs_note_kernel("igemm_wgrad16_row_kernel<%d>", BM);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, grid, dim3(256), sm, st, a);
+    WGS_LAUNCH(k, grid, dim3(256), sm, st, a);
 }
 
 template <int BM, int BN>
 void launch16(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
     auto k = igemm_wgrad16_kernel<BM, BN>;
+    wgs_note_kernel("igemm_wgrad16_kernel<%d, %d>", BM, BN);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    hipLaunchKernelGGL(k, grid, dim3(256), sm, st, a);
+    WGS_LAUNCH(k, grid, dim3(256), sm, st, a);
 }
 
 }  // namespace

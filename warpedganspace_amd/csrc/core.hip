@@ -3,6 +3,7 @@
 #include "../../include/wgs.h"
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -10,6 +11,18 @@ void wgs_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static std::atomic<long> g_launches{0};
+static std::atomic<int> g_trace{0};
+static thread_local char g_kernel[160] = "";
+void wgs_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+void wgs_note_kernel(const char* fmt, ...) {
+    if (!g_trace.load(std::memory_order_relaxed)) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
     va_end(ap);
 }
 
@@ -36,4 +49,7 @@ extern "C" {
 const char* wgs_last_error(void) { return g_err; }
 int wgs_abi_version(void) { return 3; }
 void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
+int64_t wgs_dev_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
+void wgs_dev_trace_kernels(int on) { g_trace.store(on ? 1 : 0, std::memory_order_relaxed); g_kernel[0] = 0; }
+const char* wgs_dev_last_kernel(void) { return g_kernel; }
 }

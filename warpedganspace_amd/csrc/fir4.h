@@ -111,7 +111,7 @@ inline void launch_fir4(const float* x, const float* kern, float* y, int B, int 
                         const float* a_amax = nullptr, float a_bound = 1.f) {
     const int strips = (Ho + TY - 1) / TY;
     const long total = (long)B * strips * ((Wo + 1) / 2) * (C / 4);
-    hipLaunchKernelGGL((fir4_kernel<EPI, F16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
+    WGS_LAUNCH((fir4_kernel<EPI, F16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
                        C, py0, px0, noise, noise_w, bias, y_amax, a_amax, a_bound);
 }
 

@@ -133,7 +133,7 @@ int wgs_bias_act(const float* x, const float* bias, const float* ref, float* y, 
     const int mode = act * 10 + grad;
     int grid = wgs_cdiv(size_x / 4 + 1, 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, ref, y,
+    WGS_LAUNCH(bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, ref, y,
                        mode, alpha, scale, size_x, step_b > 0 ? step_b : 1, size_b > 0 ? size_b : 1);
     WGS_CHECK_LAUNCH("bias_act_kernel");
     return WGS_OK;
@@ -163,8 +163,8 @@ int wgs_upfirdn2d(const float* x, const float* kernel, float* y, int major, int 
     const int64_t total = (int64_t)major * p.out_h * p.out_w * (v4 ? minor / 4 : minor);
     int grid = wgs_cdiv(total, 256);
     if (grid > 4096) grid = 4096;
-    if (v4) hipLaunchKernelGGL(upfirdn2d_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, kernel, y, p);
-    else    hipLaunchKernelGGL(upfirdn2d_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, kernel, y, p);
+    if (v4) WGS_LAUNCH(upfirdn2d_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, kernel, y, p);
+    else    WGS_LAUNCH(upfirdn2d_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, kernel, y, p);
     WGS_CHECK_LAUNCH("upfirdn2d_kernel");
     return WGS_OK;
 }

@@ -373,13 +373,13 @@ int wgs_rbf_fwd(const float* table, const float* alphas, const float* loggamma, 
     const int S = rbf_splits(B, n2);
     dim3 grid(S, B), block(RBF_THREADS);
     switch (rbf_nt(d)) {
-        case 1: hipLaunchKernelGGL(rbf_fwd_partial<1>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
-        case 2: hipLaunchKernelGGL(rbf_fwd_partial<2>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
-        case 4: hipLaunchKernelGGL(rbf_fwd_partial<4>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
-        default: hipLaunchKernelGGL(rbf_fwd_partial<8>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
+        case 1: WGS_LAUNCH(rbf_fwd_partial<1>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
+        case 2: WGS_LAUNCH(rbf_fwd_partial<2>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
+        case 4: WGS_LAUNCH(rbf_fwd_partial<4>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
+        default: WGS_LAUNCH(rbf_fwd_partial<8>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, z, ws, B, n2, d, S); break;
     }
     WGS_CHECK_LAUNCH("rbf_fwd_partial");
-    hipLaunchKernelGGL(rbf_fwd_finish, dim3(B), block, 0, st, ws, scale, out, B, n2, d, S);
+    WGS_LAUNCH(rbf_fwd_finish, dim3(B), block, 0, st, ws, scale, out, B, n2, d, S);
     WGS_CHECK_LAUNCH("rbf_fwd_finish");
     return WGS_OK;
 }
@@ -395,7 +395,7 @@ int wgs_rbf_bwd(const float* table, const float* alphas, const float* loggamma, 
     const int S = rbf_splits(B, n2);
     dim3 grid(S, B), block(RBF_THREADS);
 #define WGS_RBF_BWD(NT)                                                                             \
-    hipLaunchKernelGGL(rbf_bwd_kernel<NT>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, \
+    WGS_LAUNCH(rbf_bwd_kernel<NT>, grid, block, 0, st, table, alphas, loggamma, gamma, idx, \
                        z, scale, gout, ws, dtable, dloggamma, dalphas, dz, B, n2, d, S)
     switch (rbf_nt(d)) {
         case 1: WGS_RBF_BWD(1); break;
@@ -426,7 +426,7 @@ int wgs_rbf_traverse(const float* table, const float* alphas, const float* logga
         auto kfn = rbf_traverse_kernel<NT_, L_>;                                                     \
         if (smem > 48 * 1024)                                                                        \
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-        hipLaunchKernelGGL(kfn, grid, block, smem, st, table, alphas, loggamma, gamma, codes, eps, T, \
+        WGS_LAUNCH(kfn, grid, block, smem, st, table, alphas, loggamma, gamma, codes, eps, T, \
                            path, shift, n_codes, K, n2, d);                                          \
     } while (0)
     if (in_lds) {

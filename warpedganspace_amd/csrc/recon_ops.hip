@@ -431,13 +431,13 @@ extern "C" {
 
 int wgs_pack_pair_nhwc(const float* x1, const float* x2, float* y, int B, int c, int HW, int Cp, wgs_stream_t stream) {
     WGS_CHECK_ARG(x1 && x2 && y && B > 0 && c > 0 && HW > 0 && Cp >= 2 * c, "wgs_pack_pair_nhwc: bad arguments");
-    hipLaunchKernelGGL(pack_pair_kernel, dim3(grid_for((int64_t)B * HW)), dim3(256), 0, (hipStream_t)stream, x1, x2, y, B, c, HW, Cp);
+    WGS_LAUNCH(pack_pair_kernel, dim3(grid_for((int64_t)B * HW)), dim3(256), 0, (hipStream_t)stream, x1, x2, y, B, c, HW, Cp);
     WGS_CHECK_LAUNCH("pack_pair_kernel");
     return WGS_OK;
 }
 int wgs_unpack_pair_grad(const float* dy, float* d1, float* d2, int B, int c, int HW, int Cp, wgs_stream_t stream) {
     WGS_CHECK_ARG(dy && (d1 || d2) && B > 0 && c > 0 && HW > 0 && Cp >= 2 * c, "wgs_unpack_pair_grad: bad arguments");
-    hipLaunchKernelGGL(unpack_pair_kernel, dim3(grid_for((int64_t)B * HW)), dim3(256), 0, (hipStream_t)stream, dy, d1, d2, B, c, HW, Cp);
+    WGS_LAUNCH(unpack_pair_kernel, dim3(grid_for((int64_t)B * HW)), dim3(256), 0, (hipStream_t)stream, dy, d1, d2, B, c, HW, Cp);
     WGS_CHECK_LAUNCH("unpack_pair_kernel");
     return WGS_OK;
 }
@@ -461,15 +461,15 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
     if (train) {
         (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
         const int rpb = reduce_rows_per_block(N, C);
-        hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+        WGS_LAUNCH(chan_reduce_kernel<0>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                            nullptr, nullptr, ws, N, C, rpb);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(wgs_cdiv(C, 256)), dim3(256), 0, st, ws, save_mean, save_invstd,
+        WGS_LAUNCH(bn_finalize_kernel, dim3(wgs_cdiv(C, 256)), dim3(256), 0, st, ws, save_mean, save_invstd,
                            running_mean, running_var, num_batches_tracked, N, C, eps, momentum);
     } else {
-        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(wgs_cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var,
+        WGS_LAUNCH(bn_eval_stats_kernel, dim3(wgs_cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var,
                            save_mean, save_invstd, C, eps);
     }
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta,
+    WGS_LAUNCH(bn_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta,
                        residual, y, N, C, relu);
     WGS_CHECK_LAUNCH("bn_fwd");
     return WGS_OK;
@@ -483,10 +483,10 @@ int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* 
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
     const int rpb = reduce_rows_per_block(N, C);
-    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
+    WGS_LAUNCH(chan_reduce_kernel<1>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
                        save_invstd, ws, N, C, rpb);
-    hipLaunchKernelGGL(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
+    WGS_LAUNCH(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
+    WGS_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
                        save_invstd, gamma, ws, dx, dres, dgamma, dbeta, N, C, train);
     WGS_CHECK_LAUNCH("bn_bwd");
     return WGS_OK;
@@ -497,7 +497,7 @@ int wgs_maxpool_fwd(const float* x, float* y, unsigned char* idx, int B, int Hi,
     WGS_CHECK_ARG(x && y && idx && B > 0 && Hi > 0 && Wi > 0 && C >= 4 && C % 4 == 0 && k > 0 && k <= 15 && s > 0 && p >= 0,
                   "wgs_maxpool_fwd: bad arguments");
     const int Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+    WGS_LAUNCH(maxpool_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
                        idx, B, Hi, Wi, C, Ho, Wo, k, s, p);
     WGS_CHECK_LAUNCH("maxpool_fwd_kernel");
     return WGS_OK;
@@ -507,7 +507,7 @@ int wgs_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B,
     WGS_CHECK_ARG(dy && idx && dx && B > 0 && Hi > 0 && Wi > 0 && C >= 4 && C % 4 == 0 && k > 0 && s > 0 && p >= 0,
                   "wgs_maxpool_bwd: bad arguments");
     const int Ho = (Hi + 2 * p - k) / s + 1, Wo = (Wi + 2 * p - k) / s + 1;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)B * Hi * Wi * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy,
+    WGS_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((int64_t)B * Hi * Wi * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy,
                        idx, dx, B, Hi, Wi, C, Ho, Wo, k, s, p);
     WGS_CHECK_LAUNCH("maxpool_bwd_kernel");
     return WGS_OK;
@@ -515,20 +515,20 @@ int wgs_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int B,
 
 int wgs_avgpool_fwd(const float* x, float* y, int B, int P, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && y && B > 0 && P > 0 && C > 0, "wgs_avgpool_fwd: bad arguments");
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(wgs_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, P, C);
+    WGS_LAUNCH(avgpool_fwd_kernel, dim3(wgs_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, P, C);
     WGS_CHECK_LAUNCH("avgpool_fwd_kernel");
     return WGS_OK;
 }
 int wgs_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(dy && dx && B > 0 && P > 0 && C > 0, "wgs_avgpool_bwd: bad arguments");
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, P, C);
+    WGS_LAUNCH(avgpool_bwd_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, P, C);
     WGS_CHECK_LAUNCH("avgpool_bwd_kernel");
     return WGS_OK;
 }
 
 int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "wgs_upsample2x_bwd: bad arguments (C %% 4)");
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C);
+    WGS_LAUNCH(upsample2x_bwd_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C);
     WGS_CHECK_LAUNCH("upsample2x_bwd_kernel");
     return WGS_OK;
 }
@@ -538,11 +538,11 @@ int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_str
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
     const int rpb = reduce_rows_per_block(N, C);
-    hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
+    WGS_LAUNCH(chan_reduce_kernel<2>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                        nullptr, ws, N, C, rpb);
-    hipLaunchKernelGGL(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
+    WGS_LAUNCH(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
     // reuse the BN-backward epilogue's block-0 copy: dbeta = s1
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(1), dim3(256), 0, st, x, x, nullptr, nullptr, x, x, x, ws, (float*)nullptr,
+    WGS_LAUNCH(bn_bwd_apply_kernel, dim3(1), dim3(256), 0, st, x, x, nullptr, nullptr, x, x, x, ws, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, out, (int64_t)0, C, 0);
     WGS_CHECK_LAUNCH("colsum");
     return WGS_OK;
@@ -555,9 +555,9 @@ int wgs_ce_l1_loss(const float* logits, const int64_t* target, const float* mag_
                   "wgs_ce_l1_loss: null pointer");
     WGS_CHECK_ARG(B > 0 && K > 0, "wgs_ce_l1_loss: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_rows_kernel, dim3(B), dim3(256), 0, st, logits, target, mag_pred, mag_target, lambda_cls, lambda_reg,
+    WGS_LAUNCH(loss_rows_kernel, dim3(B), dim3(256), 0, st, logits, target, mag_pred, mag_target, lambda_cls, lambda_reg,
                        dlogits, dmag, ws, ws + B, argmax, B, K);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, ws, ws + B, argmax, target, lambda_cls, lambda_reg, stats, B);
+    WGS_LAUNCH(loss_finish_kernel, dim3(1), dim3(256), 0, st, ws, ws + B, argmax, target, lambda_cls, lambda_reg, stats, B);
     WGS_CHECK_LAUNCH("ce_l1_loss");
     return WGS_OK;
 }
@@ -569,7 +569,7 @@ int wgs_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+    WGS_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                        beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
     WGS_CHECK_LAUNCH("adam_kernel");
     return WGS_OK;

@@ -612,13 +612,13 @@ extern "C" {
 
 int wgs_pixelnorm_fwd(const float* x, float* y, int rows, int d, float eps, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && y && rows > 0 && d > 0, "wgs_pixelnorm_fwd: bad arguments");
-    hipLaunchKernelGGL(pixelnorm_fwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, d, eps);
+    WGS_LAUNCH(pixelnorm_fwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, d, eps);
     WGS_CHECK_LAUNCH("pixelnorm_fwd_kernel");
     return WGS_OK;
 }
 int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && gy && gx && rows > 0 && d > 0, "wgs_pixelnorm_bwd: bad arguments");
-    hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, rows, d, eps);
+    WGS_LAUNCH(pixelnorm_bwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, rows, d, eps);
     WGS_CHECK_LAUNCH("pixelnorm_bwd_kernel");
     return WGS_OK;
 }
@@ -631,7 +631,7 @@ int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
                   "wgs_linear_fwd: need K %% 4 == 0, K <= 2048, ldx %% 4 == 0 (M=%d N=%d K=%d ldx=%d)", M, N, K, ldx);
     dim3 grid(wgs_cdiv(N, 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define WGS_LIN(NT) hipLaunchKernelGGL(linear_fwd_kernel<NT>, grid, block, 0, st, x, w, bias, y, M, N, K, ldx, ldy, wscale, bscale, in_square, epilogue, eps, out_gain)
+#define WGS_LIN(NT) WGS_LAUNCH(linear_fwd_kernel<NT>, grid, block, 0, st, x, w, bias, y, M, N, K, ldx, ldy, wscale, bscale, in_square, epilogue, eps, out_gain)
     if (K <= 256) WGS_LIN(1); else if (K <= 512) WGS_LIN(2); else if (K <= 1024) WGS_LIN(4); else WGS_LIN(8);
 #undef WGS_LIN
     WGS_CHECK_LAUNCH("linear_fwd_kernel");
@@ -646,7 +646,7 @@ int wgs_mapping_mlp_fwd(const float* z, const float* const* w, const float* cons
     a.z = z; a.acts = acts; a.B = B; a.d = d; a.L = L; a.wscale = wscale; a.lr_mul = lr_mul; a.eps = eps;
     for (int l = 0; l < 16; ++l) { a.w[l] = l < L ? w[l] : nullptr; a.b[l] = l < L ? bias[l] : nullptr; }
     for (int l = 0; l < L; ++l) WGS_CHECK_ARG(a.w[l] && a.b[l], "wgs_mapping_mlp_fwd: null layer %d", l);
-    hipLaunchKernelGGL(mapping_mlp_fwd_kernel, dim3(wgs_cdiv(B, MLP_RPB)), dim3(512), 0, (hipStream_t)stream, a);
+    WGS_LAUNCH(mapping_mlp_fwd_kernel, dim3(wgs_cdiv(B, MLP_RPB)), dim3(512), 0, (hipStream_t)stream, a);
     WGS_CHECK_LAUNCH("mapping_mlp_fwd_kernel");
     return WGS_OK;
 }
@@ -663,7 +663,7 @@ int wgs_linear_fwd_batch(const wgs_linear_batch* b, wgs_stream_t stream) {
         a.wscale[i] = b->wscale[i]; a.eps[i] = b->eps[i]; a.out_gain[i] = b->out_gain[i];
         nmax = b->N[i] > nmax ? b->N[i] : nmax;
     }
-    hipLaunchKernelGGL(linear_fwd_batch_kernel, dim3(wgs_cdiv(nmax, 4), b->n), dim3(256), 0, (hipStream_t)stream, a);
+    WGS_LAUNCH(linear_fwd_batch_kernel, dim3(wgs_cdiv(nmax, 4), b->n), dim3(256), 0, (hipStream_t)stream, a);
     WGS_CHECK_LAUNCH("linear_fwd_batch_kernel");
     return WGS_OK;
 }
@@ -671,7 +671,7 @@ int wgs_linear_fwd_batch(const wgs_linear_batch* b, wgs_stream_t stream) {
 int wgs_linear_dgrad(const float* gy, const float* w, const float* gate_y, float* gx, int M, int N, int K, int ldg,
                      int ldx, float wscale, float gate_slope, float gate_gain, int accumulate, wgs_stream_t stream) {
     WGS_CHECK_ARG(gy && w && gx && M > 0 && N > 0 && K > 0, "wgs_linear_dgrad: bad arguments");
-    hipLaunchKernelGGL(linear_dgrad_kernel, dim3(wgs_cdiv(K, 16), M), dim3(256), 0, (hipStream_t)stream, gy, w, gate_y,
+    WGS_LAUNCH(linear_dgrad_kernel, dim3(wgs_cdiv(K, 16), M), dim3(256), 0, (hipStream_t)stream, gy, w, gate_y,
                        gx, M, N, K, ldg, ldx, wscale, gate_slope, gate_gain, accumulate);
     WGS_CHECK_LAUNCH("linear_dgrad_kernel");
     return WGS_OK;
@@ -679,7 +679,7 @@ int wgs_linear_dgrad(const float* gy, const float* w, const float* gate_y, float
 
 int wgs_linear_wgrad(const float* gy, const float* x, float* dw, float* db, int M, int N, int K, wgs_stream_t stream) {
     WGS_CHECK_ARG(gy && x && dw && M > 0 && N > 0 && K > 0, "wgs_linear_wgrad: bad arguments");
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(wgs_cdiv(K, 256), N), dim3(256), 0, (hipStream_t)stream, gy, x, dw, db, M, N, K);
+    WGS_LAUNCH(linear_wgrad_kernel, dim3(wgs_cdiv(K, 256), N), dim3(256), 0, (hipStream_t)stream, gy, x, dw, db, M, N, K);
     WGS_CHECK_LAUNCH("linear_wgrad_kernel");
     return WGS_OK;
 }
@@ -714,7 +714,7 @@ int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const floa
     while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 8192) ppb >>= 1;      // >= 4 rounds of ~8 workgroups per CU: prologue / epilogue
                                                                           // of one round under the streaming of the next
     if (C < 32) ppb = 256;                // a wave iteration covers 64 / (C/4) pixels: needs ppb/4 >= that
-    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale, ppb,
+    WGS_LAUNCH(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias, skip, img, P, C, wscale, ppb,
                        (const float*)nullptr, (const float*)nullptr, 0, C);
     WGS_CHECK_LAUNCH("torgb_fwd_kernel");
     return WGS_OK;
@@ -731,7 +731,7 @@ int wgs_sg2_torgb_up_fwd(const float* x, const float* s, int s_ld, const float* 
     while (ppb > 64 && (long)wgs_cdiv(P, ppb) * B < 8192) ppb >>= 1;      // >= 4 rounds of ~8 workgroups per CU: prologue / epilogue
                                                                           // of one round under the streaming of the next
     if (C < 32) ppb = 256;
-    hipLaunchKernelGGL(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias,
+    WGS_LAUNCH(torgb_fwd_kernel, dim3(wgs_cdiv(P, ppb), B), dim3(256), smem, (hipStream_t)stream, x, s, w, bias,
                        (const float*)nullptr, img, P, C, wscale, ppb, skip_lo, up_kernel4x4, W, s_ld > 0 ? s_ld : C);
     WGS_CHECK_LAUNCH("torgb_fwd_kernel<up>");
     return WGS_OK;
@@ -752,7 +752,7 @@ static int sg2_act_bwd_launch(const char* name, const float* out, const float* g
     int chunk = wgs_cdiv(P, chunks);
     if (chunk < 16) chunk = 16;
     chunks = wgs_cdiv(P, chunk);
-    hipLaunchKernelGGL(sg2_act_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
+    WGS_LAUNCH(sg2_act_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
                        rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk, s_ld > 0 ? s_ld : C,
                        reinterpret_cast<unsigned short*>(dy_h), dy_bound);
     WGS_CHECK_LAUNCH("sg2_act_bwd_kernel");
@@ -809,7 +809,7 @@ int wgs_sg2_dy_bound(const float* gA_amax, const float* sA, const float* drgb_am
     WGS_CHECK_ARG(!gA_amax || sA, "wgs_sg2_dy_bound: gA_amax needs sA");
     WGS_CHECK_ARG(!drgb_amax || (wR && sR), "wgs_sg2_dy_bound: drgb_amax needs wR and sR");
     WGS_CHECK_ARG(B > 0 && C > 0, "wgs_sg2_dy_bound: bad sizes");
-    hipLaunchKernelGGL(sg2_dy_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gA_amax, sA, drgb_amax, drgb_factor, wR, sR,
+    WGS_LAUNCH(sg2_dy_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gA_amax, sA, drgb_amax, drgb_factor, wR, sR,
                        rscale, post_scale, bound, B, C, s_ld > 0 ? s_ld : C);
     WGS_CHECK_LAUNCH("sg2_dy_bound_kernel");
     return WGS_OK;
@@ -817,7 +817,7 @@ int wgs_sg2_dy_bound(const float* gA_amax, const float* sA, const float* drgb_am
 
 int wgs_xg_reduce(const float* x, int x_batched, const float* g, float* ds, int B, int P, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && g && ds && B > 0 && P > 0 && C > 0, "wgs_xg_reduce: bad arguments");
-    hipLaunchKernelGGL(xg_reduce_kernel, dim3(wgs_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, x, x_batched, g, ds, P, C);
+    WGS_LAUNCH(xg_reduce_kernel, dim3(wgs_cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, x, x_batched, g, ds, P, C);
     WGS_CHECK_LAUNCH("xg_reduce_kernel");
     return WGS_OK;
 }
@@ -826,7 +826,7 @@ int wgs_sg2_style_grad(const float* num, const float* demod, const float* s, con
                        float scale2, float* dstyle, int B, int Co, int Ci, int ld_s, int ld_out, wgs_stream_t stream) {
     WGS_CHECK_ARG(s && dsdir && dstyle && B > 0 && Co > 0 && Ci > 0, "wgs_sg2_style_grad: bad arguments");
     WGS_CHECK_ARG(!demod || (num && wsq), "wgs_sg2_style_grad: demod needs num and wsq");
-    hipLaunchKernelGGL(sg2_style_grad_kernel, dim3(wgs_cdiv(Ci, 64), B), dim3(256), 0, (hipStream_t)stream, num, demod, s,
+    WGS_LAUNCH(sg2_style_grad_kernel, dim3(wgs_cdiv(Ci, 64), B), dim3(256), 0, (hipStream_t)stream, num, demod, s,
                        dsdir, wsq, scale2, dstyle, Co, Ci, ld_s, ld_out);
     WGS_CHECK_LAUNCH("sg2_style_grad_kernel");
     return WGS_OK;
@@ -844,14 +844,14 @@ int wgs_sg2_style_grad_batch(const wgs_style_grad_batch* d, wgs_stream_t stream)
         a.dstyle[l] = d->dstyle[l]; a.Co[l] = d->Co[l]; a.Ci[l] = d->Ci[l]; a.scale2[l] = d->scale2[l];
         cimax = d->Ci[l] > cimax ? d->Ci[l] : cimax;
     }
-    hipLaunchKernelGGL(sg2_style_grad_batch_kernel, dim3(wgs_cdiv(cimax, 64), d->B, d->n), dim3(256), 0, (hipStream_t)stream, a);
+    WGS_LAUNCH(sg2_style_grad_batch_kernel, dim3(wgs_cdiv(cimax, 64), d->B, d->n), dim3(256), 0, (hipStream_t)stream, a);
     WGS_CHECK_LAUNCH("sg2_style_grad_batch_kernel");
     return WGS_OK;
 }
 
 int wgs_sg2_wsq(const float* w_packed, float* wsq, int Co, int T, int Ci, wgs_stream_t stream) {
     WGS_CHECK_ARG(w_packed && wsq && Co > 0 && T > 0 && Ci > 0, "wgs_sg2_wsq: bad arguments");
-    hipLaunchKernelGGL(wsq_kernel, dim3(wgs_cdiv(Ci, 256), Co), dim3(256), 0, (hipStream_t)stream, w_packed, wsq, Co, T, Ci);
+    WGS_LAUNCH(wsq_kernel, dim3(wgs_cdiv(Ci, 256), Co), dim3(256), 0, (hipStream_t)stream, w_packed, wsq, Co, T, Ci);
     WGS_CHECK_LAUNCH("wsq_kernel");
     return WGS_OK;
 }

@@ -36,6 +36,14 @@ void wgs_set_error(const char* fmt, ...);
 struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap, patch_wide; };
 const WgsFlags& wgs_flags();
 
+// Launch accounting for bench.py (statistics only; nothing reads them on a launch path):
+//   wgs_count_launch()  every kernel launch of the library bumps one relaxed atomic (wgs_dev_launch_count()).
+//   wgs_note_kernel()   with wgs_dev_trace_kernels(1): the symbol of the last implicit-GEMM kernel launched on this thread,
+//                       spelled as rocprofv3 prints it, for the per-symbol roofline (wgs_dev_last_kernel()).
+void wgs_count_launch();
+void wgs_note_kernel(const char* fmt, ...);
+#define WGS_LAUNCH(...) do { wgs_count_launch(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int wgs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // n / d for a launch-uniform divisor d >= 2 as one multiply-high: magic = ceil(2^32 / d), exact for n * d < 2^32
 // (a 32-bit integer division is ~35 VALU instructions on gfx950; the short-K conv tiles do a dozen of them per lane).

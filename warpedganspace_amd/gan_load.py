@@ -24,15 +24,29 @@ class StyleGAN2Wrapper(nn.Module):
         """Z-space codes [B,512] -> W-space codes [B,512] (mapping network)."""
         return self.G.get_latent(z)
 
-    def forward(self, z, shift=None, latent_is_w=False):
+    def forward(self, z, shift=None, latent_is_w=False, precision=None):
         """z: latent codes (Z space, or W space when `latent_is_w`); shift: shift vectors in the space
-        selected by `shift_in_w_space`.  Returns images [B, 3, res, res] (NCHW, un-clamped)."""
+        selected by `shift_in_w_space`.  Returns images [B, 3, res, res] (NCHW, un-clamped).
+        precision (extension): arithmetic of this call's convs (conv.PRECISION_NAMES); default: the generator's `precision`."""
         if self.shift_in_w_space:
             if latent_is_w:
-                return self.G([z if shift is None else z + shift], input_is_latent=True)[0]
+                return self.G([z if shift is None else z + shift], input_is_latent=True, precision=precision)[0]
             w = self.G.get_latent(z)
-            return self.G([w if shift is None else w + shift], input_is_latent=True)[0]
-        return self.G([z if shift is None else z + shift], input_is_latent=False)[0]
+            return self.G([w if shift is None else w + shift], input_is_latent=True, precision=precision)[0]
+        return self.G([z if shift is None else z + shift], input_is_latent=False, precision=precision)[0]
+
+    def resolve_precision(self, requested=None):
+        return self.G.resolve_precision(requested)
+
+
+def set_generator_precision(G, precision):
+    """Arithmetic of the convs of wrapper / generator `G` for calls that do not pass `precision=` (conv.PRECISION_NAMES):
+    an attribute of that generator instance, nothing process-wide.  Returns G."""
+    from . import conv as C
+    C.precision_code(precision)                  # validates the name
+    inner = G.G if hasattr(G, 'G') else G
+    inner.precision = precision
+    return G
 
 
 def build_stylegan2(pretrained_gan_weights=None, resolution=1024, shift_in_w_space=False):

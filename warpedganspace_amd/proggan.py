@@ -40,10 +40,9 @@ class _Block(nn.Module):
 
 class _PG(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, G, z):
-        ctx.prec = C.resolve_auto('proggan', 4 << ((G.num_blocks - 2) // 2))
-        with C.resolved(ctx.prec):
-            img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
+    def forward(ctx, G, z, prec):
+        ctx.prec = prec
+        img, saved = G._fwd(z, ctx.needs_input_grad[1], prec)
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:     # leaky-relu gates, NCHW (tests)
             G.debug_keep['gates'] = [(y > 0).permute(0, 3, 1, 2) for (_, _, y) in saved[0]]
@@ -51,8 +50,7 @@ class _PG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        with C.resolved(ctx.prec), C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
-            return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
+        return None, ctx.G._bwd(ctx.saved, gimg.contiguous(), ctx.prec), None
 
 
 class Generator(nn.Module):
@@ -67,6 +65,10 @@ class Generator(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self.debug_keep = None
+        self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
+
+    def resolve_precision(self, requested=None):
+        return C.resolve(self.precision if requested is None else requested, 'proggan', 4 << ((self.num_blocks - 2) // 2))
 
     def _apply(self, fn, *a, **k):
         self._prep = None
@@ -116,7 +118,7 @@ class Generator(nn.Module):
         L.check(L.lib().wgs_pixelnorm_bwd(L.ptr(x), L.ptr(gy), L.ptr(gx), rows, d, L.c_float(eps), L.stream()), 'pixelnorm_bwd')
         return gx
 
-    def _fwd(self, z, save):
+    def _fwd(self, z, save, prec):
         """z [B,512] (the wrapper reshapes to [B,512,1,1], models/gan_load.py:115-120)."""
         P = self._prepare()
         B = z.shape[0]
@@ -130,7 +132,7 @@ class Generator(nn.Module):
             k, pad = ly['k'], ly['pad']
             taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
             C.launch(xn, ly['wp'], y, taps, Ho, Ho, w_tap_stride=ly['ci'], w_row_stride=k * k * ly['ci'], ups=1 if ly['up'] else 0,
-                     alpha=ly['scale'], bias=ly['b'], act_slope=0.2, gain=1.0, w_split=ly['ws'])
+                     alpha=ly['scale'], bias=ly['b'], act_slope=0.2, gain=1.0, w_split=ly['ws'], precision=prec)
             if save:
                 saved.append((x, xn, y))
             x = y
@@ -138,11 +140,12 @@ class Generator(nn.Module):
         o = P['out']
         Hc = x.shape[1]
         y4 = torch.empty(B, Hc, Hc, 8, device=z.device)
-        C.launch(xn, o['wp'], y4, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['scale'], bias=o['b'])
+        C.launch(xn, o['wp'], y4, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['scale'], bias=o['b'], precision=prec)
         img = y4[..., :3].permute(0, 3, 1, 2).contiguous()
         return img, ((saved, x, xn) if save else None)
 
-    def _bwd(self, saved_all, gimg):
+    def _bwd(self, saved_all, gimg, prec):
+        # fp16 modes: gradient operands without a magnitude bound run in split-bf16 (grad_operand=True)
         P = self._prepare()
         lib, st = L.lib(), L.stream()
         saved, x_last, xn_last = saved_all
@@ -153,7 +156,7 @@ class Generator(nn.Module):
         g4[..., :3] = gimg.permute(0, 2, 3, 1)
         o = P['out']
         gxn = torch.empty(B, Hc, Hc, o['ci'], device=dev)
-        C.launch(g4, o['wt'], gxn, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'] * 8, w_row_stride=8, alpha=o['scale'])
+        C.launch(g4, o['wt'], gxn, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'] * 8, w_row_stride=8, alpha=o['scale'], precision=prec, grad_operand=True)
         g = self._pixelnorm_bwd(x_last, gxn)
         for ly, (x, xn, y) in zip(reversed(P['layers']), reversed(saved)):
             # y = lrelu(scale*conv + b): dpre = g * (y > 0 ? 1 : 0.2)
@@ -165,7 +168,7 @@ class Generator(nn.Module):
             dup = torch.empty(B, Hup, Hup, ly['ci'], device=dev)
             taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
             C.launch(dpre, ly['wt'], dup, taps, Hup, Hup, w_tap_stride=ly['ci'] * ly['co'], w_row_stride=ly['co'], alpha=ly['scale'],
-                     w_split=ly['wts'])
+                     w_split=ly['wts'], precision=prec, grad_operand=True)
             if ly['up']:
                 gxn = torch.empty_like(xn)
                 L.check(lib.wgs_upsample2x_bwd(L.ptr(dup), L.ptr(gxn), B, x.shape[1], x.shape[2], ly['ci'], st), 'upsample_bwd')
@@ -174,9 +177,9 @@ class Generator(nn.Module):
             g = self._pixelnorm_bwd(x, gxn)
         return g.reshape(B, 512)
 
-    def forward(self, x):
-        """x: [B,512,1,1] like the reference (or [B,512])."""
-        return _PG.apply(self, x.reshape(x.shape[0], -1))
+    def forward(self, x, precision=None):
+        """x: [B,512,1,1] like the reference (or [B,512]).  precision (extension): arithmetic of this call's convs."""
+        return _PG.apply(self, x.reshape(x.shape[0], -1), self.resolve_precision(precision))
 
 
 class ProgGANWrapper(nn.Module):
@@ -191,8 +194,11 @@ class ProgGANWrapper(nn.Module):
     def _reshape(z):
         return z.reshape(z.size()[0], z.size()[1], 1, 1)
 
-    def forward(self, z, shift=None):
-        return self.G(self._reshape(z) if shift is None else self._reshape(z + shift))
+    def forward(self, z, shift=None, precision=None):
+        return self.G(self._reshape(z) if shift is None else self._reshape(z + shift), precision=precision)
+
+    def resolve_precision(self, requested=None):
+        return self.G.resolve_precision(requested)
 
 
 def build_proggan(pretrained_gan_weights=None, num_blocks=18):

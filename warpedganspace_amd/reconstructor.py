@@ -13,12 +13,12 @@ checkpoint compatibility but never executed: the reference runs it and discards 
 
 Execution is an explicit kernel schedule on NHWC activations: implicit-GEMM MFMA convs (fwd / dgrad /
 wgrad), fused train-mode BatchNorm(+residual)(+ReLU), max/avg pooling, small dense heads.
-The trained network's FORWARD convs use the EXACT fp32 MFMA kernels by default, whatever arithmetic the frozen generator
-runs in: ReLU gates and train-mode BatchNorm statistics are fixed by the forward, and the gates that flip between two
-fp32-class evaluations move single gradient entries by ~1e-2 (R_PRECISION below).  The input-gradient (dgrad) convs and the
->= 128-channel weight gradients are linear in dy for fixed gates / statistics and run in split-bf16 (~1e-5 relative).
+Arithmetic (RArith below): the reference's is fp32 everywhere, and that is what a Reconstructor runs unless told otherwise.  The
+fp32-class alternative, split-bf16 x3 (3 bf16 MFMAs per product, ~2^-16 per product), can be selected separately for the forward
+convs, the input-gradient convs and the weight-gradient contractions; the training step picks it when its generator runs in a
+16-bit mode (TrainStep r_precision='auto').
 """
-import os
+from collections import namedtuple
 
 import torch
 from torch import nn
@@ -27,40 +27,37 @@ from . import _lib as L
 from . import conv as C
 
 BN_EPS, BN_MOM = 1e-5, 0.1
-# Arithmetic of R's FORWARD convs.  'fp32' = exact fp32 MFMA; 'bf16x3' = split-bf16 x3 (fp32-class, ~2^-16 per product: logits
-# move by ~1e-5 relative, argmax unchanged, 1.05 ms less per 27.6 ms step); 'auto' (default) = split-bf16 when the training step's
-# GENERATOR runs in a 16-bit mode, exact otherwise — and exact for a Reconstructor used on its own (no generator_precision set).
-# Why not simply exact: with an fp16-operand generator the images R sees differ from the fp32 ones by ~7e-4, which flips far more of
-# R's ReLU gates / max-pool winners than a 1e-5 perturbation of its own convs; and the reference's own convs run in TF32 (2^-11) on
-# the GPUs it targets (torch.backends.cudnn.allow_tf32 defaults to True).  Why not always: on identical inputs the extra gate
-# flips of split-bf16 move single parameter-gradient entries by ~2e-2 of the tensor maximum against < 1e-3 for the exact kernels
-# (tests/test_reconstructor_gpu.py), so the exact path stays the reference point of the unit tests and of --precision fp32 runs.
-# WGS_R_PRECISION / bench.py --r-precision.
-R_PRECISION = os.environ.get('WGS_R_PRECISION', 'auto').lower()
 
 
-def forward_precision(generator_precision=None):
-    if R_PRECISION in ('fp32', '0', 0):
-        return 0
-    if R_PRECISION in ('bf16x3', '1', 1):
-        return 1
-    return 1 if (generator_precision is not None and generator_precision >= 1) else 0
+class RArith(namedtuple('RArith', ['forward', 'dgrad', 'wgrad'])):
+    """Arithmetic of the Reconstructor's convs: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 x3 (fp32-class).
+      forward  the forward convs.  ReLU gates and train-mode BatchNorm statistics are fixed by the forward; on identical inputs the
+               extra gate flips of split-bf16 move single parameter-gradient entries by ~2e-2 of the tensor maximum (< 1e-3 exact,
+               tests/test_reconstructor_gpu.py) - but inside a step whose generator runs in a 16-bit mode R never sees identical
+               inputs: its images differ from the fp32 ones by ~5e-4, which flips far more gates than a 1e-5 perturbation of R's
+               own convs (and the reference's own convs run in TF32, 2^-11, on the GPUs it targets);
+      dgrad    the BasicBlocks' and conv1's input-gradient convs (linear in dy for fixed gates / statistics: a smooth ~1e-5);
+      wgrad    the weight-gradient contractions where the 16-bit kernels beat the exact one (>= 128 channels on both sides, and
+               the stride-1 3x3 convs at 64 channels through the kernel-row form, conv_wgrad16.hip); the others stay exact."""
 
 
-# Arithmetic of R's input-gradient (dgrad) convs of the BasicBlocks.  The activation gates and BN statistics that make R's
-# gradients sensitive are fixed by the (exact fp32) forward; the backward is linear in dy, so split-bf16 (~1e-5 relative) is
-# a smooth perturbation there (this includes conv1's image gradient, which with only 6(+2) output channels runs 75 %-empty
-# MFMA tiles either way).  WGS_R_DGRAD_PRECISION=fp32 restores the exact kernels.
-R_DGRAD_PRECISION = 0 if os.environ.get('WGS_R_DGRAD_PRECISION', 'bf16x3').lower() in ('fp32', '0') else 1
-# Arithmetic of R's weight-gradient contractions (over pixels; gates and statistics are fixed by the forward, the result is
-# linear in dy like the input gradients): split-bf16 x3 (~1e-5 relative) for the layers with >= 128 channels on both sides,
-# where the transposing 16-bit kernel measures 1.2-1.3x the exact one (62-90 vs 55-70 TFLOP/s; at 64 channels its staging
-# costs more than the MFMAs save: 45-50 vs 63 TFLOP/s, so those layers and conv1 keep the exact kernel).
-# WGS_R_WGRAD_PRECISION=fp32 selects the exact kernel everywhere.
-R_WGRAD_PRECISION = 0 if os.environ.get('WGS_R_WGRAD_PRECISION', 'bf16x3').lower() in ('fp32', '0') else 1
-# conv1's image gradient (64 -> 6(+2) channels over B x 256^2 pixels): development A/B between the exact narrow kernel
-# (igemm_narrow_kernel, precision 0) and the 128 x 32 split-bf16 tiles
-R_CONV1_DGRAD_PRECISION = 0 if os.environ.get('WGS_R_CONV1_DGRAD', 'bf16x3').lower() in ('fp32', '0') else R_DGRAD_PRECISION
+R_EXACT = RArith(0, 0, 0)            # the reference's arithmetic
+R_FP32_CLASS = RArith(1, 1, 1)
+
+
+def r_arith(r_precision='auto', generator_code=None):
+    """RArith for a requested mode: 'fp32' exact everywhere; 'bf16x3' fp32-class everywhere; 'auto' follows the generator the
+    step runs (exact when it is exact fp32 or unknown, fp32-class when it runs in any 16-bit mode); an RArith passes through."""
+    if isinstance(r_precision, RArith):
+        return r_precision
+    key = str(r_precision).lower()
+    if key in ('fp32', '0'):
+        return R_EXACT
+    if key in ('bf16x3', '1'):
+        return R_FP32_CLASS
+    if key == 'auto':
+        return R_FP32_CLASS if (generator_code is not None and generator_code >= 1) else R_EXACT
+    raise L.WgsError("unknown reconstructor precision %r (fp32, bf16x3, auto)" % (r_precision,))
 
 
 def _conv(ci, co, k, stride, pad):
@@ -184,6 +181,7 @@ class Reconstructor(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        self.arith = R_EXACT         # arithmetic of forward() / _forward_impl() calls that do not pass one
 
     def _param_list(self):
         return list(self.parameters())
@@ -210,7 +208,7 @@ class Reconstructor(nn.Module):
         return _RFunction.apply(self, x1, x2, *self._param_list())
 
     # -- explicit schedule -------------------------------------------------------------------------------
-    def _forward_impl(self, x1, x2, save=True):
+    def _forward_impl(self, x1, x2, save=True, arith=None):
         if self.reconstructor_type == 'LeNet':
             from . import lenet
             return lenet.forward_impl(self, x1, x2, save)
@@ -226,7 +224,8 @@ class Reconstructor(nn.Module):
         L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
         # stem: conv1 weights padded from 2c to Cp input channels
         w1p = self._conv1_padded(c, Cp, dev)
-        fp = forward_precision(getattr(self, 'generator_precision', None))
+        arith = arith or self.arith
+        fp = arith.forward
         c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=fp)
         a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
         Hp = (a1.shape[1] + 2 - 3) // 2 + 1
@@ -260,7 +259,7 @@ class Reconstructor(nn.Module):
             L.check(lib.wgs_linear_fwd(L.ptr(feat), L.ptr(lin.weight), L.ptr(lin.bias), L.ptr(out), B, n, 512, 512, n,
                                        L.c_float(1.0), L.c_float(1.0), 0, 0, L.c_float(0.0), L.c_float(1.0), st), 'head')
         saved = dict(x=x, c1=c1, a1=a1, st1=st1, idx=idx, p1shape=p1.shape, blocks=saved_blocks, feat=feat, hshape=h.shape,
-                     B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws) if save else None
+                     B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws, arith=arith) if save else None
         return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
 
     def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None):
@@ -273,6 +272,7 @@ class Reconstructor(nn.Module):
         fe = self.features_extractor
         lib, st = L.lib(), L.stream()
         B, train, ws = S['B'], S['train'], S['ws']
+        arith = S['arith']           # the backward runs in the arithmetic the forward was told
         dev = dlogits.device
         K = self.dim
         grads = {}
@@ -282,7 +282,7 @@ class Reconstructor(nn.Module):
         def wgrad(x, dy, dw, k, stride, pad):
             # split-bf16 where it beats the exact kernel: >= 128 channels on both sides, and the stride-1 3x3 convs at 64
             # channels through the kernel-row form (conv_wgrad16.hip: 88 vs 65 TFLOP/s)
-            prec = R_WGRAD_PRECISION if (min(x.shape[-1], dy.shape[-1]) >= 128 or (k == 3 and stride == 1 and x.shape[-1] % 64 == 0)) else 0
+            prec = arith.wgrad if (min(x.shape[-1], dy.shape[-1]) >= 128 or (k == 3 and stride == 1 and x.shape[-1] % 64 == 0)) else 0
             if deferred is None:
                 C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad, precision=prec)
             else:
@@ -314,7 +314,7 @@ class Reconstructor(nn.Module):
             dw2 = gbuf[id(blk.conv2.weight)] if gbuf is not None else torch.zeros_like(w2)
             wgrad(aa, dcb, dw2, 3, 1, 1)
             grads[id(blk.conv2.weight)] = _grad_like(blk.conv2, dw2)
-            daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=R_DGRAD_PRECISION)
+            daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=arith.dgrad)
             dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train, gbuf=gbuf)
             grads[id(blk.bn1.weight)], grads[id(blk.bn1.bias)] = dg, db_
             w1 = _packed(blk.conv1)
@@ -322,7 +322,7 @@ class Reconstructor(nn.Module):
             dw1 = gbuf[id(blk.conv1.weight)] if gbuf is not None else torch.zeros_like(w1)
             wgrad(xin, dca, dw1, 3, blk.stride, 1)
             grads[id(blk.conv1.weight)] = _grad_like(blk.conv1, dw1)
-            dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=R_DGRAD_PRECISION)
+            dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=arith.dgrad)
             if blk.downsample is not None:
                 dcd, _, dg, db_ = _BN.bwd(blk.downsample[1], cd, sd, dres, None, None, ws, train=train, gbuf=gbuf)
                 grads[id(blk.downsample[1].weight)], grads[id(blk.downsample[1].bias)] = dg, db_
@@ -331,7 +331,7 @@ class Reconstructor(nn.Module):
                 dwd = gbuf[id(blk.downsample[0].weight)] if gbuf is not None else torch.zeros_like(wd)
                 wgrad(xin, dcd, dwd, 1, blk.stride, 0)
                 grads[id(blk.downsample[0].weight)] = _grad_like(blk.downsample[0], dwd)
-                dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0, precision=R_DGRAD_PRECISION)
+                dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0, precision=arith.dgrad)
             else:
                 dside = dres
             dyA, dyB = dmain, dside
@@ -353,7 +353,7 @@ class Reconstructor(nn.Module):
         if need_x[0] or need_x[1]:
             w1p = self._conv1_padded(c, Cp, dev)        # same weights as in the forward of this step (Adam runs after the backward)
             w1t = C.repack_w_t(w1p, 64, 49, Cp, out=self._scratch('w1t', (49, Cp, 64), torch.float32, dev))
-            dx = C.conv2d_dgrad(dc1, w1t, (S["H"], S["W"]), 7, stride=2, pad=3, precision=R_CONV1_DGRAD_PRECISION)
+            dx = C.conv2d_dgrad(dc1, w1t, (S["H"], S["W"]), 7, stride=2, pad=3, precision=arith.dgrad)
             d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
             d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
             L.check(lib.wgs_unpack_pair_grad(L.ptr(dx), L.ptr(d1), L.ptr(d2), B, c, S['H'] * S['W'], Cp, st), 'unpack_pair')

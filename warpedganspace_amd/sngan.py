@@ -10,6 +10,8 @@ epilogue.  Backward propagates only the input gradient.
 """
 from collections import namedtuple
 
+import functools
+
 import numpy as np
 import torch
 from torch import nn
@@ -53,10 +55,9 @@ class ResBlockGenerator(nn.Module):
 
 class _SN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, G, z):
-        ctx.prec = C.resolve_auto('sngan', 0)
-        with C.resolved(ctx.prec):
-            img, saved = G._fwd(z, save=ctx.needs_input_grad[1])
+    def forward(ctx, G, z, prec):
+        ctx.prec = prec
+        img, saved = G._fwd(z, ctx.needs_input_grad[1], prec)
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:     # ReLU gates in execution order, NCHW (tests)
             gates = []
@@ -67,8 +68,7 @@ class _SN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        with C.resolved(ctx.prec), C.grad_operands():      # fp16 modes: gradient operands without a magnitude bound run in split-bf16
-            return None, ctx.G._bwd(ctx.saved, gimg.contiguous())
+        return None, ctx.G._bwd(ctx.saved, gimg.contiguous(), ctx.prec), None
 
 
 class GenModel(nn.Module):
@@ -90,6 +90,7 @@ class GenModel(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self.debug_keep = None
+        self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
 
     # expose the Sequential's children under their numeric names: state_dict keys '0.weight', '2.conv1.weight', ...
     def state_dict(self, *a, **k):
@@ -159,8 +160,9 @@ class GenModel(nn.Module):
                                    L.ptr(dx), None, None, None, L.rawptr(ws), L.c_int64(N), Cn, 0, L.stream()), 'bn_eval_bwd')
         return dx
 
-    def _fwd(self, z, save):
+    def _fwd(self, z, save, prec):
         P = self._prepare()
+        launch = functools.partial(C.launch, precision=prec)
         lib, st = L.lib(), L.stream()
         z = z.contiguous()
         B, dz = z.shape
@@ -177,7 +179,7 @@ class GenModel(nn.Module):
             a1, s1 = self._bn_relu(d['bn1'], x, P['ws'])
             c1 = d['c1']
             h1 = torch.empty(B, 2 * H, 2 * H, c1['co'], device=dev)
-            C.launch(a1, c1['wp'], h1, taps, 2 * H, 2 * H, w_tap_stride=c1['ci'], w_row_stride=9 * c1['ci'], ups=1, bias=c1['b'])
+            launch(a1, c1['wp'], h1, taps, 2 * H, 2 * H, w_tap_stride=c1['ci'], w_row_stride=9 * c1['ci'], ups=1, bias=c1['b'])
             a2, s2 = self._bn_relu(d['bn2'], h1, P['ws'])
             c2 = d['c2']
             if d['byp'] is None:
@@ -185,10 +187,10 @@ class GenModel(nn.Module):
             else:
                 bp = d['byp']
                 addend = torch.empty(B, 2 * H, 2 * H, bp['co'], device=dev)
-                C.launch(x, bp['wp'], addend, taps, 2 * H, 2 * H, w_tap_stride=bp['ci'], w_row_stride=9 * bp['ci'], ups=1, bias=bp['b'])
+                launch(x, bp['wp'], addend, taps, 2 * H, 2 * H, w_tap_stride=bp['ci'], w_row_stride=9 * bp['ci'], ups=1, bias=bp['b'])
                 add_ups = 0
             y = torch.empty(B, 2 * H, 2 * H, c2['co'], device=dev)
-            C.launch(a2, c2['wp'], y, taps, 2 * H, 2 * H, w_tap_stride=c2['ci'], w_row_stride=9 * c2['ci'], bias=c2['b'],
+            launch(a2, c2['wp'], y, taps, 2 * H, 2 * H, w_tap_stride=c2['ci'], w_row_stride=9 * c2['ci'], bias=c2['b'],
                      addend=addend, add_ups=add_ups)
             if save:
                 saved.append((x, a1, s1, h1, a2, s2))
@@ -197,12 +199,14 @@ class GenModel(nn.Module):
         f = P['final']
         Hc = x.shape[1]
         y8 = torch.empty(B, Hc, Hc, 8, device=dev)
-        C.launch(af, f['wp'], y8, taps, Hc, Hc, w_tap_stride=f['ci'], w_row_stride=9 * f['ci'], bias=f['b'], act=1)
+        launch(af, f['wp'], y8, taps, Hc, Hc, w_tap_stride=f['ci'], w_row_stride=9 * f['ci'], bias=f['b'], act=1)
         img = y8[..., :self.img_channels].permute(0, 3, 1, 2).contiguous()
         return img, ((saved, x, af, sf, y8, z) if save else None)
 
-    def _bwd(self, saved_all, gimg):
+    def _bwd(self, saved_all, gimg, prec):
         P = self._prepare()
+        # fp16 modes: a gradient operand without a magnitude bound runs in split-bf16 (grad_operand)
+        launch = functools.partial(C.launch, precision=prec, grad_operand=True)
         lib, st = L.lib(), L.stream()
         saved, x_last, af, sf, y8, z = saved_all
         B = gimg.shape[0]
@@ -216,17 +220,17 @@ class GenModel(nn.Module):
         f = P['final']
         dtaps = [(1 - ky, 1 - kx, ky * 3 + kx) for ky in range(3) for kx in range(3)]
         gaf = torch.empty_like(af)
-        C.launch(dpre, f['wt'], gaf, dtaps, Hc, Hc, w_tap_stride=f['ci'] * 8, w_row_stride=8)
+        launch(dpre, f['wt'], gaf, dtaps, Hc, Hc, w_tap_stride=f['ci'] * 8, w_row_stride=8)
         g = self._bn_relu_bwd(P['bn'], x_last, sf, gaf, af, P['ws'])
         for d, (x, a1, s1, h1, a2, s2) in zip(reversed(P['blocks']), reversed(saved)):
             H = x.shape[1]
             c1, c2 = d['c1'], d['c2']
             # y = conv2(a2) + b2 + bypass(x)
             ga2 = torch.empty_like(a2)
-            C.launch(g, c2['wt'], ga2, dtaps, 2 * H, 2 * H, w_tap_stride=c2['ci'] * c2['co'], w_row_stride=c2['co'])
+            launch(g, c2['wt'], ga2, dtaps, 2 * H, 2 * H, w_tap_stride=c2['ci'] * c2['co'], w_row_stride=c2['co'])
             gh1 = self._bn_relu_bwd(d['bn2'], h1, s2, ga2, a2, P['ws'])
             gup = torch.empty(B, 2 * H, 2 * H, c1['ci'], device=dev)
-            C.launch(gh1, c1['wt'], gup, dtaps, 2 * H, 2 * H, w_tap_stride=c1['ci'] * c1['co'], w_row_stride=c1['co'])
+            launch(gh1, c1['wt'], gup, dtaps, 2 * H, 2 * H, w_tap_stride=c1['ci'] * c1['co'], w_row_stride=c1['co'])
             ga1 = torch.empty_like(a1)
             L.check(lib.wgs_upsample2x_bwd(L.ptr(gup), L.ptr(ga1), B, H, H, c1['ci'], st), 'up_bwd')
             gx = self._bn_relu_bwd(d['bn1'], x, s1, ga1, a1, P['ws'])
@@ -235,7 +239,7 @@ class GenModel(nn.Module):
             else:
                 bp = d['byp']
                 gb_up = torch.empty(B, 2 * H, 2 * H, bp['ci'], device=dev)
-                C.launch(g, bp['wt'], gb_up, dtaps, 2 * H, 2 * H, w_tap_stride=bp['ci'] * bp['co'], w_row_stride=bp['co'])
+                launch(g, bp['wt'], gb_up, dtaps, 2 * H, 2 * H, w_tap_stride=bp['ci'] * bp['co'], w_row_stride=bp['co'])
             gbyp = torch.empty_like(x)
             L.check(lib.wgs_upsample2x_bwd(L.ptr(gb_up), L.ptr(gbyp), B, H, H, x.shape[3], st), 'byp_up_bwd')
             g = gx + gbyp
@@ -245,8 +249,11 @@ class GenModel(nn.Module):
                                      L.c_float(1.0), L.c_float(1.0), L.c_float(1.0), 0, st), 'seed_linear_dgrad')
         return dz
 
-    def forward(self, z):
-        return _SN.apply(self, z)
+    def resolve_precision(self, requested=None):
+        return C.resolve(self.precision if requested is None else requested, 'sngan', 0)
+
+    def forward(self, z, precision=None):
+        return _SN.apply(self, z, self.resolve_precision(precision))
 
 
 class GenWrapper(nn.Module):
@@ -277,8 +284,11 @@ class SNGANWrapper(nn.Module):
         self.G = G.model
         self.dim_z = G.distribution.dim
 
-    def forward(self, z, shift=None):
-        return self.G(z if shift is None else z + shift)
+    def forward(self, z, shift=None, precision=None):
+        return self.G(z if shift is None else z + shift, precision=precision)
+
+    def resolve_precision(self, requested=None):
+        return self.G.resolve_precision(requested)
 
 
 def build_sngan(pretrained_gan_weights=None, gan_type='SNGAN_MNIST'):

@@ -142,10 +142,9 @@ class _Mapping(torch.autograd.Function):
 
 class _Synthesis(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, G, w):
-        ctx.prec = C.resolve_auto('stylegan2', G.size)      # the backward runs in the arithmetic its forward ran in
-        with C.resolved(ctx.prec):
-            img, saved = G._synthesis_fwd(w, save=ctx.needs_input_grad[1])
+    def forward(ctx, G, w, prec):
+        ctx.prec = prec                                      # the backward runs in the arithmetic its forward ran in
+        img, saved = G._synthesis_fwd(w, ctx.needs_input_grad[1], prec)
         ctx.G, ctx.saved = G, saved
         if G.debug_keep is not None and saved is not None:   # leaky-relu gates of every StyledConv, NCHW (tests)
             G.debug_keep['synthesis'] = [(o > 0).permute(0, 3, 1, 2) for o in saved[1]]
@@ -153,8 +152,7 @@ class _Synthesis(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        with C.resolved(ctx.prec):
-            return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous())
+        return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous(), ctx.prec), None
 
 
 class Generator(nn.Module):
@@ -196,6 +194,13 @@ class Generator(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self.debug_keep = None   # tests set this to {} to read back the activation gates of a forward
+        # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES); the reference's is fp32
+        self.precision = 'fp32'
+        self.mixed_policy = None  # conv.MixedPolicy override of 'mixed' (None: conv.mixed_policy(size))
+
+    def resolve_precision(self, requested=None):
+        """Concrete arithmetic code this generator runs in for `requested` (None: self.precision)."""
+        return C.resolve(self.precision if requested is None else requested, 'stylegan2', self.size)
 
     # -- derived, device-resident packed weights (rebuilt after load_state_dict / .to()) -----------
     def _apply(self, fn, *a, **k):
@@ -304,8 +309,9 @@ class Generator(nn.Module):
         return gz
 
     # -- synthesis network, model.py:389-403 ---------------------------------------------------------------
-    def _synthesis_fwd(self, w, save):
+    def _synthesis_fwd(self, w, save, prec):
         P = self._prepare()
+        pol = self.mixed_policy or C.mixed_policy(self.size)
         lib, st = L.lib(), L.stream()
         w = w.contiguous()
         B = w.shape[0]
@@ -321,7 +327,7 @@ class Generator(nn.Module):
         # fp16 modes: magnitude chain for the dynamic operand scale — every producer raises max|y| of its output (one atomic
         # per wave in its epilogue), the consumer scales its operand x * style by a power of two taken from max|x| * max|style|
         # before rounding it to fp16: a forward pass cannot overflow fp16 whatever the checkpoint's activation magnitudes
-        f16_chain = any(C.layer_precision(C.PRECISION, 4 << ((j + 1) // 2), ly_['up']) >= 2 for j, ly_ in enumerate(P['layers']))
+        f16_chain = any(C.layer_precision(prec, 4 << ((j + 1) // 2), ly_['up'], pol) >= 2 for j, ly_ in enumerate(P['layers']))
         xmax = [P['const_amax']] + list(torch.zeros(len(P['layers']), 1, device=dev).unbind(0)) if f16_chain else None
         smax = S.abs().max().reshape(1) if f16_chain else None
         # every layer's demodulation vector scale * rsqrt(scale^2 * sum_i s^2 wsq + 1e-8) in one batched launch
@@ -346,7 +352,7 @@ class Generator(nn.Module):
             s_view = S[:, ly['off']:]
             demod = demods[i]
             H = x.shape[1]
-            lp = C.layer_precision(C.PRECISION, 2 * H if ly['up'] else H, ly['up'])      # 'mixed': per-layer arithmetic
+            lp = C.layer_precision(prec, 2 * H if ly['up'] else H, ly['up'], pol)      # 'mixed': per-layer arithmetic
             sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp >= 2) else {}
             ymax = xmax[i + 1] if f16_chain else None
             if ly['up'] and C.upconv_fused_ok(H, Ci, Co, lp):
@@ -382,9 +388,10 @@ class Generator(nn.Module):
         saved = (S, outs, demods, B) if save else None
         return skip, saved
 
-    def _synthesis_bwd(self, saved, dimg):
+    def _synthesis_bwd(self, saved, dimg, prec):
         """d image [B,3,S,S] -> d latent [B, style_dim] (all n_latent copies of w summed)."""
         P = self._prepare()
+        pol = self.mixed_policy or C.mixed_policy(self.size)
         lib, st = L.lib(), L.stream()
         S, outs, demods, B = saved
         dev = dimg.device
@@ -422,7 +429,7 @@ class Generator(nn.Module):
             dsR = zeros(B, Co) if has_rgb else None
             sA = S[:, sA_off:] if gA is not None else None           # rows of the style matrix S, stride sumC
             sR = S[:, r['off']:] if has_rgb else None
-            lp = C.layer_precision_bwd(C.PRECISION, Hc, ly['up'])
+            lp = C.layer_precision_bwd(prec, Hc, ly['up'], pol)
             # a stride-1 layer's dy has ONE consumer, its gradient conv: in the plain-fp16 launches that fill the chip it is stored
             # only as that conv's fp16 operand plane, scaled from an a-priori bound of its magnitude (its own maximum is not known
             # before the kernel has run): max|gA| from the producing conv's epilogue, max|drgb| <= 4^levels * max|dimg|
@@ -503,17 +510,17 @@ class Generator(nn.Module):
         return _Mapping.apply(self, input)
 
     def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
-                input_is_latent=False, noise=None, randomize_noise=False):
+                input_is_latent=False, noise=None, randomize_noise=False, precision=None):
         """Same call signature as the reference (model.py:359-408).  Supported on the HIP path: a single
         style code, the registered noise buffers, no truncation — i.e. exactly what StyleGAN2Wrapper
-        (models/gan_load.py:157-179) issues."""
+        (models/gan_load.py:157-179) issues.  `precision` (extension): arithmetic of this call's convs, default self.precision."""
         if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise or truncation < 1:
             raise NotImplementedError("HIP StyleGAN2 path supports one style code, registered noise, truncation=1")
         s = styles[0]
         if s.ndim != 2:
             raise NotImplementedError("per-layer (W+) latents are not supported on the HIP path")
         w = s if input_is_latent else _Mapping.apply(self, s)
-        img = _Synthesis.apply(self, w)
+        img = _Synthesis.apply(self, w, self.resolve_precision(precision))
         if return_latents:
             return img, w.unsqueeze(1).repeat(1, self.n_latent, 1)
         return img, None

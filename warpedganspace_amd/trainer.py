@@ -31,26 +31,20 @@ from .aux import TrainingStatTracker, sample_z, sec2dhms, update_progress, updat
 from .support_sets import rbf_workspace
 
 
-# process-wide switches, read once at import (development A/B only; defaults are the measured-best path)
-_TWO_STREAMS = os.environ.get('WGS_TWO_STREAMS', '1') != '0'
-_DEFER_WGRAD = os.environ.get('WGS_DEFER_WGRAD', '1') != '0'
-_PREFETCH = os.environ.get('WGS_PREFETCH', '1') != '0'        # next step's un-shifted generator pass one step ahead
-
-
 def sampler_seed(seed, rank, world, start_iter, device):
     """Seed of this rank's device-side sampler.  Every rank must draw DIFFERENT (z, idx, magnitude) samples (the global
     batch is the union of the ranks' local batches), an unseeded run must not repeat the previous run's sequence (the
     reference samples from torch's unseeded global RNG, lib/trainer.py:195-221), and a resumed run must not replay the
     sampler from its start.  base = --seed if given, else a fresh random value drawn on rank 0 and broadcast."""
     if seed is None:
-        base = torch.seed() % (1 << 40)
+        base = int.from_bytes(os.urandom(5), 'little')       # 40 random bits; torch's global RNG is left alone
         if world > 1 and dist.is_available() and dist.is_initialized():
             t = torch.tensor([base], dtype=torch.int64, device=device if dist.get_backend() == 'nccl' else 'cpu')
             dist.broadcast(t, 0)
             base = int(t.item())
     else:
         base = int(seed)
-    return (base * 1000003 + 7919 * int(start_iter)) * max(world, 1) + rank
+    return ((base * 1000003 + 7919 * int(start_iter)) * max(world, 1) + rank) % (1 << 63)     # torch.Generator seeds are < 2^64
 
 
 class FlatBucket:
@@ -106,15 +100,23 @@ class TrainStep:
     """One optimisation step of lib/trainer.py:190-261 on this rank's share of the batch."""
 
     def __init__(self, generator, support_sets, reconstructor, params, local_batch, device, world=1, seed=None, rank=0,
-                 start_iter=0):
+                 start_iter=0, precision=None, r_precision='auto', two_streams=True, defer_wgrad=True, prefetch=True):
+        """precision: arithmetic of the frozen generator's convs (conv.PRECISION_NAMES; None = the generator's own `precision`
+        attribute, whose default is the reference's fp32).  r_precision: 'fp32' | 'bf16x3' | 'auto' | reconstructor.RArith —
+        arithmetic of the trained Reconstructor's convs ('auto': exact fp32 when the generator runs exact fp32, the fp32-class
+        split-bf16 x3 when it runs in a 16-bit mode).  Both belong to THIS engine: engines with different modes coexist."""
+        from .reconstructor import r_arith
         self.G, self.S, self.R, self.p = generator, support_sets, reconstructor, params
         self.B, self.dev, self.world, self.rank = local_batch, device, world, rank
+        self.precision = generator.resolve_precision(precision)       # concrete code 0..4
+        self.r_arith = r_arith(r_precision, self.precision)
         self.gen = torch.Generator(device=device)
         self.side_stream = torch.cuda.Stream(device=device)
         self.pre_stream = torch.cuda.Stream(device=device)
-        self.two_streams = _TWO_STREAMS      # un-shifted generator pass on the side stream
-        self.prefetch = _PREFETCH            # ... of the NEXT step's batch, next to this step's Reconstructor / backward phases
-        self._pre = None                     # (z, idx, mag, img, precision) drawn and generated one step ahead
+        self.two_streams = two_streams       # un-shifted generator pass on the side stream
+        self.defer_wgrad = defer_wgrad       # R's weight gradients on the side stream, next to the generator's backward
+        self.prefetch = prefetch             # G(z) of the NEXT step's batch, next to this step's Reconstructor / backward phases
+        self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
         self.steps_done = 0
         self.sampler_seed = sampler_seed(seed, rank, world, start_iter, device)
         self.gen.manual_seed(self.sampler_seed)
@@ -142,7 +144,6 @@ class TrainStep:
         self.argmax = torch.empty(local_batch, dtype=torch.int64, device=device)
         self.loss_ws = torch.empty(2 * local_batch, device=device)
         self.w_space = bool(getattr(params, 'shift_in_w_space', False))
-        self._last_precision = None
         self.comm_events = None      # set to a list to collect (start, end) HIP events around the all-reduce waits
         self.allreduce_bytes = 4 * self.bucket.flat.numel()     # payload of the step's collectives (R group + S group)
 
@@ -181,10 +182,8 @@ class TrainStep:
         img = None
         if auto:
             if self._pre is not None:
-                z, idx, mag, img, prec = self._pre
+                z, idx, mag, img = self._pre
                 self._pre = None
-                if prec != C.PRECISION:
-                    img = None              # generated in another arithmetic mode: redo it below
             else:
                 z, idx, mag = self.sample()
         self.bucket.zero_grad()
@@ -193,9 +192,8 @@ class TrainStep:
         cur = torch.cuda.current_stream(self.dev)
         # (not in the very first step: the generator builds its packed / split weight caches lazily in its first forward, and
         # those must be produced on the main stream, ahead of everything that reads them)
-        # (the same after a change of the conv arithmetic: the 16-bit weight planes of a mode are built on first use)
-        side = self.side_stream if (self.two_streams and self.steps_done > 0 and self._last_precision == C.PRECISION) else None
-        self._last_precision = C.PRECISION
+        side = self.side_stream if (self.two_streams and self.steps_done > 0) else None
+        prec = self.precision
         pre_img = img is not None           # G(z) of this batch was generated during the previous step (see below)
         if pre_img:
             cur.wait_stream(self.pre_stream)
@@ -203,10 +201,10 @@ class TrainStep:
         elif side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
-                img = G(z)
+                img = G(z, precision=prec)
         with torch.no_grad():
             if img is None:
-                img = G(z)                                                    # :200, nothing saved
+                img = G(z, precision=prec)                                                    # :200, nothing saved
             code = G.get_w(z) if self.w_space else z                          # :236
         # shift = mag * S(mask, code)   (:235) — fused scale
         lg = S.LOGGAMMA.reshape(-1) if S.learn_gammas else None
@@ -223,7 +221,7 @@ class TrainStep:
         if pad:
             shift = shift[:, :self.d].contiguous()
         shift.requires_grad_(True)
-        img_shifted = G(z, shift)                                             # :239, input-gradient only
+        img_shifted = G(z, shift, precision=prec)                                             # :239, input-gradient only
         if side is not None and not pre_img:
             cur.wait_stream(side)
             img.record_stream(cur)
@@ -236,11 +234,10 @@ class TrainStep:
             zn, idxn, magn = self.sample()
             self.pre_stream.wait_stream(cur)
             with torch.cuda.stream(self.pre_stream), torch.no_grad():
-                imgn = G(zn)
+                imgn = G(zn, precision=prec)
             zn.record_stream(self.pre_stream)
-            self._pre = (zn, idxn, magn, imgn, C.PRECISION)
-        R.generator_precision = C.last_resolved()       # the arithmetic G just ran in: R's 'auto' forward mode follows it
-        logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True)   # :242
+            self._pre = (zn, idxn, magn, imgn)
+        logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True, arith=self.r_arith)   # :242
         L.check(lib.wgs_ce_l1_loss(L.ptr(logits), L.ptr(idx, torch.int64), L.ptr(mag_hat.reshape(B)), L.ptr(mag),
                                    L.c_float(p.lambda_cls), L.c_float(p.lambda_reg), L.ptr(self.dlogits), L.ptr(self.dmag),
                                    L.ptr(self.stats), L.ptr(self.argmax, torch.int64), L.ptr(self.loss_ws), B, self.K, st),
@@ -248,7 +245,7 @@ class TrainStep:
         gb = self.bucket.gview
         # R's conv weight gradients are not needed for d_img: they are queued and run on the side stream, next to the
         # generator's backward (whose 4x4..32x32 layers under-fill the chip); the ResNet path only (LeNet computes them inline)
-        deferred = [] if (side is not None and R.reconstructor_type == 'ResNet' and _DEFER_WGRAD) else None
+        deferred = [] if (side is not None and R.reconstructor_type == 'ResNet' and self.defer_wgrad) else None
         _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred)
         del saved
         pending = []
@@ -354,14 +351,21 @@ class Trainer(object):
         """Resume from models/checkpoint.pt if present (lib/trainer.py:74-89): {'iter','support_sets','reconstructor'}."""
         starting_iter = 1
         self.resume_optim = None
+        self.ck_iter = None
         if osp.isfile(self.checkpoint):
             ck = torch.load(self.checkpoint, map_location='cpu')
-            starting_iter = ck['iter']
+            starting_iter = self.ck_iter = ck['iter']
             support_sets.load_state_dict(ck['support_sets'])
             reconstructor.load_state_dict(ck['reconstructor'])
             # extension: Adam moments (the reference restarts its optimizers from zero on resume, lib/trainer.py:153-156,
-            # 288-295 stores only the three keys above; its readers index by key, so the extra key is ignored there)
+            # 288-295 stores only the three keys above; its readers index by key, so the extra key is ignored there).
+            # A reference-layout checkpoint resumes as the reference does: iteration ck['iter'] is run again with fresh
+            # optimizers.  With the moments present the state is exactly the one AFTER iteration ck['iter'] (parameters,
+            # moments, Adam step count), so the run continues at ck['iter'] + 1 — no step is applied twice and the
+            # bias-correction count stays in step with the iteration number.
             self.resume_optim = ck.get('optim')
+            if self.resume_optim is not None:
+                starting_iter = ck['iter'] + 1
         return starting_iter
 
     def log_progress(self, iteration, mean_iter_time, elapsed_time, eta, stats):
@@ -401,7 +405,7 @@ class Trainer(object):
         if self.world > 1:   # identical replicas on every rank
             for t in list(support_sets.parameters()) + list(reconstructor.parameters()) + list(reconstructor.buffers()):
                 dist.broadcast(t.data, 0)
-        if starting_iter == p.max_iter:
+        if self.ck_iter == p.max_iter:
             print("#. This experiment has already been completed and can be found @ {}".format(self.wip_dir))
             if self.rank == 0:
                 try:
@@ -413,7 +417,8 @@ class Trainer(object):
             raise ValueError("--batch-size ({}) is the GLOBAL batch and must divide by the world size ({})".format(
                 p.batch_size, self.world))
         engine = TrainStep(generator, support_sets, reconstructor, p, p.batch_size // self.world, dev, world=self.world,
-                           seed=getattr(p, 'seed', None), rank=self.rank, start_iter=starting_iter)
+                           seed=getattr(p, 'seed', None), rank=self.rank, start_iter=starting_iter,
+                           precision=getattr(p, 'precision', None), r_precision=getattr(p, 'r_precision', 'auto'))
         if getattr(self, 'resume_optim', None) is not None and engine.load_optim_state(self.resume_optim) and self.rank == 0:
             print("#. Restored Adam moments (step {}) from the checkpoint".format(engine.bucket.step_count))
         if self.rank == 0:
