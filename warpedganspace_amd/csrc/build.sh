@@ -8,7 +8,7 @@ OBJS=()
 for src in *.hip; do
   obj="build/${src%.hip}.o"
   mkdir -p build
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ wgs_common.h -nt "$obj" ] || [ conv_args.h -nt "$obj" ] || [ fir4.h -nt "$obj" ] || [ conv_epilogue.h -nt "$obj" ] || [ conv_scheme.h -nt "$obj" ] || [ ../../include/wgs.h -nt "$obj" ] \
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ wgs_common.h -nt "$obj" ] || [ conv_args.h -nt "$obj" ] || [ fir4.h -nt "$obj" ] || [ conv_epilogue.h -nt "$obj" ] || [ conv_scheme.h -nt "$obj" ] || [ conv_nt_kernel.inc -nt "$obj" ] || [ conv_nt_launch.inc -nt "$obj" ] || [ ../../include/wgs.h -nt "$obj" ] \
      || { [ -f "${src%.hip}.inc" ] && [ "${src%.hip}.inc" -nt "$obj" ]; }; then
     echo "[hipcc] $src"
     $HIPCC $FLAGS -c "$src" -o "$obj" &

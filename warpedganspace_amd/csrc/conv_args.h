@@ -83,6 +83,13 @@ int launch_bf16x3(const ConvArgs& a, hipStream_t st);
 // the same for n <= 4 launches that differ only in (Hg, Wg, oy0, ox0, taps); 0 = handled as one merged launch
 int launch_bf16x3_multi(const ConvArgs* a, int n, hipStream_t st);
 
+// The same kernel template in exact fp32 (scheme 4, conv_igemm_f32.hip): a.sch must be 4; 0 = handled, 1 = shape not covered
+// (Ci % 32, > 16 taps, operands beyond 2 GiB: the caller keeps the plain fp32 kernel of conv_igemm.hip)
+int launch_f32(const ConvArgs& a, hipStream_t st);
+int launch_f32_multi(const ConvArgs* a, int n, hipStream_t st);
+// operand extents (x_bytes / w_bytes / s_bytes) for the buffer descriptors; false when a stream exceeds a 31-bit byte offset
+bool set_extents(ConvArgs& a, int wt_max);
+
 // LDS-DMA form of the 8-wave kernels (conv_igemm_dma.hip)
 void split_bf16(const float* x, const float* s, int s_ld, unsigned short* hi, unsigned short* lo, long nsamples, long per_sample,
                 int C, hipStream_t st);

@@ -580,7 +580,7 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
     a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = d->x_f16; a.a_lo = nullptr;
     WGS_CHECK_ARG(d->precision >= 0 && d->precision <= 3, "wgs_conv_igemm: precision=%d (0 fp32, 1 bf16x3, 2 f16, 3 f16x2)", d->precision);
-    a.sch = d->precision > 0 ? d->precision - 1 : 0;
+    a.sch = d->precision > 0 ? d->precision - 1 : 4;      // conv_scheme.h: 0..2 the 16-bit schemes, 4 exact fp32
     a.a_amax = d->precision >= 2 ? d->a_amax : nullptr;
     a.a_bound = d->a_bound > 0.f ? d->a_bound : 1.f;
     a.a_amax2 = d->precision >= 2 ? d->a_amax2 : nullptr;
@@ -612,6 +612,12 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         WGS_CHECK_LAUNCH("igemm_nt16_kernel");
         return WGS_OK;
     }
+    // exact fp32: the slot-interleaved kernel (conv_igemm_f32.hip) where it covers the shape, else the plain kernel below
+    a.sch = 4;
+    if (!wgs_flags().f32_old && wgsconv::launch_f32(a, st) == 0) {
+        WGS_CHECK_LAUNCH("igemm_nt16_kernel<4>");
+        return WGS_OK;
+    }
     if (d->Co > 64) {
         // too few tiles for the 256 CUs (ResNet layer3/4 at 16x16 / 8x8): split K over the caller's workspace
         const int tiles = ((a.M + 127) / 128) * ((a.Co + 127) / 128);
@@ -631,11 +637,12 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
 int wgs_conv_igemm_multi(const wgs_conv_desc* descs, int n, wgs_stream_t stream) {
     WGS_CHECK_ARG(descs && n > 0, "wgs_conv_igemm_multi: bad arguments");
     for (int i = 0; i < n; ++i) WGS_CHECK_ARG(!descs[i].x_f16, "wgs_conv_igemm_multi: x_f16 operands are single-launch only (wgs_conv_igemm)");
-    if (n >= 2 && n <= 4 && descs[0].precision >= 1) {
+    if (n >= 2 && n <= 4) {
         ConvArgs as[4];
         bool ok = true;
         for (int i = 0; i < n && ok; ++i) ok = descs[i].precision == descs[0].precision && descs[i].a_amax == descs[0].a_amax && build_conv_args(&descs[i], as[i]) == WGS_OK;
-        if (ok && wgsconv::launch_bf16x3_multi(as, n, (hipStream_t)stream) == 0) {
+        if (ok && (descs[0].precision >= 1 ? wgsconv::launch_bf16x3_multi(as, n, (hipStream_t)stream)
+                                           : (wgs_flags().f32_old ? 1 : wgsconv::launch_f32_multi(as, n, (hipStream_t)stream))) == 0) {
             WGS_CHECK_LAUNCH("igemm_nt16_kernel<multi>");
             return WGS_OK;
         }

@@ -25,6 +25,7 @@ typedef _Float16 sch_f16x4 __attribute__((ext_vector_type(4)));
 template <int SCH> struct Scheme;
 
 template <> struct Scheme<0> {
+    static constexpr int EB = 2;      // bytes per staged operand element
     static constexpr int NA = 2, NB = 2, NP = 3;
     typedef sch_bf16x8 frag;
     // 4 floats -> packed 16-bit hi (and lo) words
@@ -45,6 +46,7 @@ template <> struct Scheme<0> {
 };
 
 template <> struct Scheme<1> {
+    static constexpr int EB = 2;      // bytes per staged operand element
     static constexpr int NA = 1, NB = 1, NP = 1;
     typedef sch_f16x8 frag;
     static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) {
@@ -58,6 +60,7 @@ template <> struct Scheme<1> {
 };
 
 template <> struct Scheme<2> {
+    static constexpr int EB = 2;      // bytes per staged operand element
     static constexpr int NA = 1, NB = 2, NP = 2;
     typedef sch_f16x8 frag;
     static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) {
@@ -78,6 +81,7 @@ template <> struct Scheme<2> {
 // error class as SCH 2 (one operand to ~2^-22, the other rounded to 11 bits); used where the weight planes' LDS-DMA traffic,
 // not the MFMA rate, bounds the kernel (conv_upfused.hip): the second weight plane would double that traffic.
 template <> struct Scheme<3> {
+    static constexpr int EB = 2;      // bytes per staged operand element
     static constexpr int NA = 2, NB = 1, NP = 2;
     typedef sch_f16x8 frag;
     static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) { Scheme<2>::cvt4(f, hi, lo); }
@@ -87,6 +91,28 @@ template <> struct Scheme<3> {
         return c;
     }
 };
+
+// SCH 4: exact fp32 — the reference's arithmetic on the matrix cores.  One fp32 plane per operand; a fragment is FOUR consecutive
+// k values of a row (one ds_read_b128), consumed by four v_mfma_f32_32x32x2_f32: the instruction's two k slots are fed by
+// the two half-waves, which read adjacent 16-byte groups of the same 32-byte k block (lanes 0-31: k = 8j + e, lanes 32-63:
+// k = 8j + 4 + e for MFMA e) — A and B use the same pairing, and a contraction does not care in which order its k are summed.
+template <> struct Scheme<4> {
+    static constexpr int EB = 4;
+    static constexpr int NA = 1, NB = 1, NP = 4;
+    typedef sch_f32x4 frag;
+    static __device__ __forceinline__ void cvt4(const sch_f32x4 f, uint2& hi, uint2& lo) { hi = make_uint2(0, 0); lo = hi; }   // unused
+    static __device__ __forceinline__ sch_f32x16 mma(const frag* a, const frag* b, sch_f32x16 c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], b[0][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][1], b[0][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][2], b[0][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][3], b[0][3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// LDS row of a staged 32-deep K chunk: 32 elements + 16 bytes of padding (80 B for the 16-bit planes, 144 B for fp32: the 8
+// rows that a ds_read_b128 / ds_write_b128 serves per cycle then start 4 banks apart — conflict-free in both layouts)
+template <int SCH> struct SchemeRow { static constexpr int BYTES = 32 * Scheme<SCH>::EB + 16; };
 
 // Power-of-two operand scale for the fp16 schemes.  `amax` bounds |A| (before the per-sample a_scale factor, which the
 // caller's bound must include).  Returns mult = 2^k with amax * mult in [2^11, 2^12) — four binades below the fp16 maximum

@@ -117,6 +117,8 @@ class TrainStep:
         self.defer_wgrad = defer_wgrad       # R's weight gradients on the side stream, next to the generator's backward
         self.prefetch = prefetch             # G(z) of the NEXT step's batch, next to this step's Reconstructor / backward phases
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
+        self._cold = True                    # next step builds the generator's weight caches of this arithmetic: single stream
+        self._r_precision = r_precision
         self.steps_done = 0
         self.sampler_seed = sampler_seed(seed, rank, world, start_iter, device)
         self.gen.manual_seed(self.sampler_seed)
@@ -162,6 +164,37 @@ class TrainStep:
         b.exp_avg_sq.copy_(st['exp_avg_sq'].to(b.exp_avg_sq.device))
         return True
 
+    # -- arithmetic of this engine ---------------------------------------------------------------------
+    def set_precision(self, precision, r_precision=None):
+        """Switch this engine's generator (and, under 'auto', reconstructor) arithmetic; a batch generated ahead in the old mode
+        is dropped and the next step runs single-stream (it builds the new mode's weight planes)."""
+        from .reconstructor import r_arith
+        self.precision = self.G.resolve_precision(precision)
+        if r_precision is not None:
+            self._r_precision = r_precision
+        self.r_arith = r_arith(self._r_precision, self.precision)
+        self._pre, self._cold = None, True
+
+    def check_precision(self, gate=1e-3):
+        """Run-time guard of a 16-bit generator mode (the per-architecture policy tables were calibrated on random-init weights):
+        image error of this engine's arithmetic against the exact-fp32 kernels on a fresh batch of latent codes, with THIS
+        generator's weights.  Max-norm relative error, of the batch tensor (how the parity tests apply the north_star's 1e-3 gate)
+        and per single image.  Draws from its own generator (identical on every rank): the training sample stream is untouched.  None for fp32 engines."""
+        if self.precision == 0:
+            return None
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(0x5DEECE66D + self.steps_done)       # the same codes on every rank: every rank takes the same decision
+        z = sample_z(self.B, self.G.dim_z, truncation=getattr(self.p, 'z_truncation', None), device=self.dev, generator=g)
+        with torch.no_grad():
+            ref = self.G(z, precision='fp32')
+            img = self.G(z, precision=self.precision)
+            d, m = (img - ref).abs().flatten(1).amax(1), ref.abs().flatten(1).amax(1)
+            per = (d / m.clamp_min(1e-30)).cpu()
+            batch = float(d.max() / m.max().clamp_min(1e-30))
+        self._cold = True       # the fp32 pass may have built weight caches on this stream: keep the next step single-stream
+        return {'precision': C.precision_name(self.precision), 'batch': batch, 'per_image_median': float(per.median()),
+                'per_image_max': float(per.max()), 'gate': gate, 'ok': bool(batch < gate and batch == batch), 'n': int(per.numel())}
+
     # -- sampling (lib/trainer.py:195-221), on the device ---------------------------------------------
     def sample(self):
         p, B = self.p, self.B
@@ -192,7 +225,8 @@ class TrainStep:
         cur = torch.cuda.current_stream(self.dev)
         # (not in the very first step: the generator builds its packed / split weight caches lazily in its first forward, and
         # those must be produced on the main stream, ahead of everything that reads them)
-        side = self.side_stream if (self.two_streams and self.steps_done > 0) else None
+        side = self.side_stream if (self.two_streams and not self._cold) else None
+        self._cold = False
         prec = self.precision
         pre_img = img is not None           # G(z) of this batch was generated during the previous step (see below)
         if pre_img:
@@ -390,6 +424,23 @@ class Trainer(object):
         if sys.stdout.isatty():
             update_stdout(10)
 
+    def precision_check(self, engine, iteration):
+        """--check-precision: measure the generator arithmetic's image error on the current weights; a mode that misses the
+        1e-3 gate is replaced by the fp32-class split-bf16 for the rest of the run (every rank measures the same codes with the
+        same frozen generator, so every rank takes the same decision)."""
+        r = engine.check_precision()
+        if r is None:
+            return None
+        if self.rank == 0:
+            print("#. Precision check @ iteration {}: {} image error vs exact fp32: batch {:.2e}, single image median {:.2e} / max {:.2e} "
+                  "(gate {:.0e}, {} codes) -- {}".format(iteration, r['precision'], r['batch'], r['per_image_median'], r['per_image_max'],
+                                                          r['gate'], r['n'], 'ok' if r['ok'] else 'OVER THE GATE'))
+        if not r['ok'] and engine.precision != C.PRECISION_NAMES[C.AUTO_FALLBACK]:
+            engine.set_precision(C.AUTO_FALLBACK)
+            if self.rank == 0:
+                print("#. Generator arithmetic switched to {} (fp32-class) for the rest of the run".format(C.AUTO_FALLBACK))
+        return r
+
     def train(self, generator, support_sets, reconstructor):
         p = self.params
         if not (self.use_cuda and torch.cuda.is_available()):
@@ -423,12 +474,17 @@ class Trainer(object):
             print("#. Restored Adam moments (step {}) from the checkpoint".format(engine.bucket.step_count))
         if self.rank == 0:
             print("#. Start training from iteration {}".format(starting_iter))
+        check_every = int(getattr(p, 'check_precision', 0) or 0)
+        if engine.precision >= 2:        # an fp16-operand mode: check it once against the exact-fp32 kernels on THESE weights
+            self.precision_check(engine, starting_iter - 1)
         t0 = time.time()
         # Iteration time: the launches are asynchronous, so a per-iteration host clock would measure launch latency.  The
         # device is synchronised only where statistics are popped (log boundaries): time between those, per iteration.
         mark_t, mark_iter = t0, starting_iter - 1
         for iteration in range(starting_iter, p.max_iter + 1):
             engine.step()
+            if check_every and engine.precision >= 1 and iteration % check_every == 0:
+                self.precision_check(engine, iteration)
             if self.tb_writer is not None or iteration % p.log_freq == 0:
                 stats = engine.pop_stats()           # one device sync
                 now = time.time()
