@@ -32,12 +32,12 @@ def _symbol_of(fn):
 
 # B, Ci, Co, H, k, stride, pad — tile remainders in M and Co, several samples per tile, split-K sized maps, big maps
 CASES = [(2, 32, 64, 9, 3, 1, 1), (3, 64, 128, 8, 3, 1, 1), (2, 128, 160, 6, 3, 1, 1), (2, 64, 128, 9, 3, 2, 1), (2, 64, 128, 8, 1, 2, 0),
-         (1, 512, 512, 4, 3, 1, 1), (5, 32, 32, 3, 3, 1, 1), (2, 128, 128, 32, 3, 1, 1), (4, 256, 96, 16, 3, 1, 1), (2, 64, 24, 12, 5, 1, 2)]
+         (1, 512, 512, 4, 3, 1, 1), (5, 32, 32, 3, 3, 1, 1), (2, 128, 128, 32, 3, 1, 1), (4, 256, 96, 16, 3, 1, 1), (2, 64, 24, 12, 4, 1, 2), (8, 256, 256, 40, 3, 1, 1)]
 
 
 @pytest.mark.parametrize('B,Ci,Co,H,k,s,p', CASES)
-@pytest.mark.parametrize('big', [False, True])
-def test_f32_conv_fwd_and_dgrad_vs_fp64_and_old_kernel(dev, dev_flags, B, Ci, Co, H, k, s, p, big):
+@pytest.mark.parametrize('small', [False, True])
+def test_f32_conv_fwd_and_dgrad_vs_fp64_and_old_kernel(dev, dev_flags, B, Ci, Co, H, k, s, p, small):
     torch.manual_seed(B * 1000 + Ci + Co + H)
     x = torch.randn(B, Ci, H, H, dtype=torch.float64, requires_grad=True)
     w = (torch.randn(Co, Ci, k, k, dtype=torch.float64) / (Ci * k * k) ** 0.5).requires_grad_(True)
@@ -48,8 +48,8 @@ def test_f32_conv_fwd_and_dgrad_vs_fp64_and_old_kernel(dev, dev_flags, B, Ci, Co
     wp = C.pack_weight(w.detach().float()).to(dev)
     wt = C.repack_w_t(wp, Co, k * k, Ci)
     gd = nhwc(g.float()).to(dev)
-    if big:
-        dev_flags(WGS_F32_BIG='1')
+    if small:
+        dev_flags(WGS_F32_SMALL='1')
     sym = _symbol_of(lambda: C.conv2d(xd, wp, k, stride=s, pad=p, precision=0))
     assert sym.startswith('igemm_nt16_kernel<4,'), sym           # the launch really went through the new kernel
     yd = C.conv2d(xd, wp, k, stride=s, pad=p, precision=0)
@@ -60,12 +60,12 @@ def test_f32_conv_fwd_and_dgrad_vs_fp64_and_old_kernel(dev, dev_flags, B, Ci, Co
     assert _symbol_of(lambda: C.conv2d(xd, wp, k, stride=s, pad=p, precision=0)).startswith('igemm_nt_kernel<')
     yo = C.conv2d(xd, wp, k, stride=s, pad=p, precision=0)
     dxo = C.conv2d_dgrad(gd, wt, (H, H), k, stride=s, pad=p, precision=0)
-    assert rel_err(yd, yo) < 2e-6 and rel_err(dx, dxo) < 2e-6
+    assert rel_err(yd, yo) < 1e-5 and rel_err(dx, dxo) < 1e-5          # same products, another summation order inside a chunk
 
 
 @pytest.mark.parametrize('B,Ci,Co,H', [(2, 64, 32, 5), (3, 128, 128, 8), (2, 256, 128, 33), (32, 128, 128, 16)])
-@pytest.mark.parametrize('big', [False, True])
-def test_f32_styled_transposed_conv_and_its_dgrad(dev, dev_flags, B, Ci, Co, H, big):
+@pytest.mark.parametrize('small', [False, True])
+def test_f32_styled_transposed_conv_and_its_dgrad(dev, dev_flags, B, Ci, Co, H, small):
     """StyleGAN2's up-sampling conv (4 sub-pixel phases, style on the activation, demodulation on the columns) and the stride-2
     gradient conv behind it."""
     torch.manual_seed(77 + Ci + H)
@@ -75,8 +75,8 @@ def test_f32_styled_transposed_conv_and_its_dgrad(dev, dev_flags, B, Ci, Co, H, 
     dm = torch.rand(B, Co) + 0.5
     ref = F.conv_transpose2d((x * s[:, :, None, None]).double(), w.double(), stride=2) * dm[:, :, None, None].double()
     wp = C.pack_weight(w.permute(1, 0, 2, 3).contiguous()).to(dev)      # [Co, 9, Ci]
-    if big:
-        dev_flags(WGS_F32_BIG='1')
+    if small:
+        dev_flags(WGS_F32_SMALL='1')
     t = C.conv_transpose2d_s2(nhwc(x).to(dev), wp, a_scale=s.to(dev), col_scale=dm.to(dev), precision=0)
     assert rel_err(nchw(t), ref) < 1e-5
     g = torch.randn(B, Co, 2 * H + 1, 2 * H + 1)
@@ -86,7 +86,7 @@ def test_f32_styled_transposed_conv_and_its_dgrad(dev, dev_flags, B, Ci, Co, H, 
     assert rel_err(nchw(dx), gref) < 1e-5
     dev_flags(WGS_F32_OLD='1')
     to = C.conv_transpose2d_s2(nhwc(x).to(dev), wp, a_scale=s.to(dev), col_scale=dm.to(dev), precision=0)
-    assert rel_err(t, to) < 2e-6
+    assert rel_err(t, to) < 1e-5
 
 
 def test_f32_upsampled_gather_epilogue_and_addend(dev, dev_flags):
@@ -112,7 +112,10 @@ def test_f32_upsampled_gather_epilogue_and_addend(dev, dev_flags):
 
 
 def test_f32_falls_back_where_the_template_does_not_reach(dev):
-    """Ci % 32 != 0 (ResNet conv1: 8 padded channels; LeNet): the plain fp32 kernel keeps those launches."""
+    """Ci % 32 != 0 (ResNet conv1: 8 padded channels; LeNet) and more than 16 taps: the plain fp32 kernel keeps those launches."""
     x = torch.randn(2, 20, 20, 8, device=dev)
     w = torch.randn(64, 49, 8, device=dev)
     assert _symbol_of(lambda: C.conv2d(x, w, 7, stride=2, pad=3, precision=0)).startswith('igemm_nt_kernel<')
+    x = torch.randn(2, 12, 12, 64, device=dev)
+    w = torch.randn(24, 25, 64, device=dev)
+    assert _symbol_of(lambda: C.conv2d(x, w, 5, stride=1, pad=2, precision=0)).startswith('igemm_nt_kernel<')

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Exact-fp32 conv kernels on the StyleGAN2-256 / ResNet-18 layer shapes (B=32): the plain three-phase kernel (conv_igemm.hip,
-WGS_F32_OLD) against the slot-interleaved one (conv_igemm_f32.hip), 4-wave 128-row tiles and 8-wave 256-row tiles (WGS_F32_BIG);
+WGS_F32_OLD) against the slot-interleaved one (conv_igemm_f32.hip), 4-wave 128-row tiles only (WGS_F32_SMALL) and the default policy (8-wave 256 x 256 tiles where Cout allows, merged up-conv phases);
 checks the new results against the old ones.  usage: python tools/bench_conv32.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,11 +10,11 @@ from warpedganspace_amd import conv as C
 
 dev = torch.device('cuda:0')
 B = int(os.environ.get('B', 32))
-FORMS = [('old', {'WGS_F32_OLD': '1'}), ('new', {}), ('new-big', {'WGS_F32_BIG': '1'})]
+FORMS = [('old', {'WGS_F32_OLD': '1'}), ('small', {'WGS_F32_SMALL': '1'}), ('default', {})]
 
 
 def use(env):
-    for k in ('WGS_F32_OLD', 'WGS_F32_BIG'):
+    for k in ('WGS_F32_OLD', 'WGS_F32_SMALL'):
         os.environ.pop(k, None)
     os.environ.update(env)
     L.lib().wgs_dev_reload_flags()

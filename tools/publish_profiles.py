@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Copy the summaries of a tools/run_round.sh pass from gpurun_out/ (scratch) into profiles/ (tracked).
+usage: python tools/publish_profiles.py <tag> [round=r3]"""
+import json, os, sys
+tag = sys.argv[1]; rnd = sys.argv[2] if len(sys.argv) > 2 else 'r3'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go, pr = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
+d = json.load(open(os.path.join(go, tag + '_bench.json')))
+json.dump(d, open(os.path.join(pr, rnd + '_bench_default.json'), 'w'), indent=1)
+names = {'fp32': ('fp32', 'exact fp32 everywhere (the headline arithmetic)', '--precision fp32'),
+         'auto': ('mixed', "the product's default arithmetic (auto = mixed fp16 / split-bf16 per layer; extra[0] of the bench line)", '--precision auto')}
+for mode, (out, what, flag) in names.items():
+    src = os.path.join(go, '%s_step_%s_kernel_stats.md' % (tag, mode))
+    if not os.path.exists(src):
+        continue
+    body = open(src).read()
+    head = ("# Round 3: per-kernel time of the training step, %s\n\nStyleGAN2-256 K=128 N=32 B=32, ResNet-18 R, 1x MI355X.  Command (tools/run_round.sh):\n"
+            "`rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s_%s -o bench -- python bench.py --steps 5 --warmup 2 "
+            "--no-cpu-baseline --no-extra --no-product-run --single-stream %s`\nsummarised by tools/prof_summary.py.  12 steps in the trace "
+            "(2 warm-up + 5 timed + 2 with per-launch HIP events + 3 host-enqueue timing steps); `--single-stream` so that kernel times add up to "
+            "the step (the multi-stream step of the same build is `profiles/%s_bench_default.json`: %s).\n\n" % (
+                what, tag, mode, flag, rnd,
+                ('%.2f img/s, %.2f ms/step' % (d['value'], d['ms_per_step'])) if mode == 'fp32' else
+                ('%.2f img/s, %.2f ms/step' % (d['extra'][0]['value'], d['extra'][0]['ms_per_step']))))
+    open(os.path.join(pr, '%s_step_%s_kernel_stats.md' % (rnd, out)), 'w').write(head + body)
+r = d['roofline']
+print('headline', d['value'], d['ms_per_step'], d['dtype'], '| roofline', r['kernel'], r['achieved'], r['frac'])
+e = d['extra'][0]; r = e['roofline']
+print('extra[0]', e['value'], e['ms_per_step'], e['precision'], '| roofline', r['kernel'], r['achieved'], r['frac'])

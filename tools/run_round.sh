@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage: bash tools/run_round.sh <tag> —: GPU test suite, default bench line, rocprofv3 kernel tables of the fp32 and the default-arithmetic step
+TAG=${1:-r3b}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/${TAG}_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_tests.log
+tail -5 gpurun_out/${TAG}_tests.log
+timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"
+grep '^{' gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json
+for mode in fp32 auto; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$mode -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-product-run --single-stream --precision $mode > gpurun_out/prof_${TAG}_$mode.log 2>&1
+  python tools/prof_summary.py gpurun_out/prof_${TAG}_$mode 12 > gpurun_out/${TAG}_step_${mode}_kernel_stats.md
+  find gpurun_out/prof_${TAG}_$mode -name "*kernel_trace.csv" -delete
+  head -12 gpurun_out/${TAG}_step_${mode}_kernel_stats.md | cut -c1-160
+done

@@ -31,7 +31,9 @@ void launch_big(ConvArgs& a, hipStream_t st, int nblocks = 0) { launch_big_s<4, 
 namespace wgsconv {
 
 #define WGS_NT_16BIT 0
-#define WGS_NT_BIG_TILES (wgs_flags().f32_big)
+// 8-wave 256 x 256 tiles where Cout allows (144 vs 137 TFLOP/s on 512 -> 512 @64^2; the 256 x 128 tile of Cout = 128 loses to two
+// 128 x 128 workgroups per CU: 129 vs 134) and the merged sub-pixel phases of the up-convs; WGS_F32_SMALL: 4-wave tiles only
+#define WGS_NT_BIG_TILES (!wgs_flags().f32_small)
 #define WGS_NT_LAUNCH_NAME launch_f32
 #define WGS_NT_MULTI_NAME launch_f32_multi
 #include "conv_nt_launch.inc"

@@ -37,7 +37,7 @@ static WgsFlags read_flags() {
     g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
     g.wgrad_per_tap = getenv("WGS_WGRAD_PER_TAP") != nullptr;
     g.patch_wide = getenv("WGS_PATCH_WIDE") != nullptr;
-    g.f32_big = getenv("WGS_F32_BIG") != nullptr;      // exact fp32: 8-wave 256-row tiles (and merged up-conv phases)
+    g.f32_small = getenv("WGS_F32_SMALL") != nullptr;      // exact fp32: 4-wave 128-row tiles only (no 8-wave tiles, no merged up-conv phases)
     g.f32_old = getenv("WGS_F32_OLD") != nullptr;      // exact fp32: the plain three-phase kernel of conv_igemm.hip everywhere
     return g;
 }
