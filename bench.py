@@ -349,8 +349,8 @@ EXTRA = [
     ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16, auto", 'biggan', 128, 128, 32, 16, 'auto', 'auto', False, 8, 'biggan-128'),
     ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16, auto", 'biggan', 256, 128, 32, 16, 'auto', 'auto', False, 6, None),
     ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, exact fp32", 'stylegan2', 1024, 200, 64, 8, 'fp32', 'auto', False, 3, 'stylegan2-1024'),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path (mixed policy of this architecture)", 'stylegan2', 1024, 200, 64, 8, 'mixed', 'auto', False, 6, 'stylegan2-1024'),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, auto", 'stylegan2', 1024, 200, 64, 8, 'auto', 'auto', False, 6, 'stylegan2-1024'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path = auto (this architecture's mixed policy: fp16 x2 in the 512^2 / 1024^2 layers)", 'stylegan2', 1024, 200, 64, 8, 'auto', 'auto', False, 6, 'stylegan2-1024'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, bf16x3 everywhere", 'stylegan2', 1024, 200, 64, 8, 'bf16x3', 'auto', False, 6, 'stylegan2-1024'),
 ]
 
 
@@ -365,11 +365,11 @@ def run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, warmup, gkey,
     rec = {"precision": name, "r_arith": list(eng.r_arith), "dtype": DTYPE[name], "value": round(B * world * steps / dt, 2), "unit": "images/sec",
            "n_gpus": world, "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
            "conv_TFLOP/s": round(a_fl / a_ms / 1e9, 1), "conv_ms_per_step": round(a_ms, 2), "conv_gflop_per_step": round(a_fl / 1e9, 1)}
-    if gkey:
+    if gkey and gkey in GFLOP_PER_IMG:
         rec["step_achieved_TFLOPs"] = round(B * steps / dt * GFLOP_PER_IMG[gkey] / 1e3, 1)
     if full:
         rec["dtype_detail"] = DTYPE_TEXT[name] + R_TEXT.get(tuple(eng.r_arith), "; reconstructor arithmetic (forward, dgrad, wgrad; 0 exact fp32, 1 split-bf16 x3): %s" % (tuple(eng.r_arith),))
-        rec["roofline"] = roofline_of(recs, B * steps / dt, GFLOP_PER_IMG.get(gkey) if gkey else None)
+        rec["roofline"] = roofline_of(recs, B * steps / dt, GFLOP_PER_IMG.get(gkey))
         rec["host"] = host_overheads(eng)
     return rec, eng
 

@@ -409,6 +409,22 @@ int wgs_affine_relu_bwd(const float* x, const float* y, const float* g, const fl
 int wgs_softmax_rows_fwd(const float* x, float* y, int64_t rows, int n, wgs_stream_t stream);
 int wgs_softmax_rows_bwd(const float* y, const float* dy, float* dx, int64_t rows, int n, wgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Self-attention core of BigGAN's non-local block — replaces the two torch.bmm + F.softmax of Attention.forward
+ * (models/BigGAN/layers.py:157-166) and their autograd backward, batched over the samples and fused:
+ *     beta[b,q,:] = softmax_k( theta[b,q,:] . phi[b,k,:] ),      o[b,q,:] = sum_k beta[b,q,k] * g[b,k,:]
+ * theta [B,Pq,c8], phi [B,Pk,c8], g [B,Pk,c2], o [B,Pq,c2]: NHWC rows (pixel-major, channels contiguous).  The [B,Pq,Pk]
+ * score / attention tensors are never written; `lse` [B,Pq] (log-sum-exp of every score row) is the only state the backward
+ * needs besides the operands and o.  Exact fp32 (f32-input MFMA).  Supported: Pq % 128 == 0, Pk % 64 == 0 and
+ * (c8, c2) in {(24, 96), (48, 192), (96, 384)} (= ch in {192, 384, 768}); wgs_attn_supported() tells.
+ * wgs_attn_bwd: d_o = dL/do [B,Pq,c2]; ws = B*Pq floats of scratch; dtheta / dphi / dg are overwritten.
+ */
+int wgs_attn_supported(int B, int Pq, int Pk, int c8, int c2);
+int wgs_attn_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse, int B, int Pq, int Pk, int c8, int c2,
+                 wgs_stream_t stream);
+int wgs_attn_bwd(const float* theta, const float* phi, const float* g, const float* o, const float* lse, const float* d_o, float* ws,
+                 float* dtheta, float* dphi, float* dg, int B, int Pq, int Pk, int c8, int c2, wgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,13 +99,13 @@ def test_step_at_256x256_images_vs_oracle_replay(dev, sg2_256_case, mode):
     name = C.precision_name(eng.precision)
     print('StyleGAN2-256 step, %s: loss %.6f (oracle %.6f), dS err %.2e, worst dR err %.2e' % (name, st[2], o['loss'], e_s, worst))
     tight = mode in ('fp32', 'bf16x3')
-    assert abs(st[2] - o['loss']) < (1e-4 if tight else 2e-3) * max(1.0, abs(o['loss']))
-    assert abs(st[0] - o['ce']) < (1e-4 if tight else 2e-3) * max(1.0, abs(o['ce']))
+    assert abs(st[2] - o['loss']) < (1e-4 if tight else 3e-4) * max(1.0, abs(o['loss']))
+    assert abs(st[0] - o['ce']) < (1e-4 if tight else 3e-4) * max(1.0, abs(o['ce']))
     assert torch.equal(eng.argmax.cpu(), o['argmax'])
     a, b = gb[id(eng.S.SUPPORT_SETS)].double().cpu().reshape(-1), gr['S'].double().reshape(-1)
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     print('   dS cosine %.6f' % cos)
-    assert cos > (0.999 if tight else 0.9)     # batch of 2 through train-mode BatchNorm: entries move by per cents, the direction holds
+    assert cos > (0.999 if tight else 0.98)     # batch of 2 through train-mode BatchNorm: entries move by per cents, the direction holds
 
 
 def test_trainstep_proggan_k64_n16_vs_replay(dev):
@@ -184,13 +184,14 @@ def test_biggan256_class_conditional_batch16(dev):
 
 
 def test_cfg5_full_size_step_fp16_path(dev):
-    """cfg5 as specified: StyleGAN2-1024, K=200, N=64, batch 8, the fp16 MFMA path — one full-size training step against the
-    same step in exact fp32 (identical samples and initial weights): loss within 2e-3, argmax bit-exact, finite gradients,
-    and the support-set gradient pointing the same way."""
+    """cfg5 as specified: StyleGAN2-1024, K=200, N=64, batch 8, the fp16 MFMA path = this architecture's 'mixed' policy (what `auto`
+    resolves to and what bench.py's cfg5 line runs; its image error against the fp64 oracle is gated in
+    test_precision_schemes_gpu.py) — one full-size training step against the same step in exact fp32 (identical samples and
+    initial weights): loss within 1e-3, argmax bit-exact, finite gradients, and the support-set gradient pointing the same way."""
     from warpedganspace_amd.gan_load import build_stylegan2
     K, N, B = 200, 64, 8
     res = {}
-    for mode in ('fp32', 'f16'):
+    for mode in ('fp32', 'auto'):
         torch.manual_seed(0)
         G = build_stylegan2(None, resolution=1024)
         sd = G.G.state_dict()
@@ -206,10 +207,11 @@ def test_cfg5_full_size_step_fp16_path(dev):
         res[mode] = (st, eng.argmax.cpu().clone(), eng.bucket.gview[id(eng.S.SUPPORT_SETS)].double().cpu().reshape(-1).clone())
         del eng, G, S, R
         torch.cuda.empty_cache()
-    (s0, a0, g0), (s1, a1, g1) = res['fp32'], res['f16']
+    assert C.resolve('auto', 'stylegan2', 1024) == C.MIXED
+    (s0, a0, g0), (s1, a1, g1) = res['fp32'], res['auto']
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
-    print('cfg5 step (1024^2, K=200, N=64, B=8): loss fp32 %.6f f16 %.6f, dS cosine %.5f' % (s0[2], s1[2], cos))
+    print('cfg5 step (1024^2, K=200, N=64, B=8): loss fp32 %.6f mixed %.6f, dS cosine %.5f' % (s0[2], s1[2], cos))
     assert all(v == v for v in s1) and torch.isfinite(g1).all()
-    assert abs(s1[2] - s0[2]) < 2e-3 * max(1.0, abs(s0[2]))
+    assert abs(s1[2] - s0[2]) < 1e-3 * max(1.0, abs(s0[2]))
     assert torch.equal(a0, a1)
     assert cos > 0.9

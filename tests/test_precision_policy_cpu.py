@@ -16,6 +16,7 @@ def test_precision_names_round_trip():
 def test_auto_resolves_per_architecture():
     assert C.precision_name(C.resolve('auto', 'stylegan2', 256)) == 'mixed'
     assert C.precision_name(C.resolve(None, 'stylegan2', 256)) == 'mixed'                # None = auto
+    assert C.precision_name(C.resolve('auto', 'stylegan2', 1024)) == 'mixed'
     assert C.precision_name(C.resolve('auto', 'proggan', 256)) == 'f16'
     assert C.precision_name(C.resolve('auto', 'biggan', 128)) == 'bf16x3'
     assert C.precision_name(C.resolve('auto', 'sngan', 32)) == C.AUTO_FALLBACK
@@ -41,13 +42,23 @@ def test_no_process_wide_arithmetic_state():
 
 def test_mixed_policy_per_layer():
     M = C.MIXED
-    # forward: below 64 x 64 split-bf16, stride-1 convs fp16, up-sampling layers fp16 x2
-    assert C.layer_precision(M, 32, False) == 1 and C.layer_precision(M, 32, True) == 1
-    assert C.layer_precision(M, 64, False) == 2 and C.layer_precision(M, 256, False) == 2
-    assert C.layer_precision(M, 64, True) == 3 and C.layer_precision(M, 256, True) == 3
+    # StyleGAN2-256 (the default table): below 128 x 128 split-bf16, stride-1 convs fp16, up-sampling layers fp16 x2
+    assert C.layer_precision(M, 64, False) == 1 and C.layer_precision(M, 64, True) == 1 and C.layer_precision(M, 32, True) == 1
+    assert C.layer_precision(M, 128, False) == 2 and C.layer_precision(M, 256, False) == 2
+    assert C.layer_precision(M, 128, True) == 3 and C.layer_precision(M, 256, True) == 3
     # backward: the up-sampling layers' input-gradient convs in plain fp16, everything else as the forward
     assert C.layer_precision_bwd(M, 128, True) == 2
     assert C.layer_precision_bwd(M, 128, False) == 2 and C.layer_precision_bwd(M, 16, True) == 1
+    # StyleGAN2-1024: fp16 x2 in the HBM-bound 512^2 / 1024^2 layers only
+    pol = C.mixed_policy(1024)
+    assert pol is C.MIXED_1024 and C.mixed_policy(256) is C.MIXED_256
+    assert C.layer_precision(M, 1024, False, pol) == 3 and C.layer_precision(M, 512, True, pol) == 3
+    assert C.layer_precision(M, 256, False, pol) == 1 and C.layer_precision(M, 64, True, pol) == 1
+    assert C.layer_precision_bwd(M, 1024, True, pol) == 2 and C.layer_precision_bwd(M, 1024, False, pol) == 3
+    # an explicit table, and a policy without the plain-fp16 backward rule
+    p2 = C.MixedPolicy({64: (3, 2)}, below=0, bwd_up_f16=False)
+    assert p2.fwd(64, False) == 3 and p2.fwd(64, True) == 2 and p2.fwd(8, True) == 0 and p2.bwd(64, True) == 2
+    assert C.MixedPolicy({64: (2, 3)}, bwd_up_f16=False).bwd(64, True) == 3
     # any fixed mode is the same for every layer, forward and backward
     for code in (0, 1, 2, 3):
         assert C.layer_precision(code, 8, True) == code and C.layer_precision_bwd(code, 256, True) == code

@@ -70,10 +70,10 @@ def test_image_and_shared_gate_gradient_per_scheme(dev, size, B):
                 size, name, res['img_W'], res['img_Z'], res['grad_W'], res['grad_Z']))
     _record('stylegan2_%d' % size, rows)
     for name, res in rows.items():
-        ok = res['img_W'] < GATE and res['img_Z'] < GATE and res['grad_W'] < GATE
+        ok = res['img_W'] < GATE and res['img_Z'] < GATE and res['grad_W'] < GATE and res['grad_Z'] < GATE
         if name in ('fp32', 'bf16x3'):
             assert res['img_W'] < 1e-4 and res['grad_W'] < 2e-4, (name, res)
-        default = C.AUTO_TABLE.get(('stylegan2', size), C.AUTO_FALLBACK) if C.DEFAULT_PRECISION == 'auto' else C.DEFAULT_PRECISION
+        default = C.AUTO_TABLE.get(('stylegan2', size), C.AUTO_FALLBACK)
         if not ok:
             assert name != default, "default arithmetic %s of StyleGAN2-%d misses the 1e-3 gate: %r" % (name, size, res)
         elif name == default:
@@ -149,7 +149,7 @@ def test_fp16_image_error_distribution(dev, family):
                     per_sample.append(((img - ref).abs().flatten(1).max(1).values / ref.abs().flatten(1).max(1).values).cpu())
                     per_batch.append(float((img - ref).abs().max() / ref.abs().max()))      # tests.util.rel_err of the batch tensor
                 e = torch.cat(per_sample)
-                out[name] = {'median': float(e.median()), 'p90': float(e.quantile(0.9)), 'max': float(e.max()),
+                out[name] = {'median': float(e.median()), 'p90': float(e.quantile(0.9)), 'p99': float(e.quantile(0.99)), 'max': float(e.max()),
                              'over_gate_fraction': float((e > GATE).float().mean()), 'n': int(e.numel()),
                              'batch_median': float(torch.tensor(per_batch).median()), 'batch_max': max(per_batch)}
                 print('%s %-6s image error vs exact fp32: batch tensor (B=32) median %.2e max %.2e | per sample median %.2e  p90 %.2e  max %.2e  (%.1f %% over 1e-3)' % (
@@ -158,10 +158,10 @@ def test_fp16_image_error_distribution(dev, family):
     _record('distribution_' + family, out)
     assert out['bf16x3']['max'] < 1e-4
     default = C.AUTO_TABLE.get((fam, res), C.AUTO_FALLBACK)
-    # The gate is applied as every parity test applies it: max-norm relative error of the (batch) tensor.  The architecture's
-    # default mode must keep every BATCH inside it with margin and the bulk of the single images too; normalised by its own
-    # brightest pixel a single image can sit above 1e-3 even when every layer carries 16+ bits (a dim sample), so the
-    # per-sample tail is reported (profiles/), not gated.  The other modes are reported.
+    # The architecture's default mode must keep EVERY measure inside the north_star's 1e-3: the batch tensors (max-norm relative error
+    # of the whole tensor, as every parity test applies the gate) with 15 % margin, and the single images normalised by their OWN
+    # brightest pixel: 99th percentile under the gate and at most 1 % of the images over it (DESIGN.md section 3.2 states both
+    # normalisations).  The other modes are reported.
     assert out[default]['batch_max'] < 0.85 * GATE, (family, default, out[default])
-    assert out[default]['median'] < 0.7 * GATE and out[default]['p90'] < GATE, (family, default, out[default])
+    assert out[default]['median'] < 0.7 * GATE and out[default]['p99'] < GATE and out[default]['over_gate_fraction'] <= 0.01, (family, default, out[default])
     assert all(v['max'] < 1e-2 for v in out.values())

@@ -159,3 +159,33 @@ def test_prefetched_unshifted_pass_same_trajectory(dev):
         for x, y in zip(a[:3], b[:3]):
             assert abs(x - y) <= 5e-2 * max(1.0, abs(x)), (t0, t1)
     assert rel_err(p1, p0) < 1e-3
+
+
+def test_runtime_precision_check_and_engines_with_different_modes_coexist(dev):
+    """TrainStep.check_precision measures the engine's 16-bit mode against the exact-fp32 kernels on ITS generator's weights
+    (the guard behind train.py --check-precision); set_precision switches one engine only: two engines on the same generator,
+    one fp32 and one fp16, keep producing their own arithmetic (no process-wide state)."""
+    from warpedganspace_amd import conv as C
+    size, K, N, B = 32, 16, 4, 4
+    e32, _, _ = make(dev, size, K, N, B, precision='fp32')
+    e16 = TrainStep(e32.G, e32.S, e32.R, e32.p, B, dev, seed=1, precision='f16x2')
+    assert e32.precision == 0 and e16.precision == 3 and tuple(e32.r_arith) == (0, 0, 0) and tuple(e16.r_arith) == (1, 1, 1)
+    assert e32.check_precision() is None
+    r = e16.check_precision()
+    assert r['precision'] == 'f16x2' and r['n'] == B and 0 < r['batch'] < 1e-3 and r['ok'] and r['per_image_max'] >= r['per_image_median']
+    z = torch.randn(B, 512, device=dev)
+    with torch.no_grad():
+        i32, i16 = e32.G(z, precision=e32.precision), e16.G(z, precision=e16.precision)
+        again32 = e32.G(z, precision=e32.precision)
+    assert torch.equal(i32, again32) and not torch.equal(i32, i16) and rel_err(i16, i32) < 1e-3
+    e16.step(); e32.step(); e16.step()                     # interleaved steps of the two engines
+    torch.cuda.synchronize()
+    # a mode that misses the gate is replaced: the Trainer's policy, exercised through its hook with a gate of ~0
+    r0 = e16.check_precision(gate=1e-12)
+    assert not r0['ok']
+    e16.set_precision(C.AUTO_FALLBACK)
+    assert e16.precision == 1 and e16._pre is None and e16._cold
+    assert e16.check_precision()['batch'] < 1e-4
+    e16.step()
+    torch.cuda.synchronize()
+    assert all(v == v for v in e16.stats.tolist())

@@ -322,31 +322,41 @@ class Generator(nn.Module):
         phi, iphi = pool(phi_f)
         g, ig = pool(g_f)
         c8, c2 = ch // 8, ch // 2
-        scores = torch.empty(B, Pq, Pk, device=x.device)
+        lse = None
+        if lib.wgs_attn_supported(B, Pq, Pk, c8, c2):
+            # scores, softmax and the weighted sum of g in ONE launch over the batch (csrc/attention.hip): the [B, Pq, Pk] score /
+            # attention tensors are never written; the backward recomputes its blocks from the row log-sum-exp `lse`
+            o_pre = torch.empty(B, H, H, c2, device=x.device)
+            lse = torch.empty(B, Pq, device=x.device)
+            L.check(lib.wgs_attn_fwd(L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(o_pre), L.ptr(lse), B, Pq, Pk, c8, c2, st), 'attn_fwd')
+            beta = None
+        else:
+            beta, o_pre = self._att_core_unfused(theta, phi, g, B, H, Pq, Pk, c8, c2, prec)
+        o = a['o']
+        y = torch.empty_like(x)
+        C.launch(o_pre, o['wp'], y, [(0, 0, 0)], H, H, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['inv'] * a['gamma'], addend=x, precision=prec)
+        return y, ((x, theta, phi, iphi, g, ig, beta, o_pre, lse) if save else None)
+
+    def _att_core_unfused(self, theta, phi, g, B, H, Pq, Pk, c8, c2, prec):
+        """Fallback for attention shapes the fused kernel does not cover: per-sample GEMM -> row softmax -> GEMM (materialises
+        the [B, Pq, Pk] score tensor)."""
+        lib, st = L.lib(), L.stream()
+        scores = torch.empty(B, Pq, Pk, device=theta.device)
         for b in range(B):      # scores[b] = theta[b] (Pq x c8) . phi[b]^T : phi[b] plays the weight operand [Pk, 1, c8]
             C.launch(theta[b].reshape(1, Pq, 1, c8), phi[b], scores[b].reshape(1, Pq, 1, Pk), [(0, 0, 0)], Pq, 1,
                      w_tap_stride=c8, w_row_stride=c8, precision=prec)
         beta = torch.empty_like(scores)
         L.check(lib.wgs_softmax_rows_fwd(L.ptr(scores), L.ptr(beta), L.c_int64(B * Pq), Pk, st), 'att_softmax')
         del scores
-        o_pre = torch.empty(B, H, H, c2, device=x.device)
+        o_pre = torch.empty(B, H, H, c2, device=theta.device)
         for b in range(B):      # o_pre[b] = beta[b] (Pq x Pk) . g[b] (Pk x c2): weight operand = g[b]^T [c2, 1, Pk]
             gt = C.repack_w_t(g[b].reshape(Pk, 1, c2), Pk, 1, c2)            # [1, c2, Pk]
             C.launch(beta[b].reshape(1, Pq, 1, Pk), gt, o_pre[b].reshape(1, Pq, 1, c2), [(0, 0, 0)], Pq, 1, w_tap_stride=Pk * c2,
                      w_row_stride=Pk, precision=prec)
-        o = a['o']
-        y = torch.empty_like(x)
-        C.launch(o_pre, o['wp'], y, [(0, 0, 0)], H, H, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['inv'] * a['gamma'], addend=x, precision=prec)
-        return y, ((x, theta, phi, iphi, g, ig, beta, o_pre) if save else None)
+        return beta, o_pre
 
-    def _att_bwd(self, a, sv, gy, prec):
+    def _att_core_unfused_bwd(self, theta, phi, g, beta, do_pre, B, Pq, Pk, c8, c2, prec):
         lib, st = L.lib(), L.stream()
-        x, theta, phi, iphi, g, ig, beta, o_pre = sv
-        B, H, _, ch = x.shape
-        Pq, Pk, c8, c2 = H * H, H * H // 4, ch // 8, ch // 2
-        o = a['o']
-        do_pre = torch.empty_like(o_pre)
-        C.launch(gy, o['wt'], do_pre, [(0, 0, 0)], H, H, w_tap_stride=o['ci'] * o['co'], w_row_stride=o['co'], alpha=o['inv'] * a['gamma'], precision=prec, grad_operand=True)
         dbeta = torch.empty_like(beta)
         dg = torch.zeros_like(g)
         for b in range(B):
@@ -364,6 +374,23 @@ class Generator(nn.Module):
             C.launch(ds[b].reshape(1, Pq, 1, Pk), pt, dtheta[b].reshape(1, Pq, 1, c8), [(0, 0, 0)], Pq, 1, w_tap_stride=Pk * c8,
                      w_row_stride=Pk, precision=prec, grad_operand=True)
             C.conv2d_wgrad(theta[b].reshape(1, Pq, 1, c8), ds[b].reshape(1, Pq, 1, Pk), dphi[b].reshape(Pk, 1, c8), 1)
+        return dtheta, dphi, dg
+
+    def _att_bwd(self, a, sv, gy, prec):
+        lib, st = L.lib(), L.stream()
+        x, theta, phi, iphi, g, ig, beta, o_pre, lse = sv
+        B, H, _, ch = x.shape
+        Pq, Pk, c8, c2 = H * H, H * H // 4, ch // 8, ch // 2
+        o = a['o']
+        do_pre = torch.empty_like(o_pre)
+        C.launch(gy, o['wt'], do_pre, [(0, 0, 0)], H, H, w_tap_stride=o['ci'] * o['co'], w_row_stride=o['co'], alpha=o['inv'] * a['gamma'], precision=prec, grad_operand=True)
+        if lse is not None:
+            dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+            ws = torch.empty(B * Pq, device=x.device)
+            L.check(lib.wgs_attn_bwd(L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(o_pre), L.ptr(lse), L.ptr(do_pre), L.ptr(ws), L.ptr(dtheta),
+                                     L.ptr(dphi), L.ptr(dg), B, Pq, Pk, c8, c2, st), 'attn_bwd')
+        else:
+            dtheta, dphi, dg = self._att_core_unfused_bwd(theta, phi, g, beta, do_pre, B, Pq, Pk, c8, c2, prec)
 
         def unpool(d, idx):
             Cn = d.shape[3]

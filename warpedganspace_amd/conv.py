@@ -55,7 +55,7 @@ DEFAULT_PRECISION = 'auto'
 IMAGE_DEFAULT_PRECISION = 'bf16x3'
 # (generator family, output resolution) -> mode for 'auto'; only entries with a measurement behind them
 # (profiles/r3_precision_schemes.json); everything else falls back to the fp32-class mode.
-AUTO_TABLE = {('stylegan2', 256): 'mixed', ('proggan', 256): 'f16'}
+AUTO_TABLE = {('stylegan2', 256): 'mixed', ('stylegan2', 1024): 'mixed', ('proggan', 256): 'f16'}
 AUTO_FALLBACK = 'bf16x3'
 
 
@@ -79,10 +79,16 @@ class MixedPolicy:
         return 2 if (is_up and lp == 3 and self.bwd_up_f16) else lp
 
 
-# StyleGAN2-256 (13 modulated layers; DESIGN.md section 3.2 has the measured error of every candidate)
-MIXED_256 = MixedPolicy({64: (2, 3), 128: (2, 3), 256: (2, 3)})
-# StyleGAN2-1024 (17 layers): the 512^2 / 1024^2 layers are HBM-bound, so the two-MFMA form is free there
-MIXED_1024 = MixedPolicy({64: (3, 3), 128: (3, 3), 256: (3, 3), 512: (3, 3), 1024: (3, 3)})
+# Chosen from measured sweeps (tools/policy_sweep.py, profiles/r3_policy_sweep.md): per-image error of every candidate over 384
+# (256^2) / 64 (1024^2) latent codes and two weight fills, against the exact-fp32 kernels, and the step time under it.
+# StyleGAN2-256: fp16 in the four layers at 128^2 / 256^2 (f16 stride-1 convs, f16x2 up-convs), split-bf16 below.  Every one of the
+# 384 images within 1e-3 (max 8.5e-4, p99 7.3e-4, batch tensors <= 5.2e-4).  Round 2's table also ran the two 64^2 layers in fp16
+# (10 % faster, but p99 1.0e-3 and 1 % of single images over the gate).
+MIXED_256 = MixedPolicy({128: (2, 3), 256: (2, 3)})
+# StyleGAN2-1024 (17 layers): fp16 x2 in the four HBM-bound layers at 512^2 / 1024^2 (64 / 32 channels: the 3-MFMA split-bf16 form
+# is what costs there, not the second fp16 MFMA), split-bf16 everywhere else: 12 % faster than split-bf16 everywhere, every
+# measured image within 1e-3 (max 8.5e-4).  fp16 in the 64^2 .. 256^2 layers as well measures 1.1e-3 .. 1.4e-3 at this depth.
+MIXED_1024 = MixedPolicy({512: (3, 3), 1024: (3, 3)})
 MIXED_POLICIES = {256: MIXED_256, 1024: MIXED_1024}
 
 
