@@ -13,3 +13,11 @@ for mode in fp32 auto; do
   find gpurun_out/prof_${TAG}_$mode -name "*kernel_trace.csv" -delete
   head -12 gpurun_out/${TAG}_step_${mode}_kernel_stats.md | cut -c1-160
 done
+# PMC passes of the dominant conv kernels (counters only, no tracing besides --kernel-trace): tools/pmc_r3.py
+i=0
+for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc_${TAG}/p$i -o p -- python tools/pmc_r3.py > gpurun_out/pmc_${TAG}_p$i.log 2>&1
+done
+find gpurun_out/pmc_${TAG} -name "*kernel_trace.csv" -delete
+python tools/pmc_r3.py --summarise gpurun_out/pmc_${TAG} gpurun_out/${TAG}_conv_pmc
