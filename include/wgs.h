@@ -185,6 +185,9 @@ int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
  * stride-2 transposed conv (models/StyleGAN2/model.py:201-212).  Same results as n wgs_conv_igemm calls; when the
  * split-bf16 8-wave kernel covers the shape they run as ONE launch (short-K phases fill the chip together). */
 int wgs_conv_igemm_multi(const wgs_conv_desc* descs, int n, wgs_stream_t stream);
+/* 1 when wgs_conv_igemm_multi would run these launches as ONE merged kernel, 0 when it would issue them one by one (nothing is
+ * launched): lets a profiler time the phases separately in the second case. */
+int wgs_conv_igemm_multi_merges(const wgs_conv_desc* descs, int n);
 
 /* Weight gradient of a (strided) conv:  dw[co*w_row_stride + wt[t]*w_tap_stride + ci] +=
  *   sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*isy + dy[t], ox*isx + dx[t], ci]

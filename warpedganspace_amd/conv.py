@@ -267,10 +267,16 @@ def launch_multi(x, w, y, phases, **kw):
     """Launches that differ only in (taps, Hg, Wg, oy0, ox0) — the sub-pixel phases of a transposed conv — through
     wgs_conv_igemm_multi (one merged launch where the library supports it).  phases: list of (taps, Hg, Wg, oy0, ox0)."""
     descs = (ConvDesc * len(phases))()
-    flops = 0.0
+    flops = []
     for i, (taps, Hg, Wg, oy0, ox0) in enumerate(phases):
-        flops += _desc(x, w, y, taps, Hg, Wg, oy0=oy0, ox0=ox0, into=descs[i], **kw)[1]
-    _timed(_kind(descs[0], len(phases)), flops, lambda: L.check(L.lib().wgs_conv_igemm_multi(descs, len(phases), L.stream()), 'wgs_conv_igemm_multi'))
+        flops.append(_desc(x, w, y, taps, Hg, Wg, oy0=oy0, ox0=ox0, into=descs[i], **kw)[1])
+    if PROFILE is not None and not L.lib().wgs_conv_igemm_multi_merges(descs, len(phases)):
+        # profiling a launch group that the library issues phase by phase (small maps): time every phase on its own, so that each
+        # kernel symbol gets its own FLOPs and duration (the launches themselves are the ones wgs_conv_igemm_multi would issue)
+        for i in range(len(phases)):
+            _timed(_kind(descs[i], 1) + ' (up-conv phase)', flops[i], lambda i=i: L.check(L.lib().wgs_conv_igemm(ctypes.byref(descs[i]), L.stream()), 'wgs_conv_igemm'))
+        return y
+    _timed(_kind(descs[0], len(phases)), sum(flops), lambda: L.check(L.lib().wgs_conv_igemm_multi(descs, len(phases), L.stream()), 'wgs_conv_igemm_multi'))
     return y
 
 

@@ -81,12 +81,12 @@ void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st);
 // 1 when the shape is not supported (caller falls back to the exact fp32 kernel).
 int launch_bf16x3(const ConvArgs& a, hipStream_t st);
 // the same for n <= 4 launches that differ only in (Hg, Wg, oy0, ox0, taps); 0 = handled as one merged launch
-int launch_bf16x3_multi(const ConvArgs* a, int n, hipStream_t st);
+int launch_bf16x3_multi(const ConvArgs* a, int n, hipStream_t st, bool dry = false);   // dry: decide only, launch nothing
 
 // The same kernel template in exact fp32 (scheme 4, conv_igemm_f32.hip): a.sch must be 4; 0 = handled, 1 = shape not covered
 // (Ci % 32, > 16 taps, operands beyond 2 GiB: the caller keeps the plain fp32 kernel of conv_igemm.hip)
 int launch_f32(const ConvArgs& a, hipStream_t st);
-int launch_f32_multi(const ConvArgs* a, int n, hipStream_t st);
+int launch_f32_multi(const ConvArgs* a, int n, hipStream_t st, bool dry = false);
 // operand extents (x_bytes / w_bytes / s_bytes) for the buffer descriptors; false when a stream exceeds a 31-bit byte offset
 bool set_extents(ConvArgs& a, int wt_max);
 

@@ -634,18 +634,29 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     return WGS_OK;
 }
 
+// 0 = the launches ran (or, dry, would run) as ONE merged kernel; 1 = they do not merge
+static int multi_merged(const wgs_conv_desc* descs, int n, hipStream_t st, bool dry) {
+    if (n < 2 || n > 4) return 1;
+    ConvArgs as[4];
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) ok = descs[i].precision == descs[0].precision && descs[i].a_amax == descs[0].a_amax && build_conv_args(&descs[i], as[i]) == WGS_OK;
+    if (!ok) return 1;
+    if (descs[0].precision >= 1) return wgsconv::launch_bf16x3_multi(as, n, st, dry);
+    return wgs_flags().f32_old ? 1 : wgsconv::launch_f32_multi(as, n, st, dry);
+}
+
+int wgs_conv_igemm_multi_merges(const wgs_conv_desc* descs, int n) {
+    if (!descs || n <= 0) return 0;
+    for (int i = 0; i < n; ++i) if (descs[i].x_f16) return 0;
+    return multi_merged(descs, n, nullptr, true) == 0 ? 1 : 0;
+}
+
 int wgs_conv_igemm_multi(const wgs_conv_desc* descs, int n, wgs_stream_t stream) {
     WGS_CHECK_ARG(descs && n > 0, "wgs_conv_igemm_multi: bad arguments");
     for (int i = 0; i < n; ++i) WGS_CHECK_ARG(!descs[i].x_f16, "wgs_conv_igemm_multi: x_f16 operands are single-launch only (wgs_conv_igemm)");
-    if (n >= 2 && n <= 4) {
-        ConvArgs as[4];
-        bool ok = true;
-        for (int i = 0; i < n && ok; ++i) ok = descs[i].precision == descs[0].precision && descs[i].a_amax == descs[0].a_amax && build_conv_args(&descs[i], as[i]) == WGS_OK;
-        if (ok && (descs[0].precision >= 1 ? wgsconv::launch_bf16x3_multi(as, n, (hipStream_t)stream)
-                                           : (wgs_flags().f32_old ? 1 : wgsconv::launch_f32_multi(as, n, (hipStream_t)stream))) == 0) {
-            WGS_CHECK_LAUNCH("igemm_nt16_kernel<multi>");
-            return WGS_OK;
-        }
+    if (multi_merged(descs, n, (hipStream_t)stream, false) == 0) {
+        WGS_CHECK_LAUNCH("igemm_nt16_kernel<multi>");
+        return WGS_OK;
     }
     for (int i = 0; i < n; ++i) {
         const int rc = wgs_conv_igemm(&descs[i], stream);
