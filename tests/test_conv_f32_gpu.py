@@ -119,3 +119,24 @@ def test_f32_falls_back_where_the_template_does_not_reach(dev):
     x = torch.randn(2, 12, 12, 64, device=dev)
     w = torch.randn(24, 25, 64, device=dev)
     assert _symbol_of(lambda: C.conv2d(x, w, 5, stride=1, pad=2, precision=0)).startswith('igemm_nt_kernel<')
+
+
+def test_conv_beyond_2gib_is_split_over_samples(dev):
+    """A [B, H, W, C] operand larger than 2 GiB (ProgGAN-1024's feature maps at batch 32) is issued as consecutive launches over
+    sample ranges, each through the fast template: same result per sample as that sample on its own, with style / demodulation rows,
+    bias and a low-resolution addend following their sample."""
+    B, H, Ci, Co = 3, 1536, 96, 32                      # x: 3 x 1536^2 x 96 x 4 B = 2.7 GB; y 0.9 GB
+    torch.manual_seed(3)
+    x = torch.randn(B, H, H, Ci, device=dev)
+    w = torch.randn(Co, 9, Ci, device=dev) / (9 * Ci) ** 0.5
+    s, dm, bias = torch.randn(B, Ci, device=dev) + 1.0, torch.rand(B, Co, device=dev) + 0.5, torch.randn(Co, device=dev)
+    kw = dict(a_scale=s, col_scale=dm, bias=bias, act_slope=0.2, gain=1.3)
+    for prec in (0, 1):
+        sym = _symbol_of(lambda: C.conv2d(x, w, 3, pad=1, precision=prec, **kw))
+        assert sym.startswith('igemm_nt16_kernel<'), sym
+        y = C.conv2d(x, w, 3, pad=1, precision=prec, **kw)
+        for b in (0, B - 1):
+            yb = C.conv2d(x[b:b + 1].contiguous(), w, 3, pad=1, precision=prec, a_scale=s[b:b + 1].contiguous(), col_scale=dm[b:b + 1].contiguous(),
+                          bias=bias, act_slope=0.2, gain=1.3)
+            assert torch.equal(y[b:b + 1], yb), (prec, b)
+        del y, yb

@@ -590,6 +590,29 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
 }
 
 int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
+    // Tensors beyond 2 GiB (ProgGAN's 512^2 / 1024^2 feature maps at batch 32: 2.1 - 4.3 GB): the fast kernels address their
+    // operands through buffer descriptors with 31-bit byte offsets and would decline the launch (-> the plain fp32 kernel with
+    // 64-bit addressing, 20 - 40 TFLOP/s).  A conv is independent per sample, so such a launch is issued as consecutive launches
+    // over sample ranges that fit.
+    if (d && !d->x_f16 && d->B > 1 && d->Ci > 0 && d->Ci % 32 == 0 && d->ntaps <= 16 && d->x && d->y) {
+        const long xs = (long)d->Hi * d->Wi * d->Ci * 4, ys = (long)d->Ho * d->Wo * d->Co * 4, lim = 0x7fffffffL;
+        if (((long)d->B * xs > lim || (long)d->B * ys > lim) && xs <= lim && ys <= lim) {
+            long nb = lim / (xs > ys ? xs : ys);
+            if (nb < 1) nb = 1;
+            for (int b0 = 0; b0 < d->B; b0 += (int)nb) {
+                wgs_conv_desc c = *d;
+                c.B = d->B - b0 < nb ? d->B - b0 : (int)nb;
+                c.x = d->x + (size_t)b0 * (xs / 4);
+                c.y = d->y + (size_t)b0 * (ys / 4);
+                if (d->a_scale) c.a_scale = d->a_scale + (size_t)b0 * (d->a_ld > 0 ? d->a_ld : d->Ci);
+                if (d->col_scale) c.col_scale = d->col_scale + (size_t)b0 * (d->col_ld > 0 ? d->col_ld : d->Co);
+                if (d->addend) c.addend = d->addend + (size_t)b0 * (d->Ho >> d->add_ups) * (d->Wo >> d->add_ups) * d->Co;
+                const int rc = wgs_conv_igemm(&c, stream);
+                if (rc != WGS_OK) return rc;
+            }
+            return WGS_OK;
+        }
+    }
     ConvArgs a;
     const int rc = build_conv_args(d, a);
     if (rc != WGS_OK) return rc;
