@@ -140,3 +140,27 @@ def test_conv_beyond_2gib_is_split_over_samples(dev):
                           bias=bias, act_slope=0.2, gain=1.3)
             assert torch.equal(y[b:b + 1], yb), (prec, b)
         del y, yb
+
+
+@pytest.mark.parametrize('prec', [0, 1, 2])
+@pytest.mark.parametrize('B,Ci,Co,H,k,ups', [(2, 16, 16, 21, 3, 0), (3, 16, 32, 16, 3, 0), (2, 16, 8, 19, 2, 0), (2, 16, 16, 9, 3, 1), (1, 16, 64, 12, 4, 0)])
+def test_sixteen_input_channels_pair_their_taps(dev, B, Ci, Co, H, k, ups, prec):
+    """Ci = 16 (ProgGAN's 512^2 / 1024^2 layers): the template stages two taps x 16 channels per 32-deep chunk (an odd last tap
+    pairs with zeros); every arithmetic scheme, plain and up-sampled gathers, against a float64 convolution."""
+    torch.manual_seed(B + Co + H + k)
+    x = torch.randn(B, Ci, H, H)
+    w = torch.randn(Co, Ci, k, k) / (Ci * k * k) ** 0.5
+    bias = torch.randn(Co)
+    pad = k // 2
+    xin = F.interpolate(x.double(), scale_factor=2, mode='nearest') if ups else x.double()
+    ref = F.leaky_relu(0.9 * F.conv2d(xin, w.double(), padding=pad) + bias.double()[None, :, None, None], 0.2)
+    Ho = ref.shape[2]
+    taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
+    y = torch.empty(B, Ho, Ho, Co, device=dev)
+    xd, wd = nhwc(x).to(dev), C.pack_weight(w).to(dev)
+    amax = xd.abs().amax().reshape(1)
+    kw = dict(w_tap_stride=Ci, w_row_stride=k * k * Ci, ups=ups, alpha=0.9, bias=bias.to(dev), act_slope=0.2, gain=1.0, precision=prec,
+              a_amax=amax if prec >= 2 else None)
+    sym = _symbol_of(lambda: C.launch(xd, wd, y, taps, Ho, Ho, **kw))
+    assert sym.startswith('igemm_nt16_kernel<%d,' % (4 if prec == 0 else prec - 1)) and ', 3, ' in sym, sym
+    assert rel_err(nchw(y), ref) < (1e-5 if prec == 0 else 1e-4 if prec == 1 else 2e-3)

@@ -594,7 +594,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     // operands through buffer descriptors with 31-bit byte offsets and would decline the launch (-> the plain fp32 kernel with
     // 64-bit addressing, 20 - 40 TFLOP/s).  A conv is independent per sample, so such a launch is issued as consecutive launches
     // over sample ranges that fit.
-    if (d && !d->x_f16 && d->B > 1 && d->Ci > 0 && d->Ci % 32 == 0 && d->ntaps <= 16 && d->x && d->y) {
+    if (d && !d->x_f16 && d->B > 1 && d->Ci > 0 && d->Ci % 16 == 0 && d->ntaps <= 16 && d->x && d->y) {
         const long xs = (long)d->Hi * d->Wi * d->Ci * 4, ys = (long)d->Ho * d->Wo * d->Co * 4, lim = 0x7fffffffL;
         if (((long)d->B * xs > lim || (long)d->B * ys > lim) && xs <= lim && ys <= lim) {
             long nb = lim / (xs > ys ? xs : ys);
