@@ -49,6 +49,8 @@ def test_mixed_policy_per_layer():
     # backward: the up-sampling layers' input-gradient convs in plain fp16, everything else as the forward
     assert C.layer_precision_bwd(M, 128, True) == 2
     assert C.layer_precision_bwd(M, 128, False) == 2 and C.layer_precision_bwd(M, 16, True) == 1
+    # ... and the two 64 x 64 layers: split-bf16 forward (image gate), plain fp16 input-gradient convs (gradient gate)
+    assert C.layer_precision_bwd(M, 64, False) == 2 and C.layer_precision_bwd(M, 64, True) == 2 and C.layer_precision_bwd(M, 32, False) == 1
     # StyleGAN2-1024: fp16 x2 in the HBM-bound 512^2 / 1024^2 layers only
     pol = C.mixed_policy(1024)
     assert pol is C.MIXED_1024 and C.mixed_policy(256) is C.MIXED_256

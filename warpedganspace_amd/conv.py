@@ -65,16 +65,21 @@ class MixedPolicy:
     at >= 64x64; so those run in fp16 and the low-resolution layers (latency-bound) in split-bf16.
     table: {output resolution: (stride-1 conv code, up-conv code)}; resolutions not listed run `below` (bf16x3).
     bwd_up_f16: the up-sampling layers' INPUT-GRADIENT convs run in plain f16 when their forward is f16x2 (the two-MFMA form
-    exists for the image-error budget; the gradient has its own gate, the shared-gate gradient error)."""
+    exists for the image-error budget; the gradient has its own gate, the shared-gate gradient error).
+    bwd_table: explicit arithmetic of the input-gradient convs of the listed resolutions."""
 
-    def __init__(self, table, below=1, bwd_up_f16=True):
+    def __init__(self, table, below=1, bwd_up_f16=True, bwd_table=None):
         self.table, self.below, self.bwd_up_f16 = dict(table), below, bwd_up_f16
+        self.bwd_table = dict(bwd_table or {})     # {output resolution: (stride-1, up-conv)} arithmetic of the INPUT-GRADIENT convs only
 
     def fwd(self, out_res, is_up):
         s1, up = self.table.get(out_res, (self.below, self.below))
         return up if is_up else s1
 
     def bwd(self, out_res, is_up):
+        if out_res in self.bwd_table:
+            s1, up = self.bwd_table[out_res]
+            return up if is_up else s1
         lp = self.fwd(out_res, is_up)
         return 2 if (is_up and lp == 3 and self.bwd_up_f16) else lp
 
@@ -83,8 +88,9 @@ class MixedPolicy:
 # (256^2) / 64 (1024^2) latent codes and two weight fills, against the exact-fp32 kernels, and the step time under it.
 # StyleGAN2-256: fp16 in the four layers at 128^2 / 256^2 (f16 stride-1 convs, f16x2 up-convs), split-bf16 below.  Every one of the
 # 384 images within 1e-3 (max 8.5e-4, p99 7.3e-4, batch tensors <= 5.2e-4).  Round 2's table also ran the two 64^2 layers in fp16
-# (10 % faster, but p99 1.0e-3 and 1 % of single images over the gate).
-MIXED_256 = MixedPolicy({128: (2, 3), 256: (2, 3)})
+# (10 % faster, but p99 1.0e-3 and 1 % of single images over the gate).  Their INPUT-GRADIENT convs do run in plain fp16 (bwd_table):
+# the image gate is a forward matter, the gradient has its own (shared-gate gradient error vs the fp64 oracle, 1e-3).
+MIXED_256 = MixedPolicy({128: (2, 3), 256: (2, 3)}, bwd_table={64: (2, 2)})
 # StyleGAN2-1024 (17 layers): fp16 x2 in the four HBM-bound layers at 512^2 / 1024^2 (64 / 32 channels: the 3-MFMA split-bf16 form
 # is what costs there, not the second fp16 MFMA), split-bf16 everywhere else: 12 % faster than split-bf16 everywhere, every
 # measured image within 1e-3 (max 8.5e-4).  fp16 in the 64^2 .. 256^2 layers as well measures 1.1e-3 .. 1.4e-3 at this depth.
