@@ -57,6 +57,7 @@ def test_mixed_policy_per_layer():
     assert C.layer_precision(M, 1024, False, pol) == 3 and C.layer_precision(M, 512, True, pol) == 3
     assert C.layer_precision(M, 256, False, pol) == 1 and C.layer_precision(M, 64, True, pol) == 1
     assert C.layer_precision_bwd(M, 1024, True, pol) == 2 and C.layer_precision_bwd(M, 1024, False, pol) == 3
+    assert C.layer_precision_bwd(M, 256, False, pol) == 2 and C.layer_precision_bwd(M, 64, True, pol) == 2 and C.layer_precision_bwd(M, 32, True, pol) == 1
     # an explicit table, and a policy without the plain-fp16 backward rule
     p2 = C.MixedPolicy({64: (3, 2)}, below=0, bwd_up_f16=False)
     assert p2.fwd(64, False) == 3 and p2.fwd(64, True) == 2 and p2.fwd(8, True) == 0 and p2.bwd(64, True) == 2

@@ -94,7 +94,7 @@ MIXED_256 = MixedPolicy({128: (2, 3), 256: (2, 3)}, bwd_table={64: (2, 2)})
 # StyleGAN2-1024 (17 layers): fp16 x2 in the four HBM-bound layers at 512^2 / 1024^2 (64 / 32 channels: the 3-MFMA split-bf16 form
 # is what costs there, not the second fp16 MFMA), split-bf16 everywhere else: 12 % faster than split-bf16 everywhere, every
 # measured image within 1e-3 (max 8.5e-4).  fp16 in the 64^2 .. 256^2 layers as well measures 1.1e-3 .. 1.4e-3 at this depth.
-MIXED_1024 = MixedPolicy({512: (3, 3), 1024: (3, 3)})
+MIXED_1024 = MixedPolicy({512: (3, 3), 1024: (3, 3)}, bwd_table={64: (2, 2), 128: (2, 2), 256: (2, 2)})
 MIXED_POLICIES = {256: MIXED_256, 1024: MIXED_1024}
 
 
