@@ -5,6 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/${TAG}_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_tests.log
 tail -5 gpurun_out/${TAG}_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"
 grep '^{' gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json
 for mode in fp32 auto; do
