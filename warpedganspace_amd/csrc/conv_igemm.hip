@@ -622,14 +622,6 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         WGS_CHECK_LAUNCH("igemm_dma16_kernel<x_f16>");
         return WGS_OK;
     }
-    if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && d->ntaps <= 16 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&
-        d->act == 0 && d->act_slope == 1.f && d->gain == 1.f) {
-        const long waves = ((long)a.M + 15) / 16;
-        wgs_note_kernel("igemm_narrow_kernel");
-        WGS_LAUNCH(igemm_narrow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
-        WGS_CHECK_LAUNCH("igemm_narrow_kernel");
-        return WGS_OK;
-    }
     const bool k32 = (d->Ci % 32 == 0);
     if (d->precision >= 1 && wgsconv::launch_bf16x3(a, st) == 0) {
         WGS_CHECK_LAUNCH("igemm_nt16_kernel");
@@ -639,6 +631,16 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     a.sch = 4;
     if (!wgs_flags().f32_old && wgsconv::launch_f32(a, st) == 0) {
         WGS_CHECK_LAUNCH("igemm_nt16_kernel<4>");
+        return WGS_OK;
+    }
+    // (64 -> <= 8 channels, the image gradient of ResNet conv1: the template's 128 x 32 tiles measure 1.07 ms against this kernel's
+    // 1.47 ms at B = 32, so it is the fallback now — WGS_F32_OLD, or operands the template declines)
+    if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && d->ntaps <= 16 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&
+        d->act == 0 && d->act_slope == 1.f && d->gain == 1.f) {
+        const long waves = ((long)a.M + 15) / 16;
+        wgs_note_kernel("igemm_narrow_kernel");
+        WGS_LAUNCH(igemm_narrow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+        WGS_CHECK_LAUNCH("igemm_narrow_kernel");
         return WGS_OK;
     }
     if (d->Co > 64) {
