@@ -49,7 +49,7 @@ const WgsFlags& wgs_flags() { return flags_storage(); }
 
 extern "C" {
 const char* wgs_last_error(void) { return g_err; }
-int wgs_abi_version(void) { return 3; }
+int wgs_abi_version(void) { return 4; }
 void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
 int64_t wgs_dev_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 void wgs_dev_trace_kernels(int on) { g_trace.store(on ? 1 : 0, std::memory_order_relaxed); g_kernel[0] = 0; }
