@@ -223,6 +223,10 @@ int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stre
 /* PixelNorm (:9-15) over `rows` rows of length d: y = x * rsqrt(mean(x^2) + eps); and its backward. */
 int wgs_pixelnorm_fwd(const float* x, float* y, int rows, int d, float eps, wgs_stream_t stream);
 int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream);
+/* The same with the leaky-relu backward of the layer that PRODUCED x folded into the store: gx *= (x > 0 ? 1 : act_slope).  In ProgGAN
+ * (models/ProgGAN/model.py:35-62) the PixelNorm input of a block is the activated output of the previous block, so this replaces that
+ * block's separate activation-backward pass over the tensor. */
+int wgs_pixelnorm_bwd_act(const float* x, const float* gy, float* gx, int rows, int d, float eps, float act_slope, wgs_stream_t stream);
 
 /* The whole mapping network (model.py:288-295: PixelNorm, then L x EqualLinear(d, d, lr_mul, activation='fused_lrelu')) in ONE
  * launch.  w / bias: host arrays of L device pointers ([d,d] and [d] per layer); acts: device [(L+1), B, d] — acts[0] =

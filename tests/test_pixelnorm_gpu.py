@@ -23,3 +23,17 @@ def test_pixelnorm_fwd_bwd(dev, rows, d):
     L.check(lib.wgs_pixelnorm_fwd(L.ptr(xg), L.ptr(y), rows, d, L.c_float(1e-8), st), 'pn_fwd')
     L.check(lib.wgs_pixelnorm_bwd(L.ptr(xg), L.ptr(gg), L.ptr(gx), rows, d, L.c_float(1e-8), st), 'pn_bwd')
     assert rel_err(y, y_ref.detach()) < 1e-6 and rel_err(gx, xd.grad) < 2e-6
+
+
+def test_pixelnorm_bwd_with_folded_leaky_relu_gate(dev):
+    """wgs_pixelnorm_bwd_act = PixelNorm backward times the leaky-relu gate of its input (the previous block's activation backward)."""
+    torch.manual_seed(5)
+    rows, d = 515, 32
+    x, g = torch.randn(rows, d), torch.randn(rows, d)
+    xd = x.double().requires_grad_(True)
+    (xd * torch.rsqrt(xd.pow(2).mean(1, keepdim=True) + 1e-8)).backward(g.double())
+    ref = xd.grad * torch.where(x > 0, 1.0, 0.2).double()
+    lib, st = L.lib(), L.stream()
+    xg, gg, gx = x.to(dev), g.to(dev), torch.empty(rows, d, device=dev)
+    L.check(lib.wgs_pixelnorm_bwd_act(L.ptr(xg), L.ptr(gg), L.ptr(gx), rows, d, L.c_float(1e-8), L.c_float(0.2), st), 'pn_bwd_act')
+    assert rel_err(gx, ref) < 2e-6, rel_err(gx, ref)

@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_vec_kernel(const float* __r
     }
 }
 // y = x * f, f = (mean(x^2)+eps)^-1/2  =>  gx = f*gy - x * f^3 * (x.gy)/d
+// act_slope != 1: the result is also multiplied by the leaky-relu gate of x (x > 0 ? 1 : act_slope) — x is the activated output of
+// the previous block, so this is that block's activation backward folded into the store (ProgGAN, models/ProgGAN/model.py:35-62)
 __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                            float* __restrict__ gx, int rows, int d, float eps) {
+                                                            float* __restrict__ gx, int rows, int d, float eps, float act_slope) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
@@ -60,11 +62,11 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
     s = wave_sum(s); t = wave_sum(t);
     const float f = rsqrtf(s / d + eps);
     const float c = f * f * f * t / d;
-    for (int j = lane; j < d; j += 64) gx[(size_t)r * d + j] = f * gr[j] - xr[j] * c;
+    for (int j = lane; j < d; j += 64) gx[(size_t)r * d + j] = (f * gr[j] - xr[j] * c) * (xr[j] > 0.f ? 1.f : act_slope);
 }
 template <int LPR>
 __global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                float* __restrict__ gx, long rows, float eps) {
+                                                                float* __restrict__ gx, long rows, float eps, float act_slope) {
     constexpr int RPB = 256 / LPR;
     const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
     const float inv_d = 1.f / (4 * LPR);
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(const float* __r
         const float t = group_sum<LPR>(fmaf(v.x, g.x, fmaf(v.y, g.y, fmaf(v.z, g.z, v.w * g.w))));
         const float f = rsqrtf(s * inv_d + eps);
         const float c = f * f * f * t * inv_d;
-        *reinterpret_cast<float4*>(gx + o) = make_float4(f * g.x - v.x * c, f * g.y - v.y * c, f * g.z - v.z * c, f * g.w - v.w * c);
+        *reinterpret_cast<float4*>(gx + o) = make_float4((f * g.x - v.x * c) * (v.x > 0.f ? 1.f : act_slope), (f * g.y - v.y * c) * (v.y > 0.f ? 1.f : act_slope),
+                                                         (f * g.z - v.z * c) * (v.z > 0.f ? 1.f : act_slope), (f * g.w - v.w * c) * (v.w > 0.f ? 1.f : act_slope));
     }
 }
 
@@ -661,16 +664,22 @@ int wgs_pixelnorm_fwd(const float* x, float* y, int rows, int d, float eps, wgs_
     WGS_CHECK_LAUNCH("pixelnorm_fwd_kernel");
     return WGS_OK;
 }
-int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream) {
-    WGS_CHECK_ARG(x && gy && gx && rows > 0 && d > 0, "wgs_pixelnorm_bwd: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
+static int pixelnorm_bwd_launch(const float* x, const float* gy, float* gx, int rows, int d, float eps, float act_slope, hipStream_t st) {
 #define WGS_PN(LPR) { const long nb = ((long)rows + 256 / LPR - 1) / (256 / LPR); \
-        WGS_LAUNCH(pixelnorm_bwd_vec_kernel<LPR>, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, st, x, gy, gx, (long)rows, eps); }
+        WGS_LAUNCH(pixelnorm_bwd_vec_kernel<LPR>, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, st, x, gy, gx, (long)rows, eps, act_slope); }
     if (d == 16) WGS_PN(4) else if (d == 32) WGS_PN(8) else if (d == 64) WGS_PN(16) else if (d == 128) WGS_PN(32) else if (d == 256) WGS_PN(64)
-    else WGS_LAUNCH(pixelnorm_bwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, st, x, gy, gx, rows, d, eps);
+    else WGS_LAUNCH(pixelnorm_bwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, st, x, gy, gx, rows, d, eps, act_slope);
 #undef WGS_PN
     WGS_CHECK_LAUNCH("pixelnorm_bwd_kernel");
     return WGS_OK;
+}
+int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && gy && gx && rows > 0 && d > 0, "wgs_pixelnorm_bwd: bad arguments");
+    return pixelnorm_bwd_launch(x, gy, gx, rows, d, eps, 1.f, (hipStream_t)stream);
+}
+int wgs_pixelnorm_bwd_act(const float* x, const float* gy, float* gx, int rows, int d, float eps, float act_slope, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && gy && gx && rows > 0 && d > 0, "wgs_pixelnorm_bwd_act: bad arguments");
+    return pixelnorm_bwd_launch(x, gy, gx, rows, d, eps, act_slope, (hipStream_t)stream);
 }
 
 int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx,

@@ -112,10 +112,11 @@ class Generator(nn.Module):
         return y
 
     @staticmethod
-    def _pixelnorm_bwd(x, gy, eps=1e-8):
+    def _pixelnorm_bwd(x, gy, eps=1e-8, act_slope=1.0):
         gx = torch.empty_like(x)
         rows, d = x.numel() // x.shape[-1], x.shape[-1]
-        L.check(L.lib().wgs_pixelnorm_bwd(L.ptr(x), L.ptr(gy), L.ptr(gx), rows, d, L.c_float(eps), L.stream()), 'pixelnorm_bwd')
+        L.check(L.lib().wgs_pixelnorm_bwd_act(L.ptr(x), L.ptr(gy), L.ptr(gx), rows, d, L.c_float(eps), L.c_float(act_slope), L.stream()),
+                'pixelnorm_bwd')
         return gx
 
     def _fwd(self, z, save, prec):
@@ -157,12 +158,12 @@ class Generator(nn.Module):
         o = P['out']
         gxn = torch.empty(B, Hc, Hc, o['ci'], device=dev)
         C.launch(g4, o['wt'], gxn, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'] * 8, w_row_stride=8, alpha=o['scale'], precision=prec, grad_operand=True)
-        g = self._pixelnorm_bwd(x_last, gxn)
-        for ly, (x, xn, y) in zip(reversed(P['layers']), reversed(saved)):
-            # y = lrelu(scale*conv + b): dpre = g * (y > 0 ? 1 : 0.2)
-            dpre = torch.empty_like(y)
-            L.check(lib.wgs_bias_act(L.ptr(g), None, L.ptr(y), L.ptr(dpre), 3, 1, L.c_float(0.2), L.c_float(1.0),
-                                     L.c_int64(y.numel()), 1, 1, st), 'lrelu_bwd')
+        # The PixelNorm input of a block is the activated output y of the block before it, so the PixelNorm backward also applies that
+        # block's leaky-relu gate (y > 0 ? 1 : 0.2) while it stores: `dpre` below is d loss / d (scale * conv + b) of the block, and the
+        # separate activation-backward pass over the tensor is gone.
+        dpre = self._pixelnorm_bwd(x_last, gxn, act_slope=0.2)
+        nl = len(P['layers'])
+        for li, (ly, (x, xn, y)) in enumerate(zip(reversed(P['layers']), reversed(saved))):
             k, pad = ly['k'], ly['pad']
             Hup = x.shape[1] << (1 if ly['up'] else 0)
             dup = torch.empty(B, Hup, Hup, ly['ci'], device=dev)
@@ -174,7 +175,9 @@ class Generator(nn.Module):
                 L.check(lib.wgs_upsample2x_bwd(L.ptr(dup), L.ptr(gxn), B, x.shape[1], x.shape[2], ly['ci'], st), 'upsample_bwd')
             else:
                 gxn = dup
-            g = self._pixelnorm_bwd(x, gxn)
+            # x = the previous block's activated output (gate folded in), or — first block — the latent code itself
+            dpre = self._pixelnorm_bwd(x, gxn, act_slope=0.2 if li + 1 < nl else 1.0)
+        g = dpre
         return g.reshape(B, 512)
 
     def forward(self, x, precision=None):
