@@ -1,0 +1,84 @@
+"""GPU: the Winograd F(2x2, 3x3) fp32 conv kernel (csrc/conv_wino_f32.hip, precision 'fp32w') against float64 torch convs and
+against the direct exact-fp32 kernel — the styled forward conv of models/StyleGAN2/model.py:187-228 (style, demodulation, noise,
+bias, leaky-relu epilogue) and its input-gradient form (transposed weights, flipped taps)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import rel_err
+from warpedganspace_amd import _lib as L
+from warpedganspace_amd import conv as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _supported(x, w, y, **kw):
+    d, _ = C._desc(x, w, y, [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)], y.shape[1], y.shape[2],
+                   w_tap_stride=x.shape[3], w_row_stride=9 * x.shape[3], **kw)
+    import ctypes
+    return bool(L.lib().wgs_conv_wino_supported(ctypes.byref(d)))
+
+
+@pytest.mark.parametrize('B,H,W,ci,co', [(2, 16, 16, 64, 64), (3, 32, 16, 8, 128), (2, 48, 64, 128, 64), (1, 64, 64, 512, 512), (5, 16, 32, 24, 192)])
+def test_wino_styled_forward_vs_float64(dev, B, H, W, ci, co):
+    torch.manual_seed(B * 1000 + ci + co)
+    x = torch.randn(B, H, W, ci)
+    w = torch.randn(co, ci, 3, 3) / (9 * ci) ** 0.5
+    s = torch.randn(B, ci) + 1.0
+    dm = torch.rand(B, co) + 0.5
+    bias, noise, nw = torch.randn(co), torch.randn(H * W), torch.tensor([0.37])
+    xd = (x.double() * s.double()[:, None, None, :]).permute(0, 3, 1, 2)
+    ref = F.conv2d(xd, w.double(), padding=1) * dm.double()[:, :, None, None]
+    ref = ref + (nw.double() * noise.double()).reshape(1, 1, H, W) + bias.double()[None, :, None, None]
+    ref = (F.leaky_relu(ref, 0.2) * 2 ** 0.5).permute(0, 2, 3, 1)
+    wp = C.pack_weight(w.to(dev))
+    xg = x.to(dev)
+    epi = dict(a_scale=s.to(dev), col_scale=dm.to(dev), bias=bias.to(dev), noise=noise.to(dev), noise_w=nw.to(dev), act_slope=0.2, gain=2 ** 0.5)
+    y = torch.empty(B, H, W, co, device=dev)
+    assert _supported(xg, wp, y, **epi)
+    L.lib().wgs_dev_trace_kernels(1)
+    got = C.conv2d(xg, wp, 3, pad=1, precision=C.FP32W, **epi)
+    assert L.lib().wgs_dev_last_kernel().decode().startswith('wino_f32_kernel<true>')
+    direct = C.conv2d(xg, wp, 3, pad=1, precision=0, **epi)
+    L.lib().wgs_dev_trace_kernels(0)
+    e_w, e_d = rel_err(got, ref), rel_err(direct, ref)
+    assert e_w < 3e-6, (e_w, e_d)
+    assert rel_err(got, direct) < 4e-6
+
+
+@pytest.mark.parametrize('B,H,ci,co', [(2, 32, 64, 128), (2, 16, 256, 64)])
+def test_wino_input_gradient_form_vs_float64(dev, B, H, ci, co):
+    """dgrad of a 3x3 stride-1 pad-1 conv = the same kernel on dy with the transposed packed weights and flipped taps."""
+    torch.manual_seed(7 + ci)
+    w = torch.randn(co, ci, 3, 3) / (9 * ci) ** 0.5
+    dy = torch.randn(B, H, H, co)
+    xd = torch.zeros(B, ci, H, H, dtype=torch.double, requires_grad=True)
+    F.conv2d(xd, w.double(), padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    ref = xd.grad.permute(0, 2, 3, 1)
+    wp = C.pack_weight(w.to(dev))
+    wt = C.repack_w_t(wp, co, 9, ci)
+    cache = C.SplitCache(wt)
+    L.lib().wgs_dev_trace_kernels(1)
+    got = C.conv2d_dgrad(dy.to(dev), wt, (H, H), 3, pad=1, precision=C.FP32W, w_split=cache, alpha=1.0)
+    assert L.lib().wgs_dev_last_kernel().decode().startswith('wino_f32_kernel<false>')
+    L.lib().wgs_dev_trace_kernels(0)
+    assert rel_err(got, ref) < 3e-6
+    assert len(cache.planes) == 1           # U is kept with the weight tensor
+    again = C.conv2d_dgrad(dy.to(dev), wt, (H, H), 3, pad=1, precision=C.FP32W, w_split=cache)
+    assert torch.equal(got, again) and len(cache.planes) == 1
+
+
+def test_wino_declines_what_it_does_not_cover_and_the_direct_kernel_runs(dev):
+    torch.manual_seed(3)
+    x = torch.randn(2, 8, 8, 64, device=dev)           # 8x8: not a multiple of the 16x16 pixel block
+    wp = C.pack_weight(torch.randn(64, 64, 3, 3, device=dev) / 24)
+    y = torch.empty(2, 8, 8, 64, device=dev)
+    assert not _supported(x, wp, y)
+    L.lib().wgs_dev_trace_kernels(1)
+    got = C.conv2d(x, wp, 3, pad=1, precision=C.FP32W)
+    assert 'wino' not in L.lib().wgs_dev_last_kernel().decode()
+    L.lib().wgs_dev_trace_kernels(0)
+    assert torch.equal(got, C.conv2d(x, wp, 3, pad=1, precision=0))
+    x2 = torch.randn(2, 16, 16, 64, device=dev)
+    y2 = torch.empty(2, 8, 8, 64, device=dev)
+    assert not _supported(x2, wp, torch.empty(2, 16, 16, 64, device=dev), act=1)

@@ -42,13 +42,15 @@ class WgradDesc(ctypes.Structure):
 #   2 'f16'    fp16 operands, 1 MFMA per product, fp32 accumulate (image error ~8e-4 at 256^2: ON the 1e-3 gate, reported only)
 #   3 'f16x2'  fp16 activations x (hi + lo) fp16 weights, 2 MFMAs (image error ~5e-4)
 #   4 'mixed'  StyleGAN2 only: per-layer arithmetic from an error budget, see MixedPolicy
+#   5 'fp32w'  fp32 with the 3x3 stride-1 convs in Winograd F(2x2,3x3) form on the fp32 matrix cores (2.25x fewer multiplies, ~1e-6
+#              against the direct form: what cuDNN's algorithm search gives the reference, lib/trainer.py:166); the rest as 'fp32'
 #  -1 'auto'   per generator: the cheapest mode whose measured image error stays inside the north_star's 1e-3 gate for that
 #              architecture with margin (tests/test_precision_schemes_gpu.py): see AUTO_TABLE
 # There is NO process-wide arithmetic state: a mode is an attribute of a generator instance (`G.precision`), an argument of
 # its forward (`G(z, shift, precision=...)`) and of the step engine (`TrainStep(..., precision=..., r_precision=...)`); bare
 # conv calls without `precision=` run the reference's arithmetic (exact fp32).
-PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'mixed': 4}
-AUTO, MIXED = -1, 4
+PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'mixed': 4, 'fp32w': 5}
+AUTO, MIXED, FP32W = -1, 4, 5
 # default of the TRAINING CLIs (train.py, bench.py extra runs); the image-producing CLIs (traverse_latent_space.py,
 # sample_gan.py) default to IMAGE_DEFAULT_PRECISION, the fp32-class mode
 DEFAULT_PRECISION = 'auto'
@@ -191,7 +193,7 @@ class SplitCache:
         self.w, self.planes = w, {}
 
     def get(self, precision):
-        if precision == 0:
+        if precision in (0, FP32W):
             return None
         if precision not in self.planes:
             self.planes[precision] = split_weight(self.w, precision)
@@ -234,6 +236,8 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
         prec = PRECISION_NAMES[AUTO_FALLBACK]
     if prec == MIXED:          # per-layer policies are resolved by the generator (stylegan2.py); elsewhere: fp16 x2
         prec = 3
+    if prec == FP32W:          # launch() routes the launches the Winograd kernel covers; everything else is the direct fp32 form
+        prec = 0
     if grad_operand and prec >= 2 and a_amax is None:
         # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
         prec = 1
@@ -262,9 +266,27 @@ def _kind(d, nphase):
     return 'conv %s %d->%d @%dx%d %s B%d' % (precision_name(d.precision), d.Ci, d.Co, d.Hi << d.ups, d.Wi << d.ups, form, d.B)
 
 
+def _wino_weight(d, w, cache):
+    """U = G g G^T of a launch's weights in the Winograd kernel's staging order (wgs_conv_wino_weight); kept in the weight tensor's
+    SplitCache when the caller has one (frozen generator weights), rebuilt per launch otherwise (R's trained weights: ~10 us)."""
+    key = ('wino', d.w_tap_stride, d.w_row_stride, tuple((d.dy[i], d.dx[i], d.wt[i]) for i in range(9)))
+    if isinstance(cache, SplitCache) and key in cache.planes:
+        return cache.planes[key]
+    U = torch.empty(16 * d.Ci * d.Co, device=w.device, dtype=torch.float32)
+    L.check(L.lib().wgs_conv_wino_weight(ctypes.byref(d), L.ptr(U), L.stream()), 'wgs_conv_wino_weight')
+    if isinstance(cache, SplitCache):
+        cache.planes[key] = U
+    return U
+
+
 def launch(x, w, y, taps, Hg, Wg, **kw):
-    """One implicit-GEMM launch (wgs_conv_igemm)."""
+    """One implicit-GEMM launch (wgs_conv_igemm), or — precision 'fp32w' and a shape it covers — the Winograd kernel (wgs_conv_wino)."""
     d, flops = _desc(x, w, y, taps, Hg, Wg, **kw)
+    if kw.get('precision') == FP32W and L.lib().wgs_conv_wino_supported(ctypes.byref(d)):
+        U = _wino_weight(d, w, kw.get('w_split'))
+        kind = _kind(d, 1)
+        _timed(kind.replace('conv fp32 ', 'conv fp32w ', 1) if kind else None, flops, lambda: L.check(L.lib().wgs_conv_wino(ctypes.byref(d), L.ptr(U), L.stream()), 'wgs_conv_wino'))
+        return y
     _timed(_kind(d, 1), flops, lambda: L.check(L.lib().wgs_conv_igemm(ctypes.byref(d), L.stream()), 'wgs_conv_igemm'))
     return y
 
