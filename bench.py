@@ -51,12 +51,15 @@ import torch.distributed as dist
 GFLOP_PER_IMG = {'stylegan2-256': 285.8, 'stylegan2-1024': 687.8, 'proggan-1024': 498.7, 'proggan-256': 184.3, 'biggan-128': 127.5}
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf16,f16}, dense (no sparsity)
-MFMA_PER_PRODUCT = {'fp32': 1.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}        # per launch label (a 'mixed' run has all three 16-bit kinds)
-DTYPE = {'fp32': 'fp32', 'bf16x3': 'bf16x3 (split-bf16, fp32-class)', 'f16': 'fp16 operands, fp32 accumulate',
+MFMA_PER_PRODUCT = {'fp32': 1.0, 'fp32w': 16.0 / 36.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}        # per launch label (a 'mixed' run has all three 16-bit kinds)
+DTYPE = {'fp32': 'fp32', 'fp32w': 'fp32', 'bf16x3': 'bf16x3 (split-bf16, fp32-class)', 'f16': 'fp16 operands, fp32 accumulate',
          'f16x2': 'fp16 x2 operands, fp32 accumulate', 'mixed': 'mixed fp16 / split-bf16 per layer, fp32 accumulate'}
 DTYPE_TEXT = {
     'fp32': "fp32 everywhere (the reference's arithmetic): every conv of G and R, forward and backward, is f32-input MFMA "
             "(v_mfma_f32_32x32x2_f32) with fp32 accumulate; everything else fp32 VALU",
+    'fp32w': "fp32 everywhere, as 'fp32', with the 3x3 stride-1 convs of G and R (forward and input-gradient) in the Winograd F(2x2,3x3) "
+             "form on the f32-input MFMA (16 instead of 36 multiplies per 2x2 outputs, transforms in fp32 inside the kernel; ~1e-6 against "
+             "the direct form) - the algorithm class cuDNN's search gives the reference's F.conv2d (lib/trainer.py:166 cudnn.benchmark)",
     'bf16x3': "bf16x3: generator convs split every fp32 operand into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (~2^-16)",
     'f16': "f16: generator convs round operands to fp16 (dynamic power-of-two scale on every operand), 1 fp16 MFMA per product, "
            "fp32 accumulate / demodulation / epilogue (image error vs the fp32 kernels ~8e-4 at 256^2: on the 1e-3 gate, reported only)",
@@ -65,7 +68,9 @@ DTYPE_TEXT = {
              "3.2): fp16 operands (1 or 2 MFMAs per product) in the layers at >= 64x64, split-bf16 x3 (fp32-class) below; fp32 accumulate / "
              "demodulation / epilogue everywhere; dynamic power-of-two scale on every fp16 operand",
 }
-R_TEXT = {(0, 0, 0): "; reconstructor (trained): exact fp32 MFMA forward, input-gradient and weight-gradient convs; BatchNorm statistics in fp64 partials",
+R_TEXT = {(5, 5, 0): "; reconstructor (trained): fp32 MFMA, Winograd form of the 3x3 stride-1 forward / input-gradient convs, direct exact "
+                     "fp32 for the rest and for every weight gradient; BatchNorm statistics in fp64 partials",
+          (0, 0, 0): "; reconstructor (trained): exact fp32 MFMA forward, input-gradient and weight-gradient convs; BatchNorm statistics in fp64 partials",
           (1, 1, 1): "; reconstructor (trained): fp32-class only - split-bf16 x3 (3 MFMAs, ~2^-16 per product) forward, input-gradient and "
                      "the wide weight-gradient convs, exact fp32 MFMA for the other weight gradients; BatchNorm statistics in fp64 partials"}
 
@@ -169,7 +174,7 @@ def roofline_of(recs, img_per_s_per_gpu, gflop_per_img):
                             "TFLOP/s": round(fl / ms / 1e9, 1), "launches": round(n, 1)})
 
     def peak_of(d):
-        return FP32_MFMA_PEAK_TF if d['prec'] == {'fp32'} else F16_MFMA_PEAK_TF
+        return FP32_MFMA_PEAK_TF if d['prec'] <= {'fp32', 'fp32w'} else F16_MFMA_PEAK_TF
     dom = max(sym, key=lambda k: sym[k]['ms'])
     d = sym[dom]
     peak = peak_of(d)
@@ -432,7 +437,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default='fp32',
                     help="arithmetic of the HEADLINE run's generator convs (default: fp32 = the reference's arithmetic)")
-    ap.add_argument('--r-precision', choices=['fp32', 'bf16x3', 'auto'], default='auto',
+    ap.add_argument('--r-precision', choices=['fp32', 'fp32w', 'bf16x3', 'auto'], default='auto',
                     help="arithmetic of the Reconstructor's convs (auto = exact fp32 beside an fp32 generator, split-bf16 x3 beside a 16-bit one)")
     ap.add_argument('--product-precision', choices=tuple(C.PRECISION_NAMES), default=C.DEFAULT_PRECISION,
                     help="arithmetic of the extra[0] run (same workload, same steps / warmup): the product's default")

@@ -76,6 +76,21 @@ def test_fused_upconv_selection():
     assert not C.upconv_fused_ok(64, 24, 64, 2)
 
 
+def test_fp32w_is_fp32_with_the_winograd_form_on_the_stride_1_layers_only():
+    """'fp32w': the 3x3 stride-1 layers (forward and input-gradient) carry code 5 to conv.launch, which routes what the Winograd
+    kernel covers; up-sampling layers, and everything conv._desc hands to the library, are plain exact fp32 (code 0)."""
+    W = C.FP32W
+    assert C.precision_code('fp32w') == W and C.resolve('fp32w', 'stylegan2', 256) == W
+    for res in (4, 64, 256, 1024):
+        assert C.layer_precision(W, res, False) == W and C.layer_precision(W, res, True) == 0
+        assert C.layer_precision_bwd(W, res, False) == W and C.layer_precision_bwd(W, res, True) == 0
+    assert C.SplitCache(None).get(W) is None            # no 16-bit planes: U is kept under its own key
+    assert not C.upconv_fused_ok(128, 256, 128, W) and not C.upconv_fused_ok(128, 256, 128, 0)
+    from warpedganspace_amd import reconstructor as RR
+    assert RR.r_arith('auto', W) == RR.R_FP32_WINO == RR.RArith(5, 5, 0) and RR.r_arith('fp32w') == RR.R_FP32_WINO
+    assert RR.r_arith('fp32', W) == RR.R_EXACT
+
+
 def test_reconstructor_arithmetic_follows_the_generator():
     """r_precision 'auto': fp32-class (split-bf16 x3) convs inside a step whose generator runs in a 16-bit mode, the reference's
     exact fp32 for an fp32 generator and for a Reconstructor used on its own; 'fp32' / 'bf16x3' pin it; an RArith passes through."""

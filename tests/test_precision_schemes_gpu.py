@@ -41,7 +41,7 @@ def test_image_and_shared_gate_gradient_per_scheme(dev, size, B):
     z = GI.rt(11 + size, B, 512)
     rows = {}
     if True:
-        for name in ('fp32', 'bf16x3', 'f16', 'f16x2', 'mixed'):
+        for name in ('fp32', 'fp32w', 'bf16x3', 'f16', 'f16x2', 'mixed'):
             res = {}
             for w_space in (True, False):
                 G.debug_keep = {}
@@ -71,7 +71,7 @@ def test_image_and_shared_gate_gradient_per_scheme(dev, size, B):
     _record('stylegan2_%d' % size, rows)
     for name, res in rows.items():
         ok = res['img_W'] < GATE and res['img_Z'] < GATE and res['grad_W'] < GATE and res['grad_Z'] < GATE
-        if name in ('fp32', 'bf16x3'):
+        if name in ('fp32', 'fp32w', 'bf16x3'):
             assert res['img_W'] < 1e-4 and res['grad_W'] < 2e-4, (name, res)
         default = C.AUTO_TABLE.get(('stylegan2', size), C.AUTO_FALLBACK)
         if not ok:

@@ -106,6 +106,8 @@ def mixed_policy(size):
 
 def layer_precision(code, out_res, is_up, policy=None):
     """Concrete arithmetic of one StyleGAN2 layer's forward conv under mode `code`."""
+    if code == FP32W:          # the Winograd form exists for the 3x3 stride-1 convs; the up-convs (1/2/2/4-tap phases) stay direct
+        return 0 if is_up else FP32W
     if code != MIXED:
         return code
     return (policy or MIXED_256).fwd(out_res, is_up)
@@ -113,6 +115,8 @@ def layer_precision(code, out_res, is_up, policy=None):
 
 def layer_precision_bwd(code, out_res, is_up, policy=None):
     """Arithmetic of a layer's INPUT-GRADIENT conv under mode `code`."""
+    if code == FP32W:
+        return 0 if is_up else FP32W
     if code != MIXED:
         return code
     return (policy or MIXED_256).bwd(out_res, is_up)

@@ -7,21 +7,22 @@
 // which over channels is 16 independent GEMMs   M_pos[tile, co] = sum_ci V_pos[tile, ci] * U_pos[ci, co],   pos = (xi, nu) in 4x4.
 //
 // ONE kernel, nothing but x, U and y touches HBM:
-//   * U = G g G^T is transformed once per (frozen) weight tensor by wino_weight_kernel, straight into the LDS image order of
-//     the main kernel ([Co/64][Ci/8][pos][64 n][8 k], bank swizzle included) — a chunk of U is one contiguous 32 KB copy.
+//   * U = G g G^T is transformed once per (frozen) weight tensor by wino_weight_kernel, straight into the B-operand fragment order
+//     of the main kernel: a wave needs only the U of its own two positions, so its fragments are plain coalesced 1 KB global loads
+//     into registers — U never passes through LDS.
 //   * a workgroup (8 waves) owns 8x8 Winograd tiles (16x16 output pixels) of one sample x 64 output channels, and ALL 16
 //     positions: wave w accumulates positions 2w, 2w+1 as 64x64 blocks (128 accumulator registers per lane).
-//   * per 8-channel chunk: thread (tile, channel quad, patch column) loads its 4 patch rows (16 B each, zero padding = buffer range
+//   * per 16-channel chunk: thread (tile, channel quad, patch column) loads its 4 patch rows (16 B each, zero padding = buffer range
 //     check), does the column pass B^T d in registers and the row pass across the 4 lanes of its quad with DPP quad_perm, scales by the
-//     style and writes its 4 positions to LDS; the chunk's U block is copied beside it.  Loads fly for three quarters of a chunk, stores
-//     and loads are issued inside the MFMA slots (conv_nt_kernel.inc's scheme), operand fragments are one ds_read_b128 per 4 MFMAs
-//     (k pairing of conv_scheme.h Scheme<4>).
+//     style and writes its 4 positions to LDS (two such tasks per thread).  Patch loads fly for three quarters of a chunk, B fragments
+//     for half a chunk; loads and stores are issued inside the MFMA slots (conv_nt_kernel.inc's scheme); A fragments are one
+//     ds_read_b128 per 8 MFMAs (k pairing of conv_scheme.h Scheme<4>); one barrier per 64 MFMAs of a wave.
 //   * epilogue: the 16 position blocks go through LDS (two passes of 32 channels, 136 KB), every thread applies A^T . A to four tiles
 //     of one channel, then demodulation / noise / bias / leaky-relu as conv_epilogue.h and stores 128-byte channel runs.
-// LDS rows are 32 B (8 channels); conflict-free by swizzle: 16-byte half h of logical row r of position pos lives at
-// row r ^ (pos & 3), half h ^ ((r >> 2) & 1).
+// LDS rows are 64 B (16 channels), conflict-free by an XOR swizzle of row and 16-byte slot (see the staging role below).
 #include "wgs_common.h"
 #include "../../include/wgs.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,14 +32,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TB = 64;            // Winograd tiles per workgroup: 8 x 8  (16 x 16 output pixels)
 constexpr int BN = 64;            // output channels per workgroup
-constexpr int KC = 8;             // input channels per chunk
+constexpr int KC = 16;            // input channels per chunk
 constexpr int NT = 512;
-constexpr int V_BYTES = 16 * TB * KC * 4;      // 32 KB
-constexpr int U_BYTES = 16 * BN * KC * 4;      // 32 KB
-constexpr int STAGE = V_BYTES + U_BYTES;
+constexpr int STAGE = 16 * TB * KC * 4;        // one staged chunk of V: 64 KB
 constexpr int EPI_ROW = TB * 4 + 16;           // one (pos, n) row of the epilogue exchange: 64 tiles + 16 B (bank spread)
 constexpr int EPI_BYTES = 16 * 32 * EPI_ROW;   // 136 KB
 constexpr int SMEM = EPI_BYTES > 2 * STAGE ? EPI_BYTES : 2 * STAGE;
+constexpr int U_CHUNK = 16 * BN * KC * 4;      // bytes of U per (channel block, chunk): 64 KB
 constexpr int OOB = (int)0x80000000;
 
 struct WinoArgs {
@@ -53,20 +53,24 @@ struct WinoArgs {
     float* y_amax;
     int B, H, W, Ci, Co, a_ld, col_ld;
     float alpha, act_slope, gain;
+    int var;
 };
 
 struct WinoTaps { int w_of[9]; };      // weight slab index of spatial tap (ky, kx), -1 = absent
 
-__device__ __forceinline__ f32x4 buf_load4(const __amdgpu_buffer_rsrc_t r, int voff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+// voff: per-lane byte offset (VGPR, fixed for the whole kernel; OOB = beyond any buffer -> the load returns 0), soff: uniform byte
+// offset of the chunk / fragment (SGPR): no vector address arithmetic inside the main loop
+__device__ __forceinline__ f32x4 buf_load4(const __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return __builtin_bit_cast(f32x4, v);
 }
-// value of lane {2, 2, 1, 1}[lane & 3] of the same quad
-__device__ __forceinline__ float quad_other(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x5A, 0xf, 0xf, true));
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
-// U[pos] = G g G^T of every (co, ci) pair, written in the main kernel's LDS image order
+// U[pos] = G g G^T of every (co, ci) pair, written as the main kernel's B-operand fragments:
+// [Co/64][Ci/16][pos][k group g of 8][column block j of 32][lane = 32 * (k half) + column][4 consecutive k]
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co,
                                                           long w_row_stride, long w_tap_stride, const WinoTaps tp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -92,15 +96,17 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
         u[r][3] = t[r][2];
     }
     const int nchunks = Ci / KC;
-    const int nb = co / BN, n = co % BN, chunk = ci / KC, k = ci % KC;
+    const int nb = co / BN, n = co % BN, chunk = ci / KC, kk = ci % KC;
+    const int lane = ((kk >> 2) & 1) * 32 + (n & 31);
     float* base = U + ((size_t)nb * nchunks + chunk) * (16 * BN * KC);
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos)
-        base[((pos * BN + (n ^ (pos & 3))) * 2 + ((k >> 2) ^ ((n >> 2) & 1))) * 4 + (k & 3)] = u[pos >> 2][pos & 3];
+        base[(((pos * 2 + (kk >> 3)) * 2 + (n >> 5)) * 64 + lane) * 4 + (kk & 3)] = u[pos >> 2][pos & 3];
 }
 
-template <bool STY>
+template <bool STY, int ABL>
 __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
+    // ABL (development): 1 no transform / LDS stores, 2 no barriers, 3 no global loads in the loop, 4 no fragment reads, 5 = 1 + 3
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int ntn = p.Co / BN, tbx = p.W >> 4, tby = p.H >> 4;
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
         const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, qn = nb >> 3, rn = nb & 7;
         bid = xcd * qn + min(xcd, rn) + slot;
     }
-    const int tmi = bid / ntn, nb0 = bid - tmi * ntn;
+    const int ntm = gridDim.x / ntn;
+    const int tmi = (p.var & 1) ? bid % ntm : bid / ntn, nb0 = (p.var & 1) ? bid / ntm : bid - (bid / ntn) * ntn;
     const int b = tmi / (tbx * tby), rr = tmi - b * (tbx * tby), by = rr / tbx, bx = rr - by * tbx;
     const int nchunks = p.Ci / KC;
 
@@ -120,8 +127,11 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, 16 * p.Ci * p.Co * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(STY ? p.a_scale + (size_t)b * p.a_ld : p.x), 0, STY ? p.Ci * 4 : 0, 0x00020000);
 
-    // ---- staging role: thread = (tile t, channel quad q, patch column nu) ----
-    const int t = tid >> 3, q = (tid >> 2) & 1, nu = tid & 3, ty = t >> 3, tx = t & 7;
+    // ---- staging role: thread = (tile t, channel quads ql and ql + 2, patch column nu) ----
+    // LDS image of a chunk: [pos][row 64 B = 16 channels]; logical (t, 16-byte slot s) of position pos lives at row t ^ (nu & 1), slot
+    // s ^ ((t >> 1) & 3) ^ (nu & 2), nu = pos & 3: the quad's four positions and the two channel quads of 8 neighbouring lanes fall into
+    // 8 different 16-byte bank groups, and so do the 8 rows a fragment read touches per cycle.
+    const int t = tid >> 3, ql = (tid >> 2) & 1, nu = tid & 3, ty = t >> 3, tx = t & 7;
     int a_off[4];
     {
         const int ix = bx * 16 + 2 * tx + nu - 1;
@@ -129,55 +139,80 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
         for (int r = 0; r < 4; ++r) {
             const int iy = by * 16 + 2 * ty + r - 1;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            a_off[r] = ok ? ((iy * p.W + ix) * p.Ci + q * 4) * 4 : OOB;
+            a_off[r] = ok ? ((iy * p.W + ix) * p.Ci + ql * 4) * 4 : OOB;
+            if (p.var & 8) a_off[r] = tid * 16 + r * 8192;          // ablation: coalesced (wrong) patch loads
         }
     }
-    const int u_off = nb0 * nchunks * U_BYTES + tid * 16;
-    const int v_st = nu * 2048 + (t ^ nu) * 32 + (q ^ ((t >> 2) & 1)) * 16;       // + xi * 8192
-    const float sa = nu == 3 ? -1.f : 1.f, sb = (nu & 1) ? 1.f : -1.f;
+    const int v_st = nu * 4096 + (t ^ (nu & 1)) * 64;          // + xi * 16384 + slot * 16
+    const int v_sl = ql ^ ((t >> 1) & 3) ^ (nu & 2);           // slot of task 0; task 1: ^ 2
+    const float sa = nu == 3 ? -1.f : 1.f, sb = (nu & 1) ? 1.f : -1.f;     // row pass of lane nu: sa * own column + sb * column {2, 2, 1, 1}[nu]
 
-    f32x4 ra[4], rw[4], rsv = {1.f, 1.f, 1.f, 1.f};
-    auto load_U = [&](int c) {
-        const int cb = u_off + min(c, nchunks - 1) * U_BYTES;      // past the end: re-read the last chunk (stored into a dead buffer)
+    f32x4 ra[2][4], rsv[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    auto load_A = [&](int c, int u) {
+        const int cb = min(c, nchunks - 1) * (KC * 4) + u * 32;       // past the end: re-read the last chunk (stored into a dead buffer)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rw[i] = buf_load4(ru, cb + i * 8192);
-        if (STY) rsv = buf_load4(rs, min(c, nchunks - 1) * 32 + q * 16);
+        for (int r = 0; r < 4; ++r) ra[u][r] = buf_load4(rx, a_off[r], cb);
+        if (STY) rsv[u] = buf_load4(rs, ql * 16, cb);
     };
-    auto load_A = [&](int c) {
-        const int cb = min(c, nchunks - 1) * 32;
+    // column pass B^T d (rows of the patch) of task u, times the style and the lane's own row-pass sign -> T[u]; then, per xi, the row
+    // pass over the quad's four columns (own + sb * column {2,2,1,1}[nu]: the lanes that are read, nu = 1 and 2, have own sign +1) + store.
+    // Two-element vector types: the backend keeps them as v_pk_add_f32 / v_pk_mul_f32 (a 4-vector is split into scalars).
+    // Written as the instructions they are (the backend splits 4-vectors into scalars and keeps the quad permute as a separate
+    // v_mov_b32_dpp): v_pk_add_f32 / v_pk_mul_f32 on register pairs, and v_fmac_f32_dpp accumulating the permuted column onto the
+    // lane's own (s_nop 1 first: a VGPR written by the preceding VALU instruction may not be read through DPP for two cycles).
+    f32x2 T[2][4][2];
+    auto col_pass = [&](int u) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ra[r] = buf_load4(rx, a_off[r] < 0 ? OOB : a_off[r] + cb);
-    };
-    auto store_U = [&](int buf) {
-        unsigned char* base = smem + buf * STAGE + V_BYTES + tid * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(base + i * 8192) = rw[i];
-    };
-    auto store_A = [&](int buf) {
-        // column pass B^T d (rows of the patch), then the row pass over the quad's four columns
-        f32x4 T[4];
-        T[0] = ra[0] - ra[2];
-        T[1] = ra[1] + ra[2];
-        T[2] = ra[2] - ra[1];
-        T[3] = ra[1] - ra[3];
-        unsigned char* base = smem + buf * STAGE + v_st;
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            f32x4 o, v;
-            o[0] = quad_other(T[xi][0]); o[1] = quad_other(T[xi][1]); o[2] = quad_other(T[xi][2]); o[3] = quad_other(T[xi][3]);
-            v = sa * T[xi] + sb * o;
-            if (STY) v *= rsv;
-            *reinterpret_cast<f32x4*>(base + xi * 8192) = v;
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 d0 = {ra[u][0][2 * h], ra[u][0][2 * h + 1]}, d1 = {ra[u][1][2 * h], ra[u][1][2 * h + 1]};
+            const f32x2 d2 = {ra[u][2][2 * h], ra[u][2][2 * h + 1]}, d3 = {ra[u][3][2 * h], ra[u][3][2 * h + 1]};
+            f32x2 sg = {sa, sa};
+            if (STY) sg = pk_mul(sg, (f32x2){rsv[u][2 * h], rsv[u][2 * h + 1]});
+            T[u][0][h] = pk_mul(pk_sub(d0, d2), sg);
+            T[u][1][h] = pk_mul(pk_add(d1, d2), sg);
+            T[u][2][h] = pk_mul(pk_sub(d2, d1), sg);
+            T[u][3][h] = pk_mul(pk_sub(d1, d3), sg);
         }
     };
+    auto row_store = [&](unsigned char* dst, int u, int xi) {
+        float v0 = T[u][xi][0][0], v1 = T[u][xi][0][1], v2 = T[u][xi][1][0], v3 = T[u][xi][1][1];
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+            : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(sb));
+        const f32x4 v = {v0, v1, v2, v3};
+        *reinterpret_cast<f32x4*>(dst + xi * 16384) = v;
+    };
+    unsigned char* const v_dst0 = smem + v_st + v_sl * 16;              // task 0, buffer 0; task 1: slot ^ 2; buffer 1: + STAGE
+    unsigned char* const v_dst1 = smem + v_st + (v_sl ^ 2) * 16;
+    auto store_A = [&](int buf, int u) {
+        col_pass(u);
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) row_store((u ? v_dst1 : v_dst0) + buf * STAGE, u, xi);
+    };
 
-    // ---- MFMA role: wave w owns positions 2w, 2w + 1 ----
-    int f_off[2];
+    // ---- MFMA role: wave w owns positions 2w, 2w + 1; its B fragments come straight from global memory (no other wave needs them) ----
+    int f_off[2][2];       // [pp][g]: LDS byte offset of the A fragment (row block 0)
+    int u_off[2];          // [pp]: byte offset of the wave's U fragments inside a chunk (+ g * 2048 + j * 1024)
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
-        const int pos = 2 * wave + pp;
-        f_off[pp] = pos * 2048 + (l31 ^ (pos & 3)) * 32 + (lh ^ ((l31 >> 2) & 1)) * 16;
+        const int pos = 2 * wave + pp, nup = pos & 3;
+        const int sx = lh ^ ((l31 >> 1) & 3) ^ (nup & 2);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) f_off[pp][g] = pos * 4096 + (l31 ^ (nup & 1)) * 64 + ((sx ^ (2 * g)) * 16);
+        u_off[pp] = pos * 4096 + lane * 16;
+        if (p.var & 16) u_off[pp] = OOB;                        // ablation: no B traffic
     }
+    f32x4 bf[2][2][2];     // [g][pp][j]
+    auto load_B = [&](int c, int g) {
+        const int cb = (nb0 * nchunks + min(c, nchunks - 1)) * U_CHUNK + g * 2048;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[g][pp][j] = buf_load4(ru, u_off[pp], cb + j * 1024);
+    };
     f32x16 acc[2][2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -188,48 +223,70 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
 
-    // chunk kt multiplies LDS buffer kt & 1.  Slot s = (position pp, row block i): 8 MFMAs.  Slot 0 stores the U block of chunk
-    // kt + 1 (requested during chunk kt - 1), slot 1 transforms + stores its patch and requests U of chunk kt + 2, slot 2 requests
-    // the patch of chunk kt + 2: every load flies for three slots.
+    // Chunk kt multiplies LDS buffer kt & 1.  Slot s = (k group g, position pp, row block i): 8 MFMAs, 8 slots per chunk.  The staging
+    // work of chunk kt + 1 is cut into ten pieces (column pass and four row-pass + store pieces per patch task) spread over slots
+    // 0..6, and inside a slot the scheduler is told to alternate one MFMA with a few VALU instructions: the two waves of a SIMD run
+    // in step (one barrier per chunk), so a staging block issued as one run would leave the matrix pipe idle for its whole length.
+    //   slot 0  B fragments (kt, g = 1) requested         slot 4  B fragments (kt + 1, g = 0) requested     (four slots of flight)
+    //   slot 2 / slot 6  patch task 0 / 1 of chunk kt + 2 requested, right after its registers' last piece  (six / five slots)
     auto mma_chunk = [&](int cur, int kt) {
         const unsigned char* base = smem + cur * STAGE;
-        f32x4 af[2], bf[2][2];
-        af[0] = *reinterpret_cast<const f32x4*>(base + f_off[0]);
-        bf[0][0] = *reinterpret_cast<const f32x4*>(base + V_BYTES + f_off[0]);
-        bf[0][1] = *reinterpret_cast<const f32x4*>(base + V_BYTES + f_off[0] + 1024);
+        const int nxt = cur ^ 1;
+        f32x4 af[2];
+        af[0] = *reinterpret_cast<const f32x4*>(base + f_off[0][0]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int pp = s >> 1, i = s & 1;
-            if (s + 1 < 4) {
-                const int pn = (s + 1) >> 1, in = (s + 1) & 1;
-                af[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(base + f_off[pn] + in * 1024);
-                if (in == 0) {
-                    bf[pn][0] = *reinterpret_cast<const f32x4*>(base + V_BYTES + f_off[pn]);
-                    bf[pn][1] = *reinterpret_cast<const f32x4*>(base + V_BYTES + f_off[pn] + 1024);
-                }
+        for (int s = 0; s < 8; ++s) {
+            const int g = s >> 2, pp = (s >> 1) & 1, i = s & 1;
+            if (s + 1 < 8) {
+                const int gn = (s + 1) >> 2, pn = ((s + 1) >> 1) & 1, in = (s + 1) & 1;
+                if (ABL != 4) af[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(base + f_off[pn][gn] + in * 2048);
+                else af[(s + 1) & 1] = af[s & 1];
             }
-            if (s == 2) load_A(kt + 2);
+            if (ABL != 3 && ABL != 5) {
+                if (s == 0) load_B(kt, 1);
+                if (s == 4) load_B(kt + 1, 0);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc[pp][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][e], bf[pp][j][e], acc[pp][i][j], 0, 0, 0);
-            if (s == 0) store_U(cur ^ 1);
-            if (s == 1) { store_A(cur ^ 1); load_U(kt + 2); }
+                    acc[pp][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][e], bf[g][pp][j][e], acc[pp][i][j], 0, 0, 0);
+            if (ABL != 1 && ABL != 5) {
+            if (s == 0) { col_pass(0); row_store(v_dst0 + nxt * STAGE, 0, 0); }
+            if (s == 1) { row_store(v_dst0 + nxt * STAGE, 0, 1); row_store(v_dst0 + nxt * STAGE, 0, 2); }
+            if (s == 2) row_store(v_dst0 + nxt * STAGE, 0, 3);
+            if (s == 3) { col_pass(1); row_store(v_dst1 + nxt * STAGE, 1, 0); }
+            if (s == 4) row_store(v_dst1 + nxt * STAGE, 1, 1);
+            if (s == 5) row_store(v_dst1 + nxt * STAGE, 1, 2);
+            if (s == 6) row_store(v_dst1 + nxt * STAGE, 1, 3);
+            }
+            if (ABL != 3 && ABL != 5) {
+                if (s == 2) load_A(kt + 2, 0);
+                if (s == 6) load_A(kt + 2, 1);
+            }
+            {
+                // one MFMA, then up to five VALU instructions, eight times
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    load_U(0);
-    load_A(0);
-    store_U(0);
-    store_A(0);
-    load_U(1);
-    load_A(1);
+    load_A(0, 0);
+    load_A(0, 1);
+    load_B(0, 0);
+    store_A(0, 0);
+    store_A(0, 1);
+    load_A(1, 0);
+    load_A(1, 1);
     __syncthreads();
     for (int kt = 0; kt < nchunks; ++kt) {
         mma_chunk(kt & 1, kt);
-        __syncthreads();
+        if (ABL != 2) __syncthreads();
     }
 
     // ---- epilogue: positions -> LDS -> A^T . A per (tile, channel) -> demodulation, noise, bias, activation ----
@@ -342,17 +399,19 @@ int wgs_conv_wino(const wgs_conv_desc* d, const float* U, wgs_stream_t stream) {
     a.alpha = d->alpha != 0.f ? d->alpha : 1.f; a.act_slope = d->act_slope; a.gain = d->gain;
     const unsigned grid = (unsigned)((long)d->B * (d->Hi / 16) * (d->Wi / 16) * (d->Co / BN));
     hipStream_t st = (hipStream_t)stream;
-    if (d->a_scale) {
-        auto k = wino_f32_kernel<true>;
-        wgs_note_kernel("wino_f32_kernel<true>");
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        WGS_LAUNCH(k, dim3(grid), dim3(NT), SMEM, st, a);
-    } else {
-        auto k = wino_f32_kernel<false>;
-        wgs_note_kernel("wino_f32_kernel<false>");
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        WGS_LAUNCH(k, dim3(grid), dim3(NT), SMEM, st, a);
+    static const int var = getenv("WGS_WINO_VAR") ? atoi(getenv("WGS_WINO_VAR")) : 0;
+    a.var = var;
+#define WGS_WINO_LAUNCH(STY, V)                                                                             \
+    {                                                                                                       \
+        auto k = wino_f32_kernel<STY, V>;                                                                   \
+        wgs_note_kernel("wino_f32_kernel<%s>", STY ? "true" : "false");                                     \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);        \
+        WGS_LAUNCH(k, dim3(grid), dim3(NT), SMEM, st, a);                                                   \
     }
+#define WGS_WINO_V(STY) switch (var >> 5) { case 1: WGS_WINO_LAUNCH(STY, 1) break; case 2: WGS_WINO_LAUNCH(STY, 2) break; case 3: WGS_WINO_LAUNCH(STY, 3) break; case 4: WGS_WINO_LAUNCH(STY, 4) break; case 5: WGS_WINO_LAUNCH(STY, 5) break; default: WGS_WINO_LAUNCH(STY, 0) break; }
+    if (d->a_scale) WGS_WINO_V(true) else WGS_WINO_V(false)
+#undef WGS_WINO_V
+#undef WGS_WINO_LAUNCH
     WGS_CHECK_LAUNCH("wino_f32_kernel");
     return WGS_OK;
 }

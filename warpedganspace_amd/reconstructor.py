@@ -30,7 +30,8 @@ BN_EPS, BN_MOM = 1e-5, 0.1
 
 
 class RArith(namedtuple('RArith', ['forward', 'dgrad', 'wgrad'])):
-    """Arithmetic of the Reconstructor's convs: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 x3 (fp32-class).
+    """Arithmetic of the Reconstructor's convs: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 x3 (fp32-class),
+    5 = fp32 with the 3x3 stride-1 convs in Winograd form (conv.FP32W; forward / dgrad only).
       forward  the forward convs.  ReLU gates and train-mode BatchNorm statistics are fixed by the forward; on identical inputs the
                extra gate flips of split-bf16 move single parameter-gradient entries by ~2e-2 of the tensor maximum (< 1e-3 exact,
                tests/test_reconstructor_gpu.py) - but inside a step whose generator runs in a 16-bit mode R never sees identical
@@ -43,6 +44,7 @@ class RArith(namedtuple('RArith', ['forward', 'dgrad', 'wgrad'])):
 
 R_EXACT = RArith(0, 0, 0)            # the reference's arithmetic
 R_FP32_CLASS = RArith(1, 1, 1)
+R_FP32_WINO = RArith(5, 5, 0)        # fp32; the 3x3 stride-1 forward / input-gradient convs in Winograd F(2x2,3x3) form (conv.FP32W)
 
 
 def r_arith(r_precision='auto', generator_code=None):
@@ -53,11 +55,15 @@ def r_arith(r_precision='auto', generator_code=None):
     key = str(r_precision).lower()
     if key in ('fp32', '0'):
         return R_EXACT
+    if key in ('fp32w', '5'):
+        return R_FP32_WINO
     if key in ('bf16x3', '1'):
         return R_FP32_CLASS
     if key == 'auto':
+        if generator_code == 5:
+            return R_FP32_WINO
         return R_FP32_CLASS if (generator_code is not None and generator_code >= 1) else R_EXACT
-    raise L.WgsError("unknown reconstructor precision %r (fp32, bf16x3, auto)" % (r_precision,))
+    raise L.WgsError("unknown reconstructor precision %r (fp32, fp32w, bf16x3, auto)" % (r_precision,))
 
 
 def _conv(ci, co, k, stride, pad):

@@ -327,7 +327,7 @@ class Generator(nn.Module):
         # fp16 modes: magnitude chain for the dynamic operand scale — every producer raises max|y| of its output (one atomic
         # per wave in its epilogue), the consumer scales its operand x * style by a power of two taken from max|x| * max|style|
         # before rounding it to fp16: a forward pass cannot overflow fp16 whatever the checkpoint's activation magnitudes
-        f16_chain = any(C.layer_precision(prec, 4 << ((j + 1) // 2), ly_['up'], pol) >= 2 for j, ly_ in enumerate(P['layers']))
+        f16_chain = any(C.layer_precision(prec, 4 << ((j + 1) // 2), ly_['up'], pol) in (2, 3) for j, ly_ in enumerate(P['layers']))
         xmax = [P['const_amax']] + list(torch.zeros(len(P['layers']), 1, device=dev).unbind(0)) if f16_chain else None
         smax = S.abs().max().reshape(1) if f16_chain else None
         # every layer's demodulation vector scale * rsqrt(scale^2 * sum_i s^2 wsq + 1e-8) in one batched launch
@@ -353,7 +353,7 @@ class Generator(nn.Module):
             demod = demods[i]
             H = x.shape[1]
             lp = C.layer_precision(prec, 2 * H if ly['up'] else H, ly['up'], pol)      # 'mixed': per-layer arithmetic
-            sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp >= 2) else {}
+            sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp in (2, 3)) else {}
             ymax = xmax[i + 1] if f16_chain else None
             if ly['up'] and C.upconv_fused_ok(H, Ci, Co, lp):
                 y = C.upconv_blur_act(x, ly['wp_s'], ly['blur'], s_view, sumC, demod, ly['noise'], ly['noise_w'], ly['bias'], lp,
@@ -430,6 +430,7 @@ class Generator(nn.Module):
             sA = S[:, sA_off:] if gA is not None else None           # rows of the style matrix S, stride sumC
             sR = S[:, r['off']:] if has_rgb else None
             lp = C.layer_precision_bwd(prec, Hc, ly['up'], pol)
+            wino, lp = lp == C.FP32W, (0 if lp == C.FP32W else lp)       # 'fp32w': fp32 throughout, Winograd form of the stride-1 gradient conv
             # a stride-1 layer's dy has ONE consumer, its gradient conv: in the plain-fp16 launches that fill the chip it is stored
             # only as that conv's fp16 operand plane, scaled from an a-priori bound of its magnitude (its own maximum is not known
             # before the kernel has run): max|gA| from the producing conv's epilogue, max|drgb| <= 4^levels * max|dimg|
@@ -478,7 +479,7 @@ class Generator(nn.Module):
                         gA_amax = None
                 del dt
             else:
-                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0, precision=lp,
+                gA = C.conv2d_dgrad(dy, ly['wt'], (Hc, Hc), 3, pad=1, w_split=ly['wt_s'], a_amax=amax[i:], a_bound=1.0, precision=C.FP32W if wino else lp,
                                     x_f16=plane, y_amax=gA_amax if lp >= 1 else None)
                 if lp < 1:
                     gA_amax = None
