@@ -38,7 +38,8 @@ def test_wino_styled_forward_vs_float64(dev, B, H, W, ci, co):
     assert _supported(xg, wp, y, **epi)
     L.lib().wgs_dev_trace_kernels(1)
     got = C.conv2d(xg, wp, 3, pad=1, precision=C.FP32W, **epi)
-    assert L.lib().wgs_dev_last_kernel().decode().startswith('wino_f32_kernel<true>')
+    sym = L.lib().wgs_dev_last_kernel().decode()
+    assert sym.startswith('wino_f32_kernel<') and sym.endswith('true>'), sym
     direct = C.conv2d(xg, wp, 3, pad=1, precision=0, **epi)
     L.lib().wgs_dev_trace_kernels(0)
     e_w, e_d = rel_err(got, ref), rel_err(direct, ref)
@@ -46,7 +47,7 @@ def test_wino_styled_forward_vs_float64(dev, B, H, W, ci, co):
     assert rel_err(got, direct) < 4e-6
 
 
-@pytest.mark.parametrize('B,H,ci,co', [(2, 32, 64, 128), (2, 16, 256, 64)])
+@pytest.mark.parametrize('B,H,ci,co', [(2, 32, 64, 128), (2, 16, 256, 64), (1, 48, 128, 256)])
 def test_wino_input_gradient_form_vs_float64(dev, B, H, ci, co):
     """dgrad of a 3x3 stride-1 pad-1 conv = the same kernel on dy with the transposed packed weights and flipped taps."""
     torch.manual_seed(7 + ci)
@@ -60,7 +61,8 @@ def test_wino_input_gradient_form_vs_float64(dev, B, H, ci, co):
     cache = C.SplitCache(wt)
     L.lib().wgs_dev_trace_kernels(1)
     got = C.conv2d_dgrad(dy.to(dev), wt, (H, H), 3, pad=1, precision=C.FP32W, w_split=cache, alpha=1.0)
-    assert L.lib().wgs_dev_last_kernel().decode().startswith('wino_f32_kernel<false>')
+    sym = L.lib().wgs_dev_last_kernel().decode()
+    assert sym.startswith('wino_f32_kernel<') and sym.endswith('false>'), sym
     L.lib().wgs_dev_trace_kernels(0)
     assert rel_err(got, ref) < 3e-6
     assert len(cache.planes) == 1           # U is kept with the weight tensor

@@ -26,20 +26,30 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TB = 64;            // Winograd tiles per workgroup: 8 x 8  (16 x 16 output pixels)
-constexpr int BN = 64;            // output channels per workgroup
 constexpr int KC = 16;            // input channels per chunk
-constexpr int NT = 512;
-constexpr int STAGE = 16 * TB * KC * 4;        // one staged chunk of V: 64 KB
-constexpr int EPI_ROW = TB * 4 + 16;           // one (pos, n) row of the epilogue exchange: 64 tiles + 16 B (bank spread)
-constexpr int EPI_BYTES = 16 * 32 * EPI_ROW;   // 136 KB
-constexpr int SMEM = EPI_BYTES > 2 * STAGE ? EPI_BYTES : 2 * STAGE;
-constexpr int U_CHUNK = 16 * BN * KC * 4;      // bytes of U per (channel block, chunk): 64 KB
+constexpr int NT = 512;           // 8 waves; wave w owns Winograd positions 2w, 2w + 1
 constexpr int OOB = (int)0x80000000;
+
+// Workgroup tile: 32 * TI Winograd tiles (8 columns x 4 * TI rows of 2x2 outputs = 16 x 8 * TI pixels) x 32 * TJ output channels.
+// The input transform costs the same per tile whatever TJ is, the MFMAs grow with it: (TI, TJ) = (1, 4) where Cout % 128 == 0
+// (0.5 vector instructions per MFMA), (2, 2) for Cout % 64 == 0.
+template <int TI, int TJ>
+struct Cfg {
+    static constexpr int TB = 32 * TI, BN = 32 * TJ, PH = 8 * TI;
+    static constexpr int PS = TB * KC * 4;             // one position of a staged chunk: TB rows of 64 B
+    static constexpr int STAGE = 16 * PS;              // one staged chunk of V (64 KB / 32 KB)
+    static constexpr int NP = 16 * TJ;                 // output channels per epilogue pass (two passes)
+    static constexpr int EPI_ROW = TB * 4 + 16;        // one (pos, n) row of the epilogue exchange: TB tiles + 16 B (bank spread)
+    static constexpr int EPI_BYTES = 16 * NP * EPI_ROW;
+    static constexpr int SMEM = EPI_BYTES > 2 * STAGE ? EPI_BYTES : 2 * STAGE;
+    static constexpr int U_CHUNK = 16 * BN * KC * 4;   // bytes of U per (channel block, chunk)
+    static constexpr int NU = 2 * TJ;                  // MFMA units per chunk: (k group g, position pp, column-block pair jh), 8 * TI MFMAs each
+};
 
 struct WinoArgs {
     const float* x;
@@ -53,7 +63,6 @@ struct WinoArgs {
     float* y_amax;
     int B, H, W, Ci, Co, a_ld, col_ld;
     float alpha, act_slope, gain;
-    int var;
 };
 
 struct WinoTaps { int w_of[9]; };      // weight slab index of spatial tap (ky, kx), -1 = absent
@@ -64,14 +73,29 @@ __device__ __forceinline__ f32x4 buf_load4(const __amdgpu_buffer_rsrc_t r, int v
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return __builtin_bit_cast(f32x4, v);
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The transform's arithmetic written as the instructions it is (the backend splits 4-vectors into scalars and keeps a quad permute
+// as a separate v_mov_b32_dpp): packed fp32 adds / multiplies on register pairs ...
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// ... and v += s * (v of lane {2, 2, 1, 1}[lane & 3] of the quad), in place on the four values of a loaded float4 (s_nop 1: a VGPR
+// written by the preceding VALU instruction may not be read through DPP for two cycles)
+__device__ __forceinline__ void quad_row_pass(f32x4& v, float s) {
+    float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(s));
+    v = (f32x4){v0, v1, v2, v3};
+}
 
 // U[pos] = G g G^T of every (co, ci) pair, written as the main kernel's B-operand fragments:
-// [Co/64][Ci/16][pos][k group g of 8][column block j of 32][lane = 32 * (k half) + column][4 consecutive k]
-__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co,
+// [Co/BN][Ci/16][pos][k group g of 8][column block j of 32][lane = 32 * (k half) + column][4 consecutive k].
+// Positions with nu = 3 carry a minus sign: the kernel's row pass produces -(T1 - T3) there (own minus permuted column, the form
+// the other three columns have), and the product of the two signs is +.
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int tj,
                                                           long w_row_stride, long w_tap_stride, const WinoTaps tp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)Ci * Co) return;
@@ -93,23 +117,24 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
         u[r][0] = t[r][0];
         u[r][1] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
         u[r][2] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
-        u[r][3] = t[r][2];
+        u[r][3] = -t[r][2];
     }
-    const int nchunks = Ci / KC;
-    const int nb = co / BN, n = co % BN, chunk = ci / KC, kk = ci % KC;
+    const int bn = 32 * tj, nchunks = Ci / KC;
+    const int nb = co / bn, n = co % bn, chunk = ci / KC, kk = ci % KC;
     const int lane = ((kk >> 2) & 1) * 32 + (n & 31);
-    float* base = U + ((size_t)nb * nchunks + chunk) * (16 * BN * KC);
+    float* base = U + ((size_t)nb * nchunks + chunk) * (16 * bn * KC);
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos)
-        base[(((pos * 2 + (kk >> 3)) * 2 + (n >> 5)) * 64 + lane) * 4 + (kk & 3)] = u[pos >> 2][pos & 3];
+        base[(((pos * 2 + (kk >> 3)) * tj + (n >> 5)) * 64 + lane) * 4 + (kk & 3)] = u[pos >> 2][pos & 3];
 }
 
-template <bool STY, int ABL>
+template <int TI, int TJ, bool STY>
 __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
-    // ABL (development): 1 no transform / LDS stores, 2 no barriers, 3 no global loads in the loop, 4 no fragment reads, 5 = 1 + 3
+    typedef Cfg<TI, TJ> C;
+    constexpr int PS = C::PS, STAGE = C::STAGE, NU = C::NU, NP = C::NP, EPI_ROW = C::EPI_ROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int ntn = p.Co / BN, tbx = p.W >> 4, tby = p.H >> 4;
+    const int ntn = p.Co / C::BN, tbx = p.W >> 4, tby = p.H / C::PH;
     // XCD-aware order (hardware sends workgroup i to XCD i % 8): every XCD gets a contiguous range of the (pixel block major,
     // channel block minor) list, so the channel blocks of a pixel block share their input patch in that XCD's L2
     int bid;
@@ -117,8 +142,7 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
         const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, qn = nb >> 3, rn = nb & 7;
         bid = xcd * qn + min(xcd, rn) + slot;
     }
-    const int ntm = gridDim.x / ntn;
-    const int tmi = (p.var & 1) ? bid % ntm : bid / ntn, nb0 = (p.var & 1) ? bid / ntm : bid - (bid / ntn) * ntn;
+    const int tmi = bid / ntn, nb0 = bid - tmi * ntn;
     const int b = tmi / (tbx * tby), rr = tmi - b * (tbx * tby), by = rr / tbx, bx = rr - by * tbx;
     const int nchunks = p.Ci / KC;
 
@@ -127,173 +151,152 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, 16 * p.Ci * p.Co * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(STY ? p.a_scale + (size_t)b * p.a_ld : p.x), 0, STY ? p.Ci * 4 : 0, 0x00020000);
 
-    // ---- staging role: thread = (tile t, channel quads ql and ql + 2, patch column nu) ----
+    // ---- staging role: thread = (tile t, patch column nu, channel quad q); TI = 2: two tasks per thread, quads ql and ql + 2 ----
     // LDS image of a chunk: [pos][row 64 B = 16 channels]; logical (t, 16-byte slot s) of position pos lives at row t ^ (nu & 1), slot
     // s ^ ((t >> 1) & 3) ^ (nu & 2), nu = pos & 3: the quad's four positions and the two channel quads of 8 neighbouring lanes fall into
     // 8 different 16-byte bank groups, and so do the 8 rows a fragment read touches per cycle.
-    const int t = tid >> 3, ql = (tid >> 2) & 1, nu = tid & 3, ty = t >> 3, tx = t & 7;
+    const int t = tid >> (TI == 2 ? 3 : 4), ql = (tid >> 2) & (TI == 2 ? 1 : 3), nu = tid & 3, ty = t >> 3, tx = t & 7;
     int a_off[4];
     {
         const int ix = bx * 16 + 2 * tx + nu - 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int iy = by * 16 + 2 * ty + r - 1;
+            const int iy = by * C::PH + 2 * ty + r - 1;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             a_off[r] = ok ? ((iy * p.W + ix) * p.Ci + ql * 4) * 4 : OOB;
-            if (p.var & 8) a_off[r] = tid * 16 + r * 8192;          // ablation: coalesced (wrong) patch loads
         }
     }
-    const int v_st = nu * 4096 + (t ^ (nu & 1)) * 64;          // + xi * 16384 + slot * 16
-    const int v_sl = ql ^ ((t >> 1) & 3) ^ (nu & 2);           // slot of task 0; task 1: ^ 2
-    const float sa = nu == 3 ? -1.f : 1.f, sb = (nu & 1) ? 1.f : -1.f;     // row pass of lane nu: sa * own column + sb * column {2, 2, 1, 1}[nu]
+    // row pass of lane nu (columns of the patch live in the quad's four lanes): own + sb * column {2, 2, 1, 1}[nu]
+    //   nu 0: d0 - d2    nu 1: d1 + d2    nu 2: d2 - d1    nu 3: d3 - d1 = -(B^T row 3; the sign sits in U)
+    const float sb = nu == 1 ? 1.f : -1.f;
+    unsigned char* v_dst[TI];
+#pragma unroll
+    for (int u = 0; u < TI; ++u) v_dst[u] = smem + nu * PS + (t ^ (nu & 1)) * 64 + (((ql + 2 * u) ^ ((t >> 1) & 3) ^ (nu & 2)) * 16);
 
-    f32x4 ra[2][4], rsv[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    f32x4 ra[TI][4], rsv[TI];
     auto load_A = [&](int c, int u) {
         const int cb = min(c, nchunks - 1) * (KC * 4) + u * 32;       // past the end: re-read the last chunk (stored into a dead buffer)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ra[u][r] = buf_load4(rx, a_off[r], cb);
         if (STY) rsv[u] = buf_load4(rs, ql * 16, cb);
     };
-    // column pass B^T d (rows of the patch) of task u, times the style and the lane's own row-pass sign -> T[u]; then, per xi, the row
-    // pass over the quad's four columns (own + sb * column {2,2,1,1}[nu]: the lanes that are read, nu = 1 and 2, have own sign +1) + store.
-    // Two-element vector types: the backend keeps them as v_pk_add_f32 / v_pk_mul_f32 (a 4-vector is split into scalars).
-    // Written as the instructions they are (the backend splits 4-vectors into scalars and keeps the quad permute as a separate
-    // v_mov_b32_dpp): v_pk_add_f32 / v_pk_mul_f32 on register pairs, and v_fmac_f32_dpp accumulating the permuted column onto the
-    // lane's own (s_nop 1 first: a VGPR written by the preceding VALU instruction may not be read through DPP for two cycles).
-    f32x2 T[2][4][2];
-    auto col_pass = [&](int u) {
+    auto row_pass = [&](int u) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x2 d0 = {ra[u][0][2 * h], ra[u][0][2 * h + 1]}, d1 = {ra[u][1][2 * h], ra[u][1][2 * h + 1]};
-            const f32x2 d2 = {ra[u][2][2 * h], ra[u][2][2 * h + 1]}, d3 = {ra[u][3][2 * h], ra[u][3][2 * h + 1]};
-            f32x2 sg = {sa, sa};
-            if (STY) sg = pk_mul(sg, (f32x2){rsv[u][2 * h], rsv[u][2 * h + 1]});
-            T[u][0][h] = pk_mul(pk_sub(d0, d2), sg);
-            T[u][1][h] = pk_mul(pk_add(d1, d2), sg);
-            T[u][2][h] = pk_mul(pk_sub(d2, d1), sg);
-            T[u][3][h] = pk_mul(pk_sub(d1, d3), sg);
+        for (int r = 0; r < 4; ++r) quad_row_pass(ra[u][r], sb);
+    };
+    // column pass B^T (over the patch rows, per lane) of output row xi, times the style, stored as position (xi, nu)
+    auto col_store = [&](int buf, int u, int xi) {
+        const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1), ib = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+        f32x2 h[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x2 a = {ra[u][ia][2 * k], ra[u][ia][2 * k + 1]}, bb = {ra[u][ib][2 * k], ra[u][ib][2 * k + 1]};
+            h[k] = xi == 1 ? pk_add(a, bb) : pk_sub(a, bb);
+            if (STY) h[k] = pk_mul(h[k], (f32x2){rsv[u][2 * k], rsv[u][2 * k + 1]});
         }
+        const f32x4 v = {h[0][0], h[0][1], h[1][0], h[1][1]};
+        *reinterpret_cast<f32x4*>(v_dst[u] + buf * STAGE + xi * 4 * PS) = v;
     };
-    auto row_store = [&](unsigned char* dst, int u, int xi) {
-        float v0 = T[u][xi][0][0], v1 = T[u][xi][0][1], v2 = T[u][xi][1][0], v3 = T[u][xi][1][1];
-        asm("s_nop 1\n\t"
-            "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
-            "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
-            : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(sb));
-        const f32x4 v = {v0, v1, v2, v3};
-        *reinterpret_cast<f32x4*>(dst + xi * 16384) = v;
-    };
-    unsigned char* const v_dst0 = smem + v_st + v_sl * 16;              // task 0, buffer 0; task 1: slot ^ 2; buffer 1: + STAGE
-    unsigned char* const v_dst1 = smem + v_st + (v_sl ^ 2) * 16;
     auto store_A = [&](int buf, int u) {
-        col_pass(u);
+        row_pass(u);
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) row_store((u ? v_dst1 : v_dst0) + buf * STAGE, u, xi);
+        for (int xi = 0; xi < 4; ++xi) col_store(buf, u, xi);
     };
 
     // ---- MFMA role: wave w owns positions 2w, 2w + 1; its B fragments come straight from global memory (no other wave needs them) ----
-    int f_off[2][2];       // [pp][g]: LDS byte offset of the A fragment (row block 0)
-    int u_off[2];          // [pp]: byte offset of the wave's U fragments inside a chunk (+ g * 2048 + j * 1024)
+    int f_off[2][2];       // [pp][g]: LDS byte offset of the A fragment (row block 0; row block i: + i * 2048)
+    int u_off[2];          // [pp]: byte offset of the wave's U fragments inside a chunk (+ (g * TJ + j) * 1024)
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
         const int pos = 2 * wave + pp, nup = pos & 3;
         const int sx = lh ^ ((l31 >> 1) & 3) ^ (nup & 2);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) f_off[pp][g] = pos * 4096 + (l31 ^ (nup & 1)) * 64 + ((sx ^ (2 * g)) * 16);
-        u_off[pp] = pos * 4096 + lane * 16;
-        if (p.var & 16) u_off[pp] = OOB;                        // ablation: no B traffic
+        for (int g = 0; g < 2; ++g) f_off[pp][g] = pos * PS + (l31 ^ (nup & 1)) * 64 + ((sx ^ (2 * g)) * 16);
+        u_off[pp] = pos * (2 * TJ * 1024) + lane * 16;
     }
-    f32x4 bf[2][2][2];     // [g][pp][j]
-    auto load_B = [&](int c, int g) {
-        const int cb = (nb0 * nchunks + min(c, nchunks - 1)) * U_CHUNK + g * 2048;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[g][pp][j] = buf_load4(ru, u_off[pp], cb + j * 1024);
+    // unit u of chunk c: k group g, position pp, column blocks 2 jh, 2 jh + 1;  u = (g * 2 + pp) * (TJ / 2) + jh
+    f32x4 bfr[4][2];       // ring over units: unit u lives in slot u % 4 and is requested three units ahead
+    auto load_B = [&](int c, int u) {
+        c += u / NU; u %= NU;
+        const int gp = u / (TJ / 2), jh = u % (TJ / 2), g = gp >> 1, pp = gp & 1;
+        const int cb = (nb0 * nchunks + min(c, nchunks - 1)) * C::U_CHUNK + (g * TJ + 2 * jh) * 1024;
+        bfr[u % 4][0] = buf_load4(ru, u_off[pp], cb);
+        bfr[u % 4][1] = buf_load4(ru, u_off[pp], cb + 1024);
     };
-    f32x16 acc[2][2][2];
+    f32x16 acc[2][TI][TJ];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
 
-    // Chunk kt multiplies LDS buffer kt & 1.  Slot s = (k group g, position pp, row block i): 8 MFMAs, 8 slots per chunk.  The staging
-    // work of chunk kt + 1 is cut into ten pieces (column pass and four row-pass + store pieces per patch task) spread over slots
-    // 0..6, and inside a slot the scheduler is told to alternate one MFMA with a few VALU instructions: the two waves of a SIMD run
-    // in step (one barrier per chunk), so a staging block issued as one run would leave the matrix pipe idle for its whole length.
-    //   slot 0  B fragments (kt, g = 1) requested         slot 4  B fragments (kt + 1, g = 0) requested     (four slots of flight)
-    //   slot 2 / slot 6  patch task 0 / 1 of chunk kt + 2 requested, right after its registers' last piece  (six / five slots)
+    // Chunk kt multiplies LDS buffer kt & 1 in NU units of 8 * TI MFMAs.  The staging work of chunk kt + 1 (row pass, four column
+    // pass + store pieces per task) and the requests of chunk kt + 2 are spread over the units, and inside a unit the scheduler is
+    // told to alternate one MFMA with a few vector instructions: the waves of a workgroup run in step (one barrier per chunk), and
+    // measured on this kernel every vector instruction costs its four cycles of matrix-pipe time — a staging block issued as one
+    // run idles the pipe for its whole length.
     auto mma_chunk = [&](int cur, int kt) {
         const unsigned char* base = smem + cur * STAGE;
         const int nxt = cur ^ 1;
-        f32x4 af[2];
-        af[0] = *reinterpret_cast<const f32x4*>(base + f_off[0][0]);
+        f32x4 af[2][TI];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int g = s >> 2, pp = (s >> 1) & 1, i = s & 1;
-            if (s + 1 < 8) {
-                const int gn = (s + 1) >> 2, pn = ((s + 1) >> 1) & 1, in = (s + 1) & 1;
-                if (ABL != 4) af[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(base + f_off[pn][gn] + in * 2048);
-                else af[(s + 1) & 1] = af[s & 1];
+        for (int i = 0; i < TI; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(base + f_off[0][0] + i * 2048);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int gp = u / (TJ / 2), jh = u % (TJ / 2), g = gp >> 1, pp = gp & 1;
+            if (u + 1 < NU && (u + 1) % (TJ / 2) == 0) {          // the next unit starts a new (g, pp): fetch its A fragments now
+                const int gn = (gp + 1) >> 1, pn = (gp + 1) & 1;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[(gp + 1) & 1][i] = *reinterpret_cast<const f32x4*>(base + f_off[pn][gn] + i * 2048);
             }
-            if (ABL != 3 && ABL != 5) {
-                if (s == 0) load_B(kt, 1);
-                if (s == 4) load_B(kt + 1, 0);
+            load_B(kt, u + 3);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[pp][i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gp & 1][i][e], bfr[u % 4][jj][e], acc[pp][i][2 * jh + jj], 0, 0, 0);
+            if (TI == 2) {        // 4 units of 16 MFMAs
+                if (u == 0) { row_pass(0); col_store(nxt, 0, 0); }
+                if (u == 1) { col_store(nxt, 0, 1); col_store(nxt, 0, 2); col_store(nxt, 0, 3); load_A(kt + 2, 0); row_pass(1); }
+                if (u == 2) { col_store(nxt, 1, 0); col_store(nxt, 1, 1); col_store(nxt, 1, 2); }
+                if (u == 3) { col_store(nxt, 1, 3); load_A(kt + 2, 1); }
+            } else {              // 8 units of 8 MFMAs
+                if (u == 0) row_pass(0);
+                if (u >= 1 && u <= 4) col_store(nxt, 0, u - 1);
+                if (u == 4) load_A(kt + 2, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[pp][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][e], bf[g][pp][j][e], acc[pp][i][j], 0, 0, 0);
-            if (ABL != 1 && ABL != 5) {
-            if (s == 0) { col_pass(0); row_store(v_dst0 + nxt * STAGE, 0, 0); }
-            if (s == 1) { row_store(v_dst0 + nxt * STAGE, 0, 1); row_store(v_dst0 + nxt * STAGE, 0, 2); }
-            if (s == 2) row_store(v_dst0 + nxt * STAGE, 0, 3);
-            if (s == 3) { col_pass(1); row_store(v_dst1 + nxt * STAGE, 1, 0); }
-            if (s == 4) row_store(v_dst1 + nxt * STAGE, 1, 1);
-            if (s == 5) row_store(v_dst1 + nxt * STAGE, 1, 2);
-            if (s == 6) row_store(v_dst1 + nxt * STAGE, 1, 3);
-            }
-            if (ABL != 3 && ABL != 5) {
-                if (s == 2) load_A(kt + 2, 0);
-                if (s == 6) load_A(kt + 2, 1);
-            }
-            {
-                // one MFMA, then up to five VALU instructions, eight times
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                }
+            for (int k = 0; k < 8 * TI; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    load_A(0, 0);
-    load_A(0, 1);
-    load_B(0, 0);
-    store_A(0, 0);
-    store_A(0, 1);
-    load_A(1, 0);
-    load_A(1, 1);
+#pragma unroll
+    for (int u = 0; u < TI; ++u) load_A(0, u);
+    load_B(0, 0); load_B(0, 1); load_B(0, 2);
+#pragma unroll
+    for (int u = 0; u < TI; ++u) store_A(0, u);
+#pragma unroll
+    for (int u = 0; u < TI; ++u) load_A(1, u);
     __syncthreads();
     for (int kt = 0; kt < nchunks; ++kt) {
         mma_chunk(kt & 1, kt);
-        if (ABL != 2) __syncthreads();
+        __syncthreads();
     }
 
     // ---- epilogue: positions -> LDS -> A^T . A per (tile, channel) -> demodulation, noise, bias, activation ----
     const float alpha = p.alpha;
     const float nw = p.noise ? p.noise_w[0] : 0.f;
-    const int n_l = tid & 31, tq = tid >> 5;
-    const int oy0 = by * 16 + 2 * (tq >> 1), ox0 = bx * 16 + 8 * (tq & 1);
+    const int n_l = tid % NP, tq = tid / NP;
+    const int oy0 = by * C::PH + 2 * (tq >> 1), ox0 = bx * 16 + 8 * (tq & 1);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)b * p.H * p.W * p.Co, 0, p.H * p.W * p.Co * 4, 0x00020000);
     const float slope = p.act_slope, gain = p.gain;
     float vmax = 0.f;
@@ -303,23 +306,26 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const f32x4 v = {acc[pp][i][jj][4 * rq], acc[pp][i][jj][4 * rq + 1], acc[pp][i][jj][4 * rq + 2], acc[pp][i][jj][4 * rq + 3]};
-                    *reinterpret_cast<f32x4*>(smem + ((2 * wave + pp) * 32 + l31) * EPI_ROW + (i * 32 + 8 * rq + 4 * lh) * 4) = v;
-                }
+                for (int jl = 0; jl < TJ / 2; ++jl)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x16& a = acc[pp][i][jj * (TJ / 2) + jl];
+                        const f32x4 v = {a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+                        *reinterpret_cast<f32x4*>(smem + ((2 * wave + pp) * NP + jl * 32 + l31) * EPI_ROW + (i * 32 + 8 * rq + 4 * lh) * 4) = v;
+                    }
         __syncthreads();
         f32x4 m[4][4];
 #pragma unroll
-        for (int pos = 0; pos < 16; ++pos) m[pos >> 2][pos & 3] = *reinterpret_cast<const f32x4*>(smem + (pos * 32 + n_l) * EPI_ROW + tq * 16);
+        for (int pos = 0; pos < 16; ++pos) m[pos >> 2][pos & 3] = *reinterpret_cast<const f32x4*>(smem + (pos * NP + n_l) * EPI_ROW + tq * 16);
         f32x4 z[4][2];
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
             z[xi][0] = m[xi][0] + m[xi][1] + m[xi][2];
             z[xi][1] = m[xi][1] - m[xi][2] - m[xi][3];
         }
-        const int n = nb0 * BN + jj * 32 + n_l;
+        const int n = nb0 * C::BN + jj * NP + n_l;
         const float cs = (p.col_scale ? p.col_scale[(size_t)b * p.col_ld + n] : 1.f) * alpha;
         const float bs = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
@@ -367,9 +373,15 @@ bool wino_ok(const wgs_conv_desc* d) {
     WinoTaps tp;
     if (!wino_taps(d, tp)) return false;
     return d->isy == 1 && d->isx == 1 && d->osy == 1 && d->osx == 1 && d->oy0 == 0 && d->ox0 == 0 && d->ups == 0 && d->Hg == d->Hi && d->Wg == d->Wi &&
-           d->Ho == d->Hi && d->Wo == d->Wi && d->Hi % 16 == 0 && d->Wi % 16 == 0 && d->Ci % KC == 0 && d->Co % BN == 0 && d->act == 0 && !d->addend &&
+           d->Ho == d->Hi && d->Wo == d->Wi && d->Hi % 16 == 0 && d->Wi % 16 == 0 && d->Ci % KC == 0 && d->Co % 64 == 0 && d->act == 0 && !d->addend &&
            d->act_slope >= 0.f && d->act_slope <= 1.f && d->B > 0 && (long)d->Hi * d->Wi * d->Ci * 4 < 0x7fffffffL && (long)d->Hi * d->Wi * d->Co * 4 < 0x7fffffffL &&
            (long)16 * d->Ci * d->Co * 4 < 0x7fffffffL && (!d->noise || d->noise_w);
+}
+
+// column blocks of 32 per workgroup: 4 where Cout allows (WGS_WINO_VAR=1, development: always 2)
+int wino_tj(const wgs_conv_desc* d) {
+    static const int var = getenv("WGS_WINO_VAR") ? atoi(getenv("WGS_WINO_VAR")) : 0;
+    return (d->Co % 128 == 0 && !(var & 1)) ? 4 : 2;
 }
 
 }  // namespace
@@ -383,8 +395,8 @@ int wgs_conv_wino_weight(const wgs_conv_desc* d, float* U, wgs_stream_t stream) 
     WinoTaps tp;
     wino_taps(d, tp);
     const long n = (long)d->Ci * d->Co;
-    WGS_LAUNCH(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d->w, U, d->Ci, d->Co, (long)d->w_row_stride,
-               (long)d->w_tap_stride, tp);
+    WGS_LAUNCH(wino_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d->w, U, d->Ci, d->Co, wino_tj(d),
+               (long)d->w_row_stride, (long)d->w_tap_stride, tp);
     WGS_CHECK_LAUNCH("wino_weight_kernel");
     return WGS_OK;
 }
@@ -397,20 +409,18 @@ int wgs_conv_wino(const wgs_conv_desc* d, const float* U, wgs_stream_t stream) {
     a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.Ci = d->Ci; a.Co = d->Co;
     a.a_ld = d->a_ld > 0 ? d->a_ld : d->Ci; a.col_ld = d->col_ld > 0 ? d->col_ld : d->Co;
     a.alpha = d->alpha != 0.f ? d->alpha : 1.f; a.act_slope = d->act_slope; a.gain = d->gain;
-    const unsigned grid = (unsigned)((long)d->B * (d->Hi / 16) * (d->Wi / 16) * (d->Co / BN));
     hipStream_t st = (hipStream_t)stream;
-    static const int var = getenv("WGS_WINO_VAR") ? atoi(getenv("WGS_WINO_VAR")) : 0;
-    a.var = var;
-#define WGS_WINO_LAUNCH(STY, V)                                                                             \
-    {                                                                                                       \
-        auto k = wino_f32_kernel<STY, V>;                                                                   \
-        wgs_note_kernel("wino_f32_kernel<%s>", STY ? "true" : "false");                                     \
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);        \
-        WGS_LAUNCH(k, dim3(grid), dim3(NT), SMEM, st, a);                                                   \
+#define WGS_WINO_LAUNCH(TI, TJ, STY)                                                                                        \
+    {                                                                                                                       \
+        auto k = wino_f32_kernel<TI, TJ, STY>;                                                                              \
+        const unsigned grid = (unsigned)((long)d->B * (d->Hi / Cfg<TI, TJ>::PH) * (d->Wi / 16) * (d->Co / Cfg<TI, TJ>::BN)); \
+        wgs_note_kernel("wino_f32_kernel<%d, %d, %s>", TI, TJ, STY ? "true" : "false");                                    \
+        const int sm = Cfg<TI, TJ>::SMEM;                                                                                   \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, sm);                          \
+        WGS_LAUNCH(k, dim3(grid), dim3(NT), sm, st, a);                                                                     \
     }
-#define WGS_WINO_V(STY) switch (var >> 5) { case 1: WGS_WINO_LAUNCH(STY, 1) break; case 2: WGS_WINO_LAUNCH(STY, 2) break; case 3: WGS_WINO_LAUNCH(STY, 3) break; case 4: WGS_WINO_LAUNCH(STY, 4) break; case 5: WGS_WINO_LAUNCH(STY, 5) break; default: WGS_WINO_LAUNCH(STY, 0) break; }
-    if (d->a_scale) WGS_WINO_V(true) else WGS_WINO_V(false)
-#undef WGS_WINO_V
+    if (wino_tj(d) == 4) { if (d->a_scale) WGS_WINO_LAUNCH(1, 4, true) else WGS_WINO_LAUNCH(1, 4, false) }
+    else { if (d->a_scale) WGS_WINO_LAUNCH(2, 2, true) else WGS_WINO_LAUNCH(2, 2, false) }
 #undef WGS_WINO_LAUNCH
     WGS_CHECK_LAUNCH("wino_f32_kernel");
     return WGS_OK;
