@@ -6,10 +6,13 @@ as the reference constructors do; no checkpoints offline), K=128 warping functio
 reconstructor, batch 32 per GPU, Z-space shifts, --learn-gammas, synthetic z ~ N(0, I) sampled in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-The headline (`value`, `dtype`, `roofline`) is the REFERENCE's arithmetic: exact fp32 everywhere (f32-input MFMA, fp32
-accumulate; the reference computes in fp32).  `extra[0]` is the same workload with the same K / W in
-the product's default arithmetic (`auto` = the mixed fp16 / split-bf16 per-layer policy of DESIGN.md section 3.2), with
-its own `roofline`; it runs at every N.  The remaining `extra` entries (other modes / BASELINE configs, short runs) are N=1 only.
+The headline (`value`, `dtype`, `roofline`) is the REFERENCE's arithmetic: fp32 everywhere (f32-input MFMA, fp32 accumulate; the
+reference computes in fp32), with the 3x3 stride-1 convolutions in the Winograd F(2x2,3x3) form
+(`--precision fp32w`) - the algorithm class cuDNN's search gives the reference's F.conv2d
+(lib/trainer.py:166 sets cudnn.benchmark = True); ~1e-6 against the direct form.  `extra[0]` is the same workload with the same
+K / W in the product's default arithmetic (`auto` = the mixed fp16 / split-bf16 per-layer policy of DESIGN.md section 3.2) and
+`extra[1]` in DIRECT-form exact fp32 (`fp32`: no Winograd anywhere), each with its own `roofline`; both run at every N.  The
+remaining `extra` entries (other modes / BASELINE configs, short runs) are N=1 only.
 
 With N > 1 and no torch.distributed environment, bench.py starts the N ranks ITSELF (torch.distributed.run, one rank per
 GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line; under an external launcher (RANK / WORLD_SIZE set) it runs
@@ -206,6 +209,10 @@ def roofline_of(recs, img_per_s_per_gpu, gflop_per_img):
            "method": "HIP events on the launch stream around every conv launch of 2 extra single-stream steps; per symbol: sum of the "
                      "launches' algorithmic FLOPs (2 * pixels * Cout * Cin * taps) / sum of their durations; rocprofv3 tables of the same "
                      "build: profiles/r3_step_*_kernel_stats.md"}
+    if 'fp32w' in d['prec']:
+        out["frac_note"] = ("achieved / frac count the DIRECT form's multiplies (2 * pixels * Cout * Cin * 9, SURVEY.md section 8d): the Winograd "
+                            "F(2x2,3x3) kernel executes 16/36 of them, so frac may exceed 1; executed_mfma_frac is the matrix-pipe utilisation "
+                            "(MFMA FLOPs actually issued / duration / peak)")
     if gflop_per_img:
         out["step_achieved_TFLOPs"] = round(img_per_s_per_gpu * gflop_per_img / 1e3, 2)
         out["step_frac"] = round(img_per_s_per_gpu * gflop_per_img / 1e3 / peak, 4)
@@ -435,8 +442,9 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-threads', type=int, default=32)
-    ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default='fp32',
-                    help="arithmetic of the HEADLINE run's generator convs (default: fp32 = the reference's arithmetic)")
+    ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default='fp32w',
+                    help="arithmetic of the HEADLINE run's generator convs (default: fp32w = fp32, Winograd form of the 3x3 stride-1 convs)")
+    ap.add_argument('--no-direct-run', action='store_true', help="skip extra[1] (the direct-form exact-fp32 run with the same steps / warmup)")
     ap.add_argument('--r-precision', choices=['fp32', 'fp32w', 'bf16x3', 'auto'], default='auto',
                     help="arithmetic of the Reconstructor's convs (auto = exact fp32 beside an fp32 generator, split-bf16 x3 beside a 16-bit one)")
     ap.add_argument('--product-precision', choices=tuple(C.PRECISION_NAMES), default=C.DEFAULT_PRECISION,
@@ -497,6 +505,13 @@ def main():
             prod["comm"] = comm_section(eng, args.dist_backend)
         extra.append(dict({"config": "headline workload in the product's default arithmetic (--precision %s), same steps / warmup"
                                      % args.product_precision}, **prod))
+        del eng
+        torch.cuda.empty_cache()
+    if not args.no_direct_run and not args.no_product_run and args.precision == 'fp32w':
+        dirr, eng = run_one(dev, args.gan, args.size, args.K, args.N, args.batch, 'fp32', 'fp32', args.w_space,
+                            args.steps, args.warmup, gkey, world=world, rank=rank, full=full)
+        dirr["last_stats"] = eng.pop_stats()
+        extra.append(dict({"config": "headline workload in direct-form exact fp32 (--precision fp32: no Winograd), same steps / warmup"}, **dirr))
         del eng
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extra:

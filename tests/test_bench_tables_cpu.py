@@ -60,6 +60,15 @@ def test_roofline_groups_by_kernel_symbol(bench):
     assert [s['symbol'] for s in r['by_symbol']][:2] == ['upconv_blur_kernel<3, 16>', 'igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0>']
     fp = bench.roofline_of([('conv fp32 128->128 @256x256 9 taps B32', 'igemm_nt_kernel<128, 128, 32, 2, 2, true>', 1855.4e9, 17.0, 3.0)], 340.0, 285.8)
     assert fp['peak'] == bench.FP32_MFMA_PEAK_TF and abs(fp['achieved'] - 1855.4 / 17.0) < 0.1
+    # Winograd launches: rated on the direct form's multiplies against the fp32 MFMA peak (frac may pass 1), the executed share beside it
+    w = bench.roofline_of([('conv fp32w 512->512 @64x64 9 taps B32', 'wino_f32_kernel<1, 4, true>', 1237.0e9, 4.4, 2.0),
+                           ('conv fp32 512->256 @64x64 up-conv x4 phases B32', 'igemm_nt16_kernel<4, 256, 256, 2, 4, 2, false>', 631.4e9, 4.6, 2.0)], 560.0, 285.8)
+    assert w['kernel'] == 'igemm_nt16_kernel<4, 256, 256, 2, 4, 2, false>' and w['peak'] == bench.FP32_MFMA_PEAK_TF and 'frac_note' not in w
+    wk = [r for r in w['by_symbol'] if r['symbol'].startswith('wino')][0]
+    assert wk['peak'] == bench.FP32_MFMA_PEAK_TF and wk['frac'] > 1.0
+    w2 = bench.roofline_of([('conv fp32w 512->512 @64x64 9 taps B32', 'wino_f32_kernel<1, 4, true>', 1237.0e9, 4.4, 2.0)], 560.0, 285.8)
+    assert abs(w2['executed_mfma_frac'] - w2['frac'] * 16 / 36) < 1e-3 and 'frac_note' in w2
+    assert bench.DTYPE['fp32w'] == 'fp32'
 
 
 def test_no_gpu_means_a_loud_failure(bench, monkeypatch):

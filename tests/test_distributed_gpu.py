@@ -183,3 +183,4 @@ def test_bench_two_ranks_end_to_end_over_gloo():
     assert d['roofline']['kernel'] and d['host']['library_launches_per_step'] > 0
     e = d['extra'][0]
     assert e['n_gpus'] == 2 and e['steps'] == 3 and e['comm']['world_size_observed'] == 2 and e['roofline']['kernel']
+    assert d['config']['precision'] == 'fp32w' and d['extra'][1]['precision'] == 'fp32' and d['extra'][1]['n_gpus'] == 2    # the direct-form run beside it

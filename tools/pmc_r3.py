@@ -6,7 +6,10 @@ import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspa
 
 B = 32
 # (label, kind, precision, ci, co, h): kind 'conv' = styled stride-1 3x3, 'up' = fused up-sampling layer, 'upT' = transposed conv phases
-SHAPES = [('conv fp32 512->512 @64x64 9 taps B32', 'conv', 'fp32', 512, 512, 64),
+SHAPES = [('conv fp32w 512->512 @64x64 9 taps B32', 'conv', 'fp32w', 512, 512, 64),
+          ('conv fp32w 256->256 @128x128 9 taps B32', 'conv', 'fp32w', 256, 256, 128),
+          ('conv fp32w 128->128 @256x256 9 taps B32', 'conv', 'fp32w', 128, 128, 256),
+          ('conv fp32 512->512 @64x64 9 taps B32', 'conv', 'fp32', 512, 512, 64),
           ('conv fp32 256->256 @128x128 9 taps B32', 'conv', 'fp32', 256, 256, 128),
           ('conv fp32 128->128 @256x256 9 taps B32', 'conv', 'fp32', 128, 128, 256),
           ('conv fp32 256->128 @128x128 up-conv x4 phases B32', 'upT', 'fp32', 256, 128, 128),
@@ -24,7 +27,7 @@ def run():
         m = C.precision_code(prec)
         x = torch.randn(B, h, h, ci, device=dev); w = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
         s = torch.randn(B, ci, device=dev); dm = torch.rand(B, co, device=dev)
-        ws = C.split_weight(w, m) if m else None
+        ws = C.SplitCache(w) if m == C.FP32W else (C.split_weight(w, m) if m else None)
         if kind == 'conv':
             y = torch.empty(B, h, h, co, device=dev)
             fn = lambda: C.conv2d(x, w, 3, pad=1, out=y, a_scale=s, col_scale=dm, act_slope=0.2, gain=1.41, precision=m, w_split=ws)
@@ -47,7 +50,7 @@ def summarise(d, out):
     for f in sorted(glob.glob(d + '/*/p_counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
-            mm = re.search(r'(igemm_\w+<[^>]*>|upconv_blur_kernel<[^>]*>)', kn)
+            mm = re.search(r'(igemm_\w+<[^>]*>|upconv_blur_kernel<[^>]*>|wino_f32_kernel<[^>]*>)', kn)
             if not mm:
                 continue
             key = (int(r['Dispatch_Id']), mm.group(1))
@@ -61,7 +64,7 @@ def summarise(d, out):
             break
         sym, c = keys[2 * i + 1][1], tab[keys[2 * i + 1]]
         ho = 2 * h if kind == 'up' else (2 * h + 1 if kind == 'upT' else h)
-        rd = B * h * h * ci * 4 + co * 9 * ci * (4 if prec == 'fp32' else 2)
+        rd = B * h * h * ci * 4 + co * ci * (64 if prec == 'fp32w' else (36 if prec == 'fp32' else 18))
         wr = B * ho * ho * co * 4
         fetch, write = c.get('FETCH_SIZE', 0) * 1024 * 2, c.get('WRITE_SIZE', 0) * 1024
         mf = c.get('SQ_INSTS_MFMA', 0) or 1

@@ -8,7 +8,7 @@ tail -5 gpurun_out/${TAG}_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"
 grep '^{' gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json
-for mode in fp32 auto; do
+for mode in fp32w fp32 auto; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$mode -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-product-run --single-stream --precision $mode > gpurun_out/prof_${TAG}_$mode.log 2>&1
   python tools/prof_summary.py gpurun_out/prof_${TAG}_$mode 12 > gpurun_out/${TAG}_step_${mode}_kernel_stats.md
   find gpurun_out/prof_${TAG}_$mode -name "*kernel_trace.csv" -delete
