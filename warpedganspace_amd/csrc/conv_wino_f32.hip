@@ -293,15 +293,30 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     }
 
     // ---- epilogue: positions -> LDS -> A^T . A per (tile, channel) -> demodulation, noise, bias, activation ----
-    const float alpha = p.alpha;
-    const float nw = p.noise ? p.noise_w[0] : 0.f;
+    // Thread = (channel n_l of the pass, tile quad tq): four horizontally adjacent tiles = 2 rows x 8 columns of output pixels.  All
+    // operands come through buffer descriptors (a missing one has zero records and reads as 0): the 16 noise values are requested
+    // up front in one batch, no branches, no 64-bit address arithmetic; the stores take a per-output uniform (scalar) offset.
     const int n_l = tid % NP, tq = tid / NP;
     const int oy0 = by * C::PH + 2 * (tq >> 1), ox0 = bx * 16 + 8 * (tq & 1);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)b * p.H * p.W * p.Co, 0, p.H * p.W * p.Co * 4, 0x00020000);
-    const float slope = p.act_slope, gain = p.gain;
+    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.noise ? p.noise : p.x), 0, p.noise ? p.H * p.W * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.col_scale ? p.col_scale + (size_t)b * p.col_ld : p.x), 0, p.col_scale ? p.Co * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.x), 0, p.bias ? p.Co * 4 : 0, 0x00020000);
+    const float nw = p.noise ? p.noise_w[0] : 0.f;
+    float nz[2][8];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            nz[i2][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, ((oy0 + i2) * p.W + ox0) * 4, c * 4, 0));
+    const int y_voff = ((oy0 * p.W + ox0) * p.Co + nb0 * C::BN + n_l) * 4;
+    const float slope = p.act_slope, gain = p.gain, alpha = p.alpha;
     float vmax = 0.f;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
+        const int n = nb0 * C::BN + jj * NP + n_l;
+        const float cs_raw = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, n * 4, 0, 0));
+        const float bs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, n * 4, 0, 0));
         if (jj) __syncthreads();
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp)
@@ -325,26 +340,20 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
             z[xi][0] = m[xi][0] + m[xi][1] + m[xi][2];
             z[xi][1] = m[xi][1] - m[xi][2] - m[xi][3];
         }
-        const int n = nb0 * C::BN + jj * NP + n_l;
-        const float cs = (p.col_scale ? p.col_scale[(size_t)b * p.col_ld + n] : 1.f) * alpha;
-        const float bs = p.bias ? p.bias[n] : 0.f;
+        const float cs = (p.col_scale ? cs_raw : 1.f) * alpha;
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             f32x4 yv[2];
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) yv[j2] = i2 == 0 ? z[0][j2] + z[1][j2] + z[2][j2] : z[1][j2] - z[2][j2] - z[3][j2];
-            const int oy = oy0 + i2;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2) {
-                    const int ox = ox0 + 2 * k + j2;
-                    float v = yv[j2][k] * cs;
-                    if (p.noise) v += nw * p.noise[oy * p.W + ox];
-                    v += bs;
+                    float v = __builtin_fmaf(yv[j2][k], cs, __builtin_fmaf(nw, nz[i2][2 * k + j2], bs));
                     v = fmaxf(v, v * slope) * gain;
-                    vmax = fmaxf(vmax, fabsf(v));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, ((oy * p.W + ox) * p.Co + n) * 4, 0, 0);
+                    if (p.y_amax) vmax = fmaxf(vmax, fabsf(v));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, y_voff + jj * NP * 4, ((i2 * p.W + 2 * k + j2) * p.Co) * 4, 0);
                 }
         }
     }
