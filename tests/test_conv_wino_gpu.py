@@ -84,3 +84,26 @@ def test_wino_declines_what_it_does_not_cover_and_the_direct_kernel_runs(dev):
     x2 = torch.randn(2, 16, 16, 64, device=dev)
     y2 = torch.empty(2, 8, 8, 64, device=dev)
     assert not _supported(x2, wp, torch.empty(2, 16, 16, 64, device=dev), act=1)
+
+
+def test_wino_wide_and_narrow_workgroup_shapes_agree(dev, monkeypatch):
+    """Cout % 128 == 0 runs 32 tiles x 128 channels per workgroup, WGS_WINO_NARROW pins 64 x 64: same products, same sums per output."""
+    torch.manual_seed(9)
+    x = torch.randn(2, 32, 32, 64, device=dev)
+    wp = C.pack_weight(torch.randn(128, 64, 3, 3, device=dev) / 24)
+    s = torch.randn(2, 64, device=dev)
+    lib = L.lib()
+    lib.wgs_dev_trace_kernels(1)
+    wide = C.conv2d(x, wp, 3, pad=1, precision=C.FP32W, a_scale=s)
+    k_wide = lib.wgs_dev_last_kernel().decode()
+    monkeypatch.setenv('WGS_WINO_NARROW', '1')
+    lib.wgs_dev_reload_flags()
+    try:
+        narrow = C.conv2d(x, wp, 3, pad=1, precision=C.FP32W, a_scale=s)
+        k_narrow = lib.wgs_dev_last_kernel().decode()
+    finally:
+        monkeypatch.delenv('WGS_WINO_NARROW')
+        lib.wgs_dev_reload_flags()
+        lib.wgs_dev_trace_kernels(0)
+    assert k_wide == 'wino_f32_kernel<1, 4, true>' and k_narrow == 'wino_f32_kernel<2, 2, true>'
+    assert rel_err(wide, narrow) < 2e-6

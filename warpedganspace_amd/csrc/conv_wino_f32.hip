@@ -22,7 +22,6 @@
 // LDS rows are 64 B (16 channels), conflict-free by an XOR swizzle of row and 16-byte slot (see the staging role below).
 #include "wgs_common.h"
 #include "../../include/wgs.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -387,11 +386,8 @@ bool wino_ok(const wgs_conv_desc* d) {
            (long)16 * d->Ci * d->Co * 4 < 0x7fffffffL && (!d->noise || d->noise_w);
 }
 
-// column blocks of 32 per workgroup: 4 where Cout allows (WGS_WINO_VAR=1, development: always 2)
-int wino_tj(const wgs_conv_desc* d) {
-    static const int var = getenv("WGS_WINO_VAR") ? atoi(getenv("WGS_WINO_VAR")) : 0;
-    return (d->Co % 128 == 0 && !(var & 1)) ? 4 : 2;
-}
+// column blocks of 32 per workgroup: 4 where Cout allows (WGS_WINO_NARROW, development: always 2)
+int wino_tj(const wgs_conv_desc* d) { return (d->Co % 128 == 0 && !wgs_flags().wino_narrow) ? 4 : 2; }
 
 }  // namespace
 
