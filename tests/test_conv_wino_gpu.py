@@ -37,7 +37,9 @@ def test_wino_styled_forward_vs_float64(dev, B, H, W, ci, co):
     y = torch.empty(B, H, W, co, device=dev)
     assert _supported(xg, wp, y, **epi)
     L.lib().wgs_dev_trace_kernels(1)
-    got = C.conv2d(xg, wp, 3, pad=1, precision=C.FP32W, **epi)
+    ymax = torch.zeros(1, device=dev)
+    got = C.conv2d(xg, wp, 3, pad=1, precision=C.FP32W, y_amax=ymax, **epi)
+    assert float(ymax) == float(got.abs().max())           # the magnitude scalar the fp16 chains read (exact: a maximum, not a sum)
     sym = L.lib().wgs_dev_last_kernel().decode()
     assert sym.startswith('wino_f32_kernel<') and sym.endswith('true>'), sym
     direct = C.conv2d(xg, wp, 3, pad=1, precision=0, **epi)
