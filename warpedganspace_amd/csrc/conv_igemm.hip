@@ -256,7 +256,12 @@ struct WgradArgs {
     long w_tap_stride, w_row_stride;
     signed char dy_[64], dx_[64];
     short wt[64];
+    unsigned magic_wo, magic_ho, magic_ci;      // wgs_div_magic of Wo / Ho / Ci, or 0: plain division (an operand would overflow the 32-bit product)
 };
+
+// n / d with the launch's precomputed reciprocal (three vector instructions) instead of a ~35-instruction integer division: the pixel
+// -> (b, oy, ox) split runs once per staged float4, and next to the fp32 MFMA every vector instruction costs matrix-pipe time
+__device__ __forceinline__ int wgrad_div(int n, int d, unsigned magic) { return magic ? wgs_div_fast(n, magic) : n / d; }
 
 // FLAT (few input channels, e.g. ResNet conv1 with Ci = 8): the GEMM columns are the flattened (tap, ci) pairs, so one
 // launch reads dy once for all taps instead of once per tap; grid.y = 1.
@@ -307,13 +312,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
             const int ci = ci0 + c4 * 4;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((e < BK * CB) && (m < p.M) && (ci < ncol)) {
-                const int ox = m % p.Wo;
-                const int tt = m / p.Wo;
-                const int oy = tt % p.Ho;
-                const int b = tt / p.Ho;
+                const int tt = wgrad_div(m, p.Wo, p.magic_wo);
+                const int ox = m - tt * p.Wo;
+                const int b = wgrad_div(tt, p.Ho, p.magic_ho);
+                const int oy = tt - b * p.Ho;
                 int dyc = dyt, dxc = dxt, cic = ci;
                 if (FLAT) {
-                    const int tc = ci / p.Ci;
+                    const int tc = wgrad_div(ci, p.Ci, p.magic_ci);
                     cic = ci - tc * p.Ci;
                     const int yx = tap_yx[tc];
                     dyc = (int)(short)(yx & 0xffff); dxc = yx >> 16;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
         int ci = ci0 + wn * WN + j * 32 + l31;
         const bool cok = ci < ncol;
         size_t coff = ci;
-        if (FLAT && cok) { const int tc = ci / p.Ci; coff = (size_t)p.wt[tc] * p.w_tap_stride + (ci - tc * p.Ci); }
+        if (FLAT && cok) { const int tc = wgrad_div(ci, p.Ci, p.magic_ci); coff = (size_t)p.wt[tc] * p.w_tap_stride + (ci - tc * p.Ci); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -702,6 +707,11 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
     a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
+    // reciprocal multiplies are exact while dividend * divisor < 2^32 (wgs_div_magic); divisor 1 needs none
+    auto magic_of = [](long n_max, int dv) -> unsigned { return (dv >= 2 && n_max * dv < (1L << 32)) ? wgs_div_magic(dv) : 0u; };
+    a.magic_wo = magic_of((long)a.M + 64, d->Wo);
+    a.magic_ho = magic_of((long)d->B * d->Ho + 64, d->Ho);
+    a.magic_ci = magic_of((long)d->ntaps * d->Ci + 256, d->Ci);
     hipStream_t st = (hipStream_t)stream;
     if (d->precision == 1 && wgs_conv_wgrad16(d, st) == 0) {
         WGS_CHECK_LAUNCH("igemm_wgrad16_kernel");
