@@ -109,3 +109,34 @@ def test_wino_wide_and_narrow_workgroup_shapes_agree(dev, monkeypatch):
         lib.wgs_dev_trace_kernels(0)
     assert k_wide == 'wino_f32_kernel<1, 4, true>' and k_narrow == 'wino_f32_kernel<2, 2, true>'
     assert rel_err(wide, narrow) < 2e-6
+
+
+def test_fp32w_through_the_other_generators_plain_3x3_layers(dev):
+    """'fp32w' is a mode of every generator: ProgGAN's second conv of a block (plain 3x3, WScale alpha, bias, leaky-relu) is a launch
+    the Winograd kernel covers, its first (nearest-neighbour up-sampled gather) is not — image and input gradient against 'fp32'."""
+    from tests import golden_inputs as GI
+    from warpedganspace_amd.proggan import Generator, ProgGANWrapper
+    G = Generator(12)                               # 128 x 128
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 612))
+    wrap = ProgGANWrapper(G).to(dev).eval()
+    z = GI.rt(613, 2, 512).to(dev)
+    out = {}
+    lib = L.lib()
+    for mode in ('fp32', 'fp32w'):
+        sh = (GI.rt(614, 2, 512) * 0.1).to(dev).requires_grad_(True)
+        img = wrap(z, sh, precision=mode)
+        (img * GI.rt(615, *img.shape).to(dev)).sum().backward()
+        out[mode] = (img.detach(), sh.grad.clone())
+    assert rel_err(out['fp32w'][0], out['fp32'][0]) < 2e-5
+    assert rel_err(out['fp32w'][1], out['fp32'][1]) < 5e-3           # the envelope test_proggan_gpu.py uses between two fp32 evaluations: leaky-relu gates flip
+    lib.wgs_dev_trace_kernels(1)
+    C.PROFILE = []
+    try:
+        with torch.no_grad():
+            wrap(z, precision='fp32w')
+        torch.cuda.synchronize()
+        syms = {r[4] for r in C.PROFILE}
+    finally:
+        C.PROFILE = None
+        lib.wgs_dev_trace_kernels(0)
+    assert any(s.startswith('wino_f32_kernel') for s in syms), syms
