@@ -10,15 +10,16 @@
 //   * U = G g G^T is transformed once per (frozen) weight tensor by wino_weight_kernel, straight into the B-operand fragment order
 //     of the main kernel: a wave needs only the U of its own two positions, so its fragments are plain coalesced 1 KB global loads
 //     into registers — U never passes through LDS.
-//   * a workgroup (8 waves) owns 8x8 Winograd tiles (16x16 output pixels) of one sample x 64 output channels, and ALL 16
-//     positions: wave w accumulates positions 2w, 2w+1 as 64x64 blocks (128 accumulator registers per lane).
+//   * a workgroup (8 waves) owns 32 * TI Winograd tiles of one sample x 32 * TJ output channels and ALL 16 positions: wave w
+//     accumulates the four positions of row xi = w >> 1 for half of the channel blocks (128 accumulator registers per lane).
 //   * per 16-channel chunk: thread (tile, channel quad, patch column) loads its 4 patch rows (16 B each, zero padding = buffer range
 //     check), does the column pass B^T d in registers and the row pass across the 4 lanes of its quad with DPP quad_perm, scales by the
 //     style and writes its 4 positions to LDS (two such tasks per thread).  Patch loads fly for three quarters of a chunk, B fragments
 //     for half a chunk; loads and stores are issued inside the MFMA slots (conv_nt_kernel.inc's scheme); A fragments are one
 //     ds_read_b128 per 8 MFMAs (k pairing of conv_scheme.h Scheme<4>); one barrier per 64 MFMAs of a wave.
-//   * epilogue: the 16 position blocks go through LDS (two passes of 32 channels, 136 KB), every thread applies A^T . A to four tiles
-//     of one channel, then demodulation / noise / bias / leaky-relu as conv_epilogue.h and stores 128-byte channel runs.
+//   * epilogue: the row half of A^T . A in registers (a wave holds all four nu of its xi), the 8 remaining blocks per (tile, channel)
+//     through LDS in one pass (<= 147 KB), every thread finishes four tiles of one channel, then demodulation / noise / bias /
+//     leaky-relu as conv_epilogue.h and stores 128-byte channel runs.
 // LDS rows are 64 B (16 channels), conflict-free by an XOR swizzle of row and 16-byte slot (see the staging role below).
 #include "wgs_common.h"
 #include "../../include/wgs.h"
@@ -42,12 +43,10 @@ struct Cfg {
     static constexpr int TB = 32 * TI, BN = 32 * TJ, PH = 8 * TI;
     static constexpr int PS = TB * KC * 4;             // one position of a staged chunk: TB rows of 64 B
     static constexpr int STAGE = 16 * PS;              // one staged chunk of V (64 KB / 32 KB)
-    static constexpr int NP = 16 * TJ;                 // output channels per epilogue pass (two passes)
-    static constexpr int EPI_ROW = TB * 4 + 16;        // one (pos, n) row of the epilogue exchange: TB tiles + 16 B (bank spread)
-    static constexpr int EPI_BYTES = 16 * NP * EPI_ROW;
+    static constexpr int EPI_ROW = TB * 4 + 16;        // one (xi, j2, n) row of the epilogue exchange: TB tiles + 16 B (bank spread)
+    static constexpr int EPI_BYTES = 8 * BN * EPI_ROW; // (xi, output column j2) x channel rows: one pass
     static constexpr int SMEM = EPI_BYTES > 2 * STAGE ? EPI_BYTES : 2 * STAGE;
     static constexpr int U_CHUNK = 16 * BN * KC * 4;   // bytes of U per (channel block, chunk)
-    static constexpr int NU = 2 * TJ;                  // MFMA units per chunk: (k group g, position pp, column-block pair jh), 8 * TI MFMAs each
 };
 
 struct WinoArgs {
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 template <int TI, int TJ, bool STY>
 __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     typedef Cfg<TI, TJ> C;
-    constexpr int PS = C::PS, STAGE = C::STAGE, NU = C::NU, NP = C::NP, EPI_ROW = C::EPI_ROW;
+    constexpr int PS = C::PS, STAGE = C::STAGE, EPI_ROW = C::EPI_ROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int ntn = p.Co / C::BN, tbx = p.W >> 4, tby = p.H / C::PH;
@@ -202,41 +201,44 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
         for (int xi = 0; xi < 4; ++xi) col_store(buf, u, xi);
     };
 
-    // ---- MFMA role: wave w owns positions 2w, 2w + 1; its B fragments come straight from global memory (no other wave needs them) ----
-    int f_off[2][2];       // [pp][g]: LDS byte offset of the A fragment (row block 0; row block i: + i * 2048)
-    int u_off[2];          // [pp]: byte offset of the wave's U fragments inside a chunk (+ (g * TJ + j) * 1024)
+    // ---- MFMA role: wave w owns the four positions (xi = w >> 1, nu = 0..3) for half of the workgroup's channel blocks (w & 1): the
+    // row half of the output transform then needs no other wave's accumulators.  Its B fragments come straight from global memory. ----
+    constexpr int TJH = TJ / 2;                      // 32-channel blocks per wave
+    const int xi_w = wave >> 1, nh = wave & 1;
+    int f_off[4][2];       // [pp = nu][g]: LDS byte offset of the A fragment (row block 0; row block i: + i * 2048)
+    int u_off[4];          // [pp]: byte offset of the wave's U fragments inside a chunk (+ (g * TJ + j) * 1024)
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int pos = 2 * wave + pp, nup = pos & 3;
-        const int sx = lh ^ ((l31 >> 1) & 3) ^ (nup & 2);
+    for (int pp = 0; pp < 4; ++pp) {
+        const int pos = 4 * xi_w + pp;
+        const int sx = lh ^ ((l31 >> 1) & 3) ^ (pp & 2);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) f_off[pp][g] = pos * PS + (l31 ^ (nup & 1)) * 64 + ((sx ^ (2 * g)) * 16);
-        u_off[pp] = pos * (2 * TJ * 1024) + lane * 16;
+        for (int g = 0; g < 2; ++g) f_off[pp][g] = pos * PS + (l31 ^ (pp & 1)) * 64 + ((sx ^ (2 * g)) * 16);
+        u_off[pp] = pos * (2 * TJ * 1024) + nh * TJH * 1024 + lane * 16;
     }
-    // unit u of chunk c: k group g, position pp, column blocks 2 jh, 2 jh + 1;  u = (g * 2 + pp) * (TJ / 2) + jh
-    f32x4 bfr[4][2];       // ring over units: unit u lives in slot u % 4 and is requested three units ahead
+    // unit u of a chunk: k group g = u >> 2, position pp = u & 3: 4 * TI * TJH = 8 MFMAs, 8 units per chunk
+    f32x4 bfr[4][TJH];     // ring over units: unit u lives in slot u % 4 and is requested three units ahead
     auto load_B = [&](int c, int u) {
-        c += u / NU; u %= NU;
-        const int gp = u / (TJ / 2), jh = u % (TJ / 2), g = gp >> 1, pp = gp & 1;
-        const int cb = (nb0 * nchunks + min(c, nchunks - 1)) * C::U_CHUNK + (g * TJ + 2 * jh) * 1024;
-        bfr[u % 4][0] = buf_load4(ru, u_off[pp], cb);
-        bfr[u % 4][1] = buf_load4(ru, u_off[pp], cb + 1024);
-    };
-    f32x16 acc[2][TI][TJ];
+        c += u >> 3; u &= 7;
+        const int g = u >> 2, pp = u & 3;
+        const int cb = (nb0 * nchunks + min(c, nchunks - 1)) * C::U_CHUNK + g * TJ * 1024;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int jl = 0; jl < TJH; ++jl) bfr[u % 4][jl] = buf_load4(ru, u_off[pp], cb + jl * 1024);
+    };
+    f32x16 acc[4][TI][TJH];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
+            for (int j = 0; j < TJH; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
 
-    // Chunk kt multiplies LDS buffer kt & 1 in NU units of 8 * TI MFMAs.  The staging work of chunk kt + 1 (row pass, four column
-    // pass + store pieces per task) and the requests of chunk kt + 2 are spread over the units, and inside a unit the scheduler is
-    // told to alternate one MFMA with a few vector instructions: the waves of a workgroup run in step (one barrier per chunk), and
-    // measured on this kernel every vector instruction costs its four cycles of matrix-pipe time — a staging block issued as one
-    // run idles the pipe for its whole length.
+    // Chunk kt multiplies LDS buffer kt & 1 in 8 units of 8 MFMAs.  The staging work of chunk kt + 1 (row pass, four column pass +
+    // store pieces per task) and the requests of chunk kt + 2 are spread over the units, and inside a unit the scheduler is told to
+    // alternate one MFMA with a few vector instructions: the waves of a workgroup run in step (one barrier per chunk), and next to
+    // the fp32 MFMA every vector instruction costs 4-5 cycles of matrix-pipe time (profiles/r3_ubench_mfma_valu.txt) — a staging
+    // block issued as one run idles the pipe for its whole length.
     auto mma_chunk = [&](int cur, int kt) {
         const unsigned char* base = smem + cur * STAGE;
         const int nxt = cur ^ 1;
@@ -244,33 +246,35 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(base + f_off[0][0] + i * 2048);
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int gp = u / (TJ / 2), jh = u % (TJ / 2), g = gp >> 1, pp = gp & 1;
-            if (u + 1 < NU && (u + 1) % (TJ / 2) == 0) {          // the next unit starts a new (g, pp): fetch its A fragments now
-                const int gn = (gp + 1) >> 1, pn = (gp + 1) & 1;
+        for (int u = 0; u < 8; ++u) {
+            const int g = u >> 2, pp = u & 3;
+            if (u + 1 < 8) {
 #pragma unroll
-                for (int i = 0; i < TI; ++i) af[(gp + 1) & 1][i] = *reinterpret_cast<const f32x4*>(base + f_off[pn][gn] + i * 2048);
+                for (int i = 0; i < TI; ++i) af[(u + 1) & 1][i] = *reinterpret_cast<const f32x4*>(base + f_off[(u + 1) & 3][(u + 1) >> 2] + i * 2048);
             }
             load_B(kt, u + 3);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int jl = 0; jl < TJH; ++jl)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[pp][i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gp & 1][i][e], bfr[u % 4][jj][e], acc[pp][i][2 * jh + jj], 0, 0, 0);
-            if (TI == 2) {        // 4 units of 16 MFMAs
-                if (u == 0) { row_pass(0); col_store(nxt, 0, 0); }
-                if (u == 1) { col_store(nxt, 0, 1); col_store(nxt, 0, 2); col_store(nxt, 0, 3); load_A(kt + 2, 0); row_pass(1); }
-                if (u == 2) { col_store(nxt, 1, 0); col_store(nxt, 1, 1); col_store(nxt, 1, 2); }
-                if (u == 3) { col_store(nxt, 1, 3); load_A(kt + 2, 1); }
-            } else {              // 8 units of 8 MFMAs
+                        acc[pp][i][jl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][i][e], bfr[u % 4][jl][e], acc[pp][i][jl], 0, 0, 0);
+            if (TI == 2) {
+                if (u == 0) row_pass(0);
+                if (u == 1) { col_store(nxt, 0, 0); col_store(nxt, 0, 1); }
+                if (u == 2) { col_store(nxt, 0, 2); col_store(nxt, 0, 3); load_A(kt + 2, 0); }
+                if (u == 3) row_pass(1);
+                if (u == 4) { col_store(nxt, 1, 0); col_store(nxt, 1, 1); }
+                if (u == 5) { col_store(nxt, 1, 2); col_store(nxt, 1, 3); }
+                if (u == 6) load_A(kt + 2, 1);
+            } else {
                 if (u == 0) row_pass(0);
                 if (u >= 1 && u <= 4) col_store(nxt, 0, u - 1);
                 if (u == 4) load_A(kt + 2, 0);
             }
 #pragma unroll
-            for (int k = 0; k < 8 * TI; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
@@ -291,55 +295,65 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: positions -> LDS -> A^T . A per (tile, channel) -> demodulation, noise, bias, activation ----
-    // Thread = (channel n_l of the pass, tile quad tq): four horizontally adjacent tiles = 2 rows x 8 columns of output pixels.  All
-    // operands come through buffer descriptors (a missing one has zero records and reads as 0): the 16 noise values are requested
-    // up front in one batch, no branches, no 64-bit address arithmetic; the stores take a per-output uniform (scalar) offset.
-    const int n_l = tid % NP, tq = tid / NP;
-    const int oy0 = by * C::PH + 2 * (tq >> 1), ox0 = bx * 16 + 8 * (tq & 1);
+    // ---- epilogue: A^T . A, then demodulation, noise, bias, activation ----
+    // Row half in registers (the wave holds all four nu of its xi): z0 = m0 + m1 + m2, z1 = m1 - m2 - m3 — the exchange through LDS
+    // carries 8 instead of 16 blocks per (tile, channel) and fits in ONE pass.  Then thread = (channel n, tile quad tq), twice: four
+    // horizontally adjacent tiles = 2 rows x 8 columns of output pixels; all operands through buffer descriptors (a missing one has
+    // zero records and reads as 0), the noise values requested in one batch, the stores with a per-output uniform (scalar) offset.
+    constexpr int BN = C::BN;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int jl = 0; jl < TJH; ++jl) {
+            const f32x16 m0 = acc[0][i][jl], m1 = acc[1][i][jl], m2 = acc[2][i][jl], m3 = acc[3][i][jl];
+            acc[0][i][jl] = m0 + m1 + m2;
+            acc[1][i][jl] = m1 - m2 - m3;
+        }
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int jl = 0; jl < TJH; ++jl)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x16& a = acc[j2][i][jl];
+                    const f32x4 v = {a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
+                    *reinterpret_cast<f32x4*>(smem + ((xi_w * 2 + j2) * BN + (nh * TJH + jl) * 32 + l31) * EPI_ROW + (i * 32 + 8 * rq + 4 * lh) * 4) = v;
+                }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)b * p.H * p.W * p.Co, 0, p.H * p.W * p.Co * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.noise ? p.noise : p.x), 0, p.noise ? p.H * p.W * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.col_scale ? p.col_scale + (size_t)b * p.col_ld : p.x), 0, p.col_scale ? p.Co * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.x), 0, p.bias ? p.Co * 4 : 0, 0x00020000);
     const float nw = p.noise ? p.noise_w[0] : 0.f;
-    float nz[2][8];
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            nz[i2][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, ((oy0 + i2) * p.W + ox0) * 4, c * 4, 0));
-    const int y_voff = ((oy0 * p.W + ox0) * p.Co + nb0 * C::BN + n_l) * 4;
     const float slope = p.act_slope, gain = p.gain, alpha = p.alpha;
+    int n_l[2], oy0[2], ox0[2];
+    float nz[2][2][8], cs_raw[2], bs[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NT, tq = idx / BN;
+        n_l[it] = idx % BN;
+        oy0[it] = by * C::PH + 2 * (tq >> 1); ox0[it] = bx * 16 + 8 * (tq & 1);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                nz[it][i2][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, ((oy0[it] + i2) * p.W + ox0[it]) * 4, c * 4, 0));
+        cs_raw[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, (nb0 * BN + n_l[it]) * 4, 0, 0));
+        bs[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, (nb0 * BN + n_l[it]) * 4, 0, 0));
+    }
+    __syncthreads();
     float vmax = 0.f;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int n = nb0 * C::BN + jj * NP + n_l;
-        const float cs_raw = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, n * 4, 0, 0));
-        const float bs = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, n * 4, 0, 0));
-        if (jj) __syncthreads();
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int jl = 0; jl < TJ / 2; ++jl)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x16& a = acc[pp][i][jj * (TJ / 2) + jl];
-                        const f32x4 v = {a[4 * rq], a[4 * rq + 1], a[4 * rq + 2], a[4 * rq + 3]};
-                        *reinterpret_cast<f32x4*>(smem + ((2 * wave + pp) * NP + jl * 32 + l31) * EPI_ROW + (i * 32 + 8 * rq + 4 * lh) * 4) = v;
-                    }
-        __syncthreads();
-        f32x4 m[4][4];
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) m[pos >> 2][pos & 3] = *reinterpret_cast<const f32x4*>(smem + (pos * NP + n_l) * EPI_ROW + tq * 16);
+    for (int it = 0; it < 2; ++it) {
+        const int tq = (tid + it * NT) / BN;
         f32x4 z[4][2];
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            z[xi][0] = m[xi][0] + m[xi][1] + m[xi][2];
-            z[xi][1] = m[xi][1] - m[xi][2] - m[xi][3];
-        }
-        const float cs = (p.col_scale ? cs_raw : 1.f) * alpha;
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) z[xi][j2] = *reinterpret_cast<const f32x4*>(smem + ((xi * 2 + j2) * BN + n_l[it]) * EPI_ROW + tq * 16);
+        const float cs = (p.col_scale ? cs_raw[it] : 1.f) * alpha;
+        const int y_voff = ((oy0[it] * p.W + ox0[it]) * p.Co + nb0 * BN + n_l[it]) * 4;
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             f32x4 yv[2];
@@ -349,10 +363,10 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2) {
-                    float v = __builtin_fmaf(yv[j2][k], cs, __builtin_fmaf(nw, nz[i2][2 * k + j2], bs));
+                    float v = __builtin_fmaf(yv[j2][k], cs, __builtin_fmaf(nw, nz[it][i2][2 * k + j2], bs[it]));
                     v = fmaxf(v, v * slope) * gain;
                     if (p.y_amax) vmax = fmaxf(vmax, fabsf(v));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, y_voff + jj * NP * 4, ((i2 * p.W + 2 * k + j2) * p.Co) * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, y_voff, ((i2 * p.W + 2 * k + j2) * p.Co) * 4, 0);
                 }
         }
     }
