@@ -41,7 +41,7 @@ def test_wino_styled_forward_vs_float64(dev, B, H, W, ci, co):
     got = C.conv2d(xg, wp, 3, pad=1, precision=C.FP32W, y_amax=ymax, **epi)
     assert float(ymax) == float(got.abs().max())           # the magnitude scalar the fp16 chains read (exact: a maximum, not a sum)
     sym = L.lib().wgs_dev_last_kernel().decode()
-    assert sym.startswith('wino_f32_kernel<') and sym.endswith('true>'), sym
+    assert sym.startswith('wino_f32_kernel<') and ', true, ' in sym, sym
     direct = C.conv2d(xg, wp, 3, pad=1, precision=0, **epi)
     L.lib().wgs_dev_trace_kernels(0)
     e_w, e_d = rel_err(got, ref), rel_err(direct, ref)
@@ -64,7 +64,7 @@ def test_wino_input_gradient_form_vs_float64(dev, B, H, ci, co):
     L.lib().wgs_dev_trace_kernels(1)
     got = C.conv2d_dgrad(dy.to(dev), wt, (H, H), 3, pad=1, precision=C.FP32W, w_split=cache, alpha=1.0)
     sym = L.lib().wgs_dev_last_kernel().decode()
-    assert sym.startswith('wino_f32_kernel<') and sym.endswith('false>'), sym
+    assert sym.startswith('wino_f32_kernel<') and ', false, ' in sym, sym
     L.lib().wgs_dev_trace_kernels(0)
     assert rel_err(got, ref) < 3e-6
     assert len(cache.planes) == 1           # U is kept with the weight tensor
@@ -107,8 +107,15 @@ def test_wino_wide_and_narrow_workgroup_shapes_agree(dev, monkeypatch):
         monkeypatch.delenv('WGS_WINO_NARROW')
         lib.wgs_dev_reload_flags()
         lib.wgs_dev_trace_kernels(0)
-    assert k_wide == 'wino_f32_kernel<1, 4, true>' and k_narrow == 'wino_f32_kernel<2, 2, true>'
+    assert k_wide == 'wino_f32_kernel<1, 2, true, 4>' and k_narrow == 'wino_f32_kernel<2, 2, true, 8>'      # 16 items: the small-grid shape
     assert rel_err(wide, narrow) < 2e-6
+    xb = torch.randn(8, 64, 64, 64, device=dev)                # 256 items of the wide shape: 8 waves, 32 tiles x 128 channels
+    sb_ = torch.randn(8, 64, device=dev)
+    lib.wgs_dev_trace_kernels(1)
+    big = C.conv2d(xb, wp, 3, pad=1, precision=C.FP32W, a_scale=sb_)
+    assert lib.wgs_dev_last_kernel().decode() == 'wino_f32_kernel<1, 4, true, 8>'
+    lib.wgs_dev_trace_kernels(0)
+    assert rel_err(big, C.conv2d(xb, wp, 3, pad=1, precision=0, a_scale=sb_)) < 4e-6
 
 
 def test_fp32w_through_the_other_generators_plain_3x3_layers(dev):

@@ -32,7 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KC = 16;            // input channels per chunk
-constexpr int NT = 512;           // 8 waves; wave w owns Winograd positions 2w, 2w + 1
 constexpr int OOB = (int)0x80000000;
 
 // Workgroup tile: 32 * TI Winograd tiles (8 columns x 4 * TI rows of 2x2 outputs = 16 x 8 * TI pixels) x 32 * TJ output channels.
@@ -126,9 +125,13 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
         base[(((pos * 2 + (kk >> 3)) * tj + (n >> 5)) * 64 + lane) * 4 + (kk & 3)] = u[pos >> 2][pos & 3];
 }
 
-template <int TI, int TJ, bool STY>
-__global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
+// NW = 8: one workgroup per CU, wave = (position row xi, half of the channel blocks); NW = 4 (TI = 1, TJ = 2): two workgroups per CU, wave =
+// position row xi with both channel blocks — one workgroup's prologue / epilogue runs under the other's MFMAs (the short-K layers).
+template <int TI, int TJ, bool STY, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wino_f32_kernel(const WinoArgs p) {
     typedef Cfg<TI, TJ> C;
+    constexpr int NT = 64 * NW;
+    constexpr int NTASK = 32 * TI * 16 / NT;          // staging tasks (tile, channel quad, column) per thread: 1 or 2
     constexpr int PS = C::PS, STAGE = C::STAGE, EPI_ROW = C::EPI_ROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     // LDS image of a chunk: [pos][row 64 B = 16 channels]; logical (t, 16-byte slot s) of position pos lives at row t ^ (nu & 1), slot
     // s ^ ((t >> 1) & 3) ^ (nu & 2), nu = pos & 3: the quad's four positions and the two channel quads of 8 neighbouring lanes fall into
     // 8 different 16-byte bank groups, and so do the 8 rows a fragment read touches per cycle.
-    const int t = tid >> (TI == 2 ? 3 : 4), ql = (tid >> 2) & (TI == 2 ? 1 : 3), nu = tid & 3, ty = t >> 3, tx = t & 7;
+    const int t = tid >> (NTASK == 2 ? 3 : 4), ql = (tid >> 2) & (NTASK == 2 ? 1 : 3), nu = tid & 3, ty = t >> 3, tx = t & 7;
     int a_off[4];
     {
         const int ix = bx * 16 + 2 * tx + nu - 1;
@@ -167,11 +170,11 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     // row pass of lane nu (columns of the patch live in the quad's four lanes): own + sb * column {2, 2, 1, 1}[nu]
     //   nu 0: d0 - d2    nu 1: d1 + d2    nu 2: d2 - d1    nu 3: d3 - d1 = -(B^T row 3; the sign sits in U)
     const float sb = nu == 1 ? 1.f : -1.f;
-    unsigned char* v_dst[TI];
+    unsigned char* v_dst[NTASK];
 #pragma unroll
-    for (int u = 0; u < TI; ++u) v_dst[u] = smem + nu * PS + (t ^ (nu & 1)) * 64 + (((ql + 2 * u) ^ ((t >> 1) & 3) ^ (nu & 2)) * 16);
+    for (int u = 0; u < NTASK; ++u) v_dst[u] = smem + nu * PS + (t ^ (nu & 1)) * 64 + (((ql + 2 * u) ^ ((t >> 1) & 3) ^ (nu & 2)) * 16);
 
-    f32x4 ra[TI][4], rsv[TI];
+    f32x4 ra[NTASK][4], rsv[NTASK];
     auto load_A = [&](int c, int u) {
         const int cb = min(c, nchunks - 1) * (KC * 4) + u * 32;       // past the end: re-read the last chunk (stored into a dead buffer)
 #pragma unroll
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
 
     // ---- MFMA role: wave w owns the four positions (xi = w >> 1, nu = 0..3) for half of the workgroup's channel blocks (w & 1): the
     // row half of the output transform then needs no other wave's accumulators.  Its B fragments come straight from global memory. ----
-    constexpr int TJH = TJ / 2;                      // 32-channel blocks per wave
-    const int xi_w = wave >> 1, nh = wave & 1;
+    constexpr int TJH = NW == 8 ? TJ / 2 : TJ;       // 32-channel blocks per wave
+    const int xi_w = NW == 8 ? wave >> 1 : wave, nh = NW == 8 ? wave & 1 : 0;
     int f_off[4][2];       // [pp = nu][g]: LDS byte offset of the A fragment (row block 0; row block i: + i * 2048)
     int u_off[4];          // [pp]: byte offset of the wave's U fragments inside a chunk (+ (g * TJ + j) * 1024)
 #pragma unroll
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         acc[pp][i][jl] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][i][e], bfr[u % 4][jl][e], acc[pp][i][jl], 0, 0, 0);
-            if (TI == 2) {
+            if (NTASK == 2) {
                 if (u == 0) row_pass(0);
                 if (u == 1) { col_store(nxt, 0, 0); col_store(nxt, 0, 1); }
                 if (u == 2) { col_store(nxt, 0, 2); col_store(nxt, 0, 3); load_A(kt + 2, 0); }
@@ -283,12 +286,12 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     };
 
 #pragma unroll
-    for (int u = 0; u < TI; ++u) load_A(0, u);
+    for (int u = 0; u < NTASK; ++u) load_A(0, u);
     load_B(0, 0); load_B(0, 1); load_B(0, 2);
 #pragma unroll
-    for (int u = 0; u < TI; ++u) store_A(0, u);
+    for (int u = 0; u < NTASK; ++u) store_A(0, u);
 #pragma unroll
-    for (int u = 0; u < TI; ++u) load_A(1, u);
+    for (int u = 0; u < NTASK; ++u) load_A(1, u);
     __syncthreads();
     for (int kt = 0; kt < nchunks; ++kt) {
         mma_chunk(kt & 1, kt);
@@ -327,10 +330,11 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.x), 0, p.bias ? p.Co * 4 : 0, 0x00020000);
     const float nw = p.noise ? p.noise_w[0] : 0.f;
     const float slope = p.act_slope, gain = p.gain, alpha = p.alpha;
-    int n_l[2], oy0[2], ox0[2];
-    float nz[2][2][8], cs_raw[2], bs[2];
+    constexpr int NIT = BN * (C::TB / 4) / NT;       // (channel, tile quad) pairs per thread
+    int n_l[NIT], oy0[NIT], ox0[NIT];
+    float nz[NIT][2][8], cs_raw[NIT], bs[NIT];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * NT, tq = idx / BN;
         n_l[it] = idx % BN;
         oy0[it] = by * C::PH + 2 * (tq >> 1); ox0[it] = bx * 16 + 8 * (tq & 1);
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(NT, 1) void wino_f32_kernel(const WinoArgs p) {
     __syncthreads();
     float vmax = 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int tq = (tid + it * NT) / BN;
         f32x4 z[4][2];
 #pragma unroll
@@ -400,8 +404,18 @@ bool wino_ok(const wgs_conv_desc* d) {
            (long)16 * d->Ci * d->Co * 4 < 0x7fffffffL && (!d->noise || d->noise_w);
 }
 
-// column blocks of 32 per workgroup: 4 where Cout allows (WGS_WINO_NARROW, development: always 2)
-int wino_tj(const wgs_conv_desc* d) { return (d->Co % 128 == 0 && !wgs_flags().wino_narrow) ? 4 : 2; }
+// Workgroup shape of a launch: 1 = 32 tiles x 128 channels, 8 waves (Cout % 128 == 0); 0 = 64 tiles x 64 channels, 8 waves;
+// 2 = 32 tiles x 64 channels, 4 waves, two workgroups per CU: half the transform reuse, so 6 - 10 % slower per MFMA on the large
+// layers, but 4x the workgroups — taken when the 8-wave shape would leave CUs empty (256 -> 256 @16^2, B = 32: 71 -> 49 us).
+// Development switches: WGS_WINO_SMALL pins shape 2, WGS_WINO_NARROW shape 0.
+int wino_shape(const wgs_conv_desc* d) {
+    if (wgs_flags().wino_small) return 2;
+    if (wgs_flags().wino_narrow) return 0;
+    const int big = d->Co % 128 == 0 ? 1 : 0;
+    const long items = (long)d->B * (d->Hi / (big ? 8 : 16)) * (d->Wi / 16) * (d->Co / (big ? 128 : 64));
+    return items < 200 ? 2 : big;
+}
+int wino_tj(const wgs_conv_desc* d) { return wino_shape(d) == 1 ? 4 : 2; }
 
 }  // namespace
 
@@ -429,17 +443,19 @@ int wgs_conv_wino(const wgs_conv_desc* d, const float* U, wgs_stream_t stream) {
     a.a_ld = d->a_ld > 0 ? d->a_ld : d->Ci; a.col_ld = d->col_ld > 0 ? d->col_ld : d->Co;
     a.alpha = d->alpha != 0.f ? d->alpha : 1.f; a.act_slope = d->act_slope; a.gain = d->gain;
     hipStream_t st = (hipStream_t)stream;
-#define WGS_WINO_LAUNCH(TI, TJ, STY)                                                                                        \
+#define WGS_WINO_LAUNCH(TI, TJ, STY, NW)                                                                                    \
     {                                                                                                                       \
-        auto k = wino_f32_kernel<TI, TJ, STY>;                                                                              \
+        auto k = wino_f32_kernel<TI, TJ, STY, NW>;                                                                          \
         const unsigned grid = (unsigned)((long)d->B * (d->Hi / Cfg<TI, TJ>::PH) * (d->Wi / 16) * (d->Co / Cfg<TI, TJ>::BN)); \
-        wgs_note_kernel("wino_f32_kernel<%d, %d, %s>", TI, TJ, STY ? "true" : "false");                                    \
-        const int sm = Cfg<TI, TJ>::SMEM;                                                                                   \
+        wgs_note_kernel("wino_f32_kernel<%d, %d, %s, %d>", TI, TJ, STY ? "true" : "false", NW);                            \
+        const int sm = NW == 4 ? 8 * Cfg<TI, TJ>::BN * Cfg<TI, TJ>::EPI_ROW : Cfg<TI, TJ>::SMEM;                            \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, sm);                          \
-        WGS_LAUNCH(k, dim3(grid), dim3(NT), sm, st, a);                                                                     \
+        WGS_LAUNCH(k, dim3(grid), dim3(64 * NW), sm, st, a);                                                                \
     }
-    if (wino_tj(d) == 4) { if (d->a_scale) WGS_WINO_LAUNCH(1, 4, true) else WGS_WINO_LAUNCH(1, 4, false) }
-    else { if (d->a_scale) WGS_WINO_LAUNCH(2, 2, true) else WGS_WINO_LAUNCH(2, 2, false) }
+    const int shape = wino_shape(d);
+    if (shape == 2) { if (d->a_scale) WGS_WINO_LAUNCH(1, 2, true, 4) else WGS_WINO_LAUNCH(1, 2, false, 4) }
+    else if (shape == 1) { if (d->a_scale) WGS_WINO_LAUNCH(1, 4, true, 8) else WGS_WINO_LAUNCH(1, 4, false, 8) }
+    else { if (d->a_scale) WGS_WINO_LAUNCH(2, 2, true, 8) else WGS_WINO_LAUNCH(2, 2, false, 8) }
 #undef WGS_WINO_LAUNCH
     WGS_CHECK_LAUNCH("wino_f32_kernel");
     return WGS_OK;

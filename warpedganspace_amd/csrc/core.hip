@@ -38,6 +38,7 @@ static WgsFlags read_flags() {
     g.wgrad_per_tap = getenv("WGS_WGRAD_PER_TAP") != nullptr;
     g.patch_wide = getenv("WGS_PATCH_WIDE") != nullptr;
     g.f32_small = getenv("WGS_F32_SMALL") != nullptr;      // exact fp32: 4-wave 128-row tiles only (no 8-wave tiles, no merged up-conv phases)
+    g.wino_small = getenv("WGS_WINO_SMALL") != nullptr;      // Winograd fp32: 4-wave workgroups of 32 tiles x 64 channels, two per CU
     g.wino_narrow = getenv("WGS_WINO_NARROW") != nullptr;    // Winograd fp32: the 64-tile x 64-channel workgroup shape even where Cout % 128 == 0
     g.f32_old = getenv("WGS_F32_OLD") != nullptr;      // exact fp32: the plain three-phase kernel of conv_igemm.hip everywhere
     return g;
