@@ -8,11 +8,15 @@ reconstructor, batch 32 per GPU, Z-space shifts, --learn-gammas, synthetic z ~ N
   python bench.py --gpus N --steps K --warmup W
 The headline (`value`, `dtype`, `roofline`) is the REFERENCE's arithmetic: fp32 everywhere (f32-input MFMA, fp32 accumulate; the
 reference computes in fp32), with the 3x3 stride-1 convolutions in the Winograd F(2x2,3x3) form
-(`--precision fp32w`) - the algorithm class cuDNN's search gives the reference's F.conv2d
-(lib/trainer.py:166 sets cudnn.benchmark = True); ~1e-6 against the direct form.  `extra[0]` is the same workload with the same
-K / W in the product's default arithmetic (`auto` = the mixed fp16 / split-bf16 per-layer policy of DESIGN.md section 3.2) and
-`extra[1]` in DIRECT-form exact fp32 (`fp32`: no Winograd anywhere), each with its own `roofline`; both run at every N.  The
-remaining `extra` entries (other modes / BASELINE configs, short runs) are N=1 only.
+(`--precision fp32w`): fp32 operands, fp32 transforms, fp32 accumulate, 3e-6 against fp64.  The same
+workload is timed with the same K / W in the product's default arithmetic (`auto` = the mixed fp16 / split-bf16 per-layer policy
+of DESIGN.md section 3.2: `product` in the line) and in DIRECT-form exact fp32 (`fp32`: no Winograd anywhere: `direct_fp32`); both
+run at every N.  Short runs of the other modes / BASELINE configs are N=1 only (`others`: name -> images/sec).
+
+OUTPUT CONTRACT: the LAST stdout line is ONE JSON object of < 4 KB (the driver keeps ~8 KB of stdout): metric, value, unit, n_gpus,
+steps, warmup, ms_per_step, dtype, config, roofline, cpu_baseline, comm, product, direct_fp32, others.  Everything else - per-symbol and
+per-shape kernel tables, hbm_subpaths, host overheads, full records of every extra run - goes to `--extra-out` (default
+gpurun_out/bench_extra.json; the line's `extra_file` names it).
 
 With N > 1 and no torch.distributed environment, bench.py starts the N ranks ITSELF (torch.distributed.run, one rank per
 GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line; under an external launcher (RANK / WORLD_SIZE set) it runs
@@ -20,16 +24,17 @@ as one rank of that job and checks that WORLD_SIZE == --gpus.  Gradients of R an
 step; per-GPU batch is fixed (weak scaling); the generator is never communicated.  `--dist-backend gloo` (or
 WGS_DIST_BACKEND=gloo) swaps RCCL for gloo and lets the ranks share one device: the N > 1 code path end to end on a 1-GPU box.
 
-Prints ONE JSON line on rank 0:
+Fields (rank 0):
   value / ms_per_step  whole-job images/sec over exactly --steps timed steps (barrier + device sync on both sides, max over ranks)
   roofline             the DOMINANT KERNEL of the step by kernel symbol (largest summed HIP-event time over all its launch
-                       shapes, 2 extra single-stream steps): its summed algorithmic FLOPs / its summed duration against the
-                       dense MFMA peak of its operand dtype; the per-symbol and per-shape lists are reported beside it
-  host                 kernel launches per step issued by the library and host enqueue time per step (queue empty at start)
-  comm                 (N > 1) backend, world size, all-reduce payload per step, exposed wait of the main stream per step
-  hbm_subpaths         achieved GB/s of the HBM-bound sub-kernels (RBF fwd/bwd, Adam, blur, ToRGB, BN) on their cfg3 operands
-  extra                see above
+                       shapes, 2 extra single-stream steps).  achieved = MFMA FLOPs the kernel EXECUTES for the work / its summed
+                       duration (for a direct-form kernel that is the algorithmic 2 * pixels * Cout * Cin * taps; the Winograd kernel
+                       executes 16/36 of it), frac = achieved / dense MFMA peak of its operand dtype (<= 1 by construction);
+                       direct_equiv_TFLOPs = the algorithmic (direct-form) FLOPs / the same duration; traffic / traffic_algorithmic =
+                       launch-weighted mean HBM bytes per launch over the symbol's shapes from the committed rocprofv3 --pmc passes
   cpu_baseline         the oracle's replay of the reference step as written on this box's host cores (bounded sample)
+  comm                 (N > 1) backend, world size, all-reduce payload per step, exposed wait of the main stream per step
+  side file            host (launches / enqueue time per step), hbm_subpaths (GB/s of the HBM-bound sub-kernels), by_symbol, kernel_shapes
 """
 import argparse
 import json
@@ -61,8 +66,8 @@ DTYPE_TEXT = {
     'fp32': "fp32 everywhere (the reference's arithmetic): every conv of G and R, forward and backward, is f32-input MFMA "
             "(v_mfma_f32_32x32x2_f32) with fp32 accumulate; everything else fp32 VALU",
     'fp32w': "fp32 everywhere, as 'fp32', with the 3x3 stride-1 convs of G and R (forward and input-gradient) in the Winograd F(2x2,3x3) "
-             "form on the f32-input MFMA (16 instead of 36 multiplies per 2x2 outputs, transforms in fp32 inside the kernel; ~1e-6 against "
-             "the direct form) - the algorithm class cuDNN's search gives the reference's F.conv2d (lib/trainer.py:166 cudnn.benchmark)",
+             "form on the f32-input MFMA (16 instead of 36 multiplies per 2x2 outputs, transforms in fp32 inside the kernel; 3e-6 against "
+             "fp64 convolutions, no wider than the direct fp32 kernel)",
     'bf16x3': "bf16x3: generator convs split every fp32 operand into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate (~2^-16)",
     'f16': "f16: generator convs round operands to fp16 (dynamic power-of-two scale on every operand), 1 fp16 MFMA per product, "
            "fp32 accumulate / demodulation / epilogue (image error vs the fp32 kernels ~8e-4 at 256^2: on the 1e-3 gate, reported only)",
@@ -164,14 +169,47 @@ def _label_precision(label):
     return parts[1] if len(parts) > 1 and parts[1] in MFMA_PER_PRODUCT else 'fp32'
 
 
-def roofline_of(recs, img_per_s_per_gpu, gflop_per_img):
+def _executed_per_product(prec):
+    """MFMA FLOPs a launch executes per algorithmic (direct-form) FLOP, capped at 1: only the Winograd form executes fewer
+    multiplies than the direct form; the multi-MFMA schemes (bf16x3, f16x2) are rated on their algorithmic FLOPs."""
+    return min(1.0, MFMA_PER_PRODUCT[prec])
+
+
+def pmc_traffic(symbol, shapes, pmc_files=None):
+    """Launch-weighted mean HBM bytes per launch of `symbol` over its launch shapes, measured and algorithmic, from the newest
+    committed rocprofv3 --pmc summary (profiles/r*_conv_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes) that
+    holds the symbol.  shapes: [{shape, launches}] of this run (weights; shapes without a PMC row are left out and named)."""
+    import glob
+    files = pmc_files if pmc_files is not None else sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_conv_pmc.json')), reverse=True)
+    for f in files:
+        try:
+            rows = [r for r in json.load(open(f))['kernels'] if r.get('symbol') == symbol]
+        except Exception:  # noqa: BLE001
+            continue
+        if not rows:
+            continue
+        by_shape = {r['shape']: r for r in rows}
+        n = {sh['shape']: sh['launches'] for sh in shapes}
+        used = [k for k in by_shape if k in n] or list(by_shape)
+        wsum = sum(n.get(k, 1.0) for k in used)
+        t = sum(n.get(k, 1.0) * by_shape[k]['hbm_bytes_per_launch'] for k in used) / wsum
+        al = sum(n.get(k, 1.0) * by_shape[k]['algorithmic_bytes_per_launch'] for k in used) / wsum
+        return {"traffic": round(t / 1e9, 3), "traffic_algorithmic": round(al / 1e9, 3), "source": os.path.relpath(f, REPO),
+                "shapes_measured": len(used), "shapes_in_step": len(n)}
+    return None
+
+
+def roofline_of(recs, img_per_s_per_gpu, gflop_per_img, pmc_files=None):
     """Per-kernel-symbol accounting of the conv launches of a step.  The dominant kernel = the symbol with the largest summed
-    time; achieved = its summed algorithmic FLOPs / its summed HIP-event time."""
+    time.  achieved = MFMA FLOPs it EXECUTES for its launches / its summed HIP-event time; frac = achieved / peak, <= 1 by
+    construction; direct_equiv_TFLOPs = the algorithmic (direct-form) FLOPs over the same time."""
     sym = {}
     for label, s, fl, ms, n in recs:
-        d = sym.setdefault(s or '?', {'fl': 0.0, 'ms': 0.0, 'n': 0.0, 'mfma_fl': 0.0, 'prec': set(), 'shapes': []})
+        d = sym.setdefault(s or '?', {'fl': 0.0, 'ms': 0.0, 'n': 0.0, 'ex_fl': 0.0, 'mfma_fl': 0.0, 'prec': set(), 'shapes': []})
         prec = _label_precision(label)
-        d['fl'] += fl; d['ms'] += ms; d['n'] += n; d['mfma_fl'] += MFMA_PER_PRODUCT[prec] * fl
+        d['fl'] += fl; d['ms'] += ms; d['n'] += n
+        d['ex_fl'] += _executed_per_product(prec) * fl          # what the roofline fraction is made of
+        d['mfma_fl'] += MFMA_PER_PRODUCT[prec] * fl             # matrix-pipe occupancy (counts the 2 / 3 MFMAs of the split schemes)
         d['prec'].add(prec)
         d['shapes'].append({"shape": label, "gflop_per_step": round(fl / 1e9, 1), "ms_per_step": round(ms, 3),
                             "TFLOP/s": round(fl / ms / 1e9, 1), "launches": round(n, 1)})
@@ -181,41 +219,36 @@ def roofline_of(recs, img_per_s_per_gpu, gflop_per_img):
     dom = max(sym, key=lambda k: sym[k]['ms'])
     d = sym[dom]
     peak = peak_of(d)
-    tf = d['fl'] / d['ms'] / 1e9
-    a_fl, a_ms = sum(v['fl'] for v in sym.values()), sum(v['ms'] for v in sym.values())
-    pmc = os.path.join(REPO, 'profiles', 'r3_conv_pmc.json')
-    traffic, note = None, "not measured in this run (PMC counters need separate rocprofv3 --pmc passes: profiles/)"
-    if os.path.exists(pmc):
-        try:
-            rec = [r for r in json.load(open(pmc))['kernels'] if r.get('symbol') == dom]
-            if rec:
-                traffic = round(rec[0]['hbm_bytes_per_launch'] / 1e9, 3)
-                note = ("STATIC: mean GB per launch of this kernel symbol from the committed rocprofv3 --pmc passes profiles/r3_conv_pmc.json "
-                        "(FETCH_SIZE x2 on gfx950 + WRITE_SIZE); algorithmic %.3f GB" % (rec[0]['algorithmic_bytes_per_launch'] / 1e9))
-        except Exception:  # noqa: BLE001
-            pass
+    tf = d['ex_fl'] / d['ms'] / 1e9
+    a_fl, a_ex, a_ms = sum(v['fl'] for v in sym.values()), sum(v['ex_fl'] for v in sym.values()), sum(v['ms'] for v in sym.values())
+    tr = pmc_traffic(dom, d['shapes'], pmc_files)
     by_symbol = [{"symbol": k, "ms_per_step": round(v['ms'], 3), "share_of_conv_time": round(v['ms'] / a_ms, 4), "launches": round(v['n'], 1),
-                  "gflop_per_step": round(v['fl'] / 1e9, 1), "TFLOP/s": round(v['fl'] / v['ms'] / 1e9, 1), "peak": peak_of(v),
-                  "frac": round(v['fl'] / v['ms'] / 1e9 / peak_of(v), 4)}
+                  "gflop_per_step": round(v['fl'] / 1e9, 1), "TFLOP/s": round(v['ex_fl'] / v['ms'] / 1e9, 1), "peak": peak_of(v),
+                  "frac": round(v['ex_fl'] / v['ms'] / 1e9 / peak_of(v), 4),
+                  "direct_equiv_TFLOPs": round(v['fl'] / v['ms'] / 1e9, 1)}
                  for k, v in sorted(sym.items(), key=lambda kv: -kv[1]['ms'])]
     out = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-           "traffic": traffic, "traffic_note": note,
-           "executed_mfma_frac": round(d['mfma_fl'] / d['ms'] / 1e9 / peak, 4),
+           "direct_equiv_TFLOPs": round(d['fl'] / d['ms'] / 1e9, 2),
+           "traffic": tr["traffic"] if tr else None, "traffic_algorithmic": tr["traffic_algorithmic"] if tr else None,
+           "traffic_note": ("GB per launch, launch-weighted mean over %d of the symbol's %d shapes; STATIC, from the committed rocprofv3 --pmc passes %s "
+                            "(FETCH_SIZE x2 on gfx950 + WRITE_SIZE)" % (tr["shapes_measured"], tr["shapes_in_step"], tr["source"])) if tr else
+                           "not measured for this symbol (PMC counters need separate rocprofv3 --pmc passes: profiles/)",
+           "mfma_pipe_frac": round(d['mfma_fl'] / d['ms'] / 1e9 / peak, 4),
            "kernel_launches_per_step": round(d['n'], 1), "kernel_ms_per_step": round(d['ms'], 3),
            "kernel_avg_launch_ms": round(d['ms'] / d['n'], 4), "kernel_gflop_per_step": round(d['fl'] / 1e9, 1),
            "kernel_shapes": sorted(d['shapes'], key=lambda r: -r['ms_per_step']),
-           "all_conv_launches": {"TFLOP/s": round(a_fl / a_ms / 1e9, 2), "ms_per_step": round(a_ms, 3), "gflop_per_step": round(a_fl / 1e9, 1)},
+           "all_conv_launches": {"TFLOP/s": round(a_ex / a_ms / 1e9, 2), "direct_equiv_TFLOPs": round(a_fl / a_ms / 1e9, 2),
+                                 "ms_per_step": round(a_ms, 3), "gflop_per_step": round(a_fl / 1e9, 1)},
            "by_symbol": by_symbol[:10],
-           "method": "HIP events on the launch stream around every conv launch of 2 extra single-stream steps; per symbol: sum of the "
-                     "launches' algorithmic FLOPs (2 * pixels * Cout * Cin * taps) / sum of their durations; rocprofv3 tables of the same "
-                     "build: profiles/r3_step_*_kernel_stats.md"}
-    if 'fp32w' in d['prec']:
-        out["frac_note"] = ("achieved / frac count the DIRECT form's multiplies (2 * pixels * Cout * Cin * 9, SURVEY.md section 8d): the Winograd "
-                            "F(2x2,3x3) kernel executes 16/36 of them, so frac may exceed 1; executed_mfma_frac is the matrix-pipe utilisation "
-                            "(MFMA FLOPs actually issued / duration / peak)")
+           "method": "HIP events on the launch stream around every conv launch of 2 extra single-stream steps; per symbol: sum of the MFMA FLOPs "
+                     "the launches execute (direct form: 2 * pixels * Cout * Cin * taps; Winograd F(2x2,3x3): 16/36 of that) / sum of their "
+                     "durations; rocprofv3 tables of the same build: profiles/r4_step_*_kernel_stats.md"}
     if gflop_per_img:
-        out["step_achieved_TFLOPs"] = round(img_per_s_per_gpu * gflop_per_img / 1e3, 2)
-        out["step_frac"] = round(img_per_s_per_gpu * gflop_per_img / 1e3 / peak, 4)
+        # the step's FLOPs: SURVEY.md section 8(d)'s algorithmic count, scaled by executed / algorithmic of the profiled conv launches
+        alg = img_per_s_per_gpu * gflop_per_img / 1e3
+        out["step_achieved_TFLOPs"] = round(alg * a_ex / a_fl, 2)
+        out["step_frac"] = round(alg * a_ex / a_fl / peak, 4)
+        out["step_direct_equiv_TFLOPs"] = round(alg, 2)
     return out
 
 
@@ -349,21 +382,21 @@ def cpu_baseline(size, K, N, b, steps, threads):
 
 
 # Short runs of the other arithmetic modes and BASELINE configs (N = 1 only).
-# (name, gan, size, K, N, batch, generator precision, reconstructor precision, w_space, steps, GFLOP-per-image key or None)
+# (name, gan, size, K, N, batch, generator precision, reconstructor precision, w_space, steps, GFLOP-per-image key or None, short key of the line's `others_images_per_sec`)
 EXTRA = [
-    ("cfg3 StyleGAN2-256 bf16x3", 'stylegan2', 256, 128, 32, 32, 'bf16x3', 'auto', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', 'auto', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', 'auto', False, 10, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 auto, reconstructor convs in exact fp32 [R fp32]", 'stylegan2', 256, 128, 32, 32, 'auto', 'fp32', False, 20, 'stylegan2-256'),
-    ("cfg3 StyleGAN2-256 auto, W-space", 'stylegan2', 256, 128, 32, 32, 'auto', 'auto', True, 10, 'stylegan2-256'),
-    ("cfg2 ProgGAN native 1024, K=64 N=16 B=32, auto", 'proggan', 1024, 64, 16, 32, 'auto', 'auto', False, 4, 'proggan-1024'),
-    ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32, auto", 'proggan', 256, 64, 16, 32, 'auto', 'auto', False, 8, 'proggan-256'),
-    ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16, auto", 'biggan', 128, 128, 32, 16, 'auto', 'auto', False, 8, 'biggan-128'),
-    ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16, auto", 'biggan', 256, 128, 32, 16, 'auto', 'auto', False, 6, None),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp32 with the Winograd form (fp32w)", 'stylegan2', 1024, 200, 64, 8, 'fp32w', 'auto', False, 4, 'stylegan2-1024'),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, direct-form exact fp32", 'stylegan2', 1024, 200, 64, 8, 'fp32', 'auto', False, 3, 'stylegan2-1024'),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path = auto (this architecture's mixed policy: fp16 x2 in the 512^2 / 1024^2 layers)", 'stylegan2', 1024, 200, 64, 8, 'auto', 'auto', False, 6, 'stylegan2-1024'),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, bf16x3 everywhere", 'stylegan2', 1024, 200, 64, 8, 'bf16x3', 'auto', False, 6, 'stylegan2-1024'),
+    ("cfg3 StyleGAN2-256 bf16x3", 'stylegan2', 256, 128, 32, 32, 'bf16x3', 'auto', False, 10, 'stylegan2-256', 'cfg3_bf16x3'),
+    ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', 'auto', False, 10, 'stylegan2-256', 'cfg3_f16'),
+    ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', 'auto', False, 10, 'stylegan2-256', 'cfg3_f16x2'),
+    ("cfg3 StyleGAN2-256 auto, reconstructor convs in exact fp32 [R fp32]", 'stylegan2', 256, 128, 32, 32, 'auto', 'fp32', False, 20, 'stylegan2-256', 'cfg3_auto_Rfp32'),
+    ("cfg3 StyleGAN2-256 auto, W-space", 'stylegan2', 256, 128, 32, 32, 'auto', 'auto', True, 10, 'stylegan2-256', 'cfg3_auto_Wspace'),
+    ("cfg2 ProgGAN native 1024, K=64 N=16 B=32, auto", 'proggan', 1024, 64, 16, 32, 'auto', 'auto', False, 4, 'proggan-1024', 'cfg2_proggan1024_auto'),
+    ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32, auto", 'proggan', 256, 64, 16, 32, 'auto', 'auto', False, 8, 'proggan-256', 'cfg2_proggan256_auto'),
+    ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16, auto", 'biggan', 128, 128, 32, 16, 'auto', 'auto', False, 8, 'biggan-128', 'cfg4_biggan128_auto'),
+    ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16, auto", 'biggan', 256, 128, 32, 16, 'auto', 'auto', False, 6, None, 'cfg4_biggan256_auto'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp32 with the Winograd form (fp32w)", 'stylegan2', 1024, 200, 64, 8, 'fp32w', 'auto', False, 4, 'stylegan2-1024', 'cfg5_sg1024_fp32w'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, direct-form exact fp32", 'stylegan2', 1024, 200, 64, 8, 'fp32', 'auto', False, 3, 'stylegan2-1024', 'cfg5_sg1024_fp32'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path = auto (this architecture's mixed policy: fp16 x2 in the 512^2 / 1024^2 layers)", 'stylegan2', 1024, 200, 64, 8, 'auto', 'auto', False, 6, 'stylegan2-1024', 'cfg5_sg1024_auto'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, bf16x3 everywhere", 'stylegan2', 1024, 200, 64, 8, 'bf16x3', 'auto', False, 6, 'stylegan2-1024', 'cfg5_sg1024_bf16x3'),
 ]
 
 
@@ -389,13 +422,13 @@ def run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, warmup, gkey,
 
 def run_extra(dev):
     out = []
-    for name, gan, size, K, N, B, prec, r_prec, w_space, steps, gkey in EXTRA:
+    for name, gan, size, K, N, B, prec, r_prec, w_space, steps, gkey, short in EXTRA:
         try:
             rec, eng = run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, 6, gkey)
-            out.append(dict({"config": name}, **rec))
+            out.append(dict({"config": name, "key": short}, **rec))
             del eng
         except Exception as e:  # noqa: BLE001
-            out.append({"config": name, "precision": prec, "error": repr(e)[:300]})
+            out.append({"config": name, "key": short, "precision": prec, "error": repr(e)[:300]})
         torch.cuda.empty_cache()
     return out
 
@@ -427,6 +460,84 @@ def comm_section(eng, backend):
                     "the side stream; S group, after the RBF backward) and their completion, mean of 5 extra steps on rank 0"}
 
 
+def full_record(args, world, head, stats, comm, hbm, extra, cpu, gkey):
+    """Everything this run measured (the side file); final_line() condenses it to the < 4 KB line the driver parses."""
+    arch = {'stylegan2': 'StyleGAN2-FFHQ-%d' % args.size, 'proggan': 'ProgGAN (%d)' % args.size, 'biggan': 'BigGAN-%d' % args.size}[args.gan]
+    return {"metric": "training images/sec (warp->G->R->loss) %s K=%d" % ({'stylegan2': 'StyleGAN2-%d' % args.size}.get(args.gan, arch), args.K),
+            "value": head["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": head["dtype"], "dtype_detail": head.get("dtype_detail"),
+            "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
+            "config": {"workload": "%s arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
+                                   % (arch, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": head["precision"],
+                       "precision_requested": args.precision, "r_arith": head["r_arith"],
+                       "algorithmic_gflop_per_image": GFLOP_PER_IMG.get(gkey)},
+            "last_stats": stats, "roofline": head.get("roofline"), "host": head.get("host"), "comm": comm, "hbm_subpaths": hbm,
+            "extra": extra or None, "cpu_baseline": cpu}
+
+
+ROOFLINE_LINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic", "direct_equiv_TFLOPs",
+                      "kernel_launches_per_step", "kernel_avg_launch_ms", "step_achieved_TFLOPs", "step_frac", "step_direct_equiv_TFLOPs")
+LINE_LIMIT = 4096
+
+
+def _short_run(e):
+    """One same-workload companion run (product default / direct fp32) as the line carries it."""
+    r = e.get("roofline") or {}
+    out = {"precision": e.get("precision"), "value": e.get("value"), "ms_per_step": e.get("ms_per_step"), "dtype": e.get("dtype")}
+    if r:
+        out["roofline"] = {k: r.get(k) for k in ("kernel", "achieved", "peak", "frac", "step_frac")}
+    c = e.get("comm")
+    if c:
+        out["exposed_wait_ms_per_step"] = c.get("exposed_wait_ms_per_step")
+    return out
+
+
+def final_line(full, extra_file):
+    """The ONE stdout line the driver parses: < LINE_LIMIT bytes whatever the run measured (tests/test_bench_tables_cpu.py)."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    line["config"] = full["config"]
+    r = full.get("roofline")
+    line["roofline"] = {k: r.get(k) for k in ROOFLINE_LINE_KEYS if k in r} if r else None
+    c = full.get("cpu_baseline")
+    if c:
+        c = dict(c)
+        if isinstance(c.get("sample"), str) and len(c["sample"]) > 300:
+            c["sample"] = c["sample"][:297] + "..."
+        if "error" in c:
+            c["error"] = str(c["error"])[:200]
+    line["cpu_baseline"] = c
+    cm = full.get("comm")
+    line["comm"] = {k: cm.get(k) for k in ("backend", "world_size_observed", "allreduce_bytes_per_step", "collectives_per_step",
+                                           "exposed_wait_ms_per_step")} if cm else None
+    h = full.get("host")
+    if h:
+        line["host"] = {k: h.get(k) for k in ("library_launches_per_step", "host_enqueue_ms_per_step")}
+    extra = full.get("extra") or []
+    same = [e for e in extra if str(e.get("config", "")).startswith("headline workload")]
+    for e in same:
+        line["direct_fp32" if "direct-form" in e["config"] else "product"] = _short_run(e)
+    others = {}
+    for e in extra:
+        if e in same:
+            continue
+        others[str(e.get("key") or e.get("config", "?"))[:40]] = e.get("value") if "error" not in e else "error"
+    line["others_images_per_sec"] = others or None
+    line["extra_file"] = extra_file
+    s = json.dumps(line)
+    # belt and braces: shed the optional sections, largest first, until the line fits
+    for k in ("others_images_per_sec", "direct_fp32", "host", "product"):
+        if len(s) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+        s = json.dumps(line)
+    if len(s) >= LINE_LIMIT:
+        raise RuntimeError("bench.py: final line is %d bytes (limit %d)" % (len(s), LINE_LIMIT))
+    return s
+
+
 def main():
     from warpedganspace_amd import conv as C
     ap = argparse.ArgumentParser()
@@ -454,6 +565,8 @@ def main():
     ap.add_argument('--single-stream', action='store_true', help='no side streams (profiling: kernel times then add up to the step)')
     ap.add_argument('--no-product-run', action='store_true', help='skip extra[0] (the default-arithmetic run with the same steps / warmup)')
     ap.add_argument('--no-extra', action='store_true', help='skip the short runs of the other arithmetic modes / configs')
+    ap.add_argument('--extra-out', default=os.path.join('gpurun_out', 'bench_extra.json'),
+                    help="side file for everything the < 4 KB stdout line leaves out (relative to the repo root)")
     ap.add_argument('--dist-backend', choices=('nccl', 'gloo'), default=os.environ.get('WGS_DIST_BACKEND', 'nccl'),
                     help="nccl = RCCL (one rank per GPU); gloo = development switch, ranks share the visible device(s)")
     args = ap.parse_args()
@@ -477,6 +590,11 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    pin = None
+    if world > 1 and args.dist_backend == 'nccl':
+        # one launch thread per rank: keep it on the CPUs of its GPU's NUMA node, apart from the other ranks' 
+        from warpedganspace_amd.hostpin import pin_rank
+        pin = pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
@@ -526,20 +644,16 @@ def main():
             cpu = {"error": repr(e)}
 
     if rank == 0:
-        arch = {'stylegan2': 'StyleGAN2-FFHQ-%d' % args.size, 'proggan': 'ProgGAN (%d)' % args.size, 'biggan': 'BigGAN-%d' % args.size}[args.gan]
-        out = {"metric": "training images/sec (warp->G->R->loss) %s K=%d" % ({'stylegan2': 'StyleGAN2-%d' % args.size}.get(args.gan, arch), args.K),
-               "value": head["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": head["dtype"], "dtype_detail": head.get("dtype_detail"),
-               "data": "synthetic (random-init weights, z ~ N(0,I) sampled on the device)",
-               "config": {"workload": "%s arch, K=%d, N=%d, ResNet-18 R, batch %d/GPU, %s-space, learn_gammas"
-                                      % (arch, args.K, args.N, args.batch, 'W' if args.w_space else 'Z'),
-                          "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision": head["precision"],
-                          "precision_requested": args.precision, "r_arith": head["r_arith"],
-                          "algorithmic_gflop_per_image": GFLOP_PER_IMG.get(gkey)},
-               "last_stats": stats, "roofline": head.get("roofline"), "host": head.get("host"), "comm": comm, "hbm_subpaths": hbm,
-               "extra": extra or None, "cpu_baseline": cpu}
-        print(json.dumps(out))
+        doc = full_record(args, world, head, stats, comm, hbm, extra, cpu, gkey)
+        doc["host_pinning_rank0"] = pin
+        path = args.extra_out if os.path.isabs(args.extra_out) else os.path.join(REPO, args.extra_out)
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, 'w') as f:
+                json.dump(doc, f, indent=1)
+        except OSError as e:
+            path = "unwritable: %r" % (e,)
+        print(final_line(doc, os.path.relpath(path, REPO) if os.path.isabs(path) else path), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

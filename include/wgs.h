@@ -171,7 +171,7 @@ typedef struct wgs_conv_desc {
                                 any magnitude keep 11 significant bits and cannot overflow.  NULL: no scaling (k = 0). */
     float a_bound;           /* bound of |a_scale| (and of any linear map the caller folded into x after measuring m); 0 = 1 */
     const float* a_amax2;    /* optional second device scalar multiplied into the bound (forward launches: max |a_scale|) */
-    float* y_amax;           /* precision >= 1: optional device scalar (caller-zeroed) raised (atomic max) to max |y| of this launch
+    float* y_amax;           /* every precision: optional device scalar (caller-zeroed) raised (atomic max) to max |y| of this launch
                                 — chained into the next layer's a_amax, so that a forward pass in the fp16 modes cannot overflow
                                 whatever the magnitude of a checkpoint's activations */
     const uint16_t* x_f16;   /* optional: the activation operand ALREADY as its fp16 plane, hi = f16_rn(x * 2^k) in the layout of x
@@ -195,9 +195,12 @@ int wgs_conv_igemm_multi_merges(const wgs_conv_desc* descs, int n);
  * (lib/trainer.py:166).  Covered: all nine taps dy, dx in {-1, 0, 1} each exactly once (any weight-slab order: forward and
  * input-gradient launches alike), isy = osy = 1, ups 0, Hi = Ho % 16 == 0, Wi = Wo % 16 == 0, Ci % 16 == 0, Co % 64 == 0, act 0,
  * act_slope in [0, 1], no addend; a sample's tensors < 2 GiB (any batch).  wgs_conv_wino_supported() tells (1 / 0).
- * wgs_conv_wino_weight: U (16 * Ci * Co floats, caller-owned) = the launch's weights G g G^T in the kernel's staging order —
- * once per weight tensor; wgs_conv_wino runs the launch with it (desc->w is not read). */
+ * wgs_conv_wino_weight: U (16 * Ci * Co floats, caller-owned) = the launch's weights G g G^T in the kernel's staging order.
+ * That order depends on the workgroup shape the launch takes, which depends on B, H, W, Co: wgs_conv_wino_layout() returns the
+ * layout id (> 0) of a launch, and a U may be reused by any launch of the same weights, taps AND layout id (not "once per weight
+ * tensor": a frozen layer called at two batch sizes may need two).  wgs_conv_wino runs the launch with it (desc->w is not read). */
 int wgs_conv_wino_supported(const wgs_conv_desc* desc);
+int wgs_conv_wino_layout(const wgs_conv_desc* desc);
 int wgs_conv_wino_weight(const wgs_conv_desc* desc, float* U, wgs_stream_t stream);
 int wgs_conv_wino(const wgs_conv_desc* desc, const float* U, wgs_stream_t stream);
 
@@ -295,7 +298,14 @@ int wgs_sg2_blur_bwd_f16(const float* dy, const float* kernel4x4, uint16_t* dt_h
  * x [B,H,H,Ci] NHWC fp32, y [B,2H,2H,Co]; w_hi (w_lo) = the fp16 planes of the [Co,9,Ci] weights from wgs_split_f16.
  * precision 2 (fp16) or 3 (fp16 x2: here the ACTIVATION operand is split hi + lo against the single plane w_hi — two MFMAs per
  * product and the error class of wgs_conv_desc's weight split; w_lo is not read); Ci % 32 == 0, Co % 64 == 0;
- * a_amax / a_amax2 / a_bound / y_amax as in wgs_conv_desc. */
+ * a_amax / a_amax2 / a_bound / y_amax as in wgs_conv_desc.
+ * y_f16 (optional): the kernel also writes the fp16 operand plane of the NEXT conv (its wgs_conv_desc.x_f16), with that conv's
+ * style vector folded in:  y_f16[b,oy,ox,n] = f16_rn( fl32(y[b,oy,ox,n] * y_f16_scale[b*y_f16_ld + n]) * 2^k ),
+ * k chosen so that  bound = (y_f16_mul * a_amax[0] + y_f16_add) * a_amax2[0]  lands in [2^11, 2^12): an A-PRIORI bound of
+ * |y * scale| supplied by the caller (|t| <= sqrt(4 Ci) max|x|, blur gain 4, noise, bias, sqrt(2): see stylegan2.py), because the
+ * kernel cannot know its own output maximum before it has run.  `bound` is written to *y_f16_bound: the consumer passes it as its
+ * a_amax (a_bound = 1, a_amax2 = NULL, a_scale = NULL) and so derives the same k.  The plane holds the same bits the consumer
+ * would have produced from the fp32 tensor itself.  With y_f16 given, y may be NULL (a pass that keeps nothing for a backward). */
 typedef struct wgs_upconv_desc {
     const float* x; const void* w_hi; const void* w_lo; float* y;
     const float* a_scale; const float* col_scale; const float* bias; const float* noise; const float* noise_w;
@@ -303,6 +313,9 @@ typedef struct wgs_upconv_desc {
     const float* a_amax; const float* a_amax2; float* y_amax;
     float a_bound, alpha;
     int B, H, Ci, Co, a_ld, col_ld, precision;
+    uint16_t* y_f16; const float* y_f16_scale; float* y_f16_bound;
+    float y_f16_mul, y_f16_add;
+    int y_f16_ld;
 } wgs_upconv_desc;
 int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* desc, wgs_stream_t stream);
 

@@ -106,6 +106,12 @@ def test_step_at_256x256_images_vs_oracle_replay(dev, sg2_256_case, mode):
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     print('   dS cosine %.6f' % cos)
     assert cos > (0.999 if tight else 0.98)     # batch of 2 through train-mode BatchNorm: entries move by per cents, the direction holds
+    # max-norm errors of the gradients themselves (asserted, not only printed).  The floor is set by the evaluation, not
+    # the arithmetic: with a batch of 2 through train-mode BatchNorm a handful of ReLU gates / max-pool winners that round to the
+    # other side move single entries by per cents in ANY two evaluations (exact fp32 measures dS 1.8e-2 / worst dR 7.7e-2 against the
+    # fp64 oracle; the Winograd form the same 1.8e-2 / 7.7e-2; split-bf16 3.7e-2 / 1.4e-1; the mixed fp16 policy 1.7e-1 / 2.5e-1)
+    lim_s, lim_r = {'fp32': (4e-2, 1.5e-1), 'fp32w': (4e-2, 1.5e-1), 'bf16x3': (8e-2, 2.7e-1)}.get(mode, (3.5e-1, 5e-1))
+    assert e_s < lim_s and worst < lim_r, (mode, e_s, worst)
 
 
 def test_trainstep_proggan_k64_n16_vs_replay(dev):

@@ -147,3 +147,27 @@ def test_fp32w_through_the_other_generators_plain_3x3_layers(dev):
         C.PROFILE = None
         lib.wgs_dev_trace_kernels(0)
     assert any(s.startswith('wino_f32_kernel') for s in syms), syms
+
+
+def test_one_weight_cache_serves_launches_of_different_layouts(dev):
+    """U's fragment order follows the workgroup shape, which depends on the batch (512 -> 512 @16^2 takes the 4-wave
+    shape up to B = 24 and the 8-wave 128-channel shape from B = 25).  One SplitCache shared by a B = 1 and a B = 32 launch (what
+    sample_gan.py's final partial batch does) must hand each its own layout: both results against fp64, and two cached operands."""
+    import ctypes
+    torch.manual_seed(3)
+    ci = co = 512
+    w = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
+    cache = C.SplitCache(w)
+    wr = w.double().reshape(co, 3, 3, ci).permute(0, 3, 1, 2)
+    layouts = set()
+    for B in (32, 1, 32, 2):
+        x = torch.randn(B, 16, 16, ci, device=dev)
+        y = C.conv2d(x, w, 3, pad=1, precision=C.FP32W, w_split=cache)
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+        e = float((y.double() - ref).abs().max() / ref.abs().max())
+        assert e < 3e-6, (B, e)
+        d, _ = C._desc(x, w, y, [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)], 16, 16, w_tap_stride=ci, w_row_stride=9 * ci,
+                       precision=C.FP32W)
+        layouts.add(L.lib().wgs_conv_wino_layout(ctypes.byref(d)))
+    assert len(layouts) == 2, layouts                                   # the two batch sizes really straddle the shape threshold
+    assert sum(1 for k in cache.planes if isinstance(k, tuple) and k[0] == 'wino') == 2

@@ -98,3 +98,17 @@ def test_flat_bucket_keeps_conv_memory_layout():
     b.gview[id(conv.weight)].fill_(1.0)
     assert float(conv.weight.grad.sum()) == conv.weight.numel()
     assert all(off % 4 == 0 for _, off, _ in b.segments)                 # 16-byte aligned segments
+
+
+def test_host_pinning_plan_gives_disjoint_slices():
+    """One launch thread per rank: ranks that share a NUMA node get disjoint, equal slices of its CPUs."""
+    from warpedganspace_amd import hostpin as HP
+    assert HP._cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+    node, allowed = set(range(0, 48)), set(range(0, 96))
+    got = [HP.plan(node, allowed, 4, s) for s in range(4)]
+    assert all(len(g) == 12 for g in got) and len(set().union(*got)) == 48
+    assert all(not (got[i] & got[j]) for i in range(4) for j in range(i))
+    assert HP.plan({200, 201}, {0, 1, 2, 3}, 2, 1) == {2, 3}                      # node CPUs outside the allowed set: fall back to the allowed ones
+    assert len(HP.plan({0}, {0}, 8, 5)) == 1                                      # more ranks than CPUs: still one CPU each
+    r = HP.pin_rank(0, 1)                                                         # no GPU here: reports why, changes nothing
+    assert r['pinned'] is False and r['why']

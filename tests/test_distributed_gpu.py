@@ -161,26 +161,45 @@ def test_trainstep_world2_matches_sum_of_rank_gradients(dev):
     assert all(p.exitcode == 0 for p in procs)
 
 
-def test_bench_two_ranks_end_to_end_over_gloo():
-    """`bench.py --gpus 2 --dist-backend gloo`: the driver's N > 1 invocation end to end on ONE device (rank spawn, process
-    group, per-rank engines, barrier + max-over-ranks timing, comm section, extra[0] at N = 2, rank-0 JSON) — so that the first
-    RCCL run of the scaling bench is not also this code path's first run."""
+def _bench_two_ranks(backend, tmp_path):
     import json
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--steps', '3', '--warmup', '2', '--batch', '4',
-           '--size', '32', '-K', '16', '-N', '4', '--no-cpu-baseline', '--no-extra']
+    side = str(tmp_path / 'bench_extra.json')
+    cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--dist-backend', backend, '--steps', '3', '--warmup', '2', '--batch', '4',
+           '--size', '32', '-K', '16', '-N', '4', '--no-cpu-baseline', '--no-extra', '--extra-out', side]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=repo))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 alone prints the record
+    assert len(lines[0]) < 4096                               # the driver keeps ~8 KB of stdout: the N > 1 line obeys the size cap too
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 2 and d['scaling'] == 'weak' and d['dtype'] == 'fp32'
     assert d['config']['global_batch'] == 8 and d['config']['parallelism'] == 'dp2'
     assert abs(d['value'] - 8 * 3 / (d['ms_per_step'] * 3e-3)) < 0.02 * d['value']          # whole-job rate over both ranks
-    assert d['comm']['world_size_observed'] == 2 and d['comm']['collectives_per_step'] == 2 and d['comm']['allreduce_bytes_per_step'] > 0
-    assert d['roofline']['kernel'] and d['host']['library_launches_per_step'] > 0
-    e = d['extra'][0]
+    c = d['comm']
+    assert c['world_size_observed'] == 2 and c['collectives_per_step'] == 2 and c['allreduce_bytes_per_step'] > 0 and c['exposed_wait_ms_per_step'] >= 0
+    assert d['roofline']['kernel'] and 0 < d['roofline']['frac'] <= 1.0 and d['host']['library_launches_per_step'] > 0
+    assert d['product']['value'] > 0 and d['direct_fp32']['precision'] == 'fp32' and d['config']['precision'] == 'fp32w'
+    full = json.load(open(side))                               # the side file holds the complete records
+    e = full['extra'][0]
     assert e['n_gpus'] == 2 and e['steps'] == 3 and e['comm']['world_size_observed'] == 2 and e['roofline']['kernel']
-    assert d['config']['precision'] == 'fp32w' and d['extra'][1]['precision'] == 'fp32' and d['extra'][1]['n_gpus'] == 2    # the direct-form run beside it
+    assert full['extra'][1]['precision'] == 'fp32' and full['extra'][1]['n_gpus'] == 2     # the direct-form run beside it
+    return d
+
+
+def test_bench_two_ranks_end_to_end_over_gloo(tmp_path):
+    """`bench.py --gpus 2 --dist-backend gloo`: the driver's N > 1 invocation end to end on ONE device (rank spawn, process
+    group, per-rank engines, barrier + max-over-ranks timing, comm section, the product / direct runs at N = 2, rank-0 JSON) — so that
+    the first RCCL run of the scaling bench is not also this code path's first run."""
+    d = _bench_two_ranks('gloo', tmp_path)
+    assert d['comm']['backend'].startswith('gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: runs where >= 2 GPUs are visible')
+def test_bench_two_ranks_end_to_end_over_rccl(tmp_path):
+    """The same on RCCL (`nccl` backend, one rank per GPU) wherever the box has two GPUs: the driver's multi-GPU scaling run is then
+    never RCCL's first contact with this code."""
+    d = _bench_two_ranks('nccl', tmp_path)
+    assert d['comm']['backend'].startswith('RCCL')

@@ -49,11 +49,15 @@ def _run_pair(dev, B, K, S, arith=None):
     return R, sd, (lo, mo, x2), (lg, mg, x2d)
 
 
+@pytest.mark.parametrize('arith', ['exact', 'wino'])
 @pytest.mark.parametrize('B,K,S', [(4, 16, 64), (3, 16, 64), (4, 128, 64)])
-def test_resnet_forward_backward_vs_oracle(dev, B, K, S):
+def test_resnet_forward_backward_vs_oracle(dev, B, K, S, arith):
     """Full ResNet-18 reconstructor, train-mode BN: outputs, argmax, every parameter gradient, the input
-    gradient and the running statistics against the CPU oracle."""
-    R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, B, K, S)
+    gradient and the running statistics against the CPU oracle — in exact fp32 (the reference's arithmetic) and in R_FP32_WINO,
+    the arithmetic of the TRAINED network in the headline bench mode (fp32; Winograd form of the 3x3 stride-1 forward and
+    input-gradient convs at >= 16x16 maps): same tolerances, it is fp32 throughout."""
+    from warpedganspace_amd import reconstructor as RR
+    R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, B, K, S, arith=RR.R_FP32_WINO if arith == 'wino' else None)
     assert rel_err(lg, lo.detach()) < 1e-4
     assert rel_err(mg, mo.detach()) < 1e-4
     assert torch.equal(torch.argmax(lg, 1).cpu(), torch.argmax(lo, 1))       # path-index argmax bit-exact

@@ -73,7 +73,12 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local_rank)
+        from warpedganspace_amd.hostpin import pin_rank        # this rank's launch thread stays on its GPU's NUMA node
+        pin = pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+        if rank == 0:
+            print("#. Host placement of rank 0: {}".format(pin))
         dist.init_process_group('nccl', rank=rank, world_size=world)
     exp_dir = create_exp_dir(args) if rank == 0 else exp_dir_name(args)      # args.json: exactly the reference's keys
     if world > 1:

@@ -182,7 +182,9 @@ class Generator(nn.Module):
                     bb = torch.zeros(pad_co, device=dev)
                     bb[:co] = b
                     wp, b, co = wpp, bb, pad_co
-                return dict(wp=wp, wt=C.repack_w_t(wp, co, k * k, ci), b=b, ci=ci, co=co, k=k, inv=1.0 / m.sigma(eps))
+                wt = C.repack_w_t(wp, co, k * k, ci)
+                # frozen weights: the Winograd U operands of 'fp32w' launches are built once per layout, not per call
+                return dict(wp=wp, wt=wt, wc=C.WinoCache(wp), wtc=C.WinoCache(wt), b=b, ci=ci, co=co, k=k, inv=1.0 / m.sigma(eps))
 
             def cc(m):
                 r = torch.rsqrt(m.stored_var + self.BN_eps)
@@ -283,7 +285,7 @@ class Generator(nn.Module):
         y = torch.empty(B, H, H, c['co'], device=x.device)
         taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
         C.launch(x, c['wp'], y, taps, H, H, w_tap_stride=c['ci'], w_row_stride=k * k * c['ci'], ups=ups, alpha=c['inv'], bias=c['b'],
-                 addend=addend, act=act, precision=prec)
+                 addend=addend, act=act, precision=prec, w_split=c.get('wc'))
         return y
 
     @staticmethod
@@ -295,7 +297,8 @@ class Generator(nn.Module):
         pad = k // 2
         dx = torch.empty(B, H, H, c['ci'], device=g.device)
         taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
-        C.launch(g, c['wt'], dx, taps, H, H, w_tap_stride=c['ci'] * c['co'], w_row_stride=c['co'], alpha=c['inv'], precision=prec, grad_operand=True)
+        C.launch(g, c['wt'], dx, taps, H, H, w_tap_stride=c['ci'] * c['co'], w_row_stride=c['co'], alpha=c['inv'], precision=prec, grad_operand=True,
+                 w_split=c.get('wtc'))
         return dx
 
     @staticmethod
@@ -501,8 +504,9 @@ class BigGANWrapper(nn.Module):
             return self.target_classes.repeat(batch_size)
         return torch.from_numpy(np.random.choice(self.target_classes.cpu().numpy(), [batch_size]))
 
-    def forward(self, z, shift=None, precision=None):
-        target_classes = self.mixed_classes(z.shape[0]).to(z.device)
+    def forward(self, z, shift=None, precision=None, classes=None):
+        """classes (extension): class ids [B] of this call; None draws them as the reference does (gan_load.py:73-79)."""
+        target_classes = (self.mixed_classes(z.shape[0]) if classes is None else classes).to(z.device)
         return self.G(z if shift is None else z + shift, self.G.shared(target_classes), precision=precision)
 
     def resolve_precision(self, requested=None):

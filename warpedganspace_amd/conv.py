@@ -135,6 +135,16 @@ def precision_code(name):
     raise L.WgsError("unknown conv precision %r (choose from %s)" % (name, ', '.join(PRECISION_NAMES)))
 
 
+def is_f16_operand(code):
+    """Modes that round conv operands to fp16 (codes are labels, not an ordering: 'fp32w' is 5 and is fp32 throughout)."""
+    return code in (2, 3, MIXED)
+
+
+def is_reduced(code):
+    """Modes whose products are not exact fp32 MFMA: the ones the run-time image-error check applies to."""
+    return code in (1, 2, 3, MIXED)
+
+
 def precision_name(code):
     return [k for k, v in PRECISION_NAMES.items() if v == code][0]
 
@@ -202,6 +212,14 @@ class SplitCache:
         if precision not in self.planes:
             self.planes[precision] = split_weight(self.w, precision)
         return self.planes[precision]
+
+
+class WinoCache(SplitCache):
+    """Cache of a frozen weight tensor's Winograd U operands only ('fp32w'): no 16-bit planes, so the 16-bit modes keep the kernel
+    routing of a launch without pre-split weights (BigGAN / SNGAN convs)."""
+
+    def get(self, precision):
+        return None
 
 
 def _timed(kind, flops, fn):
@@ -273,7 +291,8 @@ def _kind(d, nphase):
 def _wino_weight(d, w, cache):
     """U = G g G^T of a launch's weights in the Winograd kernel's staging order (wgs_conv_wino_weight); kept in the weight tensor's
     SplitCache when the caller has one (frozen generator weights), rebuilt per launch otherwise (R's trained weights: ~10 us)."""
-    key = ('wino', d.w_tap_stride, d.w_row_stride, tuple((d.dy[i], d.dx[i], d.wt[i]) for i in range(9)))
+    # U's fragment order follows the workgroup shape the launch takes (a function of B, H, W, Co): the layout id is part of the key
+    key = ('wino', L.lib().wgs_conv_wino_layout(ctypes.byref(d)), d.w_tap_stride, d.w_row_stride, tuple((d.dy[i], d.dx[i], d.wt[i]) for i in range(9)))
     if isinstance(cache, SplitCache) and key in cache.planes:
         return cache.planes[key]
     U = torch.empty(16 * d.Ci * d.Co, device=w.device, dtype=torch.float32)

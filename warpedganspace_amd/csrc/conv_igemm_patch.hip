@@ -61,14 +61,21 @@ struct PatchGeom {       // uniform per launch
 // NTF: number of taps when it is known at compile time (9: every 3x3 conv), else 0.  With it the tap loop is unrolled and the
 // per-tap table entries (LDS row offsets, weight slab offsets) become loop-invariant scalar loads hoisted out of the chunk loop:
 // a scalar load inside a step shares lgkmcnt with the step's ds_reads, so waiting for it drained the fragment reads in flight.
-template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF>
+// XF16: the activation operand arrives as its fp16 plane (ConvArgs.a_hi = wgs_conv_desc.x_f16, written by the producing kernel
+// already multiplied by its style vector and the power-of-two operand scale): a staging element is 16 bytes = EIGHT channels of a
+// patch pixel, loaded and written to LDS as it is — no style multiply, no scale, no conversion, half the load bytes and
+// instructions.  (Single-plane A only: schemes 1 and 2.)
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF, bool XF16>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SCH == 1 ? 3 : 2) : 1) void igemm_patch_kernel(const ConvArgs p, const PatchGeom g) {
     typedef wgsconv::Scheme<SCH> SC;
     typedef typename SC::frag frag;
     constexpr int NA = SC::NA, NB = SC::NB;
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int PMAX = pmax_of(BM);
-    constexpr int NPL = (PMAX * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk at most (9); g.npl are issued
+    static_assert(!XF16 || NA == 1, "an fp16 activation plane is a single-plane A operand");
+    constexpr int EPP = XF16 ? 4 : 8;                 // 16-byte staging elements per patch pixel and chunk (8 fp16 / 4 fp32 channels each)
+    constexpr int EPS = XF16 ? 2 : 3;                 // log2(EPP)
+    constexpr int NPL = (PMAX * EPP + NT - 1) / NT;   // 16-byte patch loads per thread and chunk at most (9); g.npl are issued
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int P_BYTES = PMAX * PROW;                // one patch plane
     constexpr int B_BYTES = BN * ROW;                   // one weight plane of one tap
@@ -111,30 +118,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
         return true;
     };
 
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = XF16 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.a_hi), 0, p.x_bytes, 0x00020000)
+                                           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_hi), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_lo), 0, p.w_bytes, 0x00020000);
 
-    // ---- patch staging: element e = tid + j*NT -> patch pixel e / 8, float4 q = e % 8 (= tid % 8 for every j)
-    const int q = tid & 7;
+    // ---- patch staging: element e = tid + j*NT -> patch pixel e / EPP, 16-byte piece q = e % EPP (= tid % EPP for every j)
+    const int q = tid & (EPP - 1);
     const int npatch = g.PH * g.PW;
     int p_goff[NPL];        // byte offset of (pixel, q) in x for chunk 0, or OOB
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         if (j >= g.npl) break;
-        const int pp = (tid + j * NT) >> 3;
+        const int pp = (tid + j * NT) >> EPS;
         const int pr = wgs_div_fast(pp, g.pw_magic), pc = pp - pr * g.PW;
         const int iy = ty0 + g.dy_min + pr, ix = tx0 + g.dx_min + pc;
         const bool v = pp < npatch && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        p_goff[j] = v ? (((b * p.Hi + iy) * p.Wi + ix) * p.Ci + q * 4) * 4 : OOB;
+        p_goff[j] = v ? ((b * p.Hi + iy) * p.Wi + ix) * p.Ci * (XF16 ? 2 : 4) + q * 16 : OOB;
     }
     // byte offset of staging element j in the hi patch plane: linear in j (one base register + immediates)
-    const int p_lbase = (tid >> 3) * PROW + q * 8;
-    auto p_loff_of = [&](int j) { return ((tid + j * NT) >> 3) < PMAX ? p_lbase + j * (NT / 8) * PROW : -1; };
-    const float* sc_ptr = p.a_scale ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
+    const int p_lbase = (tid >> EPS) * PROW + q * (XF16 ? 16 : 8);
+    auto p_loff_of = [&](int j) { return ((tid + j * NT) >> EPS) < PMAX ? p_lbase + j * (NT / EPP) * PROW : -1; };
+    const float* sc_ptr = (p.a_scale && !XF16) ? p.a_scale + (size_t)b * p.a_ld + q * 4 : nullptr;
     constexpr bool PIPE = (NA == 1 && NB == 1);       // single-plane (fp16) form: hand-pipelined steps, explicit waits
     const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a_scale ? p.a_scale : p.x), 0, p.a_scale ? p.s_bytes : 0, 0x00020000);
-    float4 pr_[NPL];
+    u32x4 pr_[NPL];
     const int npl = g.npl;      // staging slots past the patch's own size are skipped (uniform branch), not loaded-as-zero
     // fp16 schemes: dynamic power-of-two operand scale (conv_scheme.h), folded into the style vector / undone in the epilogue
     float op_mult = 1.f, op_inv = 1.f;
@@ -142,15 +150,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
     const int cpt = p.Ci / BK;
     auto load_patch = [&](int c) {
-        const int cbyte = c < cpt ? c * (BK * 4) : OOB;
+        const int cbyte = c < cpt ? c * (BK * (XF16 ? 2 : 4)) : OOB;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             if (j >= npl) break;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (WGS_PABL != 2) v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
             else asm volatile("" : "+v"(v));
-            pr_[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            pr_[j] = v;
         }
+        if (XF16) return;
         // (no use of the loaded style vector here: touching it would make the compiler wait for it — and, vmcnt being in-order,
         // for the nine patch loads in front of it — at the top of every chunk; the operand scale is applied in store_patch)
         if (PIPE) {      // the style vector through the same buffer path as the patch (range-checked past the end)
@@ -162,7 +171,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             if (j >= npl) break;
-            float4 v = pr_[j];
+            if (XF16) {
+                const int lo16 = p_loff_of(j);
+                if (WGS_PABL == 3) { asm volatile("" :: "v"(pr_[j].x), "v"(pr_[j].y)); continue; }
+                if (lo16 >= 0) *reinterpret_cast<u32x4*>(patch + lo16) = pr_[j];
+                continue;
+            }
+            float4 v = make_float4(__uint_as_float(pr_[j].x), __uint_as_float(pr_[j].y), __uint_as_float(pr_[j].z), __uint_as_float(pr_[j].w));
             v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
             asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (no fma into the residual)
             if (SCH != 0) { v.x *= op_mult; v.y *= op_mult; v.z *= op_mult; v.w *= op_mult; }   // power of two: exact
@@ -353,20 +368,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
     wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh, op_inv);
 }
 
-template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF>
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF, bool XF16>
 void launch_patch_n(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
     typedef wgsconv::Scheme<SCH> SC;
     const size_t sm = (size_t)SC::NA * pmax_of(BM) * PROW + (size_t)2 * TPS * SC::NB * BN * ROW;
-    auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS, NTF>;
-    wgs_note_kernel("igemm_patch_kernel<%d, %d, %d, %d, %d, %d, %d>", SCH, BM, BN, WAVES_M, WAVES_N, TPS, NTF);
+    auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS, NTF, XF16>;
+    wgs_note_kernel("igemm_patch_kernel<%d, %d, %d, %d, %d, %d, %d, %s>", SCH, BM, BN, WAVES_M, WAVES_N, TPS, NTF, XF16 ? "true" : "false");
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
 }
 template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS>
 void launch_patch_t(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStream_t st) {
     // (256-row tiles only: +2.5 %; the three-per-CU 128-row tiles lose 7 % to the registers the unrolled steps take)
-    if (a.ntaps == 9 && SCH != 0 && BM == 256 && !wgs_flags().patch_ntf0) launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 9>(a, g, nblocks, st);
-    else launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 0>(a, g, nblocks, st);
+    const bool ntf9 = a.ntaps == 9 && SCH != 0 && BM == 256 && !wgs_flags().patch_ntf0;
+    if constexpr (SCH == 1 || SCH == 2) {
+        if (a.a_hi) {     // producer-written fp16 activation plane
+            if (ntf9) launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 9, true>(a, g, nblocks, st);
+            else launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 0, true>(a, g, nblocks, st);
+            return;
+        }
+    }
+    if (ntf9) launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 9, false>(a, g, nblocks, st);
+    else launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 0, false>(a, g, nblocks, st);
 }
 
 // tile shape x scheme dispatch; the fp16 schemes take a tap row per barrier when the tap count allows it
@@ -390,6 +413,8 @@ namespace wgsconv {
 int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     const ConvArgs& a = a0;
     if (!a.w_hi || (!a.w_lo && a.sch != 1) || a.ups || a.isy != 1 || a.isx != 1) return 1;
+    if (a.a_hi && (a.sch == 0 || a.a_scale)) return 1;      // an fp16 activation plane: fp16 schemes, style already folded in by the producer
+    const int epp = a.a_hi ? 4 : 8;                         // 16-byte staging elements per patch pixel (XF16: 8 fp16 channels each)
     if (a.Ci % 32 || a.Co % 128 || a.ntaps < 2 || a.ntaps > 16 || a.Wg < 2) return 1;
     int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
     for (int t = 0; t < a.ntaps; ++t) {
@@ -433,7 +458,7 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
             t.tiles_x = Wg / wt; t.tiles_per_img = (Hg / r) * t.tiles_x;
         }
         t.pw_magic = wgs_div_magic(t.PW); t.wg_magic = wgs_div_magic(Wg); t.wt_magic = wgs_div_magic(t.Wt);
-        t.npl = (t.PH * t.PW * 8 + tbm - 1) / tbm;           // threads per workgroup = tile rows (64 x 8 or 64 x 4)
+        t.npl = (t.PH * t.PW * epp + tbm - 1) / tbm;         // threads per workgroup = tile rows (64 x 8 or 64 x 4)
         const int nb = a.B * t.tiles_per_img * (a.Co / tbn);
         if (nb < 200) return;
         bm = tbm; bn = tbn; nblocks = nb; g = t;
@@ -445,7 +470,7 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
     try_shape(128, 128);
     if (!bm) return 1;
     ConvArgs b = a;
-    b.w_bytes = a.w_bytes / 2;          // extents of the 16-bit weight planes (x stays fp32)
+    b.w_bytes = a.w_bytes / 2;          // extents of the 16-bit weight planes (x_bytes: fp32, or the fp16 plane's when a.a_hi)
     if (bm == 256 && bn == 256) launch_patch<256, 256, 2, 4>(b, g, nblocks, st);
     else if (bm == 256) launch_patch<256, 128, 4, 2>(b, g, nblocks, st);
     else launch_patch<128, 128, 2, 2>(b, g, nblocks, st);

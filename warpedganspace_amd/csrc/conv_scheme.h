@@ -119,16 +119,21 @@ template <int SCH> struct SchemeRow { static constexpr int BYTES = 32 * Scheme<S
 // (2^16), 26 above its smallest normal number — and inv = 2^-k for the accumulator.  amax == 0 / NaN / inf: no scaling.
 // amax2 (optional second device scalar) multiplies the bound: forward launches pass max|x| of the producing layer and
 // max|style| separately.
-__device__ __forceinline__ void operand_scale(const float* amax_ptr, const float* amax2_ptr, float bound, float& mult, float& inv) {
+// mult = 2^k with am * 2^k in [2^11, 2^12), inv = 2^-k; am == 0 / NaN / inf / denormal: no scaling
+__device__ __forceinline__ void scale_of_bound(float am, float& mult, float& inv) {
     mult = 1.f; inv = 1.f;
-    if (!amax_ptr) return;
-    const float am = amax_ptr[0] * bound * (amax2_ptr ? amax2_ptr[0] : 1.f);
     const int e = (__float_as_int(am) >> 23) & 0xff;       // am in [2^(e-127), 2^(e-126))
     if (!(am > 0.f) || e == 0 || e == 255) return;
     int k = 127 + 12 - (e - 126);                         // biased exponent of 2^(12 - (e - 126))
     k = k < 1 ? 1 : (k > 253 ? 253 : k);
     mult = __int_as_float(k << 23);
     inv = __int_as_float((254 - k) << 23);
+}
+
+__device__ __forceinline__ void operand_scale(const float* amax_ptr, const float* amax2_ptr, float bound, float& mult, float& inv) {
+    mult = 1.f; inv = 1.f;
+    if (!amax_ptr) return;
+    scale_of_bound(amax_ptr[0] * bound * (amax2_ptr ? amax2_ptr[0] : 1.f), mult, inv);
 }
 
 }  // namespace wgsconv

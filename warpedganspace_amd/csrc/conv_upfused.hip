@@ -25,6 +25,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -57,6 +58,8 @@ struct UpArgs {
     int B, H, Ci, Co, a_ld, col_ld;
     int x_bytes, w_bytes, s_bytes, y_bytes;
     int tiles_x, tiles_per_img;
+    unsigned short* y_f16; const float* y_f16_scale; float* y_f16_bound;     // optional plane of the NEXT conv's operand (wgs.h)
+    float y_f16_mul, y_f16_add; int y_f16_ld, yh_bytes;
     int w_row_stride;          // elements between output channels of a weight plane (9 * Ci)
     int tap_w[9];              // element offset of issue-order product t's weight tap (T_W[t] * Ci)
 };
@@ -82,7 +85,7 @@ struct UpCfg {
     static constexpr int K_BYTES = 2 * NA * P_BYTES + 2 * B_STAGE;
     static constexpr int T_BYTES = TW * TH * 32 * 4;                   // t tile: TH x TW positions x 32 channels fp32
     static constexpr int MAIN = K_BYTES > T_BYTES ? K_BYTES : T_BYTES;
-    static constexpr int AUX_FLOATS = OR * OW + 2 * BN;                // noise of the output block | bias | demodulation
+    static constexpr int AUX_FLOATS = OR * OW + 3 * BN;                // noise of the output block | bias | demodulation | next layer's style
     static constexpr int SMEM = MAIN + AUX_FLOATS * 4;
 };
 
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     float* aux_nz = reinterpret_cast<float*>(smem_b + CF::MAIN);
     float* aux_bias = aux_nz + OR * OW;
     float* aux_cs = aux_bias + BN;
+    float* aux_sn = aux_cs + BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         if (tid < BN) {
             aux_bias[tid] = p.bias[n0 + tid];
             aux_cs[tid] = p.col_scale[(size_t)b * p.col_ld + n0 + tid];
+            aux_sn[tid] = p.y_f16 ? p.y_f16_scale[(size_t)b * p.y_f16_ld + n0 + tid] : 0.f;
         }
     };
 
@@ -338,7 +343,19 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         }
         sep = sep && dev <= 2e-7f * kmax;
     }
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y : reinterpret_cast<float*>(p.y_f16), 0, p.y ? p.y_bytes : 0, 0x00020000);
+    // The consumer's fp16 operand plane, written here: f16_rn(y * style_next * 2^k).  k comes from an A-PRIORI bound of |y * style_next|
+    // (this kernel cannot know its own output maximum before it has run): |t| <= sqrt(taps * Ci) * max|x| by Cauchy-Schwarz (the
+    // demodulation factor is 1 / ||w * s||), the blur sums to <= 4, then noise, bias and the activation gain — folded by the caller
+    // into y_f16_mul / y_f16_add — times max|style| (a_amax2).  The value is published for the consumer's operand_scale().
+    const __amdgpu_buffer_rsrc_t ryh = __builtin_amdgcn_make_buffer_rsrc(p.y_f16 ? p.y_f16 : const_cast<unsigned short*>(p.w_hi), 0, p.y_f16 ? p.yh_bytes : 0, 0x00020000);
+    float pl_mult = 1.f;
+    if (p.y_f16) {
+        const float am = (p.a_amax[0] * p.y_f16_mul + p.y_f16_add) * (p.a_amax2 ? p.a_amax2[0] : 1.f);
+        float pl_inv;
+        wgsconv::scale_of_bound(am, pl_mult, pl_inv);
+        if (p.y_f16_bound && blockIdx.x == 0 && tid == 0) p.y_f16_bound[0] = am;
+    }
     constexpr int NSTRIP = (NT / 8) / OW, RS = OR / NSTRIP;  // row strips of the blur stage (2 x 12 rows / 1 x 12 rows)
     static_assert(NSTRIP >= 1 && RS * NSTRIP == OR, "blur strips");
     const int bslot = tid >> 3;                           // (strip, column) of the blur stage
@@ -370,6 +387,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         if (bl_live) {
             const int c = n0 + half * 32 + q * 4;
             const float4 bv = *reinterpret_cast<const float4*>(aux_bias + half * 32 + q * 4);
+            const float4 sn = *reinterpret_cast<const float4*>(aux_sn + half * 32 + q * 4);
             const int ox = 2 * x0 + lx;
             // finish one output pixel: noise, bias, activation, magnitude, store
             auto emit = [&](float4 a, int ly) {
@@ -385,7 +403,17 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
                 const int off = ok ? (((b * Ho + oy) * Ho + ox) * p.Co + c) * 4 : OOB;
                 const u32x4 sv = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)};
                 if (WGS_UABL == 7) { asm volatile("" :: "v"(sv), "v"(off)); return; }
-                __builtin_amdgcn_raw_buffer_store_b128(sv, ry, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(sv, ry, off, 0, 0);          // (y == NULL: zero-extent descriptor, the store is dropped)
+                if (p.y_f16) {
+                    // same roundings as the consumer's own staging of the fp32 tensor: fl32(y * s), exact power of two, f16_rn
+                    float4 v;
+                    v.x = __fmul_rn(a.x, sn.x); v.y = __fmul_rn(a.y, sn.y); v.z = __fmul_rn(a.z, sn.z); v.w = __fmul_rn(a.w, sn.w);
+                    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+                    const f32x4 f = {v.x * pl_mult, v.y * pl_mult, v.z * pl_mult, v.w * pl_mult};
+                    uint2 h, l;
+                    wgsconv::Scheme<1>::cvt4(f, h, l);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ryh, ok ? off >> 1 : OOB, 0, 0);
+                }
             };
             if (sep) {
                 // separable kernel (StyleGAN2's [1,3,3,1] outer product): horizontal pass on each loaded row, vertical pass over a
@@ -457,8 +485,10 @@ void launch_up(const UpArgs& a0, hipStream_t st) {
 }  // namespace
 
 extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t stream) {
-    WGS_CHECK_ARG(d && d->x && d->w_hi && d->y && d->a_scale && d->col_scale && d->bias && d->kernel4x4,
+    WGS_CHECK_ARG(d && d->x && d->w_hi && (d->y || d->y_f16) && d->a_scale && d->col_scale && d->bias && d->kernel4x4,
                   "wgs_sg2_upconv_blur_act: null pointer");
+    WGS_CHECK_ARG(!d->y_f16 || (d->y_f16_scale && d->a_amax && d->y_f16_ld >= d->Co && d->y_f16_mul > 0.f && d->y_f16_add >= 0.f),
+                  "wgs_sg2_upconv_blur_act: y_f16 needs y_f16_scale, y_f16_ld >= Co, a_amax and the bound coefficients y_f16_mul > 0, y_f16_add >= 0");
     WGS_CHECK_ARG(d->precision == 2 || d->precision == 3, "wgs_sg2_upconv_blur_act: precision %d (fp16 schemes 2 / 3 only)", d->precision);
     WGS_CHECK_ARG(d->B > 0 && d->H >= 4 && d->Ci % 32 == 0 && d->Ci > 0 && d->Co % 64 == 0 && d->Co > 0,
                   "wgs_sg2_upconv_blur_act: B=%d H=%d Ci=%d (%%32) Co=%d (%%64)", d->B, d->H, d->Ci, d->Co);
@@ -475,6 +505,8 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     a.B = d->B; a.H = d->H; a.Ci = d->Ci; a.Co = d->Co; a.a_ld = d->a_ld; a.col_ld = d->col_ld;
     a.x_bytes = (int)xb; a.w_bytes = (int)wb; a.s_bytes = (int)sb; a.y_bytes = (int)yb;
     a.tiles_x = a.tiles_per_img = 0;
+    a.y_f16 = (unsigned short*)d->y_f16; a.y_f16_scale = d->y_f16_scale; a.y_f16_bound = d->y_f16_bound;
+    a.y_f16_mul = d->y_f16_mul; a.y_f16_add = d->y_f16_add; a.y_f16_ld = d->y_f16_ld; a.yh_bytes = (int)(yb / 2);
     a.w_row_stride = 9 * d->Ci;
     for (int t = 0; t < 9; ++t) a.tap_w[t] = T_W_HOST[t] * d->Ci;
     // 16 x 12-cell tiles (one 8-wave workgroup per CU) unless they would leave the chip short of workgroups: then 14 x 6-cell

@@ -423,6 +423,11 @@ extern "C" {
 
 int wgs_conv_wino_supported(const wgs_conv_desc* d) { return wino_ok(d) ? 1 : 0; }
 
+// U's fragment order depends on the workgroup shape the launch will take (TJ output-channel blocks per wave), and the shape on
+// the batch and map size: a cached U is valid for launches with the same layout id only (a cache keyed on the taps alone
+// handed a B = 1 launch the B = 32 launch's layout).
+int wgs_conv_wino_layout(const wgs_conv_desc* d) { return wino_ok(d) ? wino_tj(d) : -1; }
+
 int wgs_conv_wino_weight(const wgs_conv_desc* d, float* U, wgs_stream_t stream) {
     WGS_CHECK_ARG(wino_ok(d) && U, "wgs_conv_wino_weight: not a 3x3 stride-1 'same' launch the Winograd kernel covers (wgs_conv_wino_supported)");
     WinoTaps tp;

@@ -41,6 +41,9 @@ static WgsFlags read_flags() {
     g.wino_small = getenv("WGS_WINO_SMALL") != nullptr;      // Winograd fp32: 4-wave workgroups of 32 tiles x 64 channels, two per CU
     g.wino_narrow = getenv("WGS_WINO_NARROW") != nullptr;    // Winograd fp32: the 64-tile x 64-channel workgroup shape even where Cout % 128 == 0
     g.f32_old = getenv("WGS_F32_OLD") != nullptr;      // exact fp32: the plain three-phase kernel of conv_igemm.hip everywhere
+    // producer-written fp16 activation planes (x_f16): stride-1 3x3 launches with fewer output columns than this take the patch form,
+    // the others the LDS-DMA kernel (development: WGS_PLANE_PATCH_MAX_CO=0 pins the LDS-DMA kernel, 100000 the patch form)
+    g.plane_patch_max_co = getenv("WGS_PLANE_PATCH_MAX_CO") ? atoi(getenv("WGS_PLANE_PATCH_MAX_CO")) : 512;
     return g;
 }
 static WgsFlags& flags_storage() {
@@ -51,7 +54,7 @@ const WgsFlags& wgs_flags() { return flags_storage(); }
 
 extern "C" {
 const char* wgs_last_error(void) { return g_err; }
-int wgs_abi_version(void) { return 5; }      // 5: wgs_conv_wino_*, wgs_pixelnorm_bwd_act
+int wgs_abi_version(void) { return 6; }      // 6: wgs_conv_wino_layout; fp16 activation planes through the patch kernel
 void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
 int64_t wgs_dev_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 void wgs_dev_trace_kernels(int on) { g_trace.store(on ? 1 : 0, std::memory_order_relaxed); g_kernel[0] = 0; }

@@ -33,7 +33,8 @@ void wgs_set_error(const char* fmt, ...);
 // WGS_PATCH_NTF0, WGS_WGRAD_PER_TAP, WGS_PATCH_WIDE, WGS_F32_SMALL, WGS_F32_OLD, WGS_WINO_NARROW, WGS_WINO_SMALL): read from the
 // environment ONCE, when the first launch asks for them, and immutable afterwards — no getenv on launch paths, no mutable
 // global state.  All default to off = the measured-best path.
-struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap, patch_wide, f32_small, f32_old, wino_narrow, wino_small; };
+struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap, patch_wide, f32_small, f32_old, wino_narrow, wino_small;
+                  int plane_patch_max_co; };
 const WgsFlags& wgs_flags();
 
 // Launch accounting for bench.py (statistics only; nothing reads them on a launch path):

@@ -128,7 +128,8 @@ class GenModel(nn.Module):
                     bb = torch.zeros(pad_co, device=dev)
                     bb[:co] = b
                     wp, b, co = wpp, bb, pad_co
-                return dict(wp=wp, wt=C.repack_w_t(wp, co, 9, ci), b=b, ci=ci, co=co)
+                wt = C.repack_w_t(wp, co, 9, ci)
+                return dict(wp=wp, wt=wt, wc=C.WinoCache(wp), wtc=C.WinoCache(wt), b=b, ci=ci, co=co)
             for i in range(self.nblocks):
                 blk = self.seq[2 + i]
                 d = dict(bn1=blk.model[0], bn2=blk.model[4], c1=packs(blk.conv1), c2=packs(blk.conv2),
@@ -227,10 +228,10 @@ class GenModel(nn.Module):
             c1, c2 = d['c1'], d['c2']
             # y = conv2(a2) + b2 + bypass(x)
             ga2 = torch.empty_like(a2)
-            launch(g, c2['wt'], ga2, dtaps, 2 * H, 2 * H, w_tap_stride=c2['ci'] * c2['co'], w_row_stride=c2['co'])
+            launch(g, c2['wt'], ga2, dtaps, 2 * H, 2 * H, w_tap_stride=c2['ci'] * c2['co'], w_row_stride=c2['co'], w_split=c2['wtc'])
             gh1 = self._bn_relu_bwd(d['bn2'], h1, s2, ga2, a2, P['ws'])
             gup = torch.empty(B, 2 * H, 2 * H, c1['ci'], device=dev)
-            launch(gh1, c1['wt'], gup, dtaps, 2 * H, 2 * H, w_tap_stride=c1['ci'] * c1['co'], w_row_stride=c1['co'])
+            launch(gh1, c1['wt'], gup, dtaps, 2 * H, 2 * H, w_tap_stride=c1['ci'] * c1['co'], w_row_stride=c1['co'], w_split=c1['wtc'])
             ga1 = torch.empty_like(a1)
             L.check(lib.wgs_upsample2x_bwd(L.ptr(gup), L.ptr(ga1), B, H, H, c1['ci'], st), 'up_bwd')
             gx = self._bn_relu_bwd(d['bn1'], x, s1, ga1, a1, P['ws'])
@@ -239,7 +240,7 @@ class GenModel(nn.Module):
             else:
                 bp = d['byp']
                 gb_up = torch.empty(B, 2 * H, 2 * H, bp['ci'], device=dev)
-                launch(g, bp['wt'], gb_up, dtaps, 2 * H, 2 * H, w_tap_stride=bp['ci'] * bp['co'], w_row_stride=bp['co'])
+                launch(g, bp['wt'], gb_up, dtaps, 2 * H, 2 * H, w_tap_stride=bp['ci'] * bp['co'], w_row_stride=bp['co'], w_split=bp['wtc'])
             gbyp = torch.empty_like(x)
             L.check(lib.wgs_upsample2x_bwd(L.ptr(gb_up), L.ptr(gbyp), B, H, H, x.shape[3], st), 'byp_up_bwd')
             g = gx + gbyp

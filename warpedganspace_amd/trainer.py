@@ -180,14 +180,21 @@ class TrainStep:
         image error of this engine's arithmetic against the exact-fp32 kernels on a fresh batch of latent codes, with THIS
         generator's weights.  Max-norm relative error, of the batch tensor (how the parity tests apply the north_star's 1e-3 gate)
         and per single image.  Draws from its own generator (identical on every rank): the training sample stream is untouched.  None for fp32 engines."""
-        if self.precision == 0:
+        if not C.is_reduced(self.precision):
             return None
         g = torch.Generator(device=self.dev)
         g.manual_seed(0x5DEECE66D + self.steps_done)       # the same codes on every rank: every rank takes the same decision
         z = sample_z(self.B, self.G.dim_z, truncation=getattr(self.p, 'z_truncation', None), device=self.dev, generator=g)
+        # a class-conditional wrapper draws its class ids per call (numpy RNG, different on every rank): both passes must render the
+        # SAME classes, and every rank the same ones — drawn here from the check's own generator (ADVICE r3)
+        kw = {}
+        tc = getattr(self.G, 'target_classes', None)
+        if tc is not None and hasattr(self.G, 'mixed_classes'):
+            pool = tc.detach().reshape(-1).to(self.dev)
+            kw['classes'] = pool[torch.randint(0, pool.numel(), (self.B,), device=self.dev, generator=g)]
         with torch.no_grad():
-            ref = self.G(z, precision='fp32')
-            img = self.G(z, precision=self.precision)
+            ref = self.G(z, precision='fp32', **kw)
+            img = self.G(z, precision=self.precision, **kw)
             d, m = (img - ref).abs().flatten(1).amax(1), ref.abs().flatten(1).amax(1)
             per = (d / m.clamp_min(1e-30)).cpu()
             batch = float(d.max() / m.max().clamp_min(1e-30))
@@ -475,7 +482,7 @@ class Trainer(object):
         if self.rank == 0:
             print("#. Start training from iteration {}".format(starting_iter))
         check_every = int(getattr(p, 'check_precision', 0) or 0)
-        if engine.precision >= 2:        # an fp16-operand mode: check it once against the exact-fp32 kernels on THESE weights
+        if C.is_f16_operand(engine.precision):      # an fp16-operand mode: check it once against the exact-fp32 kernels on THESE weights
             self.precision_check(engine, starting_iter - 1)
         t0 = time.time()
         # Iteration time: the launches are asynchronous, so a per-iteration host clock would measure launch latency.  The
@@ -483,7 +490,7 @@ class Trainer(object):
         mark_t, mark_iter = t0, starting_iter - 1
         for iteration in range(starting_iter, p.max_iter + 1):
             engine.step()
-            if check_every and engine.precision >= 1 and iteration % check_every == 0:
+            if check_every and C.is_reduced(engine.precision) and iteration % check_every == 0:
                 self.precision_check(engine, iteration)
             if self.tb_writer is not None or iteration % p.log_freq == 0:
                 stats = engine.pop_stats()           # one device sync
