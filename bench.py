@@ -573,6 +573,11 @@ def main():
     if args.single_stream:
         ENGINE_KW['two_streams'] = False
 
+    if os.environ.get('WGS_PRIO') == '0':            # development A/B: no high-priority stream for the step's critical path
+        ENGINE_KW['priority_main'] = False
+    if os.environ.get('WGS_FWD_PLANE') == '0':       # development A/B: forward fp16 planes off (conv.FWD_PLANE)
+        C.FWD_PLANE = False
+        C.DY_PLANE_MIN_CO = 256
     in_job = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
     if args.gpus > 1 and not in_job:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.dist_backend))

@@ -1,0 +1,172 @@
+"""GPU: forward fp16 activation planes — the fused up-sampling kernel writes the operand plane of the
+stride-1 conv behind it (wgs_upconv_desc.y_f16: that conv's style vector and power-of-two scale folded in), and the conv stages
+the plane as it is through the patch kernel's XF16 form (wgs_conv_desc.x_f16).  Replaces, between the two kernels, the fp32 tensor
+the reference moves (models/StyleGAN2/model.py:187-228 modulation of the NEXT layer, op/fused_bias_act_kernel.cu:18-49 the store).
+
+  * the plane holds exactly f16_rn(fl32(y * s_next) * 2^k), k from the a-priori bound the kernel publishes; y itself is unchanged;
+  * a pass that keeps nothing (y = NULL) writes the same plane;
+  * the conv fed with the plane returns the SAME BITS as the conv fed with the fp32 tensor + style vector under the same scale,
+    through the patch kernel (Cout < 512) and through the LDS-DMA kernel;
+  * the a-priori bound is a bound (>= the true maximum) and not absurdly loose;
+  * a generator forward / backward with the route on and off: same image bits (scales differ by powers of two only), same gradient."""
+import math
+
+import pytest
+import torch
+
+from warpedganspace_amd import _lib as L
+from warpedganspace_amd import conv as C
+
+pytestmark = pytest.mark.gpu
+SQRT2 = 2.0 ** 0.5
+
+
+def blur_kernel(dev):
+    k = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k2 = k[:, None] * k[None, :]
+    return (k2 / k2.sum() * 4.0).to(dev).contiguous()
+
+
+def _layer(dev, B, Ci, Co, H, seed, xmag=1.0):
+    torch.manual_seed(seed)
+    x = (torch.randn(B, H, H, Ci, device=dev) * xmag).contiguous()
+    w = torch.randn(Co, 9, Ci, device=dev) / (9 * Ci) ** 0.5
+    sumC = Ci + Co + 40
+    S = (torch.randn(B, sumC, device=dev) + 1.0).contiguous()
+    wsq = (w * w).sum(1)                                                      # [Co, Ci]
+    demod = torch.rsqrt((S[:, :Ci] ** 2) @ wsq.t() + 1e-8).contiguous()      # the layer's real demodulation vector: the bound relies on it
+    noise, nw, bias = torch.randn(4 * H * H, device=dev), torch.full((1,), 0.3, device=dev), torch.randn(Co, device=dev) * 0.2
+    xmax = x.abs().amax().reshape(1).contiguous()
+    smax = S.abs().amax().reshape(1).contiguous()
+    mul = SQRT2 * 4.0 * 2.0 * math.sqrt(Ci)
+    add = SQRT2 * (0.3 * float(noise.abs().max()) + float(bias.abs().max()))
+    return dict(x=x, w=w, ws=C.split_weight(w, 3), S=S, sumC=sumC, demod=demod, noise=noise, nw=nw, bias=bias, xmax=xmax, smax=smax, mul=mul, add=add,
+                s_next=S[:, Ci + 8:])
+
+
+def _k_of(a):
+    k = 0
+    while a * 2.0 ** k < 2048.0:
+        k += 1
+    while a * 2.0 ** k >= 4096.0:
+        k -= 1
+    return k
+
+
+@pytest.mark.parametrize('prec', [2, 3])
+@pytest.mark.parametrize('B,Ci,Co,H,xmag', [(2, 64, 128, 32, 1.0), (1, 32, 64, 20, 1e-5), (3, 96, 128, 16, 3e4), (2, 64, 64, 33, 1.0)])
+def test_plane_bits_bound_and_unchanged_output(dev, prec, B, Ci, Co, H, xmag):
+    t = _layer(dev, B, Ci, Co, H, 11 * Ci + H + prec, xmag)
+    kern = blur_kernel(dev)
+    args = (t['x'], t['ws'], kern, t['S'], t['sumC'], t['demod'], t['noise'], t['nw'], t['bias'], prec)
+    kw = dict(a_amax=t['xmax'], a_amax2=t['smax'])
+    y0 = C.upconv_blur_act(*args, **kw)
+    pl = dict(scale=t['s_next'], ld=t['sumC'], mul=t['mul'], add=t['add'])
+    y1, plane, bound = C.upconv_blur_act(*args, plane=dict(pl, keep_y=True), **kw)
+    assert torch.equal(y0, y1)
+    yn, plane2, bound2 = C.upconv_blur_act(*args, plane=dict(pl, keep_y=False), **kw)
+    assert yn is None and torch.equal(plane, plane2) and torch.equal(bound, bound2)
+    want_bound = (t['xmax'] * t['mul'] + t['add']) * t['smax']
+    assert abs(bound.item() - want_bound.item()) <= 1e-6 * want_bound.item()
+    ys = (y0 * t['s_next'][:, None, None, :Co])                              # fl32(y * s)
+    true_max = ys.abs().max().item()
+    assert true_max <= bound.item() <= 4096.0 * true_max, (true_max, bound.item())     # a bound, and inside fp16's exponent head-room
+    k = _k_of(bound.item())
+    assert torch.equal(plane, (ys * 2.0 ** k).half().view(torch.int16))
+
+
+@pytest.mark.parametrize('B,C1,C2,H,route', [(32, 128, 128, 64, 'patch'), (8, 256, 256, 64, 'patch'), (32, 128, 128, 64, 'dma'), (4, 64, 256, 64, 'auto')])
+def test_conv_fed_with_the_plane_returns_the_same_bits(dev, B, C1, C2, H, route):
+    """y [B,H,H,C1] -> 3x3 stride-1 conv to C2 channels, plain fp16: plane route vs fp32 tensor + style vector under the same scale."""
+    torch.manual_seed(C1 + C2 + H)
+    lib = L.lib()
+    y = torch.randn(B, H, H, C1, device=dev)
+    S = (torch.randn(B, C1 + 30, device=dev) + 1.0).contiguous()
+    s_next = S[:, 6:]
+    w = torch.randn(C2, 9, C1, device=dev) / (9 * C1) ** 0.5
+    ws = C.split_weight(w, 2)
+    demod = torch.rand(B, C2, device=dev) + 0.5
+    noise, nw, bias = torch.randn(H * H, device=dev), torch.full((1,), 0.3, device=dev), torch.randn(C2, device=dev) * 0.2
+    bound = ((y * s_next[:, None, None, :C1]).abs().amax() * 37.0).reshape(1).contiguous()        # any over-estimate
+    k = _k_of(bound.item())
+    plane = ((y * s_next[:, None, None, :C1]) * 2.0 ** k).half().view(torch.int16).contiguous()
+    epi = dict(col_scale=demod, noise=noise, noise_w=nw, bias=bias, act_slope=0.2, gain=SQRT2, w_split=ws, precision=2)
+    ref = C.conv2d(y, w, 3, pad=1, a_scale=s_next, a_ld=S.shape[1], a_amax=bound, a_bound=1.0, **epi)
+    import os
+    if route != 'auto':
+        os.environ['WGS_PLANE_PATCH_MAX_CO'] = '100000' if route == 'patch' else '0'
+        lib.wgs_dev_reload_flags()
+    try:
+        lib.wgs_dev_trace_kernels(1)
+        got = C.conv2d(plane, w, 3, pad=1, a_amax=bound, a_bound=1.0, x_f16=True, out=torch.empty_like(ref), **epi)
+        sym = lib.wgs_dev_last_kernel().decode()
+    finally:
+        lib.wgs_dev_trace_kernels(0)
+        os.environ.pop('WGS_PLANE_PATCH_MAX_CO', None)
+        lib.wgs_dev_reload_flags()
+    want = {'patch': 'igemm_patch_kernel', 'dma': 'igemm_dma16_kernel', 'auto': 'igemm_dma16_kernel'}[route]       # auto: Cout >= 256 -> LDS-DMA
+    assert sym.startswith(want) and ((', true>' in sym) if want == 'igemm_patch_kernel' else True), sym
+    if route == 'patch':
+        assert torch.equal(got, ref)              # same kernel family, same tile, same MFMA order: same bits
+    assert (got - ref).abs().max() <= 2e-6 * ref.abs().max()
+    full = torch.nn.functional.conv2d((y * s_next[:, None, None, :C1]).permute(0, 3, 1, 2).double(),
+                                      w.double().reshape(C2, 3, 3, C1).permute(0, 3, 1, 2), padding=1)
+    full = torch.nn.functional.leaky_relu(full * demod.double()[:, :, None, None] + 0.3 * noise.double().view(1, 1, H, H) + bias.double()[None, :, None, None], 0.2) * SQRT2
+    assert (got.double().permute(0, 3, 1, 2) - full).abs().max() <= 2e-3 * full.abs().max()
+
+
+@pytest.mark.parametrize('size,prec', [(256, 'auto'), (128, 'f16')])
+def test_generator_same_image_and_gradient_with_and_without_forward_planes(dev, monkeypatch, size, prec):
+    from tests import golden_inputs as GI
+    from warpedganspace_amd.stylegan2 import Generator
+    torch.manual_seed(0)
+    G = Generator(size, 512, 8)
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 977))
+    G = G.to(dev).eval()
+    G.precision = 'auto'
+    B = 32 if size == 128 else 16
+    z = torch.randn(B, 512, device=dev)
+    imgs, grads, nograd = [], [], []
+    lib = L.lib()
+    for on in (True, False):
+        monkeypatch.setattr(C, 'FWD_PLANE', on)
+        with torch.no_grad():
+            nograd.append(G([z], precision=prec)[0].clone())        # the pass that keeps nothing: the up-convs write only the planes
+        zz = z.clone().requires_grad_(True)
+        img = G([zz], precision=prec)[0]
+        gi = torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)
+        img.backward(gi)
+        imgs.append(img.detach().clone()); grads.append(zz.grad.clone())
+    assert torch.isfinite(imgs[0]).all() and torch.isfinite(grads[0]).all()
+    # the pass that keeps nothing and the pass that saves for the backward take the same route: same bits
+    assert torch.equal(nograd[0], imgs[0]) and torch.equal(nograd[1], imgs[1])
+    # On vs off: every operand gets the same fp16 rounding unless it lies below the looser (a-priori) scale's normal range; those
+    # values (activations next to a leaky-relu zero crossing) move the consuming conv's fp32 sums by ~1 ulp in ~1 % of its outputs, and
+    # a 1-ulp fp32 difference flips the fp16 rounding of the NEXT layer's operand once in 2^13: measured 2e-5 of the image maximum
+    # (the fp16 mode's own error is 5e-4, the gate 1e-3).  Bit-equality of the kernels themselves is asserted above.
+    e_img = float((imgs[0] - imgs[1]).abs().max() / imgs[1].abs().max())
+    e_g = float((grads[0] - grads[1]).abs().max() / grads[1].abs().max())
+    print('forward planes on vs off, StyleGAN2-%d %s: image %.2e, gradient %.2e' % (size, prec, e_img, e_g))
+    assert e_img <= 1e-4
+    assert e_g <= 1e-3
+
+
+def test_the_route_is_taken_in_the_default_policy(dev):
+    """StyleGAN2-256 under 'auto' at the training batch: both plain-fp16 stride-1 convs (128^2, 256^2) read a producer-written plane."""
+    from warpedganspace_amd.gan_load import build_stylegan2
+    torch.manual_seed(0)
+    G = build_stylegan2(None, resolution=256).to(dev).eval()
+    z = torch.randn(32, 512, device=dev)
+    C.PROFILE = []
+    L.lib().wgs_dev_trace_kernels(1)
+    try:
+        with torch.no_grad():
+            G(z, precision='auto')
+        torch.cuda.synchronize()
+        syms = [r[4] for r in C.PROFILE if r[0] and ' 9 taps' in r[0] and (r[0].startswith('conv f16 128->128 @256') or r[0].startswith('conv f16 256->256 @128'))]
+    finally:
+        L.lib().wgs_dev_trace_kernels(0)
+        C.PROFILE = None
+    # the 128-column launch through the patch kernel's XF16 form, the 256-column one through the LDS-DMA kernel: neither stages fp32
+    assert len(syms) == 2 and sorted(s.split('<')[0] for s in syms) == ['igemm_dma16_kernel', 'igemm_patch_kernel'] and \
+        all(s.endswith(', true>') for s in syms if s.startswith('igemm_patch')), syms

@@ -390,7 +390,9 @@ class UpconvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'w_hi', 'w_lo', 'y', 'a_scale', 'col_scale', 'bias', 'noise', 'noise_w',
                                                'kernel4x4', 'a_amax', 'a_amax2', 'y_amax')] + \
                [('a_bound', ctypes.c_float), ('alpha', ctypes.c_float)] + \
-               [(n, ctypes.c_int32) for n in ('B', 'H', 'Ci', 'Co', 'a_ld', 'col_ld', 'precision')]
+               [(n, ctypes.c_int32) for n in ('B', 'H', 'Ci', 'Co', 'a_ld', 'col_ld', 'precision')] + \
+               [(n, ctypes.c_void_p) for n in ('y_f16', 'y_f16_scale', 'y_f16_bound')] + \
+               [('y_f16_mul', ctypes.c_float), ('y_f16_add', ctypes.c_float), ('y_f16_ld', ctypes.c_int32)]
 
 
 # The fused up-sampling layer (conv_upfused.hip) is taken for the fp16 modes from this input size up (below it a 14 x 14-cell
@@ -402,20 +404,41 @@ def upconv_fused_ok(H, Ci, Co, precision):
     return precision in (2, 3) and H >= UPCONV_FUSED_MIN_H[precision] and Ci % 32 == 0 and Co % 64 == 0
 
 
+# Forward planes: the fused up-sampling kernel writes the fp16 operand plane of the stride-1 conv that follows it (that conv's style
+# vector and power-of-two scale folded in, wgs_upconv_desc.y_f16), and that conv stages the plane as it is through the patch kernel's
+# XF16 form — same bits as staging the fp32 tensor, without the multiply / scale / convert work and with half the operand bytes.
+FWD_PLANE = True
+
+
+def fwd_plane_ok(B, Hout, C, Co_next, lp_next):
+    """the up-conv's output [B,Hout,Hout,C] may be handed to the next (stride-1, plain fp16) conv as its operand plane"""
+    return FWD_PLANE and lp_next == 2 and C % 32 == 0 and Co_next % 128 == 0 and _plane_fits(B, Hout, Hout, C) and \
+        (B * Hout * Hout // 256) * (Co_next // 128) >= 200
+
+
 def upconv_blur_act(x, w_split, blur_kernel, a_scale, a_ld, col_scale, noise, noise_w, bias, precision,
-                    a_amax=None, a_amax2=None, y_amax=None, alpha=1.0):
+                    a_amax=None, a_amax2=None, y_amax=None, alpha=1.0, plane=None):
     """StyleGAN2's up-sampling StyledConv in one launch (wgs_sg2_upconv_blur_act): modulated conv_transpose2d(stride 2) +
     Blur(pad (1,1)) + noise + bias + leaky-relu*sqrt(2) (models/StyleGAN2/model.py:201-212,231-241,264).
-    x [B,H,H,Ci] NHWC; w_split: SplitCache / (hi, lo) fp16 planes of the [Co,9,Ci] weights; returns y [B,2H,2H,Co]."""
+    x [B,H,H,Ci] NHWC; w_split: SplitCache / (hi, lo) fp16 planes of the [Co,9,Ci] weights; returns y [B,2H,2H,Co].
+    plane = dict(scale=<next layer's style rows>, ld=<their row stride>, mul=, add=, keep_y=): also write the next conv's fp16 operand
+    plane (needs a_amax); returns (y or None, plane int16 [B,2H,2H,Co], bound [1]) instead of y."""
     B, H, W, Ci = x.shape
     if isinstance(w_split, SplitCache):
         w_split = w_split.get(precision)
     Co = w_split[0].shape[0]
     if not (x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and H == W):
         raise L.WgsError("upconv_blur_act needs a contiguous square fp32 GPU tensor (no CPU fallback)")
-    y = torch.empty(B, 2 * H, 2 * H, Co, device=x.device)
+    y = torch.empty(B, 2 * H, 2 * H, Co, device=x.device) if (plane is None or plane.get('keep_y', True)) else None
     d = UpconvDesc()
-    d.x, d.w_hi, d.w_lo, d.y = x.data_ptr(), w_split[0].data_ptr(), _p(w_split[1]), y.data_ptr()
+    d.x, d.w_hi, d.w_lo, d.y = x.data_ptr(), w_split[0].data_ptr(), _p(w_split[1]), _p(y)
+    if plane is not None:
+        if a_amax is None:
+            raise L.WgsError("upconv_blur_act: a forward plane needs the magnitude scalar of the input (a_amax)")
+        yh = torch.empty(B, 2 * H, 2 * H, Co, device=x.device, dtype=torch.int16)
+        yb = torch.empty(1, device=x.device)
+        d.y_f16, d.y_f16_scale, d.y_f16_bound = yh.data_ptr(), plane['scale'].data_ptr(), yb.data_ptr()
+        d.y_f16_mul, d.y_f16_add, d.y_f16_ld = plane['mul'], plane['add'], plane['ld']
     d.a_scale, d.col_scale, d.bias, d.noise, d.noise_w = _p(a_scale), _p(col_scale), _p(bias), _p(noise), _p(noise_w)
     d.kernel4x4, d.a_amax, d.a_amax2, d.y_amax = _p(blur_kernel), _p(a_amax), _p(a_amax2), _p(y_amax)
     d.a_bound, d.alpha = 1.0, alpha
@@ -423,7 +446,7 @@ def upconv_blur_act(x, w_split, blur_kernel, a_scale, a_ld, col_scale, noise, no
     kind = ('conv %s %d->%d @%dx%d up-conv + blur fused B%d' % (precision_name(precision), Ci, Co, H, H, B)) if PROFILE is not None else None
     _timed(kind, 2.0 * B * H * H * 9 * Co * Ci,
            lambda: L.check(L.lib().wgs_sg2_upconv_blur_act(ctypes.byref(d), L.stream()), 'wgs_sg2_upconv_blur_act'))
-    return y
+    return y if plane is None else (y, yh, yb)
 
 
 def conv_transpose2d_s2_dgrad(dy, wt_packed, k=3, **epi):
@@ -443,7 +466,8 @@ BLUR_BWD_F16 = True
 # The same for the stride-1 layers: sg2_act_bwd stores dy only as the fp16 plane of the gradient conv (wgs_sg2_act_bwd_f16), scaled
 # from an a-priori magnitude bound (wgs_sg2_dy_bound) since its own maximum is not known before it has run.
 DY_PLANE = True
-DY_PLANE_MIN_CO = 256       # below: the DMA form re-reads every activation row nine times from L2 (128 -> 128 @256^2: 0.98 vs 0.83 ms)
+DY_PLANE_MIN_CO = 128       # (round 3: 256 — the plane then had only the LDS-DMA kernel, which re-reads every activation row nine times from L2;
+                            #  planes of stride-1 launches with < 512 output columns now go through the patch kernel's XF16 form)
 # The LDS-DMA kernel addresses an fp16 operand plane through one buffer descriptor: its extent (2 bytes per element) must stay
 # below 2^31 bytes; larger planes (StyleGAN2-256 at a per-GPU batch >= 64: dt [64,257,257,128]) take the fp32 route.
 PLANE_MAX_BYTES = (1 << 31) - 1

@@ -43,7 +43,7 @@ static WgsFlags read_flags() {
     g.f32_old = getenv("WGS_F32_OLD") != nullptr;      // exact fp32: the plain three-phase kernel of conv_igemm.hip everywhere
     // producer-written fp16 activation planes (x_f16): stride-1 3x3 launches with fewer output columns than this take the patch form,
     // the others the LDS-DMA kernel (development: WGS_PLANE_PATCH_MAX_CO=0 pins the LDS-DMA kernel, 100000 the patch form)
-    g.plane_patch_max_co = getenv("WGS_PLANE_PATCH_MAX_CO") ? atoi(getenv("WGS_PLANE_PATCH_MAX_CO")) : 512;
+    g.plane_patch_max_co = getenv("WGS_PLANE_PATCH_MAX_CO") ? atoi(getenv("WGS_PLANE_PATCH_MAX_CO")) : 256;
     return g;
 }
 static WgsFlags& flags_storage() {

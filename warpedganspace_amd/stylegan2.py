@@ -239,6 +239,13 @@ class Generator(nn.Module):
                     noise_w=sc.noise.weight.contiguous(), bias=sc.activate.bias.contiguous(),
                     blur=(m.blur.kernel.contiguous() if m.upsample else None),
                     blur_f=(torch.flip(m.blur.kernel, [0, 1]).contiguous() if m.upsample else None)))
+                if m.upsample:
+                    # a-priori bound of the layer's output for a forward fp16 plane (wgs_upconv_desc.y_f16): |t| <= sqrt(4 Ci) max|x|
+                    # (Cauchy-Schwarz over a phase's <= 4 taps; the demodulation factor is <= 1 / ||w s||), blur gain sum|k|, then
+                    # noise, bias and the activation's sqrt(2)
+                    ly_ = P['layers'][-1]
+                    ly_['plane_mul'] = SQRT2 * float(m.blur.kernel.abs().sum()) * 2.0 * math.sqrt(m.in_channel)
+                    ly_['plane_add'] = SQRT2 * (float(sc.noise.weight.abs().max()) * float(ly_['noise'].abs().max()) + float(sc.activate.bias.abs().max()))
                 mods.append(m.modulation)
                 off += m.in_channel
                 # ToRGB sits after conv1 and after every second conv of `convs`
@@ -347,17 +354,31 @@ class Generator(nn.Module):
                 L.check(lib.wgs_linear_fwd(L.rawptr(S[:, ly['off']:]), L.ptr(ly['wsq']), None, L.ptr(demods[i]), B, ly['Co'], ly['Ci'],
                                            sumC, ly['Co'], L.c_float(ly['scale'] ** 2), L.c_float(0.0), 1, 2, L.c_float(1e-8),
                                            L.c_float(ly['scale']), st), 'demod')
+        xplane = None          # (fp16 operand plane, its magnitude bound) of the current layer's input, written by the producing up-conv
         for i, ly in enumerate(P['layers']):
             Ci, Co = ly['Ci'], ly['Co']
             s_view = S[:, ly['off']:]
             demod = demods[i]
-            H = x.shape[1]
+            H = (x if x is not None else xplane[0]).shape[1]
             lp = C.layer_precision(prec, 2 * H if ly['up'] else H, ly['up'], pol)      # 'mixed': per-layer arithmetic
             sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp in (2, 3)) else {}
             ymax = xmax[i + 1] if f16_chain else None
-            if ly['up'] and C.upconv_fused_ok(H, Ci, Co, lp):
-                y = C.upconv_blur_act(x, ly['wp_s'], ly['blur'], s_view, sumC, demod, ly['noise'], ly['noise_w'], ly['bias'], lp,
-                                      y_amax=ymax, **sc_kw)
+            if xplane is not None:
+                # the producing up-conv wrote this conv's fp16 operand plane (style and scale folded in): staged as it is
+                y = C.conv2d(xplane[0], ly['wp'], 3, pad=1, col_scale=demod, noise=ly['noise'], noise_w=ly['noise_w'], bias=ly['bias'],
+                             act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'], precision=lp, y_amax=ymax, a_amax=xplane[1], a_bound=1.0, x_f16=True,
+                             out=torch.empty(B, H, H, Co, device=dev))
+                xplane = None
+            elif ly['up'] and C.upconv_fused_ok(H, Ci, Co, lp):
+                nxt = P['layers'][i + 1] if i + 1 < len(P['layers']) else None
+                if nxt is not None and f16_chain and C.fwd_plane_ok(B, 2 * H, Co, nxt['Co'], C.layer_precision(prec, 2 * H, False, pol)):
+                    y, yh, yb = C.upconv_blur_act(x, ly['wp_s'], ly['blur'], s_view, sumC, demod, ly['noise'], ly['noise_w'], ly['bias'], lp,
+                                                  y_amax=ymax, plane=dict(scale=S[:, nxt['off']:], ld=sumC, mul=ly['plane_mul'], add=ly['plane_add'],
+                                                                          keep_y=save), **sc_kw)
+                    xplane = (yh, yb)
+                else:
+                    y = C.upconv_blur_act(x, ly['wp_s'], ly['blur'], s_view, sumC, demod, ly['noise'], ly['noise_w'], ly['bias'], lp,
+                                          y_amax=ymax, **sc_kw)
             elif ly['up']:
                 t = C.conv_transpose2d_s2(x, ly['wp'], a_scale=s_view, a_ld=sumC, col_scale=demod, w_split=ly['wp_s'], precision=lp,
                                           **sc_kw)

@@ -100,7 +100,7 @@ class TrainStep:
     """One optimisation step of lib/trainer.py:190-261 on this rank's share of the batch."""
 
     def __init__(self, generator, support_sets, reconstructor, params, local_batch, device, world=1, seed=None, rank=0,
-                 start_iter=0, precision=None, r_precision='auto', two_streams=True, defer_wgrad=True, prefetch=True):
+                 start_iter=0, precision=None, r_precision='auto', two_streams=True, defer_wgrad=True, prefetch=True, priority_main=True):
         """precision: arithmetic of the frozen generator's convs (conv.PRECISION_NAMES; None = the generator's own `precision`
         attribute, whose default is the reference's fp32).  r_precision: 'fp32' | 'bf16x3' | 'auto' | reconstructor.RArith —
         arithmetic of the trained Reconstructor's convs ('auto': exact fp32 when the generator runs exact fp32, the fp32-class
@@ -113,6 +113,12 @@ class TrainStep:
         self.gen = torch.Generator(device=device)
         self.side_stream = torch.cuda.Stream(device=device)
         self.pre_stream = torch.cuda.Stream(device=device)
+        # The step's critical path (shifted forward -> R -> loss -> R backward -> G backward -> Adam) runs on a HIGH-priority stream of
+        # its own; the side work that only has to be finished by the end of the step (the un-shifted pass of this / the next batch,
+        # R's weight gradients) stays on default-priority streams: when a CU frees up, the critical path's next workgroups — the
+        # Reconstructor's ~300 short launches in particular — are dispatched ahead of the side streams' long-running generator tiles
+        # instead of queueing behind them.
+        self.main_stream = torch.cuda.Stream(device=device, priority=-1) if (priority_main and two_streams) else None
         self.two_streams = two_streams       # un-shifted generator pass on the side stream
         self.defer_wgrad = defer_wgrad       # R's weight gradients on the side stream, next to the generator's backward
         self.prefetch = prefetch             # G(z) of the NEXT step's batch, next to this step's Reconstructor / backward phases
@@ -216,6 +222,18 @@ class TrainStep:
         return z, idx, mag
 
     def step(self, z=None, idx=None, mag=None):
+        """One training step.  Enqueues on the engine's high-priority stream (ordered after the caller's current stream, which in turn
+        waits for the step: the caller sees ordinary stream semantics) or, without it, on the current stream."""
+        if self.main_stream is None or not self.two_streams:
+            return self._step(z, idx, mag)
+        outer = torch.cuda.current_stream(self.dev)
+        self.main_stream.wait_stream(outer)
+        with torch.cuda.stream(self.main_stream):
+            st = self._step(z, idx, mag)
+        outer.wait_stream(self.main_stream)
+        return st
+
+    def _step(self, z=None, idx=None, mag=None):
         G, S, R, p, B = self.G, self.S, self.R, self.p, self.B
         lib, st = L.lib(), L.stream()
         auto = z is None
