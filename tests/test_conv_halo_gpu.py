@@ -1,0 +1,124 @@
+"""GPU: the few-channel 3x3 stride-1 kernel (csrc/conv_halo16.hip, halo3x3_kernel) — the 64- / 32- / 16-channel layers at 256^2 ..
+1024^2 of StyleGAN2-1024 (models/StyleGAN2/model.py:297-307) and ProgGAN (models/ProgGAN/model.py:65-95).
+
+  * every 16-bit scheme against a float64 convolution of the SAME rounded operands is not needed to pin it: the GEMM-tiled kernels
+    (themselves pinned to fp64, tests/test_conv_gpu.py / test_conv_f16_gpu.py) compute the same products from the same roundings, so the
+    two routes must agree to fp32 summation order (2e-6), forward (styled, demodulated, noise, bias, leaky-relu) and input-gradient
+    (transposed weights, flipped taps) launches alike; plus the mode's own accuracy against fp64 F.conv2d;
+  * the launch really takes the kernel (by symbol), and declines what it does not cover (strides, up-sampling gathers, 1x1, > 64 channels);
+  * Cout = 16 (ProgGAN's last block: half-empty column block) and Cin = 16 (one 16-deep chunk per tap)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from warpedganspace_amd import _lib as L
+from warpedganspace_amd import conv as C
+
+pytestmark = pytest.mark.gpu
+SQRT2 = 2.0 ** 0.5
+
+
+@pytest.fixture()
+def halo_everywhere():
+    os.environ['WGS_HALO_MIN_TILES'] = '1'
+    L.lib().wgs_dev_reload_flags()
+    yield
+    os.environ.pop('WGS_HALO_MIN_TILES', None)
+    os.environ.pop('WGS_NO_HALO', None)
+    L.lib().wgs_dev_reload_flags()
+
+
+def _route(fn, halo):
+    lib = L.lib()
+    if halo:
+        os.environ.pop('WGS_NO_HALO', None)
+    else:
+        os.environ['WGS_NO_HALO'] = '1'
+    lib.wgs_dev_reload_flags()
+    lib.wgs_dev_trace_kernels(1)
+    try:
+        y = fn()
+        sym = lib.wgs_dev_last_kernel().decode()
+    finally:
+        lib.wgs_dev_trace_kernels(0)
+    return y, sym
+
+
+TOL = {1: 3e-5, 2: 3e-3, 3: 2e-3}
+
+
+@pytest.mark.parametrize('prec', [1, 2, 3])
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 32, 32, 64, 64), (1, 64, 64, 32, 96), (3, 64, 32, 16, 32), (2, 32, 64, 40, 64)])
+def test_styled_forward_launch_vs_gemm_tiled_route_and_fp64(dev, halo_everywhere, prec, B, Ci, Co, H, W):
+    torch.manual_seed(Ci + Co + H + prec)
+    x = torch.randn(B, H, W, Ci, device=dev)
+    w = torch.randn(Co, 9, Ci, device=dev) / (9 * Ci) ** 0.5
+    S = (torch.randn(B, Ci + 24, device=dev) + 1.0).contiguous()
+    s = S[:, 8:]
+    dm = torch.rand(B, Co, device=dev) + 0.5
+    nz, nw, bias = torch.randn(H * W, device=dev), torch.full((1,), 0.3, device=dev), torch.randn(Co, device=dev) * 0.2
+    xm, sm = x.abs().amax().reshape(1), S.abs().amax().reshape(1)
+    ws = C.split_weight(w, prec)
+    ym = [torch.zeros(1, device=dev), torch.zeros(1, device=dev)]
+
+    def run(i):
+        return C.conv2d(x, w, 3, pad=1, a_scale=s, a_ld=S.shape[1], col_scale=dm, noise=nz, noise_w=nw, bias=bias, act_slope=0.2, gain=SQRT2,
+                        precision=prec, w_split=ws, a_amax=xm, a_amax2=sm, y_amax=ym[i])
+    y1, k1 = _route(lambda: run(0), True)
+    y0, k0 = _route(lambda: run(1), False)
+    assert k1.startswith('halo3x3_kernel<%d, 32, %d>' % (prec - 1, 64 if Co > 32 else 32)) and not k0.startswith('halo'), (k1, k0)
+    assert (y1 - y0).abs().max() <= 2e-6 * y0.abs().max()
+    assert ym[0].item() == y1.abs().max().item() and abs(ym[0].item() - ym[1].item()) <= 2e-6 * ym[1].item()
+    ref = F.conv2d((x * s[:, None, None, :Ci]).permute(0, 3, 1, 2).double(), w.double().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2), padding=1)
+    ref = F.leaky_relu(ref * dm.double()[:, :, None, None] + 0.3 * nz.double().view(1, 1, H, W) + bias.double()[None, :, None, None], 0.2) * SQRT2
+    assert (y1.double().permute(0, 3, 1, 2) - ref).abs().max() <= TOL[prec] * ref.abs().max()
+
+
+@pytest.mark.parametrize('prec', [1, 2])
+@pytest.mark.parametrize('B,Cy,Cx,H', [(2, 32, 32, 64), (2, 64, 64, 32), (1, 16, 16, 64), (2, 32, 16, 32)])
+def test_input_gradient_launch_and_narrow_channel_counts(dev, halo_everywhere, prec, B, Cy, Cx, H):
+    """dgrad of a conv Cx -> Cy: contraction over Cy (the launch's Ci), Cx output columns; [T, Cx, Cy] weights, flipped taps.  Cy = 16 runs
+    16-deep chunks, Cx = 16 a half-empty column block."""
+    torch.manual_seed(Cy * 3 + Cx + H + prec)
+    dy = torch.randn(B, H, H, Cy, device=dev) * 1e-3
+    wp = torch.randn(Cy, 9, Cx, device=dev) / (9 * Cx) ** 0.5            # forward weights [Co = Cy, 9, Ci = Cx]
+    wt = C.repack_w_t(wp, Cy, 9, Cx)                                      # [9, Cx, Cy]
+    wts = C.split_weight(wt, prec)
+    am = dy.abs().amax().reshape(1) * 1.7
+
+    def run():
+        return C.conv2d_dgrad(dy, wt, (H, H), 3, pad=1, w_split=wts, a_amax=am, a_bound=1.0, precision=prec)
+    g1, k1 = _route(run, True)
+    g0, k0 = _route(run, False)
+    assert k1.startswith('halo3x3_kernel<%d, %d, %d>' % (prec - 1, 32 if Cy % 32 == 0 else 16, 64 if Cx > 32 else 32)) and not k0.startswith('halo'), (k1, k0)
+    assert (g1 - g0).abs().max() <= 2e-6 * g0.abs().max()
+    ref = torch.autograd.functional.vjp(lambda xx: F.conv2d(xx, wp.double().reshape(Cy, 3, 3, Cx).permute(0, 3, 1, 2), padding=1),
+                                        torch.zeros(B, Cx, H, H, dtype=torch.float64, device=dev), dy.double().permute(0, 3, 1, 2))[1]
+    assert (g1.double().permute(0, 3, 1, 2) - ref).abs().max() <= TOL[prec] * ref.abs().max()
+
+
+def test_shapes_the_kernel_declines(dev, halo_everywhere):
+    lib = L.lib()
+    w = torch.randn(32, 9, 32, device=dev) * 0.05
+    ws = C.split_weight(w, 1)
+    x = torch.randn(1, 64, 64, 32, device=dev)
+    lib.wgs_dev_trace_kernels(1)
+    try:
+        C.conv2d(x, w, 3, stride=2, pad=1, precision=1, w_split=ws)                                   # strided
+        assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
+        C.conv2d(x[:, :60], w, 3, pad=1, precision=1, w_split=ws)                                     # height not a multiple of 8
+        assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
+        C.conv2d(x, w, 3, pad=1, precision=1)                                                         # no pre-split weights
+        assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
+        w1 = torch.randn(32, 1, 32, device=dev)
+        C.conv2d(x, w1, 1, precision=1, w_split=C.split_weight(w1, 1))                                # 1x1
+        assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
+        w128 = torch.randn(128, 9, 32, device=dev) * 0.05
+        C.conv2d(x, w128, 3, pad=1, precision=1, w_split=C.split_weight(w128, 1))                     # 128 output channels: the patch / GEMM kernels
+        assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
+        C.conv2d(x, w, 3, pad=1, precision=1, w_split=ws)
+        assert lib.wgs_dev_last_kernel().decode().startswith('halo3x3_kernel<0, 32, 32>')
+    finally:
+        lib.wgs_dev_trace_kernels(0)

@@ -98,6 +98,9 @@ void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, uns
                int C, const float* a_amax, const float* a_amax2, float a_bound, hipStream_t st);
 void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st);
 
+// few-channel 3x3 stride-1 convs on large maps (conv_halo16.hip): 0 = launch taken.  Needs x_bytes / w_bytes and the tap tables.
+int launch_halo16(const ConvArgs& a, hipStream_t st);
+
 // patch form for stride-1 convs (conv_igemm_patch.hip); 0 = launch taken.  Needs x_bytes / w_bytes (fp32 extents) and the
 // 64-entry tap tables filled.
 int launch_patch_bf16x3(const ConvArgs& a, hipStream_t st);

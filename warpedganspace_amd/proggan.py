@@ -90,7 +90,7 @@ class Generator(nn.Module):
                 wp = C.pack_weight(blk.conv.weight.float())
                 wt = C.repack_w_t(wp, co, k * k, ci)
                 # frozen weights: 16-bit planes (built per arithmetic mode on first use) for the patch / DMA conv kernels
-                ws, wts = (C.SplitCache(wp), C.SplitCache(wt)) if (wp.numel() % 4 == 0 and ci % 32 == 0) else (None, None)
+                ws, wts = (C.SplitCache(wp), C.SplitCache(wt)) if (wp.numel() % 4 == 0 and ci % 16 == 0) else (None, None)      # (ci = 16: the few-channel halo kernel)
                 P['layers'].append(dict(wp=wp, wt=wt, ws=ws, wts=wts, ci=ci, co=co, k=k, pad=pad, up=up,
                                         scale=float(blk.wscale.scale.item()), b=blk.wscale.b.contiguous()))
             co = self.output.conv.weight.shape[0]
