@@ -220,6 +220,8 @@ typedef struct wgs_wgrad_desc {
     int32_t precision;   /* 0: exact fp32 MFMA.  1: split-bf16 x3 (operands split into bf16 hi + lo while they are transposed into the
                             [channel][pixel] LDS image, 3 bf16 MFMAs per product, fp32 accumulate: ~2^-16 per product) for
                             Ci % 64 == 0 and Co % 64 == 0; other shapes use the exact kernel. */
+    int32_t x_s2d;       /* != 0: x is stored space-to-depth, [B, Hi/2, Wi/2, 4*Ci] with channel (py*2 + px)*Ci + c (wgs_pack_pair_s2d);
+                            Ci == 8, precision 0: the ResNet stem's weight gradient without a second copy of its input */
 } wgs_wgrad_desc;
 int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
 
@@ -381,6 +383,14 @@ int wgs_sg2_wsq(const float* w_packed, float* wsq, int Co, int T, int Ci, wgs_st
  * and the gradient of that w.r.t. x1 / x2 (either may be NULL). */
 int wgs_pack_pair_nhwc(const float* x1, const float* x2, float* y, int B, int c, int HW, int Cp, wgs_stream_t stream);
 int wgs_unpack_pair_grad(const float* dy, float* d1, float* d2, int B, int c, int HW, int Cp, wgs_stream_t stream);
+/* The same concatenation in SPACE-TO-DEPTH form: y [B, H/2, W/2, 32], channel (py*2 + px)*8 + j = channel j (x1 | x2 | zeros, 2c <= 8) of
+ * image pixel (2 oy + py, 2 ox + px); its gradient; and the matching re-indexing of the ResNet stem's weights (torchvision resnet18
+ * conv1: 7 x 7, stride 2, pad 3 — lib/reconstructor.py:54-63): w [Co, 49, Ci] -> ws [Co, 16, 32], tap r*4 + s = block offset
+ * (r - 2, s - 2), so that conv7x7/2(x) == conv over the 4 x 4 block window of the s2d tensor with ws (zeros where 2r + py - 1 or
+ * 2s + px - 1 leaves 0..6); back != 0: the reverse gather ws -> w (a weight gradient computed in the s2d form). */
+int wgs_pack_pair_s2d(const float* x1, const float* x2, float* y, int B, int c, int H, int W, wgs_stream_t stream);
+int wgs_unpack_pair_s2d_grad(const float* dys, float* d1, float* d2, int B, int c, int H, int W, wgs_stream_t stream);
+int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, wgs_stream_t stream);
 
 /* nn.BatchNorm2d / BatchNorm1d on [N rows, C] (N = B*H*W) fused with the residual add and ReLU of a
  * BasicBlock:  y = relu?( (x - mean)*invstd*gamma + beta (+ residual) ).

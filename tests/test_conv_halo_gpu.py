@@ -68,7 +68,7 @@ def test_styled_forward_launch_vs_gemm_tiled_route_and_fp64(dev, halo_everywhere
                         precision=prec, w_split=ws, a_amax=xm, a_amax2=sm, y_amax=ym[i])
     y1, k1 = _route(lambda: run(0), True)
     y0, k0 = _route(lambda: run(1), False)
-    assert k1.startswith('halo3x3_kernel<%d, 32, %d>' % (prec - 1, 64 if Co > 32 else 32)) and not k0.startswith('halo'), (k1, k0)
+    assert k1.startswith('halo3x3_kernel<%d, 32, %d, 3>' % (prec - 1, 64 if Co > 32 else 32)) and not k0.startswith('halo'), (k1, k0)
     assert (y1 - y0).abs().max() <= 2e-6 * y0.abs().max()
     assert ym[0].item() == y1.abs().max().item() and abs(ym[0].item() - ym[1].item()) <= 2e-6 * ym[1].item()
     ref = F.conv2d((x * s[:, None, None, :Ci]).permute(0, 3, 1, 2).double(), w.double().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2), padding=1)
@@ -92,11 +92,23 @@ def test_input_gradient_launch_and_narrow_channel_counts(dev, halo_everywhere, p
         return C.conv2d_dgrad(dy, wt, (H, H), 3, pad=1, w_split=wts, a_amax=am, a_bound=1.0, precision=prec)
     g1, k1 = _route(run, True)
     g0, k0 = _route(run, False)
-    assert k1.startswith('halo3x3_kernel<%d, %d, %d>' % (prec - 1, 32 if Cy % 32 == 0 else 16, 64 if Cx > 32 else 32)) and not k0.startswith('halo'), (k1, k0)
+    assert k1.startswith('halo3x3_kernel<%d, %d, %d, 3>' % (prec - 1, 32 if Cy % 32 == 0 else 16, 64 if Cx > 32 else 32)) and not k0.startswith('halo'), (k1, k0)
     assert (g1 - g0).abs().max() <= 2e-6 * g0.abs().max()
     ref = torch.autograd.functional.vjp(lambda xx: F.conv2d(xx, wp.double().reshape(Cy, 3, 3, Cx).permute(0, 3, 1, 2), padding=1),
                                         torch.zeros(B, Cx, H, H, dtype=torch.float64, device=dev), dy.double().permute(0, 3, 1, 2))[1]
     assert (g1.double().permute(0, 3, 1, 2) - ref).abs().max() <= TOL[prec] * ref.abs().max()
+
+
+def test_trained_weights_without_planes_give_the_same_bits(dev, halo_everywhere):
+    """The Reconstructor's convs carry no pre-split weight planes (the weights change every step): the pre-pass splits the fp32 weights
+    itself, with the roundings of wgs_split_bf16 / wgs_split_f16."""
+    torch.manual_seed(1)
+    x = torch.randn(2, 32, 64, 64, device=dev)
+    w = torch.randn(64, 9, 64, device=dev) * 0.04
+    for prec in (1, 2, 3):
+        a = C.conv2d(x, w, 3, pad=1, precision=prec, w_split=C.split_weight(w, prec))
+        b = C.conv2d(x, w, 3, pad=1, precision=prec)
+        assert torch.equal(a, b)
 
 
 def test_shapes_the_kernel_declines(dev, halo_everywhere):
@@ -110,8 +122,8 @@ def test_shapes_the_kernel_declines(dev, halo_everywhere):
         assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
         C.conv2d(x[:, :60], w, 3, pad=1, precision=1, w_split=ws)                                     # height not a multiple of 8
         assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
-        C.conv2d(x, w, 3, pad=1, precision=1)                                                         # no pre-split weights
-        assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
+        C.conv2d(x, w, 3, pad=1, precision=1)                                                         # no pre-split planes: split from the fp32 weights in the pre-pass
+        assert lib.wgs_dev_last_kernel().decode().startswith('halo3x3_kernel<0, 32, 32, 3>')
         w1 = torch.randn(32, 1, 32, device=dev)
         C.conv2d(x, w1, 1, precision=1, w_split=C.split_weight(w1, 1))                                # 1x1
         assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
@@ -119,6 +131,6 @@ def test_shapes_the_kernel_declines(dev, halo_everywhere):
         C.conv2d(x, w128, 3, pad=1, precision=1, w_split=C.split_weight(w128, 1))                     # 128 output channels: the patch / GEMM kernels
         assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
         C.conv2d(x, w, 3, pad=1, precision=1, w_split=ws)
-        assert lib.wgs_dev_last_kernel().decode().startswith('halo3x3_kernel<0, 32, 32>')
+        assert lib.wgs_dev_last_kernel().decode().startswith('halo3x3_kernel<0, 32, 32, 3>')
     finally:
         lib.wgs_dev_trace_kernels(0)

@@ -104,7 +104,9 @@ def test_resnet_split_bf16_option(dev):
     Reconstructor on its own, and every step with an exact-fp32 generator, keeps the exact kernels (reconstructor.py)."""
     from warpedganspace_amd import reconstructor as RR
     R, sd, (lo, mo, x2), (lg, mg, x2d) = _run_pair(dev, 4, 128, 64, arith=RR.R_FP32_CLASS)
-    assert rel_err(lg, lo.detach()) < 1e-4 and rel_err(mg, mo.detach()) < 1e-4
+    # (round 4: the stem runs in split-bf16 too — space-to-depth through the few-channel kernel; until then its 6 input channels kept it
+    # on the exact fp32 kernel.  Four samples through 20 train-mode BatchNorms: logits 3.8e-5, the 4-element magnitude head 1.2e-4)
+    assert rel_err(lg, lo.detach()) < 1e-4 and rel_err(mg, mo.detach()) < 3e-4
     assert torch.equal(torch.argmax(lg, 1).cpu(), torch.argmax(lo, 1))
     errs = sorted(rel_err(p.grad, sd[n].grad) for n, p in R.named_parameters() if p.grad is not None)
     print('split-bf16 forward: median / max parameter-gradient rel err', errs[len(errs) // 2], errs[-1])

@@ -33,7 +33,7 @@ class WgradDesc(ctypes.Structure):
                                               'ksplit')] + \
                [('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
                 ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
-                ('precision', ctypes.c_int32)]
+                ('precision', ctypes.c_int32), ('x_s2d', ctypes.c_int32)]
 
 
 # Arithmetic of a generator's implicit-GEMM launches (wgs_conv_desc.precision, include/wgs.h):
@@ -499,16 +499,21 @@ def blur_bwd_f16(dy, blur_f, a_amax, a_bound):
     return dt
 
 
-def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0, precision=0):
+def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0, precision=0, x_s2d=False):
     """Accumulate the weight gradient into the zero-initialised dw_packed [Co, k*k, Ci] memory.
-    precision 0: exact fp32 MFMA; 1: split-bf16 x3 (fp32-class) where the shape allows it."""
-    B, Hi, Wi, Ci = x.shape
+    precision 0: exact fp32 MFMA; 1: split-bf16 x3 (fp32-class) where the shape allows it.
+    x_s2d: x is the space-to-depth tensor [B, Hi/2, Wi/2, 32] of a logical [B, Hi, Wi, 8] input (wgs_pack_pair_s2d)."""
+    if x_s2d:
+        B, Hi, Wi, Ci = x.shape[0], 2 * x.shape[1], 2 * x.shape[2], 8
+    else:
+        B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
     d = WgradDesc()
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw_packed.data_ptr()
     d.B, d.Hi, d.Wi, d.Ci, d.Ho, d.Wo, d.Co = B, Hi, Wi, Ci, Ho, Wo, Co
     d.isy, d.isx, d.ntaps, d.ksplit = stride, stride, k * k, ksplit
     d.precision = precision
+    d.x_s2d = int(bool(x_s2d))
     d.w_tap_stride, d.w_row_stride = Ci, k * k * Ci
     i = 0
     for ky in range(k):

@@ -35,16 +35,19 @@ namespace {
 using wgsconv::ConvArgs;
 
 constexpr int TH = 8, TW = 32, BM = TH * TW;             // output block of a workgroup: 256 GEMM rows
-constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;   // input patch: 340 pixels
 constexpr int OOB = (int)0x80000000;
 
+// WIN = side of the tap window: 3 (the 3 x 3 'same' convs: 9 taps at dy, dx in [-1, 1]) or 4 (<= 16 taps at dy, dx in [dy_min, dy_min + 3]:
+// a 7 x 7 stride-2 conv over a space-to-depth input, the ResNet stem of the Reconstructor and its input gradient, reconstructor.py)
 struct HaloGeom {
-    int tiles_x, tiles_per_img;
-    int tapoff[9];        // patch pixel offset of tap t: (dy + 1) * PW + (dx + 1)
+    int tiles_x, tiles_per_img, dy_min, dx_min;
+    int tapoff[16];       // patch pixel offset of tap t: (dy - dy_min) * PW + (dx - dx_min)
 };
 
-template <int SCH, int KC, int CO>
+template <int SCH, int KC, int CO, int WIN>
 struct HaloCfg {
+    static constexpr int NT = WIN * WIN;                   // taps (a 4 x 4 window may list fewer: the launcher pads with zero weights)
+    static constexpr int PH = TH + WIN - 1, PW = TW + WIN - 1, NPIX = PH * PW;     // input patch: 340 / 385 pixels
     typedef wgsconv::Scheme<SCH> SC;
     static constexpr int NA = SC::NA, NB = SC::NB;
     static constexpr int PROW = KC * 2 + 16;               // bytes per patch pixel / weight row of a chunk (padded: conflict-free b128 reads)
@@ -54,14 +57,14 @@ struct HaloCfg {
     static constexpr int FRAGS_PER_TAP = KS * TN * NB;     // 1-KB B fragments of one (chunk, tap)
     // three workgroups per CU (170 VGPRs) unless the double-buffered weight fragments (2 x FRAGS_PER_TAP x 4 registers) need more
     static constexpr int WGS_PER_CU = (SMEM <= 52 * 1024 && FRAGS_PER_TAP <= 4) ? 3 : 2;
-    static constexpr long wfrag_bytes(int nchunks) { return (long)nchunks * 9 * FRAGS_PER_TAP * 1024; }
+    static constexpr long wfrag_bytes(int nchunks) { return (long)nchunks * NT * FRAGS_PER_TAP * 1024; }
 };
 
 // B-operand fragments of the launch in issue order: frag[((c * 9 + t) * KS + ks) * TN + j][plane][lane] = the 8 consecutive k
 // (chunk c, k-step ks, half lane / 32) of weight row co = j * 32 + lane % 32 of tap t; rows past Cout are zero.
-template <int SCH, int KC, int CO>
+template <int SCH, int KC, int CO, int WIN>
 __global__ __launch_bounds__(256) void halo_wfrag_kernel(const ConvArgs p, unsigned short* __restrict__ dst, int total) {
-    typedef HaloCfg<SCH, KC, CO> CF;
+    typedef HaloCfg<SCH, KC, CO, WIN> CF;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int lane = e & 63;
@@ -69,19 +72,29 @@ __global__ __launch_bounds__(256) void halo_wfrag_kernel(const ConvArgs p, unsig
     const int pl = f % CF::NB; f /= CF::NB;
     const int j = f % CF::TN; f /= CF::TN;
     const int ks = f % CF::KS; f /= CF::KS;
-    const int t = f % 9, c = f / 9;
+    const int t = f % CF::NT, c = f / CF::NT;
     const int co = j * 32 + (lane & 31), ci = c * KC + ks * 16 + (lane >> 5) * 8;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (co < p.Co) {
-        const unsigned short* src = (pl ? p.w_lo : p.w_hi) + (size_t)co * p.w_row_stride + (size_t)p.wt[t] * p.w_tap_stride + ci;
-        v = *reinterpret_cast<const uint4*>(src);
+    if (co < p.Co && t < p.ntaps) {
+        const size_t off = (size_t)co * p.w_row_stride + (size_t)p.wt[t] * p.w_tap_stride + ci;
+        if (p.w_hi) v = *reinterpret_cast<const uint4*>((pl ? p.w_lo : p.w_hi) + off);
+        else {
+            // no pre-split planes (trained weights: the Reconstructor's convs): split the fp32 weights here, the same roundings
+            const float4 a = *reinterpret_cast<const float4*>(p.w + off), b = *reinterpret_cast<const float4*>(p.w + off + 4);
+            const f32x4 fa = {a.x, a.y, a.z, a.w}, fb = {b.x, b.y, b.z, b.w};
+            uint2 ha, la, hb, lb;
+            wgsconv::Scheme<SCH>::cvt4(fa, ha, la);
+            wgsconv::Scheme<SCH>::cvt4(fb, hb, lb);
+            v = pl ? make_uint4(la.x, la.y, lb.x, lb.y) : make_uint4(ha.x, ha.y, hb.x, hb.y);
+        }
     }
     *reinterpret_cast<uint4*>(dst + (size_t)e * 8) = v;
 }
 
-template <int SCH, int KC, int CO>
-__global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO>::WGS_PER_CU)) void halo3x3_kernel(const ConvArgs p, const HaloGeom g, const unsigned short* __restrict__ wfrag, int wfrag_bytes) {
-    typedef HaloCfg<SCH, KC, CO> CF;
+template <int SCH, int KC, int CO, int WIN>
+__global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO, WIN>::WGS_PER_CU)) void halo3x3_kernel(const ConvArgs p, const HaloGeom g, const unsigned short* __restrict__ wfrag, int wfrag_bytes) {
+    typedef HaloCfg<SCH, KC, CO, WIN> CF;
+    constexpr int NT = CF::NT, PW = CF::PW, NPIX = CF::NPIX;
     typedef wgsconv::Scheme<SCH> SC;
     typedef typename SC::frag frag;
     constexpr int NA = SC::NA, NB = SC::NB, PROW = CF::PROW, P_BYTES = CF::P_BYTES, KS = CF::KS;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO>::WGS_PER_CU)) void halo3
     for (int j = 0; j < NPL; ++j) {
         const int pp = (tid + j * 256) / EP;
         const int pr = pp / PW, pc = pp - pr * PW;
-        const int iy = ty0 - 1 + pr, ix = tx0 - 1 + pc;
+        const int iy = ty0 + g.dy_min + pr, ix = tx0 + g.dx_min + pc;
         const bool v = pp < NPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         p_goff[j] = v ? (((b * p.Hi + iy) * p.Wi + ix) * p.Ci + q * 4) * 4 : OOB;
         p_loff[j] = pp < NPIX ? pp * PROW + q * 8 : -1;
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO>::WGS_PER_CU)) void halo3
     // B fragments of (chunk c, tap t): FRAGS_PER_TAP coalesced 1-KB wave loads from the fragment-ordered weights
     frag bq[2][KS][TN][NB];
     auto load_b = [&](int set, int c, int t) {
-        const int base = (c * 9 + t) * CF::FRAGS_PER_TAP * 1024 + lane * 16;
+        const int base = (c * NT + t) * CF::FRAGS_PER_TAP * 1024 + lane * 16;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO>::WGS_PER_CU)) void halo3
 
     load_chunk(0);
     load_b(0, 0, 0);
-    // (at most two chunks — Cin = 64 — and the loop is unrolled: the register set of a tap's weight fragments, (9 c + t) & 1, is then
+    // (at most two chunks — Cin = 64 — and the loop is unrolled: the register set of a tap's weight fragments, (NT c + t) & 1, is then
     // a compile-time index)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -188,10 +201,10 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO>::WGS_PER_CU)) void halo3
         __syncthreads();
         if (c + 1 < cpt) load_chunk(c + 1);          // in flight behind the MFMAs
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < NT; ++t) {
             // the next tap's weight fragments (the next chunk's first tap after the last one) are requested before this tap's MFMAs
-            if (t + 1 < 9) load_b((9 * c + t + 1) & 1, c, t + 1);
-            else if (c + 1 < cpt) load_b((9 * c + t + 1) & 1, c + 1, 0);
+            if (t + 1 < NT) load_b((NT * c + t + 1) & 1, c, t + 1);
+            else if (c + 1 < cpt) load_b((NT * c + t + 1) & 1, c + 1, 0);
             const int to = g.tapoff[t] * PROW;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO>::WGS_PER_CU)) void halo3
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(af[i], bq[(9 * c + t) & 1][ks][j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = SC::mma(af[i], bq[(NT * c + t) & 1][ks][j], acc[i][j]);
             }
         }
     }
@@ -227,26 +240,30 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO>::WGS_PER_CU)) void halo3
     wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, 0, wm, 0, l31, lh, op_inv);
 }
 
-template <int SCH, int KC, int CO>
+template <int SCH, int KC, int CO, int WIN>
 int launch_halo_k(const ConvArgs& a, const HaloGeom& g, int nblocks, hipStream_t st) {
-    typedef HaloCfg<SCH, KC, CO> CF;
+    typedef HaloCfg<SCH, KC, CO, WIN> CF;
     const long wfb = CF::wfrag_bytes(a.Ci / KC);
     if (!a.ws || a.ws_bytes < wfb) return 1;            // needs the caller's workspace for the fragment-ordered weights (<= 150 KB)
     unsigned short* wf = reinterpret_cast<unsigned short*>(a.ws);
     const int total = (int)(wfb / 16);
-    WGS_LAUNCH((halo_wfrag_kernel<SCH, KC, CO>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, wf, total);
-    auto k = halo3x3_kernel<SCH, KC, CO>;
-    wgs_note_kernel("halo3x3_kernel<%d, %d, %d>", SCH, KC, CO);
+    WGS_LAUNCH((halo_wfrag_kernel<SCH, KC, CO, WIN>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, wf, total);
+    auto k = halo3x3_kernel<SCH, KC, CO, WIN>;
+    wgs_note_kernel("halo3x3_kernel<%d, %d, %d, %d>", SCH, KC, CO, WIN);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
     WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(256), CF::SMEM, st, a, g, (const unsigned short*)wf, (int)wfb);
     return 0;
 }
 
 template <int SCH>
-int launch_halo_s(const ConvArgs& a, const HaloGeom& g, int nblocks, hipStream_t st) {
+int launch_halo_s(const ConvArgs& a, const HaloGeom& g, int nblocks, int win, hipStream_t st) {
     const bool k16 = a.Ci % 32 != 0;
-    if (a.Co > 32) return k16 ? launch_halo_k<SCH, 16, 64>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 64>(a, g, nblocks, st);
-    return k16 ? launch_halo_k<SCH, 16, 32>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 32>(a, g, nblocks, st);
+    if (win == 4) {       // the stem's space-to-depth form: 32 -> 64 (forward) and 64 -> 32 (input gradient) channels
+        if (k16) return 1;
+        return a.Co > 32 ? launch_halo_k<SCH, 32, 64, 4>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 32, 4>(a, g, nblocks, st);
+    }
+    if (a.Co > 32) return k16 ? launch_halo_k<SCH, 16, 64, 3>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 64, 3>(a, g, nblocks, st);
+    return k16 ? launch_halo_k<SCH, 16, 32, 3>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 32, 3>(a, g, nblocks, st);
 }
 
 }  // namespace
@@ -255,26 +272,38 @@ namespace wgsconv {
 
 // 0 = launch taken.  Needs pre-split weight planes, the extents (set_extents) and the tap tables.
 int launch_halo16(const ConvArgs& a, hipStream_t st) {
-    if (wgs_flags().no_halo || !a.w_hi || (!a.w_lo && a.sch != 1) || a.a_hi || a.ups || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 ||
-        a.oy0 || a.ox0 || a.ntaps != 9)
+    if (wgs_flags().no_halo || (a.w_hi && !a.w_lo && a.sch != 1) || a.a_hi || a.ups || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 ||
+        a.oy0 || a.ox0 || a.ntaps < 9 || a.ntaps > 16)
         return 1;
     if ((a.Ci != 16 && a.Ci != 32 && a.Ci != 64) || a.Co % 4 || a.Co > 64 || a.Hg != a.Hi || a.Wg != a.Wi || a.Ho != a.Hi || a.Wo != a.Wi || a.Hi % TH || a.Wi % TW) return 1;
     if ((long)a.B * (a.Hi / TH) * (a.Wi / TW) < wgs_flags().halo_min_tiles) return 1;      // small maps: the GEMM-tiled kernels (split K, 128-row tiles)
     HaloGeom g;
-    unsigned seen = 0;
-    for (int t = 0; t < 9; ++t) {
-        if (a.dy[t] < -1 || a.dy[t] > 1 || a.dx[t] < -1 || a.dx[t] > 1) return 1;
-        seen |= 1u << ((a.dy[t] + 1) * 3 + a.dx[t] + 1);
-        g.tapoff[t] = (a.dy[t] + 1) * PW + (a.dx[t] + 1);
+    int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
+    for (int t = 0; t < a.ntaps; ++t) {
+        dy0 = a.dy[t] < dy0 ? a.dy[t] : dy0; dy1 = a.dy[t] > dy1 ? a.dy[t] : dy1;
+        dx0 = a.dx[t] < dx0 ? a.dx[t] : dx0; dx1 = a.dx[t] > dx1 ? a.dx[t] : dx1;
     }
-    if (seen != 0x1ffu) return 1;
+    // 3 x 3 'same' convs (all nine taps around the pixel), or <= 16 taps inside a 4 x 4 window that reaches at most 2 pixels out
+    const bool w3 = a.ntaps == 9 && dy0 == -1 && dy1 == 1 && dx0 == -1 && dx1 == 1;
+    const bool w4 = !w3 && dy1 - dy0 <= 3 && dx1 - dx0 <= 3 && dy0 >= -3 && dy1 <= 3 && dx0 >= -3 && dx1 <= 3;
+    if (!w3 && !w4) return 1;
+    const int win = w3 ? 3 : 4, pw = TW + win - 1;
+    unsigned seen = 0;
+    for (int t = 0; t < 16; ++t) g.tapoff[t] = 0;
+    for (int t = 0; t < a.ntaps; ++t) {
+        const unsigned bit = 1u << ((a.dy[t] - dy0) * 4 + a.dx[t] - dx0);
+        if (seen & bit) return 1;                      // a tap listed twice
+        seen |= bit;
+        g.tapoff[t] = (a.dy[t] - dy0) * pw + (a.dx[t] - dx0);
+    }
+    g.dy_min = dy0; g.dx_min = dx0;
     g.tiles_x = a.Wi / TW; g.tiles_per_img = (a.Hi / TH) * g.tiles_x;
     const int nblocks = a.B * g.tiles_per_img;
     ConvArgs b = a;
     b.w_bytes = a.w_bytes / 2;          // extents of the 16-bit weight planes
-    if (a.sch == 0) return launch_halo_s<0>(b, g, nblocks, st);
-    if (a.sch == 1) return launch_halo_s<1>(b, g, nblocks, st);
-    return launch_halo_s<2>(b, g, nblocks, st);
+    if (a.sch == 0) return launch_halo_s<0>(b, g, nblocks, win, st);
+    if (a.sch == 1) return launch_halo_s<1>(b, g, nblocks, win, st);
+    return launch_halo_s<2>(b, g, nblocks, win, st);
 }
 
 }  // namespace wgsconv

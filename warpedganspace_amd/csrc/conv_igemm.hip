@@ -257,6 +257,7 @@ struct WgradArgs {
     signed char dy_[64], dx_[64];
     short wt[64];
     unsigned magic_wo, magic_ho, magic_ci;      // wgs_div_magic of Wo / Ho / Ci, or 0: plain division (an operand would overflow the 32-bit product)
+    int x_s2d;        // x is stored space-to-depth: [B, Hi/2, Wi/2, 4 * Ci], channel (py*2 + px)*Ci + c (wgs_pack_pair_s2d; Ci == 8)
 };
 
 // n / d with the launch's precomputed reciprocal (three vector instructions) instead of a ~35-instruction integer division: the pixel
@@ -324,8 +325,12 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs p) {
                     dyc = (int)(short)(yx & 0xffff); dxc = yx >> 16;
                 }
                 const int iy = oy * p.isy + dyc, ix = ox * p.isx + dxc;
-                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                    val = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + cic);
+                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) {
+                    if (p.x_s2d)
+                        val = *reinterpret_cast<const float4*>(p.x + (((size_t)(b * (p.Hi >> 1) + (iy >> 1)) * (p.Wi >> 1) + (ix >> 1)) * 4 + ((iy & 1) * 2 + (ix & 1))) * p.Ci + cic);
+                    else
+                        val = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + cic);
+                }
             }
             rb[pb] = val;
         }
@@ -706,6 +711,9 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
+    a.x_s2d = d->x_s2d;
+    WGS_CHECK_ARG(!d->x_s2d || (d->Ci == 8 && d->Hi % 2 == 0 && d->Wi % 2 == 0 && d->precision == 0),
+                  "wgs_conv_wgrad: x_s2d needs Ci == 8, even Hi / Wi and precision 0 (the stem's weight gradient)");
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
     // reciprocal multiplies are exact while dividend * divisor < 2^32 (wgs_div_magic); divisor 1 needs none
     auto magic_of = [](long n_max, int dv) -> unsigned { return (dv >= 2 && n_max * dv < (1L << 32)) ? wgs_div_magic(dv) : 0u; };

@@ -24,6 +24,68 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(const float* __restrict_
         }
     }
 }
+// ---- the same in SPACE-TO-DEPTH form: y [B, H/2, W/2, 32], channel (py*2 + px)*8 + j = channel j of pixel (2 oy + py, 2 ox + px)
+// (j < c: x1, j < 2c: x2, else 0).  A 7 x 7 stride-2 conv over [B,H,W,2c] is a 4 x 4-window stride-1 conv over this tensor
+// (wgs_stem_weight_s2d): the ResNet stem then runs through the few-channel halo kernel instead of a gather over 6 channels.
+__global__ __launch_bounds__(256) void pack_pair_s2d_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                            float* __restrict__ y, int B, int c, int H, int W) {
+    const int Wo = W >> 1, Ho = H >> 1;
+    const int64_t total = (int64_t)B * Ho * Wo * 4;          // one thread per (output pixel, sub-pixel): 8 channels = two float4
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int sp = (int)(e & 3);
+        const int64_t op = e >> 2;
+        const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), b = (int)(op / ((int64_t)Wo * Ho));
+        const int iy = 2 * oy + (sp >> 1), ix = 2 * ox + (sp & 1);
+        const size_t pix = (size_t)iy * W + ix, HW = (size_t)H * W;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = 0.f;
+            if (j < c) v[j] = x1[((size_t)b * c + j) * HW + pix];
+            else if (j < 2 * c) v[j] = x2[((size_t)b * c + (j - c)) * HW + pix];
+        }
+        float4* o = reinterpret_cast<float4*>(y + (size_t)op * 32 + sp * 8);
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+// gradient of the above w.r.t. x1 / x2 (either may be NULL): dys [B, H/2, W/2, 32]
+__global__ __launch_bounds__(256) void unpack_pair_s2d_kernel(const float* __restrict__ dys, float* __restrict__ d1,
+                                                              float* __restrict__ d2, int B, int c, int H, int W) {
+    const int64_t total = (int64_t)B * H * W;                // one thread per image pixel (coalesced NCHW stores)
+    const size_t HW = (size_t)H * W;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ix = (int)(e % W), iy = (int)((e / W) % H), b = (int)(e / HW);
+        const float* g = dys + (((size_t)b * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1)) * 32 + ((iy & 1) * 2 + (ix & 1)) * 8;
+        const float4 g0 = reinterpret_cast<const float4*>(g)[0], g1 = reinterpret_cast<const float4*>(g)[1];
+        const float v[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const size_t pix = (size_t)iy * W + ix;
+        for (int j = 0; j < c; ++j) {
+            if (d1) d1[((size_t)b * c + j) * HW + pix] = v[j];
+            if (d2) d2[((size_t)b * c + j) * HW + pix] = v[c + j];
+        }
+    }
+}
+// stem weights w [Co, 49, Ci] (7 x 7 taps ky*7 + kx, Ci = 2c <= 8 input channels) -> ws [Co, 16, 32]: tap r*4 + s of the 4 x 4 window
+// (block offsets r - 2, s - 2), channel (py*2 + px)*8 + j  <-  ky = 2r + py - 1, kx = 2s + px - 1 (zero where that falls outside 0..6
+// or j >= Ci).  back != 0: the reverse gather, w[co][ky*7 + kx][j] = ws[co][...] (the weight gradient computed in the s2d form).
+__global__ __launch_bounds__(256) void stem_weight_s2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int Co, int Ci, int back) {
+    if (!back) {
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        if (e >= Co * 16 * 32) return;
+        const int n = e & 31, t = (e >> 5) & 15, co = e >> 9;
+        const int j = n & 7, px = (n >> 3) & 1, py = n >> 4;
+        const int ky = 2 * (t >> 2) + py - 1, kx = 2 * (t & 3) + px - 1;
+        dst[e] = (j < Ci && (unsigned)ky < 7u && (unsigned)kx < 7u) ? src[((size_t)co * 49 + ky * 7 + kx) * Ci + j] : 0.f;
+    } else {
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        if (e >= Co * 49 * Ci) return;
+        const int j = e % Ci, tap = (e / Ci) % 49, co = e / (Ci * 49);
+        const int ky = tap / 7, kx = tap % 7;
+        const int r = (ky + 1) >> 1, py = (ky + 1) & 1, sx = (kx + 1) >> 1, px = (kx + 1) & 1;
+        dst[e] = src[((size_t)co * 16 + r * 4 + sx) * 32 + (py * 2 + px) * 8 + j];
+    }
+}
 // gradient of the above w.r.t. x1 / x2 (either may be NULL)
 __global__ __launch_bounds__(256) void unpack_pair_kernel(const float* __restrict__ dy, float* __restrict__ d1,
                                                           float* __restrict__ d2, int B, int c, int HW, int Cp) {
@@ -435,6 +497,26 @@ int wgs_pack_pair_nhwc(const float* x1, const float* x2, float* y, int B, int c,
     WGS_CHECK_LAUNCH("pack_pair_kernel");
     return WGS_OK;
 }
+int wgs_pack_pair_s2d(const float* x1, const float* x2, float* y, int B, int c, int H, int W, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x1 && x2 && y && B > 0 && c > 0 && 2 * c <= 8 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "wgs_pack_pair_s2d: bad arguments (2c <= 8, even H / W)");
+    WGS_LAUNCH(pack_pair_s2d_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, x1, x2, y, B, c, H, W);
+    WGS_CHECK_LAUNCH("pack_pair_s2d_kernel");
+    return WGS_OK;
+}
+int wgs_unpack_pair_s2d_grad(const float* dys, float* d1, float* d2, int B, int c, int H, int W, wgs_stream_t stream) {
+    WGS_CHECK_ARG(dys && B > 0 && c > 0 && 2 * c <= 8 && H % 2 == 0 && W % 2 == 0, "wgs_unpack_pair_s2d_grad: bad arguments");
+    WGS_LAUNCH(unpack_pair_s2d_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, dys, d1, d2, B, c, H, W);
+    WGS_CHECK_LAUNCH("unpack_pair_s2d_kernel");
+    return WGS_OK;
+}
+int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, wgs_stream_t stream) {
+    WGS_CHECK_ARG(src && dst && Co > 0 && Ci > 0 && Ci <= 8, "wgs_stem_weight_s2d: bad arguments (Ci <= 8)");
+    const int n = back ? Co * 49 * Ci : Co * 16 * 32;
+    WGS_LAUNCH(stem_weight_s2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, Co, Ci, back);
+    WGS_CHECK_LAUNCH("stem_weight_s2d_kernel");
+    return WGS_OK;
+}
+
 int wgs_unpack_pair_grad(const float* dy, float* d1, float* d2, int B, int c, int HW, int Cp, wgs_stream_t stream) {
     WGS_CHECK_ARG(dy && (d1 || d2) && B > 0 && c > 0 && HW > 0 && Cp >= 2 * c, "wgs_unpack_pair_grad: bad arguments");
     WGS_LAUNCH(unpack_pair_kernel, dim3(grid_for((int64_t)B * HW)), dim3(256), 0, (hipStream_t)stream, dy, d1, d2, B, c, HW, Cp);

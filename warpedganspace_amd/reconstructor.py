@@ -66,6 +66,11 @@ def r_arith(r_precision='auto', generator_code=None):
     raise L.WgsError("unknown reconstructor precision %r (fp32, fp32w, bf16x3, auto)" % (r_precision,))
 
 
+# The ResNet stem in space-to-depth form (Reconstructor._forward_impl): taps (dy, dx, weight index r*4 + s) of the 4 x 4 block window
+STEM_S2D = True
+_S2D_TAPS = [(r - 2, s_ - 2, r * 4 + s_) for r in range(4) for s_ in range(4)]
+
+
 def _conv(ci, co, k, stride, pad):
     m = nn.Conv2d(ci, co, k, stride=stride, padding=pad, bias=False)
     nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
@@ -226,13 +231,26 @@ class Reconstructor(nn.Module):
         B, c, H, W = x1.shape
         ws = self._scratch('bn_ws', (64 * 512,), torch.float64, dev)      # WGS_BN_WS_DOUBLES(512), reused every step
         Cp = 8
-        x = torch.empty(B, H, W, Cp, device=dev)
-        L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
-        # stem: conv1 weights padded from 2c to Cp input channels
-        w1p = self._conv1_padded(c, Cp, dev)
         arith = arith or self.arith
         fp = arith.forward
-        c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=fp)
+        # The stem (7 x 7, stride 2, 2c = 6 input channels) in the 16-bit modes: SPACE-TO-DEPTH.  The image pair is packed as
+        # [B, H/2, W/2, 32] (2 x 2 pixel block x 8 channels) and the 7 x 7 / 2 conv becomes a 4 x 4-window stride-1 conv 32 -> 64 channels
+        # over it (zeros where a tap falls outside the 7 x 7: 49 * 6 of 16 * 32 weights live) — a shape the few-channel halo kernel
+        # (conv_halo16.hip) runs HBM-bound, instead of a GEMM whose rows gather 49 taps of 6 channels.  Same products, same roundings.
+        s2d = STEM_S2D and fp == 1 and H % 16 == 0 and W % 64 == 0 and 2 * c <= 8
+        if s2d:
+            x = torch.empty(B, H // 2, W // 2, 32, device=dev)
+            L.check(lib.wgs_pack_pair_s2d(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H, W, st), 'pack_pair_s2d')
+            w1s = self._scratch('w1s', (64, 16, 32), torch.float32, dev)
+            L.check(lib.wgs_stem_weight_s2d(L.rawptr(_packed(fe.conv1)), L.ptr(w1s), 64, 2 * c, 0, st), 'stem_weight_s2d')
+            c1 = torch.empty(B, H // 2, W // 2, 64, device=dev)
+            C.launch(x, w1s, c1, _S2D_TAPS, H // 2, W // 2, w_tap_stride=32, w_row_stride=16 * 32, precision=fp)
+        else:
+            x = torch.empty(B, H, W, Cp, device=dev)
+            L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
+            # stem: conv1 weights padded from 2c to Cp input channels
+            w1p = self._conv1_padded(c, Cp, dev)
+            c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=fp)
         a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
         Hp = (a1.shape[1] + 2 - 3) // 2 + 1
         p1 = torch.empty(B, Hp, Hp, 64, device=dev)
@@ -265,7 +283,7 @@ class Reconstructor(nn.Module):
             L.check(lib.wgs_linear_fwd(L.ptr(feat), L.ptr(lin.weight), L.ptr(lin.bias), L.ptr(out), B, n, 512, 512, n,
                                        L.c_float(1.0), L.c_float(1.0), 0, 0, L.c_float(0.0), L.c_float(1.0), st), 'head')
         saved = dict(x=x, c1=c1, a1=a1, st1=st1, idx=idx, p1shape=p1.shape, blocks=saved_blocks, feat=feat, hshape=h.shape,
-                     B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws, arith=arith) if save else None
+                     B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws, arith=arith, s2d=s2d) if save else None
         return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
 
     def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None):
@@ -351,12 +369,24 @@ class Reconstructor(nn.Module):
         grads[id(fe.bn1.weight)], grads[id(fe.bn1.bias)] = dg, db_
         c, Cp = S['c'], S['Cp']
         dw1p = torch.zeros(64, 49, Cp, device=dev)
-        C.conv2d_wgrad(S['x'], dc1, dw1p, 7, stride=2, pad=3)
+        C.conv2d_wgrad(S['x'], dc1, dw1p, 7, stride=2, pad=3, x_s2d=S['s2d'])          # (reads the s2d input in place)
         if gbuf is not None:
             gbuf[id(fe.conv1.weight)].copy_(dw1p[:, :, :2 * c])
         grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, dw1p[:, :, :2 * c].contiguous())
         d1 = d2 = None
-        if need_x[0] or need_x[1]:
+        if (need_x[0] or need_x[1]) and S['s2d'] and arith.dgrad == 1:
+            # image gradient in the space-to-depth form: 64 -> 32 channels over the transposed 4 x 4 window, then depth-to-space
+            w1s = self._scratch('w1s', (64, 16, 32), torch.float32, dev)      # this step's forward weights (Adam runs after the backward)
+            w1st = C.repack_w_t(w1s, 64, 16, 32, out=self._scratch('w1st', (16, 32, 64), torch.float32, dev))
+            dxs = torch.empty(B, S['H'] // 2, S['W'] // 2, 32, device=dev)
+            C.launch(dc1, w1st, dxs, [(-dy, -dx, t) for dy, dx, t in _S2D_TAPS], S['H'] // 2, S['W'] // 2, w_tap_stride=32 * 64, w_row_stride=64,
+                     precision=arith.dgrad, grad_operand=True)
+            d1 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[0] else None
+            d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
+            L.check(lib.wgs_unpack_pair_s2d_grad(L.ptr(dxs), L.ptr(d1), L.ptr(d2), B, c, S['H'], S['W'], st), 'unpack_pair_s2d')
+        elif need_x[0] or need_x[1]:
+            if S['s2d']:
+                raise L.WgsError("Reconstructor: a space-to-depth stem forward needs the 16-bit input-gradient arithmetic (RArith.dgrad == 1)")
             w1p = self._conv1_padded(c, Cp, dev)        # same weights as in the forward of this step (Adam runs after the backward)
             w1t = C.repack_w_t(w1p, 64, 49, Cp, out=self._scratch('w1t', (49, Cp, 64), torch.float32, dev))
             dx = C.conv2d_dgrad(dc1, w1t, (S["H"], S["W"]), 7, stride=2, pad=3, precision=arith.dgrad)
