@@ -251,6 +251,11 @@ int wgs_pixelnorm_bwd_act(const float* x, const float* gy, float* gx, int rows, 
  * Bit-identical to wgs_pixelnorm_fwd + L x wgs_linear_fwd(..., epilogue 1).  d must be 512 (the reference's style_dim). */
 int wgs_mapping_mlp_fwd(const float* z, const float* const* w, const float* const* bias, float* acts, int B, int d, int L,
                         float wscale, float lr_mul, float eps, wgs_stream_t stream);
+/* Backward of those L layers in ONE launch (the PixelNorm backward stays wgs_pixelnorm_bwd): gw [B,d] = gradient w.r.t. the latent
+ * acts[L]; gx [B,d] = gradient w.r.t. acts[0], i.e. L x wgs_linear_dgrad(g, w[l], gate_y = acts[l+1], slope 0.2, gain sqrt 2) for
+ * l = L-1 .. 0 (fp32, different summation order: ~1e-6).  d must be 512. */
+int wgs_mapping_mlp_bwd(const float* gw, const float* const* w, const float* acts, float* gx, int B, int d, int L, float wscale,
+                        wgs_stream_t stream);
 
 /* EqualLinear (:110-136) and friends, M = batch rows:
  *   y[m*ldy + n] = out_gain * epi( wscale * sum_k f(x[m*ldx + k]) * w[n*K + k] + bscale * bias[n] )

@@ -26,7 +26,7 @@ def first(pred, start=0):
 i_rbf = first(lambda n: n.startswith('rbf_fwd'))
 i_gs_end = first(lambda n: n.startswith('pack_pair_kernel'), i_rbf)   # R's input packing (the two images -> one NHWC tensor)
 i_loss = first(lambda n: n.startswith('loss_rows_kernel'))
-i_gb = first(lambda n: n.startswith('unpack_pair_kernel'), i_loss) + 1      # R's input gradient -> d image: the generator's backward follows
+i_gb = first(lambda n: n.startswith('unpack_pair'), i_loss) + 1      # R's input gradient -> d image: the generator's backward follows
 i_rbfb = first(lambda n: n.startswith('rbf_bwd'), i_loss)
 i_adam = first(lambda n: n.startswith('adam_kernel'), i_loss)
 # R forward starts at the first kernel after the last ToRGB of the second generator pass

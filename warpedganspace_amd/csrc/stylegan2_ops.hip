@@ -225,6 +225,51 @@ __global__ __launch_bounds__(512) void mapping_mlp_fwd_kernel(const MappingArgs 
     }
 }
 
+// Backward of the same stack in ONE launch: gx_l = wscale * (g_l o gate(act_{l+1})) W_l for l = L-1 .. 0 (gate: the fused leaky-relu's
+// slope * sqrt 2), i.e. L x wgs_linear_dgrad.  The per-layer launches are M = 32 rows of a 512 x 512 contraction: 44 us each, nine of
+// them at the very end of the generator's backward (the step's critical path).  Here a workgroup carries two batch rows through all
+// layers: thread k owns input column k, streams W[:, k] (consecutive k: coalesced 2-KB wave rows) against the gated gradient rows in LDS.
+struct MappingBwdArgs {
+    const float* gw; const float* acts; float* gx;
+    const float* w[16];
+    int B, L;
+    float wscale;
+};
+__global__ __launch_bounds__(MLP_D) void mapping_mlp_bwd_kernel(const MappingBwdArgs a) {
+    __shared__ float gs[MLP_RPB][MLP_D];
+    const int k = threadIdx.x;
+    const int row0 = blockIdx.x * MLP_RPB;
+    const size_t plane = (size_t)a.B * MLP_D;
+    float g[MLP_RPB];
+#pragma unroll
+    for (int r = 0; r < MLP_RPB; ++r) g[r] = row0 + r < a.B ? a.gw[(size_t)(row0 + r) * MLP_D + k] : 0.f;
+    for (int l = a.L - 1; l >= 0; --l) {
+        const float* __restrict__ w = a.w[l];
+        const float* act = a.acts + (size_t)(l + 1) * plane;
+#pragma unroll
+        for (int r = 0; r < MLP_RPB; ++r) {
+            const float o = row0 + r < a.B ? act[(size_t)(row0 + r) * MLP_D + k] : 0.f;
+            gs[r][k] = g[r] * (o > 0.f ? SQRT2 : 0.2f * SQRT2);
+        }
+        __syncthreads();
+        float acc[MLP_RPB];
+#pragma unroll
+        for (int r = 0; r < MLP_RPB; ++r) acc[r] = 0.f;
+#pragma unroll 16
+        for (int n = 0; n < MLP_D; ++n) {
+            const float wv = w[(size_t)n * MLP_D + k];
+#pragma unroll
+            for (int r = 0; r < MLP_RPB; ++r) acc[r] = fmaf(gs[r][n], wv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < MLP_RPB; ++r) g[r] = acc[r] * a.wscale;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < MLP_RPB; ++r)
+        if (row0 + r < a.B) a.gx[(size_t)(row0 + r) * MLP_D + k] = g[r];
+}
+
 // The same for up to 16 independent small layers in ONE launch (blockIdx.y = layer): the per-layer demodulation
 // vectors of the synthesis network are 13 such GEMVs per pass, each too small to fill the chip or hide its latency.
 struct LinearBatchArgs {
@@ -707,6 +752,19 @@ int wgs_mapping_mlp_fwd(const float* z, const float* const* w, const float* cons
     for (int l = 0; l < L; ++l) WGS_CHECK_ARG(a.w[l] && a.b[l], "wgs_mapping_mlp_fwd: null layer %d", l);
     WGS_LAUNCH(mapping_mlp_fwd_kernel, dim3(wgs_cdiv(B, MLP_RPB)), dim3(512), 0, (hipStream_t)stream, a);
     WGS_CHECK_LAUNCH("mapping_mlp_fwd_kernel");
+    return WGS_OK;
+}
+
+int wgs_mapping_mlp_bwd(const float* gw, const float* const* w, const float* acts, float* gx, int B, int d, int L, float wscale,
+                        wgs_stream_t stream) {
+    WGS_CHECK_ARG(gw && w && acts && gx && B > 0, "wgs_mapping_mlp_bwd: null pointer");
+    WGS_CHECK_ARG(d == MLP_D && L >= 1 && L <= 16, "wgs_mapping_mlp_bwd: d = %d (must be %d), L = %d (1..16)", d, MLP_D, L);
+    MappingBwdArgs a;
+    a.gw = gw; a.acts = acts; a.gx = gx; a.B = B; a.L = L; a.wscale = wscale;
+    for (int l = 0; l < 16; ++l) a.w[l] = l < L ? w[l] : nullptr;
+    for (int l = 0; l < L; ++l) WGS_CHECK_ARG(a.w[l], "wgs_mapping_mlp_bwd: null layer %d", l);
+    WGS_LAUNCH(mapping_mlp_bwd_kernel, dim3(wgs_cdiv(B, MLP_RPB)), dim3(MLP_D), 0, (hipStream_t)stream, a);
+    WGS_CHECK_LAUNCH("mapping_mlp_bwd_kernel");
     return WGS_OK;
 }
 

@@ -39,6 +39,7 @@ class LinearBatch(ctypes.Structure):
                 ('wscale', ctypes.c_float * 16), ('eps', ctypes.c_float * 16), ('out_gain', ctypes.c_float * 16)]
 
 SQRT2 = 2 ** 0.5
+MAPPING_BWD_FUSED = True      # the mapping network's backward in one launch (tests switch it off to compare with the per-layer launches)
 
 
 def _dp(t):
@@ -304,6 +305,17 @@ class Generator(nn.Module):
         B, d = z.shape
         lib, st = L.lib(), L.stream()
         g = gw
+        mp = P['map']
+        fused = (acts[0].data_ptr() + 4 * B * d == acts[1].data_ptr()) if len(acts) > 1 else False       # acts are views of the fused forward's one buffer
+        if MAPPING_BWD_FUSED and fused and d == 512 and all(m[0].shape == (512, 512) and m[2] == mp[0][2] for m in mp):
+            # all L layers in one launch (wgs_mapping_mlp_bwd): nine 44-us launches at the end of the backward become two
+            n = len(mp)
+            wp = (ctypes.c_void_p * n)(*[m[0].data_ptr() for m in mp])
+            gx = torch.empty(B, d, device=z.device)
+            L.check(lib.wgs_mapping_mlp_bwd(L.ptr(g), wp, L.rawptr(acts[0]), L.ptr(gx), B, d, n, L.c_float(mp[0][2]), st), 'mapping_mlp_bwd')
+            gz = torch.empty_like(z)
+            L.check(lib.wgs_pixelnorm_bwd(L.ptr(z), L.ptr(gx), L.ptr(gz), B, d, L.c_float(1e-8), st), 'pixelnorm_bwd')
+            return gz
         for i in range(len(P['map']) - 1, -1, -1):
             w, _, scale, _ = P['map'][i]
             gx = torch.empty(B, w.shape[1], device=z.device)
