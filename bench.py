@@ -338,7 +338,7 @@ def hbm_subpaths(eng, dev, B):
     xb = torch.randn(N_, Cb, device=dev); yb = torch.empty_like(xb)
     g_, b_ = torch.ones(Cb, device=dev), torch.zeros(Cb, device=dev)
     mean, invstd = torch.empty(Cb, device=dev), torch.empty(Cb, device=dev)
-    ws = torch.empty(64 * Cb, dtype=torch.float64, device=dev)
+    ws = torch.zeros(64 * Cb, dtype=torch.float64, device=dev)
     t = timed(lambda: L.check(lib.wgs_bn_fwd(L.ptr(xb), L.ptr(g_), L.ptr(b_), None, L.ptr(yb), L.ptr(mean), L.ptr(invstd), None, None,
                                              None, L.rawptr(ws), L.c_int64(N_), Cb, L.c_float(1e-5), L.c_float(0.1), 1, 1, st), 'bn'))
     by = 3 * xb.numel() * 4

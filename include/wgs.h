@@ -401,15 +401,19 @@ int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, 
  * BasicBlock:  y = relu?( (x - mean)*invstd*gamma + beta (+ residual) ).
  * train != 0: batch statistics (biased variance), running stats updated with `momentum` and the unbiased
  * variance, num_batches_tracked += 1 (all three may be NULL); else running statistics are used.
- * save_mean / save_invstd [C] are written for the backward; ws = WGS_BN_WS_DOUBLES(C) doubles of scratch
- * (32 replicas of the 2*C partial sums, so that the reduction's fp64 atomics do not all hit the same addresses). C % 4 == 0. */
+ * save_mean / save_invstd [C] are written for the backward; ws = WGS_BN_WS_DOUBLES(C) doubles of scratch: 32 replicas of the 2*C
+ * partial sums (so that the reduction's fp64 atomics do not all hit the same addresses).  ws MUST BE ZERO ON ENTRY and is left zero
+ * on exit (zero it once when allocating it; one buffer serves any sequence of wgs_bn_fwd / wgs_bn_bwd / wgs_colsum calls on one
+ * stream, with any C): the launch that sums the replicas zeroes them again, so no reduction needs a memset.  C % 4 == 0. */
 #define WGS_BN_WS_DOUBLES(C) (64 * (C))
 int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
                int64_t N, int C, float eps, float momentum, int relu, int train, wgs_stream_t stream);
 /* Backward: g = (dyA + (dyB ? dyB : 0)) * (out ? out > 0 : 1)   [out = the saved post-ReLU output]
  *   dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) (train) ;  dgamma = sum g*xhat ; dbeta = sum g ;
- *   dres (optional) = g  (gradient of the residual branch). */
+ *   dres (optional) = g  (gradient of the residual branch).
+ * dgamma and dbeta are REQUIRED in train mode (the reduction launch writes the two sums there and the input-gradient launch reads them
+ * back); in eval mode pass both or neither (neither: no reduction is launched).  ws as in wgs_bn_fwd. */
 int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* out, const float* save_mean,
                const float* save_invstd, const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta,
                double* ws, int64_t N, int C, int train, wgs_stream_t stream);
@@ -426,7 +430,7 @@ int wgs_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, wgs_stream_
 /* Backward of nn.Upsample(scale_factor=2, nearest) on NHWC: dx[b,y,x,:] = sum of dy[b,2y..2y+1,2x..2x+1,:]
  * (models/ProgGAN/model.py:53, models/SNGAN/sn_gen_resnet.py:37,45, BigGAN GBlock). dy [B,2H,2W,C] -> dx [B,H,W,C]. */
 int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wgs_stream_t stream);
-/* out[c] = sum over rows of x[N,C] (conv bias gradient); ws = WGS_BN_WS_DOUBLES(C) doubles. */
+/* out[c] = sum over rows of x[N,C] (conv bias gradient); ws = WGS_BN_WS_DOUBLES(C) doubles, zero on entry / exit as above. */
 int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_stream_t stream);
 
 /* Loss of lib/trainer.py:245-249 and the statistics of :257-261:

@@ -25,7 +25,7 @@ def test_bn_residual_relu_fwd_bwd(dev, B, Cc, H):
     pre = F.batch_norm(x, rm, rv, ga, be, training=True, momentum=0.1, eps=1e-5) + res
     bn = torch.nn.BatchNorm2d(Cc).to(dev)
     bn.weight.data, bn.bias.data = ga.detach().float().to(dev), be.detach().float().to(dev)
-    ws = torch.empty(64 * 512, dtype=torch.float64, device=dev)
+    ws = torch.zeros(64 * 512, dtype=torch.float64, device=dev)
     xd, rd = nhwc(x.detach().float()).to(dev), nhwc(res.detach().float()).to(dev)
     yd, st = _BN.fwd(bn, xd, ws, residual=rd, relu=True, train=True)
     assert rel_err(nchw(yd), F.relu(pre).detach()) < 1e-6
@@ -79,7 +79,7 @@ def test_avgpool_pack_colsum(dev):
     assert torch.equal(d1.cpu(), a) and torch.equal(d2.cpu(), b)
     xs = torch.randn(1000, 64)
     cs = torch.empty(64, device=dev)
-    ws = torch.empty(64 * 64, dtype=torch.float64, device=dev)
+    ws = torch.zeros(64 * 64, dtype=torch.float64, device=dev)
     xsd = xs.to(dev)
     L.check(L.lib().wgs_colsum(L.ptr(xsd), L.ptr(cs), L.rawptr(ws), L.c_int64(1000), 64, L.stream()))
     assert rel_err(cs, xs.double().sum(0)) < 1e-6

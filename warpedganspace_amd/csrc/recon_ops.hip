@@ -105,9 +105,14 @@ __global__ __launch_bounds__(256) void unpack_pair_kernel(const float* __restric
 // MODE 0: s1 = sum x, s2 = sum x^2                                   (BN forward statistics)
 // MODE 1: g = (dyA + dyB) * (out > 0),  s1 = sum g, s2 = sum g*xhat    (BN backward statistics)
 // MODE 2: s1 = sum x                                                  (bias gradient)
-// ws: double[WS_REP][2*C], zeroed by the caller; workgroup b accumulates into replica b % WS_REP with fp64 atomics
-// (hundreds of workgroups adding to the same 2*C addresses serialise in the L2 atomic units: replicas cut that 32x);
-// ws_collapse_kernel then sums the replicas into replica 0, which the consumers read.
+// ws: double[WS_REP][2*C], ZERO ON ENTRY AND LEFT ZERO ON EXIT (the caller zeroes it once, when it allocates it); workgroup b
+// accumulates into replica b % WS_REP with fp64 atomics (hundreds of workgroups adding to the same 2*C addresses serialise in the L2
+// atomic units: replicas cut that 32x); the small second launch (bn_finalize_kernel / ws_collapse_kernel) sums the replicas, writes what
+// the consumer needs (mean / invstd / running statistics, or dbeta / dgamma) and ZEROES the replicas again — no memset launch per
+// reduction (40 per training step over the Reconstructor's 20 BatchNorms).
+// (Tried and dropped, round 4: the whole reduction in ONE launch, the last workgroup to finish — ticket counter — finalising.  The
+// agent-scope fence every workgroup needs in front of its ticket writes back its XCD's L2 on this 8-XCD part: 112 us instead of 72 us
+// for the stem's BatchNorm forward, the training step 27.4 -> 29.5 ms.  Kernel boundaries do that write-back once.)
 constexpr int WS_REP = 32;
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dyA,
@@ -183,13 +188,17 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void ws_collapse_kernel(double* __restrict__ ws, int n) {
+// totals of a MODE 1 / 2 reduction: out1[c] = sum of replica s1 (dbeta / the column sums), out2[c] = s2 (dgamma; may be NULL);
+// the replicas are zeroed again
+__global__ __launch_bounds__(256) void ws_collapse_kernel(double* __restrict__ ws, int C, float* __restrict__ out1, float* __restrict__ out2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = 2 * C;
     if (i >= n) return;
     double t = 0.0;
 #pragma unroll 8
-    for (int r = 0; r < WS_REP; ++r) t += ws[(size_t)r * n + i];
-    ws[i] = t;
+    for (int r = 0; r < WS_REP; ++r) { t += ws[(size_t)r * n + i]; ws[(size_t)r * n + i] = 0.0; }
+    if (i < C) { if (out1) out1[i] = (float)t; }
+    else if (out2) out2[i - C] = (float)t;
 }
 
 // BN forward finalize (train mode): batch mean / biased var -> mean, invstd; running stats as nn.BatchNorm
@@ -203,7 +212,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* __restr
     // sums the WS_REP replicas itself (same order as ws_collapse_kernel): one launch less per BatchNorm forward
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll 8
-    for (int r = 0; r < WS_REP; ++r) { s1 += ws[(size_t)r * 2 * C + c]; s2 += ws[(size_t)r * 2 * C + C + c]; }
+    for (int r = 0; r < WS_REP; ++r) {
+        double* pr = const_cast<double*>(ws) + (size_t)r * 2 * C;
+        s1 += pr[c]; s2 += pr[C + c];
+        pr[c] = 0.0; pr[C + c] = 0.0;               // left zero for the next reduction (no memset launch)
+    }
     const double m = s1 / (double)N;
     double var = s2 / (double)N - m * m;
     if (var < 0.0) var = 0.0;
@@ -259,12 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, float* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t N,
                                                            int C, int train) {
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < C; c += 256) {
-            if (dbeta) dbeta[c] = (float)ws[c];
-            if (dgamma) dgamma[c] = (float)ws[C + c];
-        }
-    }
+    // (dbeta = sum g and dgamma = sum g*xhat were written by ws_collapse_kernel, the launch in front of this one)
     const int c4n = C >> 2;
     const int64_t total = N * c4n;
     const double invN = 1.0 / (double)N;
@@ -287,8 +295,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
         float4 d;
         if (train) {
-            const float m1x = (float)(ws[c] * invN), m1y = (float)(ws[c + 1] * invN), m1z = (float)(ws[c + 2] * invN), m1w = (float)(ws[c + 3] * invN);
-            const float m2x = (float)(ws[C + c] * invN), m2y = (float)(ws[C + c + 1] * invN), m2z = (float)(ws[C + c + 2] * invN), m2w = (float)(ws[C + c + 3] * invN);
+            const float4 s1 = *reinterpret_cast<const float4*>(dbeta + c), s2 = *reinterpret_cast<const float4*>(dgamma + c);
+            const float m1x = (float)(s1.x * invN), m1y = (float)(s1.y * invN), m1z = (float)(s1.z * invN), m1w = (float)(s1.w * invN);
+            const float m2x = (float)(s2.x * invN), m2y = (float)(s2.y * invN), m2z = (float)(s2.z * invN), m2w = (float)(s2.w * invN);
             d.x = ga.x * is.x * (g.x - m1x - (v.x - mu.x) * is.x * m2x);
             d.y = ga.y * is.y * (g.y - m1y - (v.y - mu.y) * is.y * m2y);
             d.z = ga.z * is.z * (g.z - m1z - (v.z - mu.z) * is.z * m2z);
@@ -541,7 +550,6 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
     WGS_CHECK_ARG(train || (running_mean && running_var), "wgs_bn_fwd: eval mode needs running stats");
     hipStream_t st = (hipStream_t)stream;
     if (train) {
-        (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
         const int rpb = reduce_rows_per_block(N, C);
         WGS_LAUNCH(chan_reduce_kernel<0>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                            nullptr, nullptr, ws, N, C, rpb);
@@ -562,12 +570,15 @@ int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* 
                double* ws, int64_t N, int C, int train, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && dyA && save_mean && save_invstd && gamma && dx && ws, "wgs_bn_bwd: null pointer");
     WGS_CHECK_ARG(N > 0 && C >= 4 && C % 4 == 0, "wgs_bn_bwd: C=%d must be a multiple of 4", C);
+    WGS_CHECK_ARG((dgamma && dbeta) || (!train && !dgamma && !dbeta),
+                  "wgs_bn_bwd: dgamma and dbeta are required in train mode (the input gradient reads the sums back from them); eval mode takes both or neither");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
     const int rpb = reduce_rows_per_block(N, C);
-    WGS_LAUNCH(chan_reduce_kernel<1>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
-                       save_invstd, ws, N, C, rpb);
-    WGS_LAUNCH(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
+    if (dgamma) {        // (eval mode without parameter gradients — a frozen generator's BatchNorm — needs no reduction at all)
+        WGS_LAUNCH(chan_reduce_kernel<1>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
+                           save_invstd, ws, N, C, rpb);
+        WGS_LAUNCH(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, C, dbeta, dgamma);
+    }
     WGS_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
                        save_invstd, gamma, ws, dx, dres, dgamma, dbeta, N, C, train);
     WGS_CHECK_LAUNCH("bn_bwd");
@@ -618,14 +629,10 @@ int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, w
 int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && out && ws && N > 0 && C >= 4 && C % 4 == 0, "wgs_colsum: bad arguments (C %% 4)");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C * WS_REP, st);
     const int rpb = reduce_rows_per_block(N, C);
     WGS_LAUNCH(chan_reduce_kernel<2>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                        nullptr, ws, N, C, rpb);
-    WGS_LAUNCH(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, 2 * C);
-    // reuse the BN-backward epilogue's block-0 copy: dbeta = s1
-    WGS_LAUNCH(bn_bwd_apply_kernel, dim3(1), dim3(256), 0, st, x, x, nullptr, nullptr, x, x, x, ws, (float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, out, (int64_t)0, C, 0);
+    WGS_LAUNCH(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, C, out, (float*)nullptr);
     WGS_CHECK_LAUNCH("colsum");
     return WGS_OK;
 }

@@ -124,7 +124,7 @@ def forward_impl(R, x1, x2, save=True):
     dev = x1.device
     x1, x2 = x1.contiguous(), x2.contiguous()
     B, c, H, W = x1.shape
-    ws = torch.empty(64 * 128, dtype=torch.float64, device=dev)      # WGS_BN_WS_DOUBLES(128)
+    ws = torch.zeros(64 * 128, dtype=torch.float64, device=dev)      # WGS_BN_WS_DOUBLES(128)
     Cp0 = _pad8(2 * c)
     x = torch.empty(B, H, W, Cp0, device=dev)
     L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp0, st), 'pack_pair')

@@ -229,7 +229,7 @@ class Reconstructor(nn.Module):
         dev = x1.device
         x1, x2 = x1.contiguous(), x2.contiguous()
         B, c, H, W = x1.shape
-        ws = self._scratch('bn_ws', (64 * 512,), torch.float64, dev)      # WGS_BN_WS_DOUBLES(512), reused every step
+        ws = self._scratch('bn_ws', (64 * 512,), torch.float64, dev, zero=True)      # WGS_BN_WS_DOUBLES(512): zero on entry, left zero
         Cp = 8
         arith = arith or self.arith
         fp = arith.forward

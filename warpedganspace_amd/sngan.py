@@ -138,7 +138,7 @@ class GenModel(nn.Module):
             n = 2 + self.nblocks
             P['bn'] = self.seq[n]
             P['final'] = packs(self.seq[n + 2], pad_co=8)
-            P["ws"] = torch.empty(64 * 1024, dtype=torch.float64, device=dev)    # WGS_BN_WS_DOUBLES(1024)
+            P["ws"] = torch.zeros(64 * 1024, dtype=torch.float64, device=dev)    # WGS_BN_WS_DOUBLES(1024)
         self._prep = P
         return P
 
