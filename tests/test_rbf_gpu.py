@@ -138,3 +138,39 @@ def test_latent_dimension_not_multiple_of_four(dev):
     ref_path, _ = O.traverse_paths(c['sd'], c['z'][:2], 0.2, 3, True, c['gamma'])
     assert path.shape == (2, K, 7, d)
     assert float((path.cpu() - ref_path).abs().max()) < 1e-4
+
+
+def test_one_launch_forward_equals_the_split_forward(dev):
+    """wgs_rbf_fwd is one launch (a 16-wave workgroup per sample); WGS_RBF_SPLIT restores the two-launch form (support vectors split over
+    workgroups + finish).  Same field, norm and saved squared distances to fp32 summation order; the backward reads either's workspace."""
+    import os
+    from warpedganspace_amd import _lib as L
+    lib = L.lib()
+    torch.manual_seed(4)
+    for K, N, d, B in ((128, 32, 512, 32), (200, 64, 512, 8), (32, 8, 128, 16), (16, 3, 1024, 5)):
+        n2 = 2 * N
+        table = torch.randn(K, n2 * d, device=dev) * 0.7
+        alphas = torch.where(torch.arange(n2, device=dev) % 2 == 0, 1.0, -1.0).repeat(K, 1).contiguous()
+        lg = (torch.randn(K, device=dev) * 0.1 - 6.0).contiguous()
+        idx = torch.randint(0, K, (B,), device=dev)
+        z, mag = torch.randn(B, d, device=dev), torch.rand(B, device=dev) + 0.2
+        res = []
+        for split in (False, True):
+            if split:
+                os.environ['WGS_RBF_SPLIT'] = '1'
+            else:
+                os.environ.pop('WGS_RBF_SPLIT', None)
+            lib.wgs_dev_reload_flags()
+            ws = torch.zeros(int(lib.wgs_rbf_ws_floats(B, n2, d)), device=dev)
+            out = torch.empty(B, d, device=dev)
+            c0 = lib.wgs_dev_launch_count()
+            L.check(lib.wgs_rbf_fwd(L.ptr(table), L.ptr(alphas), L.ptr(lg), L.c_float(0.0), L.ptr(idx, torch.int64), L.ptr(z), L.ptr(mag), L.ptr(out),
+                                    L.ptr(ws), B, K, n2, d, L.stream()), 'rbf')
+            o_r2 = B * d + ((B + 3) & ~3)        # workspace layout (rbf.hip rbf_ws): g_raw [B,d] | gnorm [B] (padded to 4) | r2 [B,n2] | split partials
+            res.append((out.clone(), torch.cat([ws[:B * d + B], ws[o_r2:o_r2 + B * n2]]).clone(), lib.wgs_dev_launch_count() - c0))
+        os.environ.pop('WGS_RBF_SPLIT', None)
+        lib.wgs_dev_reload_flags()
+        (o1, w1, n1), (o2, w2, n2_) = res
+        assert n1 == 1 and n2_ == 2
+        assert (o1 - o2).abs().max() <= 2e-6 * o2.abs().max()
+        assert (w1 - w2).abs().max() <= 2e-6 * w2.abs().max()

@@ -41,6 +41,7 @@ static WgsFlags read_flags() {
     g.wino_small = getenv("WGS_WINO_SMALL") != nullptr;      // Winograd fp32: 4-wave workgroups of 32 tiles x 64 channels, two per CU
     g.wino_narrow = getenv("WGS_WINO_NARROW") != nullptr;    // Winograd fp32: the 64-tile x 64-channel workgroup shape even where Cout % 128 == 0
     g.halo_min_tiles = getenv("WGS_HALO_MIN_TILES") ? atoi(getenv("WGS_HALO_MIN_TILES")) : 512;      // (tests: 1 = every covered shape)
+    g.rbf_split = getenv("WGS_RBF_SPLIT") != nullptr;      // RBF forward as two launches (support vectors split over workgroups + finish)
     g.no_halo = getenv("WGS_NO_HALO") != nullptr;      // few-channel 3x3 convs on large maps through the GEMM-tiled kernels (conv_halo16.hip off)
     g.f32_old = getenv("WGS_F32_OLD") != nullptr;      // exact fp32: the plain three-phase kernel of conv_igemm.hip everywhere
     // producer-written fp16 activation planes (x_f16): stride-1 3x3 launches with fewer output columns than this take the patch form,

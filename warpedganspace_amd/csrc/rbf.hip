@@ -154,6 +154,75 @@ __global__ __launch_bounds__(RBF_THREADS) void rbf_fwd_finish(float* __restrict_
     if (threadIdx.x == 0) w.gnorm[b] = norm;
 }
 
+// forward in ONE launch: a workgroup of 16 waves owns a sample — wave w streams support vectors w, w + 16, ... of the selected row (each a
+// coalesced 16-B-per-lane read), the 16 partial fields meet in LDS, the norm is a block reduction.  The two-launch form above spreads a
+// sample over S workgroups to keep all CUs streaming, but at the training batch the whole table row is 131 KB per sample and the step is
+// launch latency, not bandwidth: 2 launches of ~8 us against one.
+constexpr int RBF1_WAVES = 16;
+template <int NT>
+__global__ __launch_bounds__(64 * RBF1_WAVES) void rbf_fwd_one(
+    const float* __restrict__ table, const float* __restrict__ alphas, const float* __restrict__ loggamma, float gamma_c,
+    const int64_t* __restrict__ idx, const float* __restrict__ z, const float* __restrict__ scale, float* __restrict__ out,
+    float* __restrict__ ws, int B, int n2, int d) {
+    __shared__ float4 red[RBF1_WAVES][64 * NT];
+    __shared__ float nred[RBF1_WAVES];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = (int)idx[b];
+    const float gamma = loggamma ? expf(loggamma[k]) : gamma_c;
+    const RbfWs w = rbf_ws(ws, B, n2, d);
+    const float* srow = table + (size_t)k * n2 * d;
+    const float* arow = alphas + (size_t)k * n2;
+    float4 zr[NT], acc[NT];
+    load_vec<NT>(zr, z + (size_t)b * d, lane, d);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = wave; i < n2; i += RBF1_WAVES) {
+        float4 sv[NT];
+        load_vec<NT>(sv, srow + (size_t)i * d, lane, d);
+        float p = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            sv[t] = sub4(zr[t], sv[t]);
+            p += dot4(sv[t], sv[t]);
+        }
+        const float r2 = wave_sum(p);
+        const float c = -2.f * arow[i] * gamma * expf(-gamma * r2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fma4(acc[t], c, sv[t]);
+        if (lane == 0) w.r2[(size_t)b * n2 + i] = r2;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) red[wave][lane + 64 * t] = acc[t];
+    __syncthreads();
+    // threads 0 .. 64 NT - 1 each finish one float4 slot of the field; everybody joins the norm reduction
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int slot = threadIdx.x;
+    const int jl = 4 * (slot & 63) + 256 * (slot >> 6);
+    const bool live = slot < 64 * NT && jl < d;
+    if (live) {
+        g4 = red[0][slot];
+#pragma unroll
+        for (int ww = 1; ww < RBF1_WAVES; ++ww) {
+            const float4 o = red[ww][slot];
+            g4.x += o.x; g4.y += o.y; g4.z += o.z; g4.w += o.w;
+        }
+    }
+    float nn = wave_sum(dot4(g4, g4));
+    if (lane == 0) nred[wave] = nn;
+    __syncthreads();
+    nn = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < RBF1_WAVES; ++ww) nn += nred[ww];
+    const float norm = sqrtf(nn);
+    const float f = (scale ? scale[b] : 1.f) / norm;
+    if (live) {
+        *reinterpret_cast<float4*>(w.g_raw + (size_t)b * d + jl) = g4;
+        *reinterpret_cast<float4*>(out + (size_t)b * d + jl) = make_float4(g4.x * f, g4.y * f, g4.z * f, g4.w * f);
+    }
+    if (threadIdx.x == 0) w.gnorm[b] = norm;
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward.  With u = g/|g| and go = dL/du (times scale[b]):  h = dL/dg = (go - u (u.go)) / |g|.
 //   dL/ds_i      =  2 a_i y e_i (h - 2 y (h.D_i) D_i)        (y = gamma, D_i = z - s_i)
@@ -370,6 +439,16 @@ int wgs_rbf_fwd(const float* table, const float* alphas, const float* loggamma, 
     WGS_CHECK_ARG(B > 0 && K > 0 && n2 > 0, "wgs_rbf_fwd: bad sizes B=%d K=%d n2=%d", B, K, n2);
     WGS_CHECK_ARG(d > 0 && d % 4 == 0 && d <= 2048, "wgs_rbf_fwd: d=%d must be a multiple of 4 and <= 2048", d);
     hipStream_t st = (hipStream_t)stream;
+    if (!wgs_flags().rbf_split && d <= 1024) {       // one launch: a 16-wave workgroup per sample (d <= 1024: NT <= 4, 64 KB of LDS)
+        dim3 g1(B), b1(64 * RBF1_WAVES);
+        switch (rbf_nt(d)) {
+            case 1: WGS_LAUNCH(rbf_fwd_one<1>, g1, b1, 0, st, table, alphas, loggamma, gamma, idx, z, scale, out, ws, B, n2, d); break;
+            case 2: WGS_LAUNCH(rbf_fwd_one<2>, g1, b1, 0, st, table, alphas, loggamma, gamma, idx, z, scale, out, ws, B, n2, d); break;
+            default: WGS_LAUNCH(rbf_fwd_one<4>, g1, b1, 0, st, table, alphas, loggamma, gamma, idx, z, scale, out, ws, B, n2, d); break;
+        }
+        WGS_CHECK_LAUNCH("rbf_fwd_one");
+        return WGS_OK;
+    }
     const int S = rbf_splits(B, n2);
     dim3 grid(S, B), block(RBF_THREADS);
     switch (rbf_nt(d)) {
