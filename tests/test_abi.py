@@ -32,3 +32,10 @@ def test_product_path_rejects_cpu_tensors():
     mask[:, 1] = 1
     with pytest.raises(L.WgsError):
         S(mask, torch.randn(2, 8))
+
+
+def test_prebuilt_library_matches_the_sources_beside_it():
+    """The built .so travels with a snapshot (it is git-ignored, not gpurun-ignored): its fingerprint must be the sources' (VERDICT r3,
+    robustness).  __graft_entry__.build() rebuilds from scratch on a mismatch."""
+    from warpedganspace_amd import _lib
+    assert _lib.library_matches_sources() is True, "run `python -c 'import __graft_entry__ as g; g.build()'`"

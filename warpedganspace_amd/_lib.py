@@ -27,6 +27,27 @@ def header_symbols(header_path=HEADER_PATH):
     return sorted(set(re.findall(r"\b(wgs_[a-z0-9_]+)\s*\(", src)))
 
 
+def source_fingerprint():
+    """sha256 over csrc/*.hip, *.h, *.inc and include/wgs.h in the order build.sh hashes them (shell glob order = sorted names)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for pat in ("*.hip", "*.h", "*.inc"):
+        for f in sorted(glob.glob(os.path.join(csrc, pat))):
+            h.update(open(f, "rb").read())
+    h.update(open(HEADER_PATH, "rb").read())
+    return h.hexdigest()
+
+
+def library_matches_sources():
+    """True / False: libwgs_hip.so was built from the sources beside it (fingerprint written by csrc/build.sh); None: no fingerprint."""
+    fp = LIB_PATH + ".sources.sha256"
+    if not os.path.isfile(fp):
+        return None
+    return open(fp).read().strip() == source_fingerprint()
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises WgsError when the extension is not built."""
     global _lib

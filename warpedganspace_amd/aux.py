@@ -73,24 +73,28 @@ def create_exp_dir(args, root="experiments"):
     return exp_dir
 
 
-def update_progress(msg, total, progress):
-    bar_length, status = 20, ""
-    progress = float(progress) / float(total)
-    if progress >= 1.:
-        progress, status = 1, "\r\n"
-    block = int(round(bar_length * progress))
-    text = "\r{}{} {:.0f}% {}".format(msg, u"█" * block + u"░" * (bar_length - block), round(progress * 100, 0), status)
-    sys.stdout.write(text)
+def update_progress(msg, total, progress, width=20):
+    """One-line console progress bar (cosmetic; the training log of lib/trainer.py uses the same 20-cell bar)."""
+    frac = min(max(float(progress) / float(total), 0.0), 1.0)
+    cells = int(round(width * frac))
+    done = frac >= 1.0
+    sys.stdout.write("\r{}{}{} {:.0f}% {}".format(msg, "\u2588" * cells, "\u2591" * (width - cells), round(100 * frac), "\r\n" if done else ""))
     sys.stdout.flush()
 
 
 def update_stdout(num_lines):
-    for _ in range(num_lines):
-        print('\x1b[1A' + '\x1b[1A')
+    """Move the cursor up over the block the log just printed, so that the next log overwrites it (interactive terminals only)."""
+    sys.stdout.write('\x1b[1A\x1b[1A\n' * num_lines)       # up two, down one (the newline): one line up per repetition
+    sys.stdout.flush()
+
+
+_UNITS = (("days", 86400), ("hours", 3600), ("minutes", 60))
 
 
 def sec2dhms(t):
-    day, t = t // (24 * 3600), t % (24 * 3600)
-    hour, t = t // 3600, t % 3600
-    minutes, seconds = t // 60, t % 60
-    return "%02d days, %02d hours, %02d minutes, and %02d seconds" % (day, hour, minutes, seconds)
+    """Seconds -> 'DD days, HH hours, MM minutes, and SS seconds' (the reference log's format)."""
+    parts, t = [], int(t)
+    for name, size in _UNITS:
+        q, t = divmod(t, size)
+        parts.append("%02d %s" % (q, name))
+    return ", ".join(parts) + ", and %02d seconds" % t

@@ -17,4 +17,7 @@ for src in *.hip; do
 done
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libwgs_hip.so "${OBJS[@]}"
+# fingerprint of the sources this library was built from (checked by __graft_entry__.build() and warpedganspace_amd._lib: a prebuilt
+# .so that travels with a snapshot must match the sources beside it)
+LC_ALL=C; export LC_ALL; cat *.hip *.h *.inc ../../include/wgs.h | sha256sum | cut -d' ' -f1 > ../libwgs_hip.so.sources.sha256
 echo "built $(cd .. && pwd)/libwgs_hip.so"
