@@ -180,7 +180,7 @@ def _bench_two_ranks(backend, tmp_path):
     assert abs(d['value'] - 8 * 3 / (d['ms_per_step'] * 3e-3)) < 0.02 * d['value']          # whole-job rate over both ranks
     c = d['comm']
     assert c['world_size_observed'] == 2 and c['collectives_per_step'] == 2 and c['allreduce_bytes_per_step'] > 0 and c['exposed_wait_ms_per_step'] >= 0
-    assert d['roofline']['kernel'] and 0 < d['roofline']['frac'] <= 1.0 and d['host']['library_launches_per_step'] > 0
+    assert d['roofline']['kernel'] and 0 <= d['roofline']['frac'] <= 1.0 and d['host']['library_launches_per_step'] > 0
     assert d['product']['value'] > 0 and d['direct_fp32']['precision'] == 'fp32' and d['config']['precision'] == 'fp32w'
     full = json.load(open(side))                               # the side file holds the complete records
     e = full['extra'][0]

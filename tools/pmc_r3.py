@@ -16,7 +16,11 @@ SHAPES = [('conv fp32w 512->512 @64x64 9 taps B32', 'conv', 'fp32w', 512, 512, 6
           ('conv f16 256->256 @128x128 9 taps B32', 'conv', 'f16', 256, 256, 128),
           ('conv f16 128->128 @256x256 9 taps B32', 'conv', 'f16', 128, 128, 256),
           ('conv f16x2 256->128 @128x128 up-conv + blur fused B32', 'up', 'f16x2', 256, 128, 128),
-          ('conv f16x2 512->256 @64x64 up-conv + blur fused B32', 'up', 'f16x2', 512, 256, 64)]
+          ('conv f16x2 512->256 @64x64 up-conv + blur fused B32', 'up', 'f16x2', 512, 256, 64),
+          # round 4: producer-written fp16 plane through the patch kernel's XF16 form, and the few-channel halo kernel (StyleGAN2-1024, B = 8)
+          ('conv f16 128->128 @256x256 9 taps B32 (fp16 plane)', 'plane', 'f16', 128, 128, 256),
+          ('conv f16x2 32->32 @1024x1024 9 taps B8', 'halo', 'f16x2', 32, 32, 1024),
+          ('conv f16x2 64->64 @512x512 9 taps B8', 'halo', 'f16x2', 64, 64, 512)]
 
 
 def run():
@@ -25,12 +29,19 @@ def run():
     dev = torch.device('cuda:0')
     for label, kind, prec, ci, co, h in SHAPES:
         m = C.precision_code(prec)
+        B = 8 if kind == 'halo' else 32
         x = torch.randn(B, h, h, ci, device=dev); w = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
         s = torch.randn(B, ci, device=dev); dm = torch.rand(B, co, device=dev)
         ws = C.SplitCache(w) if m == C.FP32W else (C.split_weight(w, m) if m else None)
-        if kind == 'conv':
+        if kind in ('conv', 'halo'):
             y = torch.empty(B, h, h, co, device=dev)
-            fn = lambda: C.conv2d(x, w, 3, pad=1, out=y, a_scale=s, col_scale=dm, act_slope=0.2, gain=1.41, precision=m, w_split=ws)
+            am = x.abs().amax().reshape(1)
+            fn = lambda: C.conv2d(x, w, 3, pad=1, out=y, a_scale=s, col_scale=dm, act_slope=0.2, gain=1.41, precision=m, w_split=ws, a_amax=am)
+        elif kind == 'plane':
+            y = torch.empty(B, h, h, co, device=dev)
+            am = torch.full((1,), 4.0, device=dev)
+            xp = (x * 512.0).half().view(torch.int16)
+            fn = lambda: C.conv2d(xp, w, 3, pad=1, out=y, col_scale=dm, act_slope=0.2, gain=1.41, precision=m, w_split=ws, a_amax=am, x_f16=True)
         elif kind == 'upT':
             t = torch.empty(B, 2 * h + 1, 2 * h + 1, co, device=dev)
             fn = lambda: C.conv_transpose2d_s2(x, w, out=t, a_scale=s, col_scale=dm, precision=m, w_split=ws)
@@ -50,7 +61,7 @@ def summarise(d, out):
     for f in sorted(glob.glob(d + '/*/p_counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
-            mm = re.search(r'(igemm_\w+<[^>]*>|upconv_blur_kernel<[^>]*>|wino_f32_kernel<[^>]*>)', kn)
+            mm = re.search(r'(igemm_\w+<[^>]*>|upconv_blur_kernel<[^>]*>|wino_f32_kernel<[^>]*>|halo3x3_kernel<[^>]*>)', kn)
             if not mm:
                 continue
             key = (int(r['Dispatch_Id']), mm.group(1))
@@ -63,8 +74,9 @@ def summarise(d, out):
         if 2 * i + 1 >= len(keys):
             break
         sym, c = keys[2 * i + 1][1], tab[keys[2 * i + 1]]
+        B = 8 if kind == 'halo' else 32
         ho = 2 * h if kind == 'up' else (2 * h + 1 if kind == 'upT' else h)
-        rd = B * h * h * ci * 4 + co * ci * (64 if prec == 'fp32w' else (36 if prec == 'fp32' else 18))
+        rd = B * h * h * ci * (2 if kind == 'plane' else 4) + co * ci * (64 if prec == 'fp32w' else (36 if prec == 'fp32' else 18))
         wr = B * ho * ho * co * 4
         fetch, write = c.get('FETCH_SIZE', 0) * 1024 * 2, c.get('WRITE_SIZE', 0) * 1024
         mf = c.get('SQ_INSTS_MFMA', 0) or 1

@@ -1,16 +1,20 @@
 #!/bin/bash
-# usage: bash tools/run_round.sh <tag> —: GPU test suite, default bench line, rocprofv3 kernel tables of the fp32 and the default-arithmetic step
-TAG=${1:-r3b}
+# usage: bash tools/run_round.sh <tag> [notests] — GPU test suite, default bench line (+ side file), rocprofv3 kernel tables and phase
+# breakdowns of the fp32w / fp32 / auto step, PMC passes of the dominant conv kernels, host-enqueue measurement with 8 processes
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/${TAG}_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_tests.log
-tail -5 gpurun_out/${TAG}_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-timeout 900 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"
-grep '^{' gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json
+if [ "$2" != "notests" ]; then
+  timeout 2400 python -m pytest tests -q -m gpu -x > gpurun_out/${TAG}_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_tests.log
+  tail -5 gpurun_out/${TAG}_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+fi
+timeout 900 python bench.py --extra-out gpurun_out/${TAG}_bench_extra.json > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"
+tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; wc -c gpurun_out/${TAG}_bench.json
 for mode in fp32w fp32 auto; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$mode -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-product-run --single-stream --precision $mode > gpurun_out/prof_${TAG}_$mode.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$mode -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-product-run --single-stream --precision $mode --extra-out gpurun_out/prof_${TAG}_${mode}_extra.json > gpurun_out/prof_${TAG}_$mode.log 2>&1
   python tools/prof_summary.py gpurun_out/prof_${TAG}_$mode 12 > gpurun_out/${TAG}_step_${mode}_kernel_stats.md
+  python tools/phase_breakdown.py gpurun_out/prof_${TAG}_$mode 8 > gpurun_out/${TAG}_phases_${mode}.md 2>&1
   find gpurun_out/prof_${TAG}_$mode -name "*kernel_trace.csv" -delete
   head -12 gpurun_out/${TAG}_step_${mode}_kernel_stats.md | cut -c1-160
 done
@@ -21,4 +25,5 @@ for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc_${TAG}/p$i -o p -- python tools/pmc_r3.py > gpurun_out/pmc_${TAG}_p$i.log 2>&1
 done
 find gpurun_out/pmc_${TAG} -name "*kernel_trace.csv" -delete
-python tools/pmc_r3.py --summarise gpurun_out/pmc_${TAG} gpurun_out/${TAG}_conv_pmc
+python tools/pmc_r3.py --summarise gpurun_out/pmc_${TAG} gpurun_out/${TAG}_conv_pmc | tail -16 | cut -c1-220
+timeout 900 python tools/host_enqueue_n.py 8 auto | tail -1 > gpurun_out/${TAG}_host_enqueue_8.json

@@ -236,8 +236,12 @@ struct MappingBwdArgs {
     float wscale;
 };
 __global__ __launch_bounds__(MLP_D) void mapping_mlp_bwd_kernel(const MappingBwdArgs a) {
+    // thread t: in the contraction, column group cg = t % 128 (columns 4 cg .. 4 cg + 3, one 16-byte load per weight row) and row
+    // residue ng = t / 128 (weight rows n = ng, ng + 4, ...): four times the bytes in flight of one dword per thread and row (the first
+    // version: 30 us per layer); outside it, thread t owns column t (gate, the cross-residue sum)
     __shared__ float gs[MLP_RPB][MLP_D];
-    const int k = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float part[4][MLP_RPB][MLP_D];
+    const int k = threadIdx.x, cg = k & 127, ng = k >> 7;
     const int row0 = blockIdx.x * MLP_RPB;
     const size_t plane = (size_t)a.B * MLP_D;
     float g[MLP_RPB];
@@ -252,18 +256,27 @@ __global__ __launch_bounds__(MLP_D) void mapping_mlp_bwd_kernel(const MappingBwd
             gs[r][k] = g[r] * (o > 0.f ? SQRT2 : 0.2f * SQRT2);
         }
         __syncthreads();
-        float acc[MLP_RPB];
+        float4 acc[MLP_RPB];
 #pragma unroll
-        for (int r = 0; r < MLP_RPB; ++r) acc[r] = 0.f;
+        for (int r = 0; r < MLP_RPB; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 16
-        for (int n = 0; n < MLP_D; ++n) {
-            const float wv = w[(size_t)n * MLP_D + k];
+        for (int i = 0; i < MLP_D / 4; ++i) {
+            const int n = 4 * i + ng;
+            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)n * MLP_D + 4 * cg);
 #pragma unroll
-            for (int r = 0; r < MLP_RPB; ++r) acc[r] = fmaf(gs[r][n], wv, acc[r]);
+            for (int r = 0; r < MLP_RPB; ++r) {
+                const float gv = gs[r][n];
+                acc[r].x = fmaf(gv, wv.x, acc[r].x); acc[r].y = fmaf(gv, wv.y, acc[r].y);
+                acc[r].z = fmaf(gv, wv.z, acc[r].z); acc[r].w = fmaf(gv, wv.w, acc[r].w);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < MLP_RPB; ++r) g[r] = acc[r] * a.wscale;
+        for (int r = 0; r < MLP_RPB; ++r) *reinterpret_cast<float4*>(&part[ng][r][4 * cg]) = acc[r];
         __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MLP_RPB; ++r) g[r] = ((part[0][r][k] + part[1][r][k]) + (part[2][r][k] + part[3][r][k])) * a.wscale;
+        // (the next layer's gs / part writes come after its own barrier: gs is rewritten only after every thread has passed the barrier
+        // above, and part only after the next contraction, behind the next barrier)
     }
 #pragma unroll
     for (int r = 0; r < MLP_RPB; ++r)

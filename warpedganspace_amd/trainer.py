@@ -47,6 +47,17 @@ def sampler_seed(seed, rank, world, start_iter, device):
     return ((base * 1000003 + 7919 * int(start_iter)) * max(world, 1) + rank) % (1 << 63)     # torch.Generator seeds are < 2^64
 
 
+_STREAMS = {}
+
+
+def _engine_streams(device):
+    """(side, prefetch, high-priority main) streams of `device`, created once per process."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _STREAMS:
+        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device), torch.cuda.Stream(device=device, priority=-1))
+    return _STREAMS[key]
+
+
 class FlatBucket:
     """Re-homes parameters into one flat fp32 buffer (memory order preserved) with a matching flat gradient
     and Adam moment buffers.  `gview[id(p)]` is the gradient region of p in p's MEMORY layout (conv weights:
@@ -111,14 +122,16 @@ class TrainStep:
         self.precision = generator.resolve_precision(precision)       # concrete code 0..4
         self.r_arith = r_arith(r_precision, self.precision)
         self.gen = torch.Generator(device=device)
-        self.side_stream = torch.cuda.Stream(device=device)
-        self.pre_stream = torch.cuda.Stream(device=device)
+        # HIP maps streams onto a handful of hardware queues (4 per process by default); every engine of a process making its own
+        # three streams put the fourth engine's "concurrent" streams on ONE queue — bench.py's second engine ran 37.5 instead of
+        # 27.5 ms per step.  The streams are per device, shared by all engines.
+        self.side_stream, self.pre_stream, main_stream = _engine_streams(device)
         # The step's critical path (shifted forward -> R -> loss -> R backward -> G backward -> Adam) runs on a HIGH-priority stream of
         # its own; the side work that only has to be finished by the end of the step (the un-shifted pass of this / the next batch,
         # R's weight gradients) stays on default-priority streams: when a CU frees up, the critical path's next workgroups — the
         # Reconstructor's ~300 short launches in particular — are dispatched ahead of the side streams' long-running generator tiles
         # instead of queueing behind them.
-        self.main_stream = torch.cuda.Stream(device=device, priority=-1) if (priority_main and two_streams) else None
+        self.main_stream = main_stream if (priority_main and two_streams) else None
         self.two_streams = two_streams       # un-shifted generator pass on the side stream
         self.defer_wgrad = defer_wgrad       # R's weight gradients on the side stream, next to the generator's backward
         self.prefetch = prefetch             # G(z) of the NEXT step's batch, next to this step's Reconstructor / backward phases
