@@ -99,6 +99,30 @@ def test_input_gradient_launch_and_narrow_channel_counts(dev, halo_everywhere, p
     assert (g1.double().permute(0, 3, 1, 2) - ref).abs().max() <= TOL[prec] * ref.abs().max()
 
 
+@pytest.mark.parametrize('prec', [1, 2])
+@pytest.mark.parametrize('B,Ci,Co,H', [(2, 64, 32, 32), (1, 32, 16, 64)])
+def test_upsampling_gather_launch(dev, halo_everywhere, prec, B, Ci, Co, H):
+    """ProgGAN's nearest-neighbour Upsample + conv (models/ProgGAN/model.py:53-62) as ONE launch: x [B,H,H,Ci] -> y [B,2H,2H,Co], ups = 1."""
+    torch.manual_seed(Ci + Co + H + prec)
+    x = torch.randn(B, H, H, Ci, device=dev)
+    w = torch.randn(Co, 9, Ci, device=dev) / (9 * Ci) ** 0.5
+    bias = torch.randn(Co, device=dev) * 0.2
+    taps = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    am = x.abs().amax().reshape(1)
+
+    def run():
+        y = torch.empty(B, 2 * H, 2 * H, Co, device=dev)
+        return C.launch(x, w, y, taps, 2 * H, 2 * H, w_tap_stride=Ci, w_row_stride=9 * Ci, ups=1, alpha=0.7, bias=bias, act_slope=0.2, gain=1.0,
+                        w_split=C.split_weight(w, prec), precision=prec, a_amax=am)
+    y1, k1 = _route(run, True)
+    y0, k0 = _route(run, False)
+    assert k1.startswith('halo3x3_kernel<%d, 32, %d, 3>' % (prec - 1, 64 if Co > 32 else 32)) and not k0.startswith('halo'), (k1, k0)
+    assert (y1 - y0).abs().max() <= 2e-6 * y0.abs().max()
+    xu = F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=2, mode='nearest')
+    ref = F.leaky_relu(F.conv2d(xu, w.double().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2), padding=1) * 0.7 + bias.double()[None, :, None, None], 0.2)
+    assert (y1.double().permute(0, 3, 1, 2) - ref).abs().max() <= TOL[prec] * ref.abs().max()
+
+
 def test_trained_weights_without_planes_give_the_same_bits(dev, halo_everywhere):
     """The Reconstructor's convs carry no pre-split weight planes (the weights change every step): the pre-pass splits the fp32 weights
     itself, with the roundings of wgs_split_bf16 / wgs_split_f16."""
@@ -120,7 +144,7 @@ def test_shapes_the_kernel_declines(dev, halo_everywhere):
     try:
         C.conv2d(x, w, 3, stride=2, pad=1, precision=1, w_split=ws)                                   # strided
         assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
-        C.conv2d(x[:, :60], w, 3, pad=1, precision=1, w_split=ws)                                     # height not a multiple of 8
+        C.conv2d(x[:, :60].contiguous(), w, 3, pad=1, precision=1, w_split=ws)                        # height not a multiple of 8
         assert not lib.wgs_dev_last_kernel().decode().startswith('halo')
         C.conv2d(x, w, 3, pad=1, precision=1)                                                         # no pre-split planes: split from the fp32 weights in the pre-pass
         assert lib.wgs_dev_last_kernel().decode().startswith('halo3x3_kernel<0, 32, 32, 3>')

@@ -128,8 +128,10 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO, WIN>::WGS_PER_CU)) void 
         const int pp = (tid + j * 256) / EP;
         const int pr = pp / PW, pc = pp - pr * PW;
         const int iy = ty0 + g.dy_min + pr, ix = tx0 + g.dx_min + pc;
-        const bool v = pp < NPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        p_goff[j] = v ? (((b * p.Hi + iy) * p.Wi + ix) * p.Ci + q * 4) * 4 : OOB;
+        // p.ups: the conv runs on the nearest-neighbour up-sampled grid of x (ProgGAN's Upsample + conv, models/ProgGAN/model.py:53-62):
+        // grid pixel (iy, ix) reads stored pixel (iy >> ups, ix >> ups); the four copies of a stored pixel come out of L1 / L2
+        const bool v = pp < NPIX && (unsigned)iy < (unsigned)(p.Hi << p.ups) && (unsigned)ix < (unsigned)(p.Wi << p.ups);
+        p_goff[j] = v ? (((b * p.Hi + (iy >> p.ups)) * p.Wi + (ix >> p.ups)) * p.Ci + q * 4) * 4 : OOB;
         p_loff[j] = pp < NPIX ? pp * PROW + q * 8 : -1;
     }
     float op_mult = 1.f, op_inv = 1.f;
@@ -272,11 +274,11 @@ namespace wgsconv {
 
 // 0 = launch taken.  Needs pre-split weight planes, the extents (set_extents) and the tap tables.
 int launch_halo16(const ConvArgs& a, hipStream_t st) {
-    if (wgs_flags().no_halo || (a.w_hi && !a.w_lo && a.sch != 1) || a.a_hi || a.ups || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 ||
+    if (wgs_flags().no_halo || (a.w_hi && !a.w_lo && a.sch != 1) || a.a_hi || a.ups > 1 || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 ||
         a.oy0 || a.ox0 || a.ntaps < 9 || a.ntaps > 16)
         return 1;
-    if ((a.Ci != 16 && a.Ci != 32 && a.Ci != 64) || a.Co % 4 || a.Co > 64 || a.Hg != a.Hi || a.Wg != a.Wi || a.Ho != a.Hi || a.Wo != a.Wi || a.Hi % TH || a.Wi % TW) return 1;
-    if ((long)a.B * (a.Hi / TH) * (a.Wi / TW) < wgs_flags().halo_min_tiles) return 1;      // small maps: the GEMM-tiled kernels (split K, 128-row tiles)
+    if ((a.Ci != 16 && a.Ci != 32 && a.Ci != 64) || a.Co % 4 || a.Co > 64 || a.Hg != (a.Hi << a.ups) || a.Wg != (a.Wi << a.ups) || a.Ho != a.Hg || a.Wo != a.Wg || a.Hg % TH || a.Wg % TW) return 1;
+    if ((long)a.B * (a.Hg / TH) * (a.Wg / TW) < wgs_flags().halo_min_tiles) return 1;      // small maps: the GEMM-tiled kernels (split K, 128-row tiles)
     HaloGeom g;
     int dy0 = 127, dy1 = -127, dx0 = 127, dx1 = -127;
     for (int t = 0; t < a.ntaps; ++t) {
@@ -297,7 +299,7 @@ int launch_halo16(const ConvArgs& a, hipStream_t st) {
         g.tapoff[t] = (a.dy[t] - dy0) * pw + (a.dx[t] - dx0);
     }
     g.dy_min = dy0; g.dx_min = dx0;
-    g.tiles_x = a.Wi / TW; g.tiles_per_img = (a.Hi / TH) * g.tiles_x;
+    g.tiles_x = a.Wg / TW; g.tiles_per_img = (a.Hg / TH) * g.tiles_x;
     const int nblocks = a.B * g.tiles_per_img;
     ConvArgs b = a;
     b.w_bytes = a.w_bytes / 2;          // extents of the 16-bit weight planes
