@@ -233,11 +233,13 @@ class Reconstructor(nn.Module):
         Cp = 8
         arith = arith or self.arith
         fp = arith.forward
-        # The stem (7 x 7, stride 2, 2c = 6 input channels) in the 16-bit modes: SPACE-TO-DEPTH.  The image pair is packed as
+        # The stem (7 x 7, stride 2, 2c = 6 input channels): SPACE-TO-DEPTH.  The image pair is packed as
         # [B, H/2, W/2, 32] (2 x 2 pixel block x 8 channels) and the 7 x 7 / 2 conv becomes a 4 x 4-window stride-1 conv 32 -> 64 channels
         # over it (zeros where a tap falls outside the 7 x 7: 49 * 6 of 16 * 32 weights live) — a shape the few-channel halo kernel
-        # (conv_halo16.hip) runs HBM-bound, instead of a GEMM whose rows gather 49 taps of 6 channels.  Same products, same roundings.
-        s2d = STEM_S2D and fp == 1 and H % 16 == 0 and W % 64 == 0 and 2 * c <= 8
+        # (conv_halo16.hip) runs HBM-bound in the 16-bit modes, instead of a GEMM whose rows gather 49 taps of 6 channels.  Same products,
+        # same roundings.  In exact fp32 the two launches go through the fp32 template (conv_igemm_f32.hip): the forward costs what the
+        # gather form did, the image gradient — 64 -> 8 channels in four stride phases of 128 x 32 tiles before — a third (0.95 -> 0.34 ms).
+        s2d = STEM_S2D and H % 16 == 0 and W % 64 == 0 and 2 * c <= 8
         if s2d:
             x = torch.empty(B, H // 2, W // 2, 32, device=dev)
             L.check(lib.wgs_pack_pair_s2d(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H, W, st), 'pack_pair_s2d')
@@ -374,7 +376,7 @@ class Reconstructor(nn.Module):
             gbuf[id(fe.conv1.weight)].copy_(dw1p[:, :, :2 * c])
         grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, dw1p[:, :, :2 * c].contiguous())
         d1 = d2 = None
-        if (need_x[0] or need_x[1]) and S['s2d'] and arith.dgrad == 1:
+        if (need_x[0] or need_x[1]) and S['s2d']:
             # image gradient in the space-to-depth form: 64 -> 32 channels over the transposed 4 x 4 window, then depth-to-space
             w1s = self._scratch('w1s', (64, 16, 32), torch.float32, dev)      # this step's forward weights (Adam runs after the backward)
             w1st = C.repack_w_t(w1s, 64, 16, 32, out=self._scratch('w1st', (16, 32, 64), torch.float32, dev))
@@ -385,8 +387,6 @@ class Reconstructor(nn.Module):
             d2 = torch.empty(B, c, S['H'], S['W'], device=dev) if need_x[1] else None
             L.check(lib.wgs_unpack_pair_s2d_grad(L.ptr(dxs), L.ptr(d1), L.ptr(d2), B, c, S['H'], S['W'], st), 'unpack_pair_s2d')
         elif need_x[0] or need_x[1]:
-            if S['s2d']:
-                raise L.WgsError("Reconstructor: a space-to-depth stem forward needs the 16-bit input-gradient arithmetic (RArith.dgrad == 1)")
             w1p = self._conv1_padded(c, Cp, dev)        # same weights as in the forward of this step (Adam runs after the backward)
             w1t = C.repack_w_t(w1p, 64, 49, Cp, out=self._scratch('w1t', (49, Cp, 64), torch.float32, dev))
             dx = C.conv2d_dgrad(dc1, w1t, (S["H"], S["W"]), 7, stride=2, pad=3, precision=arith.dgrad)
