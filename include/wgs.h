@@ -191,8 +191,7 @@ int wgs_conv_igemm_multi_merges(const wgs_conv_desc* descs, int n);
 
 /* 3x3 stride-1 'same' convolutions in fp32 through Winograd F(2x2, 3x3) on the fp32 matrix cores (conv_wino_f32.hip): the same
  * contract and epilogue as wgs_conv_igemm with precision 0, 2.25x fewer multiplies, results equal to the direct form up to fp32
- * rounding of the transforms (~1e-6 relative) — the algorithm class the reference's F.conv2d gets under cudnn.benchmark = True
- * (lib/trainer.py:166).  Covered: all nine taps dy, dx in {-1, 0, 1} each exactly once (any weight-slab order: forward and
+ * rounding of the transforms (~1e-6 relative; 3e-6 against fp64 convolutions, no wider than the direct fp32 kernel).  Covered: all nine taps dy, dx in {-1, 0, 1} each exactly once (any weight-slab order: forward and
  * input-gradient launches alike), isy = osy = 1, ups 0, Hi = Ho % 16 == 0, Wi = Wo % 16 == 0, Ci % 16 == 0, Co % 64 == 0, act 0,
  * act_slope in [0, 1], no addend; a sample's tensors < 2 GiB (any batch).  wgs_conv_wino_supported() tells (1 / 0).
  * wgs_conv_wino_weight: U (16 * Ci * Co floats, caller-owned) = the launch's weights G g G^T in the kernel's staging order.

@@ -43,7 +43,7 @@ class WgradDesc(ctypes.Structure):
 #   3 'f16x2'  fp16 activations x (hi + lo) fp16 weights, 2 MFMAs (image error ~5e-4)
 #   4 'mixed'  StyleGAN2 only: per-layer arithmetic from an error budget, see MixedPolicy
 #   5 'fp32w'  fp32 with the 3x3 stride-1 convs in Winograd F(2x2,3x3) form on the fp32 matrix cores (2.25x fewer multiplies, ~1e-6
-#              against the direct form: what cuDNN's algorithm search gives the reference, lib/trainer.py:166); the rest as 'fp32'
+#              against the direct form, 3e-6 against fp64: no wider than the direct fp32 kernel); the rest as 'fp32'
 #  -1 'auto'   per generator: the cheapest mode whose measured image error stays inside the north_star's 1e-3 gate for that
 #              architecture with margin (tests/test_precision_schemes_gpu.py): see AUTO_TABLE
 # There is NO process-wide arithmetic state: a mode is an attribute of a generator instance (`G.precision`), an argument of
