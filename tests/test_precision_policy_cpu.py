@@ -112,9 +112,13 @@ def test_plane_route_gates():
     assert C.blur_bwd_f16_ok(32, 256, 128, 256, 2) and C.blur_bwd_f16_ok(32, 64, 512, 512, 2)
     assert not C.blur_bwd_f16_ok(32, 256, 128, 256, 3) and not C.blur_bwd_f16_ok(32, 256, 128, 256, 1)
     assert not C.blur_bwd_f16_ok(2, 32, 512, 512, 2) and not C.blur_bwd_f16_ok(32, 256, 24, 256, 2)
-    # dy plane of the stride-1 layers: from 256 channels up (the 128-column DMA tile loses to the patch form)
-    assert C.dy_plane_ok(32, 128, 256, 256, 2) and C.dy_plane_ok(32, 64, 512, 512, 2)
-    assert not C.dy_plane_ok(32, 256, 128, 128, 2) and not C.dy_plane_ok(32, 128, 256, 256, 1)
+    # dy plane of the stride-1 layers: from 128 channels up since round 4 (a 128-column plane goes through the patch kernel's XF16 form;
+    # round 3 had only the LDS-DMA kernel for planes, whose 128-column tile loses to the patch form)
+    assert C.dy_plane_ok(32, 128, 256, 256, 2) and C.dy_plane_ok(32, 64, 512, 512, 2) and C.dy_plane_ok(32, 256, 128, 128, 2)
+    assert not C.dy_plane_ok(32, 512, 64, 64, 2) and not C.dy_plane_ok(32, 128, 256, 256, 1)
+    # forward planes: the up-conv's output for a plain-fp16 stride-1 conv with >= 128 output columns that fills the chip
+    assert C.fwd_plane_ok(32, 256, 128, 128, 2) and C.fwd_plane_ok(32, 128, 256, 256, 2)
+    assert not C.fwd_plane_ok(32, 256, 128, 128, 3) and not C.fwd_plane_ok(32, 512, 64, 64, 2) and not C.fwd_plane_ok(1, 16, 512, 512, 2)
     # a plane must stay addressable through one buffer descriptor (< 2^31 bytes at 2 bytes per element, which is how the library
     # sizes it): per-GPU batch 64 at 256^2 is fine ([64, 257, 257, 128] fp16 = 1.08e9 bytes), batch 128 keeps the fp32 route
     assert C.blur_bwd_f16_ok(64, 256, 128, 256, 2) and not C.blur_bwd_f16_ok(128, 256, 128, 256, 2)
