@@ -576,6 +576,8 @@ def main():
     if os.environ.get('WGS_STEM') == '0':            # development A/B: the Reconstructor's stem in the gather form
         from warpedganspace_amd import reconstructor as _RR
         _RR.STEM_S2D = False
+    if os.environ.get('WGS_RGB') == '0':             # development A/B: ToRGB as its own launch everywhere
+        C.RGB_FUSED = False
     if os.environ.get('WGS_PRIO') == '0':            # development A/B: no high-priority stream for the step's critical path
         ENGINE_KW['priority_main'] = False
     if os.environ.get('WGS_FWD_PLANE') == '0':       # development A/B: forward fp16 planes off (conv.FWD_PLANE)

@@ -179,6 +179,13 @@ typedef struct wgs_conv_desc {
                                 (wgs_sg2_blur_bwd_f16) instead of the fp32 tensor.  Then x may be NULL; precision must be 2,
                                 a_scale NULL, ups 0, w_hi given, Ci % 32 == 0, Co % 128 == 0: the launch runs the LDS-DMA
                                 kernel without its pre-pass (same bits as the fp32 route) or fails with WGS_EINVAL. */
+    /* ToRGB in the epilogue (models/StyleGAN2/model.py:270-282: the 1 x 1 modulated conv to 3 channels that reads the layer's output
+       again): rgb_out[b*Ho*Wo + p][o] = rgb_scale * sum_n y[b,p,n] * rgb_s[b*rgb_ld + n] * rgb_w[o*Co + n], o = 0..2 (slot 3 = 0), written as
+       one 16-byte pixel; wgs_sg2_torgb_up_fwd(x = rgb_out, C = 4, unit style, identity weight) then adds bias and the up-sampled skip.
+       With rgb_out given y may be NULL (a pass that keeps nothing: the 1 GB output of StyleGAN2-256's last layer is neither written nor
+       read back).  Supported for the launch the generators use it for — x_f16 operand, precision 2, Co == 128, Ci <= 128, stride-1 3 x 3
+       (igemm_patch_kernel's 128 x 128 tile holds all output channels of its pixels) — otherwise WGS_EINVAL. */
+    float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int32_t rgb_ld;
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
 /* n launches that share every operand and differ only in (Hg, Wg, oy0, ox0, taps) — the 4 sub-pixel phases of a

@@ -170,3 +170,79 @@ def test_the_route_is_taken_in_the_default_policy(dev):
     # the 128-column launch through the patch kernel's XF16 form, the 256-column one through the LDS-DMA kernel: neither stages fp32
     assert len(syms) == 2 and sorted(s.split('<')[0] for s in syms) == ['igemm_dma16_kernel', 'igemm_patch_kernel'] and \
         all(s.endswith(', true>') for s in syms if s.startswith('igemm_patch')), syms
+
+
+@pytest.mark.parametrize('B,Ci,H,with_y', [(8, 128, 64, True), (8, 128, 64, False), (7, 64, 64, True)])
+def test_torgb_in_the_conv_epilogue(dev, B, Ci, H, with_y):
+    """wgs_conv_desc.rgb_out: ToRGB's channel sums (models/StyleGAN2/model.py:270-282) from the epilogue of the 128-channel conv that
+    produces its input — against wgs_sg2_torgb_fwd on that conv's stored output (fp32 summation order), with and without storing y;
+    y itself is bit-identical to the launch without the fusion."""
+    import os
+    torch.manual_seed(B + Ci + H)
+    lib, st = L.lib(), L.stream()
+    os.environ['WGS_HALO_MIN_TILES'] = '1000000'; lib.wgs_dev_reload_flags()
+    try:
+        Co = 128
+        yin = torch.randn(B, H, H, Ci, device=dev)
+        S = (torch.randn(B, Ci + Co + 20, device=dev) + 1.0).contiguous()
+        s_in, s_rgb = S[:, 4:], S[:, Ci + 10:]
+        w = torch.randn(Co, 9, Ci, device=dev) / (9 * Ci) ** 0.5
+        ws = C.split_weight(w, 2)
+        demod = torch.rand(B, Co, device=dev) + 0.5
+        noise, nw, bias = torch.randn(H * H, device=dev), torch.full((1,), 0.3, device=dev), torch.randn(Co, device=dev) * 0.2
+        bound = ((yin * s_in[:, None, None, :Ci]).abs().amax() * 3.0).reshape(1).contiguous()
+        k = _k_of(bound.item())
+        plane = ((yin * s_in[:, None, None, :Ci]) * 2.0 ** k).half().view(torch.int16).contiguous()
+        w_rgb = torch.randn(3, Co, device=dev).contiguous()
+        epi = dict(col_scale=demod, noise=noise, noise_w=nw, bias=bias, act_slope=0.2, gain=SQRT2, w_split=ws, precision=2, a_amax=bound, a_bound=1.0, x_f16=True)
+        ref = C.conv2d(plane, w, 3, pad=1, out=torch.empty(B, H, H, Co, device=dev), **epi)
+        rgbp = torch.full((B, H, H, 4), float('nan'), device=dev)
+        am = torch.zeros(1, device=dev)
+        out = torch.empty(B, H, H, Co, device=dev) if with_y else C.NoOutput(B, H, H, Co)
+        lib.wgs_dev_trace_kernels(1)
+        got = C.conv2d(plane, w, 3, pad=1, out=out, y_amax=am, rgb=dict(out=rgbp, s=s_rgb, ld=S.shape[1], w=w_rgb, scale=0.37), **epi)
+        sym = lib.wgs_dev_last_kernel().decode()
+        lib.wgs_dev_trace_kernels(0)
+        assert sym.startswith('igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0, true, true>'), sym
+        if with_y:
+            assert torch.equal(got, ref)
+        assert am.item() == ref.abs().max().item()
+        want = torch.empty(B, 3, H * H, device=dev)
+        L.check(lib.wgs_sg2_torgb_fwd(L.ptr(ref), L.ptr(s_rgb[:, :Co].contiguous()), L.ptr(w_rgb), L.ptr(torch.zeros(3, device=dev)), None, L.ptr(want),
+                                      B, H * H, Co, L.c_float(0.37), st), 'torgb')
+        gotc = rgbp.view(B, H * H, 4)
+        assert float(gotc[..., 3].abs().max()) == 0.0
+        assert (gotc[..., :3].permute(0, 2, 1) - want).abs().max() <= 3e-6 * want.abs().max()
+        f64 = torch.einsum('bpc,bc,oc->bop', ref.double().view(B, H * H, Co), s_rgb[:, :Co].double(), w_rgb.double()) * 0.37
+        assert (gotc[..., :3].permute(0, 2, 1).double() - f64).abs().max() <= 3e-6 * f64.abs().max()
+    finally:
+        os.environ.pop('WGS_HALO_MIN_TILES', None); lib.wgs_dev_reload_flags()
+
+
+def test_rgb_epilogue_rejects_other_shapes(dev):
+    x = torch.zeros(1, 16, 16, 64, device=dev, dtype=torch.int16)
+    w = torch.zeros(256, 9, 64, device=dev)
+    with pytest.raises(L.WgsError):        # 256 output channels: not one tile
+        C.conv2d(x, w, 3, pad=1, out=torch.empty(1, 16, 16, 256, device=dev), precision=2, w_split=C.split_weight(w, 2), a_amax=torch.ones(1, device=dev), x_f16=True,
+                 rgb=dict(out=torch.empty(1, 16, 16, 4, device=dev), s=torch.ones(1, 256, device=dev), ld=256, w=torch.zeros(3, 256, device=dev), scale=1.0))
+
+
+def test_generator_same_image_with_and_without_the_fused_torgb(dev, monkeypatch):
+    from warpedganspace_amd.gan_load import build_stylegan2
+    torch.manual_seed(0)
+    G = build_stylegan2(None, resolution=256).to(dev).eval()
+    z = torch.randn(32, 512, device=dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(C, 'RGB_FUSED', on)
+        with torch.no_grad():
+            a = G(z, precision='auto').clone()
+        zz = z.clone().requires_grad_(True)
+        img = G(zz, precision='auto')
+        img.backward(torch.linspace(-1, 1, img.numel(), device=dev).view_as(img))
+        res[on] = (a, img.detach().clone(), zz.grad.clone())
+    assert torch.equal(res[True][0], res[True][1])             # the pass that stores nothing and the pass that saves: same image
+    e = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
+    g = float((res[True][2] - res[False][2]).abs().max() / res[False][2].abs().max())
+    print('fused ToRGB on vs off: image %.2e, gradient %.2e' % (e, g))
+    assert e <= 3e-6 and g <= 1e-4

@@ -24,7 +24,21 @@ class ConvDesc(ctypes.Structure):
                 ('w_hi', ctypes.c_void_p), ('w_lo', ctypes.c_void_p),
                 ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64),
                 ('a_amax', ctypes.c_void_p), ('a_bound', ctypes.c_float), ('a_amax2', ctypes.c_void_p), ('y_amax', ctypes.c_void_p),
-                ('x_f16', ctypes.c_void_p)]
+                ('x_f16', ctypes.c_void_p),
+                ('rgb_out', ctypes.c_void_p), ('rgb_s', ctypes.c_void_p), ('rgb_w', ctypes.c_void_p), ('rgb_scale', ctypes.c_float), ('rgb_ld', ctypes.c_int32)]
+
+
+class NoOutput:
+    """Stands in for the output tensor of a launch that stores none (wgs_conv_desc.y = NULL with rgb_out): carries the shape only."""
+
+    def __init__(self, *shape):
+        self.shape = tuple(shape)
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return None
 
 
 class WgradDesc(ctypes.Structure):
@@ -236,7 +250,7 @@ def _timed(kind, flops, fn):
 def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None, w_split=None,
-          a_amax=None, a_bound=1.0, grad_operand=False, a_amax2=None, y_amax=None, x_f16=False):
+          a_amax=None, a_bound=1.0, grad_operand=False, a_amax2=None, y_amax=None, x_f16=False, rgb=None):
     """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous).
     x_f16: x is the int16 tensor holding the operand's fp16 plane (wgs_conv_desc.x_f16), written by the producing kernel."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == (torch.int16 if x_f16 else torch.float32)):
@@ -244,6 +258,10 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
     d = ConvDesc() if into is None else into
     d.x, d.w, d.y = (None if x_f16 else x.data_ptr()), w.data_ptr(), y.data_ptr()
     d.x_f16 = x.data_ptr() if x_f16 else None
+    if rgb is not None:       # ToRGB in the epilogue: dict(out=[B,Ho,Wo,4], s=<style rows>, ld=<row stride>, w=[3,Co], scale=)
+        d.rgb_out, d.rgb_s, d.rgb_w, d.rgb_scale, d.rgb_ld = rgb['out'].data_ptr(), rgb['s'].data_ptr(), rgb['w'].data_ptr(), rgb['scale'], rgb['ld']
+    else:
+        d.rgb_out, d.rgb_s, d.rgb_w, d.rgb_scale, d.rgb_ld = None, None, None, 0.0, 0
     d.a_scale, d.col_scale, d.bias = _p(a_scale), _p(col_scale), _p(bias)
     d.noise, d.noise_w = _p(noise), _p(noise_w)
     d.B, d.Hi, d.Wi, d.Ci = x.shape
@@ -408,6 +426,14 @@ def upconv_fused_ok(H, Ci, Co, precision):
 # vector and power-of-two scale folded in, wgs_upconv_desc.y_f16), and that conv stages the plane as it is through the patch kernel's
 # XF16 form — same bits as staging the fp32 tensor, without the multiply / scale / convert work and with half the operand bytes.
 FWD_PLANE = True
+# ToRGB of StyleGAN2's 128-channel layer at 256^2 in that conv's epilogue (wgs_conv_desc.rgb_out): its 1 GB output is not read back by a
+# ToRGB launch, and in the pass that keeps nothing it is not written at all.
+RGB_FUSED = True
+
+
+def rgb_fused_ok(B, H, Ci, Co, lp, has_plane):
+    # (the patch kernel's 128 x 128 tile takes launches of >= 200 tiles: B * H * H / 128)
+    return RGB_FUSED and has_plane and lp == 2 and Co == 128 and Ci <= 128 and B * H * H // 128 >= 200 and H >= 16 and (H & (H - 1)) == 0
 
 
 def fwd_plane_ok(B, Hout, C, Co_next, lp_next):

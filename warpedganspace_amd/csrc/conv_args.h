@@ -34,6 +34,7 @@ struct ConvArgs {
     float a_bound;                  // ... times this factor (bound of |a_scale|, blur gain ...)
     const float* a_amax2;           // ... times this optional second device scalar (bound of |a_scale| in forward launches)
     float* y_amax;                  // optional device scalar raised (atomic max) to max |y| of this launch: the next layer's a_amax
+    float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int rgb_ld;      // ToRGB in the epilogue (wgs_conv_desc.rgb_out)
     const unsigned short* a_hi;     // split (and style-modulated) activation planes: set by launch_bf16x3 (LDS-DMA path)
     const unsigned short* a_lo;
     float* ws;          // split-K workspace or null

@@ -102,6 +102,87 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
     if (p.y_amax) raise_amax(p.y_amax, vmax_s);
 }
 
+// Sum over the 16 lanes of a DPP row, on the vector ALU (quad permutes, then the half-row and row mirrors): every lane ends with the total.
+// (First version of the epilogue below: __shfl_xor butterflies = 15 ds_bpermute per accumulator row; with three workgroups per CU the LDS
+// pipe then carried 5 760 permutes per tile round and the kernel went from 780 to 1 064 us.)
+__device__ __forceinline__ float dpp_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));    // row_mirror
+    return v;
+}
+
+// The fast path above plus ToRGB (wgs_conv_desc.rgb_out): the workgroup's tile holds ALL output channels of its pixels (n0 = 0, BN = Co), so
+// the three channel sums of a pixel are finished here — per accumulator row: 3 fused multiply-adds per column block, a butterfly over the 32
+// 16-lane DPP rows of the half-wave (dpp_sum16), one LDS slot per DPP row; then the 2 WAVES_N partials are summed and stored as one 16-byte pixel.  y itself is
+// stored only when the caller wants it (p.y): in a pass that keeps nothing, the layer's output never reaches HBM.
+template <int BM, int TM, int TN, int WM, int WN, int WAVES_N>
+__device__ __forceinline__ void conv_epilogue_rgb(const ConvArgs& p, epi_f32x16 (&acc)[TM][TN], unsigned char* smem_b, int wm, int wn, int l31, int lh,
+                                                  int tid, float alpha_mul) {
+    const float alpha = p.alpha * alpha_mul;
+    const int* r_pix = reinterpret_cast<const int*>(smem_b);
+    const int* r_b = r_pix + BM;
+    const float* r_nz = reinterpret_cast<const float*>(r_b + BM);
+    float* part = reinterpret_cast<float*>(smem_b) + 4 * BM;          // [2 WAVES_N][BM][4], behind the four row arrays
+    const int b = r_b[0];
+    const long ybytes = p.y ? (long)p.B * p.Ho * p.Wo * p.Co * 4 : 0;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y : p.rgb_out, 0, (int)ybytes, 0x00020000);   // (y == NULL: stores dropped)
+    float cs[TN], bs[TN], q0[TN], q1[TN], q2[TN];
+    int noff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = wn * WN + j * 32 + l31;
+        cs[j] = p.col_scale ? p.col_scale[(size_t)b * p.col_ld + n] : 1.f;
+        bs[j] = p.bias ? p.bias[n] : 0.f;
+        noff[j] = n * 4;
+        const float sr = p.rgb_s[(size_t)b * p.rgb_ld + n] * p.rgb_scale;
+        q0[j] = p.rgb_w[n] * sr; q1[j] = p.rgb_w[p.Co + n] * sr; q2[j] = p.rgb_w[2 * p.Co + n] * sr;
+    }
+    const int rowbytes = p.Co * 4;
+    const float slope = p.act_slope, gain = p.gain;
+    float vmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int pix = r_pix[row];
+            const float nz = r_nz[row];
+            const int ro = pix >= 0 ? pix * rowbytes : (int)0x80000000;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = acc[i][j][r] * alpha;
+                v *= cs[j];
+                v += nz + bs[j];
+                v = fmaxf(v, v * slope) * gain;
+                vmax = fmaxf(vmax, pix >= 0 ? fabsf(v) : 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)((unsigned)ro + (unsigned)noff[j]), 0, 0);
+                t0 = fmaf(v, q0[j], t0); t1 = fmaf(v, q1[j], t1); t2 = fmaf(v, q2[j], t2);
+            }
+            // the 32 lanes of a half-wave hold the row's 32 columns of each block: two DPP rows of 16, summed separately
+            t0 = dpp_sum16(t0); t1 = dpp_sum16(t1); t2 = dpp_sum16(t2);
+            if ((l31 & 15) == 0) *reinterpret_cast<float4*>(part + ((size_t)(wn * 2 + (l31 >> 4)) * BM + row) * 4) = make_float4(t0, t1, t2, 0.f);
+        }
+    }
+    if (p.y_amax) {
+        vmax = wave_max(vmax);
+        if (l31 == 0 && lh == 0) raise_amax(p.y_amax, vmax);
+    }
+    __syncthreads();
+    if (tid < BM) {
+        float4 t = *reinterpret_cast<const float4*>(part + (size_t)tid * 4);
+#pragma unroll
+        for (int w2 = 1; w2 < 2 * WAVES_N; ++w2) {
+            const float4 o = *reinterpret_cast<const float4*>(part + ((size_t)w2 * BM + tid) * 4);
+            t.x += o.x; t.y += o.y; t.z += o.z;
+        }
+        const int pix = r_pix[tid];
+        if (pix >= 0) *reinterpret_cast<float4*>(p.rgb_out + (size_t)pix * 4) = t;
+    }
+}
+
 template <int BM, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs& P, epi_f32x16 (&acc)[TM][TN], unsigned char* smem_b,
                                               int m0, int n0, int wm, int wn, int tid, int l31, int lh, float alpha_mul = 1.f) {

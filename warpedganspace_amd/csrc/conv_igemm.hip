@@ -562,7 +562,9 @@ int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stre
 }
 
 static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
-    WGS_CHECK_ARG(d && (d->x || d->x_f16) && d->w && d->y, "wgs_conv_igemm: null pointer");
+    WGS_CHECK_ARG(d && (d->x || d->x_f16) && d->w && (d->y || d->rgb_out), "wgs_conv_igemm: null pointer");
+    WGS_CHECK_ARG(!d->rgb_out || (d->x_f16 && d->rgb_s && d->rgb_w && d->Co == 128 && d->Ci <= 128 && d->ntaps == 9 && d->rgb_ld >= d->Co && !d->addend && d->act == 0),
+                  "wgs_conv_igemm: rgb_out needs an x_f16 operand, Co == 128, Ci <= 128, 9 taps, rgb_s / rgb_w / rgb_ld >= Co, leaky-relu epilogue");
     WGS_CHECK_ARG(!d->x_f16 || (d->precision == 2 && !d->a_scale && !d->ups && d->w_hi && d->Ci % 32 == 0 && d->Co % 128 == 0 && d->ntaps <= 16),
                   "wgs_conv_igemm: x_f16 needs precision 2, no a_scale / ups, pre-split weights, Ci %% 32 == 0, Co %% 128 == 0, <= 16 taps");
     WGS_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hg > 0 && d->Wg > 0 && d->Ho > 0 && d->Wo > 0,
@@ -589,6 +591,7 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     for (int t = 0; t < d->ntaps; ++t) { a.dy[t] = d->dy[t]; a.dx[t] = d->dx[t]; a.wt[t] = d->wt[t]; }
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
     a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = d->x_f16; a.a_lo = nullptr;
+    a.rgb_out = d->rgb_out; a.rgb_s = d->rgb_s; a.rgb_w = d->rgb_w; a.rgb_scale = d->rgb_scale; a.rgb_ld = d->rgb_ld;
     WGS_CHECK_ARG(d->precision >= 0 && d->precision <= 3, "wgs_conv_igemm: precision=%d (0 fp32, 1 bf16x3, 2 f16, 3 f16x2)", d->precision);
     a.sch = d->precision > 0 ? d->precision - 1 : 4;      // conv_scheme.h: 0..2 the 16-bit schemes, 4 exact fp32
     a.a_amax = d->precision >= 2 ? d->a_amax : nullptr;

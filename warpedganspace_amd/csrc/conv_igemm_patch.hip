@@ -65,7 +65,9 @@ struct PatchGeom {       // uniform per launch
 // already multiplied by its style vector and the power-of-two operand scale): a staging element is 16 bytes = EIGHT channels of a
 // patch pixel, loaded and written to LDS as it is — no style multiply, no scale, no conversion, half the load bytes and
 // instructions.  (Single-plane A only: schemes 1 and 2.)
-template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF, bool XF16>
+// RGB: ToRGB in the epilogue (wgs_conv_desc.rgb_out) — its own instantiation, so that the epilogue's extra registers do not touch the
+// plain kernel's allocation (170 VGPRs at three workgroups per CU)
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, int TPS, int NTF, bool XF16, bool RGB = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SCH == 1 ? 3 : 2) : 1) void igemm_patch_kernel(const ConvArgs p, const PatchGeom g) {
     typedef wgsconv::Scheme<SCH> SC;
     typedef typename SC::frag frag;
@@ -365,6 +367,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, BM == 128 ? (TPS == 1 && SC
         r_add[tid] = (b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
     }
     __syncthreads();
+    if constexpr (RGB) {          // ToRGB in the epilogue (the tile holds all 128 output channels)
+        wgsconv::conv_epilogue_rgb<BM, TM, TN, WM, WN, WAVES_N>(p, acc, smem_b, wm, wn, l31, lh, tid, op_inv);
+        return;
+    }
     wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh, op_inv);
 }
 
@@ -383,6 +389,17 @@ void launch_patch_t(const ConvArgs& a, const PatchGeom& g, int nblocks, hipStrea
     const bool ntf9 = a.ntaps == 9 && SCH != 0 && BM == 256 && !wgs_flags().patch_ntf0;
     if constexpr (SCH == 1 || SCH == 2) {
         if (a.a_hi) {     // producer-written fp16 activation plane
+            if constexpr (SCH == 1 && BM == 128 && BN == 128 && TPS == 1) {
+                if (a.rgb_out) {
+                    typedef wgsconv::Scheme<SCH> SC;
+                    const size_t sm = (size_t)SC::NA * pmax_of(BM) * PROW + (size_t)2 * TPS * SC::NB * BN * ROW;
+                    auto k = igemm_patch_kernel<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 0, true, true>;
+                    wgs_note_kernel("igemm_patch_kernel<%d, %d, %d, %d, %d, %d, 0, true, true>", SCH, BM, BN, WAVES_M, WAVES_N, TPS);
+                    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+                    WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(64 * WAVES_M * WAVES_N), sm, st, a, g);
+                    return;
+                }
+            }
             if (ntf9) launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 9, true>(a, g, nblocks, st);
             else launch_patch_n<SCH, BM, BN, WAVES_M, WAVES_N, TPS, 0, true>(a, g, nblocks, st);
             return;
@@ -464,7 +481,8 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
         bm = tbm; bn = tbn; nblocks = nb; g = t;
         for (int i = 0; i < 16; ++i) g.tapoff[i] = i < a.ntaps ? ((a.dy[i] - dy0) * t.PW + (a.dx[i] - dx0)) * PROW : 0;
     };
-    if (a.Co == 128 && a.Ci <= 128 && !wgs_flags().patch_bm256) try_shape(128, 128);
+    if (a.Co == 128 && a.Ci <= 128 && (!wgs_flags().patch_bm256 || a.rgb_out)) try_shape(128, 128);
+    if (a.rgb_out && !(bm == 128 && bn == 128 && a.a_hi && a.sch == 1)) return 1;      // ToRGB epilogue: the 128 x 128 fp16-plane tile only
     try_shape(256, 256);
     try_shape(256, 128);
     try_shape(128, 128);

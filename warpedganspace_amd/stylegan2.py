@@ -266,6 +266,7 @@ class Generator(nn.Module):
             P['map'] = [(l.weight.contiguous(), l.bias.contiguous(), l.scale, l.lr_mul) for l in list(self.style)[1:]]
             P['const'] = self.input.input[0].permute(1, 2, 0).contiguous()       # [4,4,C] NHWC
             P['const_amax'] = P['const'].abs().max().reshape(1).contiguous()     # magnitude bound of the first layer's input
+            P['rgb_finish'] = (torch.ones(1024, 4, device=dev), torch.eye(3, 4, device=dev).contiguous())   # unit style / identity weight of a fused ToRGB's finish
         self._prep = P
         return P
 
@@ -375,11 +376,21 @@ class Generator(nn.Module):
             lp = C.layer_precision(prec, 2 * H if ly['up'] else H, ly['up'], pol)      # 'mixed': per-layer arithmetic
             sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp in (2, 3)) else {}
             ymax = xmax[i + 1] if f16_chain else None
+            rgbp = None
             if xplane is not None:
                 # the producing up-conv wrote this conv's fp16 operand plane (style and scale folded in): staged as it is
+                rgb_kw = {}
+                if i % 2 == 0 and C.rgb_fused_ok(B, H, Ci, Co, lp, True):
+                    # ... and its ToRGB runs in this conv's epilogue; without a backward to feed, the layer's output is not stored at all
+                    r_ = P['rgbs'][i // 2]
+                    rgbp = torch.empty(B, H, H, 4, device=dev)
+                    rgb_kw = dict(rgb=dict(out=rgbp, s=S[:, r_['off']:], ld=sumC, w=r_['w'], scale=r_['scale']))
+                keep = save or not rgb_kw or i + 1 < len(P['layers'])
                 y = C.conv2d(xplane[0], ly['wp'], 3, pad=1, col_scale=demod, noise=ly['noise'], noise_w=ly['noise_w'], bias=ly['bias'],
                              act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'], precision=lp, y_amax=ymax, a_amax=xplane[1], a_bound=1.0, x_f16=True,
-                             out=torch.empty(B, H, H, Co, device=dev))
+                             out=torch.empty(B, H, H, Co, device=dev) if keep else C.NoOutput(B, H, H, Co), **rgb_kw)
+                if not keep:
+                    y = None
                 xplane = None
             elif ly['up'] and C.upconv_fused_ok(H, Ci, Co, lp):
                 nxt = P['layers'][i + 1] if i + 1 < len(P['layers']) else None
@@ -407,9 +418,16 @@ class Generator(nn.Module):
             x = y
             if i % 2 == 0:
                 r = P['rgbs'][i // 2]
-                Hc = x.shape[1]
+                Hc = H if not ly['up'] else 2 * H
                 img = torch.empty(B, 3, Hc, Hc, device=dev)
-                if skip is not None:    # + Upsample(skip) (model.py:279-281), evaluated inside the ToRGB kernel's epilogue
+                if rgbp is not None:
+                    # the channel sums came out of the conv's epilogue: bias + up-sampled skip through the same kernel (C = 4, unit style)
+                    one4, eye34 = P['rgb_finish']
+                    if B > one4.shape[0]:
+                        one4 = torch.ones(B, 4, device=dev)
+                    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(rgbp), L.ptr(one4[:B]), 4, L.ptr(eye34), L.ptr(r['bias']), L.ptr(skip),
+                                                     L.ptr(r['upk']), L.ptr(img), B, Hc, Hc, 4, L.c_float(1.0), st), 'torgb_finish')
+                elif skip is not None:    # + Upsample(skip) (model.py:279-281), evaluated inside the ToRGB kernel's epilogue
                     L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(x), L.rawptr(S[:, r['off']:]), sumC, L.ptr(r['w']), L.ptr(r['bias']), L.ptr(skip),
                                                      L.ptr(r['upk']), L.ptr(img), B, Hc, Hc, r['C'], L.c_float(r['scale']), st), 'torgb_up')
                 else:
