@@ -183,8 +183,9 @@ typedef struct wgs_conv_desc {
        again): rgb_out[b*Ho*Wo + p][o] = rgb_scale * sum_n y[b,p,n] * rgb_s[b*rgb_ld + n] * rgb_w[o*Co + n], o = 0..2 (slot 3 = 0), written as
        one 16-byte pixel; wgs_sg2_torgb_up_fwd(x = rgb_out, C = 4, unit style, identity weight) then adds bias and the up-sampled skip.
        With rgb_out given y may be NULL (a pass that keeps nothing: the 1 GB output of StyleGAN2-256's last layer is neither written nor
-       read back).  Supported for the launch the generators use it for — x_f16 operand, precision 2, Co == 128, Ci <= 128, stride-1 3 x 3
-       (igemm_patch_kernel's 128 x 128 tile holds all output channels of its pixels) — otherwise WGS_EINVAL. */
+       read back).  Supported for the launches the generators use it for — x_f16 operand, precision 2, stride-1 3 x 3, and either Co == 128 with
+       Ci <= 128 (igemm_patch_kernel's 128 x 128 tile) or Co == 256 with Hg * Wg % 256 == 0 (igemm_dma16_kernel's 256 x 256 tile): one tile then
+       holds all output channels of its pixels — otherwise WGS_EINVAL. */
     float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int32_t rgb_ld;
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);

@@ -172,8 +172,8 @@ def test_the_route_is_taken_in_the_default_policy(dev):
         all(s.endswith(', true>') for s in syms if s.startswith('igemm_patch')), syms
 
 
-@pytest.mark.parametrize('B,Ci,H,with_y', [(8, 128, 64, True), (8, 128, 64, False), (7, 64, 64, True)])
-def test_torgb_in_the_conv_epilogue(dev, B, Ci, H, with_y):
+@pytest.mark.parametrize('B,Ci,Co,H,with_y', [(8, 128, 128, 64, True), (8, 128, 128, 64, False), (7, 64, 128, 64, True), (16, 256, 256, 64, True), (13, 128, 256, 64, False)])
+def test_torgb_in_the_conv_epilogue(dev, B, Ci, Co, H, with_y):
     """wgs_conv_desc.rgb_out: ToRGB's channel sums (models/StyleGAN2/model.py:270-282) from the epilogue of the 128-channel conv that
     produces its input — against wgs_sg2_torgb_fwd on that conv's stored output (fp32 summation order), with and without storing y;
     y itself is bit-identical to the launch without the fusion."""
@@ -182,7 +182,6 @@ def test_torgb_in_the_conv_epilogue(dev, B, Ci, H, with_y):
     lib, st = L.lib(), L.stream()
     os.environ['WGS_HALO_MIN_TILES'] = '1000000'; lib.wgs_dev_reload_flags()
     try:
-        Co = 128
         yin = torch.randn(B, H, H, Ci, device=dev)
         S = (torch.randn(B, Ci + Co + 20, device=dev) + 1.0).contiguous()
         s_in, s_rgb = S[:, 4:], S[:, Ci + 10:]
@@ -203,7 +202,7 @@ def test_torgb_in_the_conv_epilogue(dev, B, Ci, H, with_y):
         got = C.conv2d(plane, w, 3, pad=1, out=out, y_amax=am, rgb=dict(out=rgbp, s=s_rgb, ld=S.shape[1], w=w_rgb, scale=0.37), **epi)
         sym = lib.wgs_dev_last_kernel().decode()
         lib.wgs_dev_trace_kernels(0)
-        assert sym.startswith('igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0, true, true>'), sym
+        assert sym.startswith('igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0, true, true>' if Co == 128 else 'igemm_dma16_kernel<1, 256, 256, 2, 4, true>'), sym
         if with_y:
             assert torch.equal(got, ref)
         assert am.item() == ref.abs().max().item()
@@ -222,9 +221,13 @@ def test_torgb_in_the_conv_epilogue(dev, B, Ci, H, with_y):
 def test_rgb_epilogue_rejects_other_shapes(dev):
     x = torch.zeros(1, 16, 16, 64, device=dev, dtype=torch.int16)
     w = torch.zeros(256, 9, 64, device=dev)
-    with pytest.raises(L.WgsError):        # 256 output channels: not one tile
+    with pytest.raises(L.WgsError):        # too few tiles for the 256 x 256 form (and not a multiple of 256 rows... the library declines loudly)
         C.conv2d(x, w, 3, pad=1, out=torch.empty(1, 16, 16, 256, device=dev), precision=2, w_split=C.split_weight(w, 2), a_amax=torch.ones(1, device=dev), x_f16=True,
                  rgb=dict(out=torch.empty(1, 16, 16, 4, device=dev), s=torch.ones(1, 256, device=dev), ld=256, w=torch.zeros(3, 256, device=dev), scale=1.0))
+    w5 = torch.zeros(512, 9, 64, device=dev)
+    with pytest.raises(L.WgsError):        # 512 output channels: no tile holds them all
+        C.conv2d(x, w5, 3, pad=1, out=torch.empty(1, 16, 16, 512, device=dev), precision=2, w_split=C.split_weight(w5, 2), a_amax=torch.ones(1, device=dev), x_f16=True,
+                 rgb=dict(out=torch.empty(1, 16, 16, 4, device=dev), s=torch.ones(1, 512, device=dev), ld=512, w=torch.zeros(3, 512, device=dev), scale=1.0))
 
 
 def test_generator_same_image_with_and_without_the_fused_torgb(dev, monkeypatch):

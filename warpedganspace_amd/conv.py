@@ -433,7 +433,11 @@ RGB_FUSED = True
 
 def rgb_fused_ok(B, H, Ci, Co, lp, has_plane):
     # (the patch kernel's 128 x 128 tile takes launches of >= 200 tiles: B * H * H / 128)
-    return RGB_FUSED and has_plane and lp == 2 and Co == 128 and Ci <= 128 and B * H * H // 128 >= 200 and H >= 16 and (H & (H - 1)) == 0
+    if not (RGB_FUSED and has_plane and lp == 2 and H >= 16 and (H & (H - 1)) == 0):
+        return False
+    if Co == 128:
+        return Ci <= 128 and B * H * H // 128 >= 200
+    return Co == 256 and B * H * H // 256 >= 200            # the LDS-DMA kernel's 256 x 256 tile
 
 
 def fwd_plane_ok(B, Hout, C, Co_next, lp_next):

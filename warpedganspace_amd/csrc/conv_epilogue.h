@@ -183,9 +183,9 @@ __device__ __forceinline__ void conv_epilogue_rgb(const ConvArgs& p, epi_f32x16 
     }
 }
 
-template <int BM, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs& P, epi_f32x16 (&acc)[TM][TN], unsigned char* smem_b,
-                                              int m0, int n0, int wm, int wn, int tid, int l31, int lh, float alpha_mul = 1.f) {
+// first half of the epilogue: the staged row arrays of a tile of BM GEMM rows starting at m0 (published with a barrier)
+template <int BM>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& p, const PhaseArgs& P, unsigned char* smem_b, int m0, int tid) {
     int* r_pix = reinterpret_cast<int*>(smem_b);
     int* r_b = r_pix + BM;
     float* r_nz = reinterpret_cast<float*>(r_b + BM);
@@ -208,6 +208,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs
         r_pix[tid] = pix; r_b[tid] = bb; r_nz[tid] = nz; r_add[tid] = ap;
     }
     __syncthreads();
+}
+
+template <int BM, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const PhaseArgs& P, epi_f32x16 (&acc)[TM][TN], unsigned char* smem_b,
+                                              int m0, int n0, int wm, int wn, int tid, int l31, int lh, float alpha_mul = 1.f) {
+    conv_epilogue_rows<BM>(p, P, smem_b, m0, tid);
     conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, n0, wm, wn, l31, lh, alpha_mul);
 }
 

@@ -563,7 +563,7 @@ int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stre
 
 static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     WGS_CHECK_ARG(d && (d->x || d->x_f16) && d->w && (d->y || d->rgb_out), "wgs_conv_igemm: null pointer");
-    WGS_CHECK_ARG(!d->rgb_out || (d->x_f16 && d->rgb_s && d->rgb_w && d->Co == 128 && d->Ci <= 128 && d->ntaps == 9 && d->rgb_ld >= d->Co && !d->addend && d->act == 0),
+    WGS_CHECK_ARG(!d->rgb_out || (d->x_f16 && d->rgb_s && d->rgb_w && ((d->Co == 128 && d->Ci <= 128) || d->Co == 256) && d->ntaps == 9 && d->rgb_ld >= d->Co && !d->addend && d->act == 0),
                   "wgs_conv_igemm: rgb_out needs an x_f16 operand, Co == 128, Ci <= 128, 9 taps, rgb_s / rgb_w / rgb_ld >= Co, leaky-relu epilogue");
     WGS_CHECK_ARG(!d->x_f16 || (d->precision == 2 && !d->a_scale && !d->ups && d->w_hi && d->Ci % 32 == 0 && d->Co % 128 == 0 && d->ntaps <= 16),
                   "wgs_conv_igemm: x_f16 needs precision 2, no a_scale / ups, pre-split weights, Ci %% 32 == 0, Co %% 128 == 0, <= 16 taps");

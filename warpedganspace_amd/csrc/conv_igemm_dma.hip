@@ -51,7 +51,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
 constexpr int dma_stages(int stage_bytes) { return 160 * 1024 / stage_bytes >= 4 ? 4 : (160 * 1024 / stage_bytes >= 3 ? 3 : 2); }
 
-template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N>
+// RGB: ToRGB in the epilogue (wgs_conv_desc.rgb_out; the tile's BN columns are all of Cout) — its own instantiation
+template <int SCH, int BM, int BN, int WAVES_M, int WAVES_N, bool RGB = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(const ConvArgs p) {
     typedef wgsconv::Scheme<SCH> SC;
     typedef typename SC::frag frag;
@@ -264,6 +265,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void igemm_dma16_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-fill DMAs past the last chunk: the epilogue re-uses the LDS
     __syncthreads();
+    if constexpr (RGB) {
+        wgsconv::conv_epilogue_rows<BM>(p, P, smem_b, m0, tid);
+        wgsconv::conv_epilogue_rgb<BM, TM, TN, WM, WN, WAVES_N>(p, acc, smem_b, wm, wn, l31, lh, tid, op_inv);
+        return;
+    }
     wgsconv::conv_epilogue<BM, TM, TN, WM, WN>(p, P, acc, smem_b, m0, n0, wm, wn, tid, l31, lh, op_inv);
 }
 
@@ -350,6 +356,16 @@ void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, uns
 
 // a: fully prepared arguments (phases filled, a_hi/a_lo/w_hi/w_lo and extents set); bn = 256 or 128
 void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st) {
+    if (a.rgb_out && a.sch == 1 && bn == 256 && a.Co == 256) {       // ToRGB in the epilogue: one 256-column tile holds all of Cout
+        constexpr int BM = 256, BN = 256;
+        const size_t stage = (size_t)(BM + BN) * ROW;
+        const size_t sm = dma_stages((int)stage) * stage;
+        auto k = igemm_dma16_kernel<1, BM, BN, 2, 4, true>;
+        wgs_note_kernel("igemm_dma16_kernel<1, 256, 256, 2, 4, true>");
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(512), sm, st, a);
+        return;
+    }
     if (bn == 256) launch_dma<256, 256, 2, 4>(a, st, nblocks);
     else launch_dma<256, 128, 4, 2>(a, st, nblocks);
 }
