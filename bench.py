@@ -576,6 +576,12 @@ def main():
     if os.environ.get('WGS_STEM') == '0':            # development A/B: the Reconstructor's stem in the gather form
         from warpedganspace_amd import reconstructor as _RR
         _RR.STEM_S2D = False
+    if os.environ.get('WGS_SPLIT') == '0':           # development A/B: the prefetched pass in one piece behind the shifted forward
+        from warpedganspace_amd import trainer as _T
+        _T.TrainStep.split_prefetch_default = False
+    if os.environ.get('WGS_PAUSE_RES'):
+        from warpedganspace_amd import trainer as _T2
+        _T2.TrainStep.split_pause_res_default = int(os.environ['WGS_PAUSE_RES'])
     if os.environ.get('WGS_RGB') == '0':             # development A/B: ToRGB as its own launch everywhere
         C.RGB_FUSED = False
     if os.environ.get('WGS_PRIO') == '0':            # development A/B: no high-priority stream for the step's critical path

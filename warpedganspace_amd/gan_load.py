@@ -38,6 +38,16 @@ class StyleGAN2Wrapper(nn.Module):
     def resolve_precision(self, requested=None):
         return self.G.resolve_precision(requested)
 
+    # -- the un-shifted pass G(z) in two stages (extension; trainer.TrainStep) ------------------------------------------------------
+    def begin(self, z, precision=None, pause_res=32):
+        """Enqueue the mapping network and the synthesis layers up to `pause_res` for G(z) (no shift, nothing saved): a handle."""
+        w, _ = self.G._mapping_fwd(z, save=False)
+        return self.G.synthesis_begin(w, self.G.resolve_precision(precision), pause_res)
+
+    def finish(self, handle):
+        """Enqueue the remaining layers: the image [B, 3, res, res]."""
+        return self.G.synthesis_finish(handle)
+
 
 def set_generator_precision(G, precision):
     """Arithmetic of the convs of wrapper / generator `G` for calls that do not pass `precision=` (conv.PRECISION_NAMES):

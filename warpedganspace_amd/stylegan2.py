@@ -330,6 +330,32 @@ class Generator(nn.Module):
 
     # -- synthesis network, model.py:389-403 ---------------------------------------------------------------
     def _synthesis_fwd(self, w, save, prec):
+        g = self._synthesis_gen(w, save, prec, None)
+        try:
+            next(g)
+        except StopIteration as e:
+            return e.value
+        raise L.WgsError("synthesis generator paused without a pause resolution")
+
+    def synthesis_begin(self, w, prec, pause_res):
+        """Enqueue the synthesis layers whose output is <= pause_res (nothing saved) and return a handle for synthesis_finish().  The
+        low-resolution layers are latency-bound (a tenth of the FLOPs, a quarter of the pass's time): the training step runs them for
+        the NEXT batch's un-shifted pass next to the same layers of this batch's shifted pass (trainer.TrainStep)."""
+        g = self._synthesis_gen(w.contiguous(), False, prec, pause_res)
+        next(g)
+        return g
+
+    @staticmethod
+    def synthesis_finish(handle):
+        try:
+            next(handle)
+        except StopIteration as e:
+            return e.value[0]
+        raise L.WgsError("synthesis generator paused twice")
+
+    def _synthesis_gen(self, w, save, prec, pause_res):
+        """The synthesis pass as a Python generator: yields once, before the first layer whose output exceeds `pause_res` (None: never),
+        and returns (image, saved)."""
         P = self._prepare()
         pol = self.mixed_policy or C.mixed_policy(self.size)
         lib, st = L.lib(), L.stream()
@@ -368,11 +394,15 @@ class Generator(nn.Module):
                                            sumC, ly['Co'], L.c_float(ly['scale'] ** 2), L.c_float(0.0), 1, 2, L.c_float(1e-8),
                                            L.c_float(ly['scale']), st), 'demod')
         xplane = None          # (fp16 operand plane, its magnitude bound) of the current layer's input, written by the producing up-conv
+        paused = False
         for i, ly in enumerate(P['layers']):
             Ci, Co = ly['Ci'], ly['Co']
             s_view = S[:, ly['off']:]
             demod = demods[i]
             H = (x if x is not None else xplane[0]).shape[1]
+            if pause_res is not None and not paused and (2 * H if ly['up'] else H) > pause_res:
+                paused = True
+                yield None
             lp = C.layer_precision(prec, 2 * H if ly['up'] else H, ly['up'], pol)      # 'mixed': per-layer arithmetic
             sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp in (2, 3)) else {}
             ymax = xmax[i + 1] if f16_chain else None
@@ -437,6 +467,8 @@ class Generator(nn.Module):
                                                   L.ptr(img), B, Hc * Hc, r['C'], L.c_float(r['scale']), st), 'torgb')
                 skip = img
         saved = (S, outs, demods, B) if save else None
+        if pause_res is not None and not paused:
+            yield None                    # (a generator smaller than the pause resolution: everything ran in the first stage)
         return skip, saved
 
     def _synthesis_bwd(self, saved, dimg, prec):

@@ -135,6 +135,8 @@ class TrainStep:
         self.two_streams = two_streams       # un-shifted generator pass on the side stream
         self.defer_wgrad = defer_wgrad       # R's weight gradients on the side stream, next to the generator's backward
         self.prefetch = prefetch             # G(z) of the NEXT step's batch, next to this step's Reconstructor / backward phases
+        self.split_pause_res = getattr(TrainStep, 'split_pause_res_default', 32)
+        self.split_prefetch = getattr(TrainStep, 'split_prefetch_default', True)           # ... its low-resolution layers already next to this step's shifted forward (StyleGAN2)
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
         self._cold = True                    # next step builds the generator's weight caches of this arithmetic: single stream
         self._r_precision = r_precision
@@ -278,6 +280,21 @@ class TrainStep:
             if img is None:
                 img = G(z, precision=prec)                                                    # :200, nothing saved
             code = G.get_w(z) if self.w_space else z                          # :236
+        # G(z) has no trainable ancestor (:200), so the NEXT step's un-shifted pass does not depend on this step's update: its batch
+        # is drawn now (same order of draws from the sampler's generator as one draw per step) and generated on a third stream.  Its
+        # layers up to 32 x 32 — latency-bound: a tenth of the FLOPs, a quarter of a pass's time — are enqueued HERE, so that they run
+        # next to the same layers of this batch's shifted pass (two latency-bound chains side by side); the chip-filling rest is
+        # gated behind the shifted forward (below), where it fills the CUs that the Reconstructor's short launches leave idle.
+        nxt = None
+        if auto and side is not None and self.prefetch:
+            zn, idxn, magn = self.sample()
+            handle = None
+            if self.split_prefetch and hasattr(G, 'begin') and not self.w_space:
+                self.pre_stream.wait_stream(cur)
+                with torch.cuda.stream(self.pre_stream), torch.no_grad():
+                    handle = G.begin(zn, precision=prec, pause_res=self.split_pause_res)
+                zn.record_stream(self.pre_stream)
+            nxt = (zn, idxn, magn, handle)
         # shift = mag * S(mask, code)   (:235) — fused scale
         lg = S.LOGGAMMA.reshape(-1) if S.learn_gammas else None
         pad = self.dp - self.d
@@ -297,16 +314,13 @@ class TrainStep:
         if side is not None and not pre_img:
             cur.wait_stream(side)
             img.record_stream(cur)
-        # G(z) has no trainable ancestor (:200), so the NEXT step's un-shifted pass does not depend on this step's update: its
-        # batch is drawn now (same order of draws from the sampler's generator as one draw per step) and generated on a third
-        # stream, gated behind this step's shifted forward — it fills the CUs that the Reconstructor's small layers, the loss
-        # and the generator's low-resolution backward layers leave idle, instead of competing with the shifted forward's
-        # chip-filling layers.  Same arithmetic, same values; one generated batch stays unused when training stops.
-        if auto and side is not None and self.prefetch:
-            zn, idxn, magn = self.sample()
+        # the next batch's un-shifted pass (its remaining, chip-filling layers), gated behind this step's shifted forward.  Same
+        # arithmetic, same values as an ordinary call; one generated batch stays unused when training stops.
+        if nxt is not None:
+            zn, idxn, magn, handle = nxt
             self.pre_stream.wait_stream(cur)
             with torch.cuda.stream(self.pre_stream), torch.no_grad():
-                imgn = G(zn, precision=prec)
+                imgn = G.finish(handle) if handle is not None else G(zn, precision=prec)
             zn.record_stream(self.pre_stream)
             self._pre = (zn, idxn, magn, imgn)
         logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True, arith=self.r_arith)   # :242
