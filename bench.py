@@ -579,6 +579,9 @@ def main():
     if os.environ.get('WGS_SPLIT') == '0':           # development A/B: the prefetched pass in one piece behind the shifted forward
         from warpedganspace_amd import trainer as _T
         _T.TrainStep.split_prefetch_default = False
+    if os.environ.get('WGS_EAGER') == '1':           # development A/B: R's weight gradients as soon as their dy exists, next to R's own backward
+        from warpedganspace_amd import trainer as _T3
+        _T3.TrainStep.eager_wgrad_default = True
     if os.environ.get('WGS_PAUSE_RES'):
         from warpedganspace_amd import trainer as _T2
         _T2.TrainStep.split_pause_res_default = int(os.environ['WGS_PAUSE_RES'])

@@ -47,6 +47,20 @@ def sampler_seed(seed, rank, world, start_iter, device):
     return ((base * 1000003 + 7919 * int(start_iter)) * max(world, 1) + rank) % (1 << 63)     # torch.Generator seeds are < 2^64
 
 
+class _EagerSide:
+    """Runs queued closures at once on `side`, behind what the current stream has enqueued so far (list-like: .append((x, dy, fn)))."""
+
+    def __init__(self, side):
+        self.side = side
+
+    def append(self, item):
+        x, dy, fn = item
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            fn()
+        x.record_stream(self.side); dy.record_stream(self.side)
+
+
 _STREAMS = {}
 
 
@@ -135,6 +149,7 @@ class TrainStep:
         self.two_streams = two_streams       # un-shifted generator pass on the side stream
         self.defer_wgrad = defer_wgrad       # R's weight gradients on the side stream, next to the generator's backward
         self.prefetch = prefetch             # G(z) of the NEXT step's batch, next to this step's Reconstructor / backward phases
+        self.eager_wgrad = getattr(TrainStep, 'eager_wgrad_default', False)     # R's weight gradients next to R's own backward (measured: 26.47 -> 26.71 ms, off)
         self.split_pause_res = getattr(TrainStep, 'split_pause_res_default', 32)
         self.split_prefetch = getattr(TrainStep, 'split_prefetch_default', True)           # ... its low-resolution layers already next to this step's shifted forward (StyleGAN2)
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
@@ -331,16 +346,22 @@ class TrainStep:
         gb = self.bucket.gview
         # R's conv weight gradients are not needed for d_img: they are queued and run on the side stream, next to the
         # generator's backward (whose 4x4..32x32 layers under-fill the chip); the ResNet path only (LeNet computes them inline)
-        deferred = [] if (side is not None and R.reconstructor_type == 'ResNet' and self.defer_wgrad) else None
+        deferred = None
+        if side is not None and R.reconstructor_type == 'ResNet' and self.defer_wgrad:
+            # (eager_wgrad: a layer's weight gradient goes to the side stream as soon as its dy exists, i.e. next to the REST of R's
+            # backward instead of next to the generator's backward.  Measured slower — auto 26.47 -> 26.71 ms, fp32w +-0: during R's
+            # phases the prefetched pass already fills the chip, a third stream only adds contention.  Off.)
+            deferred = _EagerSide(side) if self.eager_wgrad else []
         _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred)
         del saved
         pending = []
-        if deferred:
+        if deferred is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                for x_, dy_, fn in deferred:
-                    fn()
-                    x_.record_stream(side); dy_.record_stream(side)
+                if not isinstance(deferred, _EagerSide):
+                    for x_, dy_, fn in deferred:
+                        fn()
+                        x_.record_stream(side); dy_.record_stream(side)
                 if self.world > 1:
                     # R's gradients (the first bucket group, 47 MB at cfg3) are final after these launches: their all-reduce
                     # is queued behind them and overlaps the generator's backward (no trainable parameters)
