@@ -207,8 +207,8 @@ def test_torgb_in_the_conv_epilogue(dev, B, Ci, Co, H, with_y):
             assert torch.equal(got, ref)
         assert am.item() == ref.abs().max().item()
         want = torch.empty(B, 3, H * H, device=dev)
-        L.check(lib.wgs_sg2_torgb_fwd(L.ptr(ref), L.ptr(s_rgb[:, :Co].contiguous()), L.ptr(w_rgb), L.ptr(torch.zeros(3, device=dev)), None, L.ptr(want),
-                                      B, H * H, Co, L.c_float(0.37), st), 'torgb')
+        s_c, b0 = s_rgb[:, :Co].contiguous(), torch.zeros(3, device=dev)       # (named: a temporary dies — and its block is re-used — before the launch)
+        L.check(lib.wgs_sg2_torgb_fwd(L.ptr(ref), L.ptr(s_c), L.ptr(w_rgb), L.ptr(b0), None, L.ptr(want), B, H * H, Co, L.c_float(0.37), st), 'torgb')
         gotc = rgbp.view(B, H * H, 4)
         assert float(gotc[..., 3].abs().max()) == 0.0
         assert (gotc[..., :3].permute(0, 2, 1) - want).abs().max() <= 3e-6 * want.abs().max()
