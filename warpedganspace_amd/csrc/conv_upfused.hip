@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -372,14 +373,20 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cr = (r & 3) + 8 * (r >> 2);       // compile-time row offset (<= 27)
-                    int gx = mbr + cr, gy = mbq;
-                    if (gx >= GX) { gx -= GX; ++gy; }
-                    if (gx >= GX) { gx -= GX; ++gy; }
-                    if (gy < GY) {
-                        const int pos = (2 * gy + (ph >> 1)) * TW + 2 * gx + (ph & 1);
-                        T[pos * 32 + l31] = (half ? acc[ph][1][r] : acc[ph][0][r]) * al * cs;
+                for (int r2 = 0; r2 < 16; r2 += 2) {
+                    // (acc * alpha) * column scale for two rows per packed multiply
+                    const f32x2 tv = f32x2{half ? acc[ph][1][r2] : acc[ph][0][r2], half ? acc[ph][1][r2 + 1] : acc[ph][0][r2 + 1]} * al * cs;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = r2 + e;
+                        const int cr = (r & 3) + 8 * (r >> 2);       // compile-time row offset (<= 27)
+                        int gx = mbr + cr, gy = mbq;
+                        if (gx >= GX) { gx -= GX; ++gy; }
+                        if (gx >= GX) { gx -= GX; ++gy; }
+                        if (gy < GY) {
+                            const int pos = (2 * gy + (ph >> 1)) * TW + 2 * gx + (ph & 1);
+                            T[pos * 32 + l31] = e ? tv.y : tv.x;
+                        }
                     }
                 }
         }
@@ -390,26 +397,29 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             const float4 sn = *reinterpret_cast<const float4*>(aux_sn + half * 32 + q * 4);
             const int ox = 2 * x0 + lx;
             // finish one output pixel: noise, bias, activation, magnitude, store
-            auto emit = [&](float4 a, int ly) {
+            // (two channels per instruction throughout: v_pk_add / v_pk_mul; the leaky ReLU as max(a, 0.2 a), which equals the
+            //  select for every finite a, signed zeros included)
+            const f32x2 bv0 = {bv.x, bv.y}, bv1 = {bv.z, bv.w}, sn0 = {sn.x, sn.y}, sn1 = {sn.z, sn.w};
+            auto emit = [&](f32x2 a0, f32x2 a1, int ly) {
                 const int oy = 2 * y0 + ly;
                 const bool ok = oy < Ho && ox < Ho;
                 const float nz = aux_nz[ly * OW + lx];
-                a.x += nz + bv.x; a.y += nz + bv.y; a.z += nz + bv.z; a.w += nz + bv.w;
-                a.x = (a.x > 0.f ? a.x : 0.2f * a.x) * 1.4142135623730951f;
-                a.y = (a.y > 0.f ? a.y : 0.2f * a.y) * 1.4142135623730951f;
-                a.z = (a.z > 0.f ? a.z : 0.2f * a.z) * 1.4142135623730951f;
-                a.w = (a.w > 0.f ? a.w : 0.2f * a.w) * 1.4142135623730951f;
-                if (ok) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+                const f32x2 nz2 = {nz, nz};
+                a0 += nz2 + bv0; a1 += nz2 + bv1;
+                const f32x2 s0 = a0 * 0.2f, s1 = a1 * 0.2f;
+                a0 = f32x2{fmaxf(a0.x, s0.x), fmaxf(a0.y, s0.y)} * 1.4142135623730951f;
+                a1 = f32x2{fmaxf(a1.x, s1.x), fmaxf(a1.y, s1.y)} * 1.4142135623730951f;
+                if (ok) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a0.x), fabsf(a0.y))), fmaxf(fabsf(a1.x), fabsf(a1.y)));
                 const int off = ok ? (((b * Ho + oy) * Ho + ox) * p.Co + c) * 4 : OOB;
-                const u32x4 sv = {__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)};
+                const u32x4 sv = {__float_as_uint(a0.x), __float_as_uint(a0.y), __float_as_uint(a1.x), __float_as_uint(a1.y)};
                 if (WGS_UABL == 7) { asm volatile("" :: "v"(sv), "v"(off)); return; }
                 __builtin_amdgcn_raw_buffer_store_b128(sv, ry, off, 0, 0);          // (y == NULL: zero-extent descriptor, the store is dropped)
                 if (p.y_f16) {
                     // same roundings as the consumer's own staging of the fp32 tensor: fl32(y * s), exact power of two, f16_rn
-                    float4 v;
-                    v.x = __fmul_rn(a.x, sn.x); v.y = __fmul_rn(a.y, sn.y); v.z = __fmul_rn(a.z, sn.z); v.w = __fmul_rn(a.w, sn.w);
-                    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-                    const f32x4 f = {v.x * pl_mult, v.y * pl_mult, v.z * pl_mult, v.w * pl_mult};
+                    f32x2 v0 = a0 * sn0, v1 = a1 * sn1;
+                    asm volatile("" : "+v"(v0), "+v"(v1));
+                    v0 *= pl_mult; v1 *= pl_mult;
+                    const f32x4 f = {v0.x, v0.y, v1.x, v1.y};
                     uint2 h, l;
                     wgsconv::Scheme<1>::cvt4(f, h, l);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ryh, ok ? off >> 1 : OOB, 0, 0);
@@ -417,26 +427,30 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             };
             if (sep) {
                 // separable kernel (StyleGAN2's [1,3,3,1] outer product): horizontal pass on each loaded row, vertical pass over a
-                // four-row window of the results: 8 instead of 16 multiply-adds per output and channel
-                float4 hwin[4];
+                // four-row window of the results: 8 instead of 16 multiply-adds per output and channel — as PACKED fp32 FMAs
+                // (v_pk_fma_f32: two channels per instruction; the epilogue is a third of this kernel and pure vector work)
+                f32x2 hlo[4], hhi[4];
 #pragma unroll
                 for (int rr = 0; rr < RS + 3; ++rr) {
                     const int uy = strip * RS + rr + 1;
-                    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+                    f32x2 h0 = {0.f, 0.f}, h1 = {0.f, 0.f};
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx) {
-                        const float4 v = *reinterpret_cast<const float4*>(T + ((uy * TW + lx + 1 + jx) * 32 + q * 4));
-                        h.x = fmaf(v.x, kh[jx], h.x); h.y = fmaf(v.y, kh[jx], h.y); h.z = fmaf(v.z, kh[jx], h.z); h.w = fmaf(v.w, kh[jx], h.w);
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(T + ((uy * TW + lx + 1 + jx) * 32 + q * 4));
+                        const f32x2 kk = {kh[jx], kh[jx]};
+                        h0 = __builtin_elementwise_fma(f32x2{v.x, v.y}, kk, h0);
+                        h1 = __builtin_elementwise_fma(f32x2{v.z, v.w}, kk, h1);
                     }
-                    hwin[rr & 3] = h;
+                    hlo[rr & 3] = h0; hhi[rr & 3] = h1;
                     if (rr >= 3) {
-                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
                         for (int ky = 0; ky < 4; ++ky) {
-                            const float4 v = hwin[(rr - 3 + ky) & 3];
-                            a.x = fmaf(v.x, kv[ky], a.x); a.y = fmaf(v.y, kv[ky], a.y); a.z = fmaf(v.z, kv[ky], a.z); a.w = fmaf(v.w, kv[ky], a.w);
+                            const f32x2 kk = {kv[ky], kv[ky]};
+                            a0 = __builtin_elementwise_fma(hlo[(rr - 3 + ky) & 3], kk, a0);
+                            a1 = __builtin_elementwise_fma(hhi[(rr - 3 + ky) & 3], kk, a1);
                         }
-                        emit(a, strip * RS + rr - 3);
+                        emit(a0, a1, strip * RS + rr - 3);
                     }
                 }
             } else {
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
                                 const float4 v = win[(rr - 3 + ky) & 3][kx];
                                 a.x = fmaf(v.x, wv, a.x); a.y = fmaf(v.y, wv, a.y); a.z = fmaf(v.z, wv, a.z); a.w = fmaf(v.w, wv, a.w);
                             }
-                        emit(a, strip * RS + rr - 3);
+                        emit(f32x2{a.x, a.y}, f32x2{a.z, a.w}, strip * RS + rr - 3);
                     }
                 }
             }
