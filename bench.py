@@ -585,6 +585,13 @@ def main():
     if os.environ.get('WGS_PAUSE_RES'):
         from warpedganspace_amd import trainer as _T2
         _T2.TrainStep.split_pause_res_default = int(os.environ['WGS_PAUSE_RES'])
+    if os.environ.get('WGS_TAIL'):                   # development A/B: tail stage of the prefetched pass: '0' off, 'pause,hook' resolutions
+        from warpedganspace_amd import trainer as _T4
+        if os.environ['WGS_TAIL'] == '0':
+            _T4.TrainStep.tail_prefetch_default = False
+        else:
+            _pr, _hr = os.environ['WGS_TAIL'].split(',')
+            _T4.TrainStep.tail_pause_res_default, _T4.TrainStep.tail_hook_res_default = int(_pr), int(_hr)
     if os.environ.get('WGS_RGB') == '0':             # development A/B: ToRGB as its own launch everywhere
         C.RGB_FUSED = False
     if os.environ.get('WGS_PRIO') == '0':            # development A/B: no high-priority stream for the step's critical path

@@ -1,0 +1,62 @@
+"""Same-process, same-box A/B of the prefetched pass's schedule (trainer.TrainStep: split / tail stages).
+
+  python tools/ab_tail.py [--precision fp32w,mixed] [--steps 60] [--rounds 2]
+
+One engine per arithmetic; the variants are attribute settings of that engine, timed round-robin (`rounds` times each, so that a drift
+of the box shows up as a spread instead of as a difference).  Prints one JSON line per (precision, variant)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import bench  # noqa: E402
+
+VARIANTS = [
+    ('tail off', dict(tail_prefetch=False)),
+    ('tail 128/32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=32)),
+    ('tail 128/64', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=64)),
+    ('tail 64/32', dict(tail_prefetch=True, tail_pause_res=64, tail_hook_res=32)),
+    ('tail 64/64', dict(tail_prefetch=True, tail_pause_res=64, tail_hook_res=64)),
+    ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16)),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--precision', default='fp32w,mixed')
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--rounds', type=int, default=2)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    for prec in args.precision.split(','):
+        eng = bench.build(dev, 'stylegan2', 128, 32, 32, precision=prec)
+        for _ in range(10):
+            eng.step()
+        torch.cuda.synchronize()
+        res = {name: [] for name, _ in VARIANTS}
+        for _ in range(args.rounds):
+            for name, kw in VARIANTS:
+                for k, v in kw.items():
+                    setattr(eng, k, v)
+                for _ in range(args.warmup):
+                    eng.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    eng.step()
+                torch.cuda.synchronize()
+                res[name].append(1e3 * (time.perf_counter() - t0) / args.steps)
+        for name, _ in VARIANTS:
+            print(json.dumps({'precision': prec, 'variant': name, 'ms_per_step': [round(v, 3) for v in res[name]],
+                              'img_per_s': round(32e3 / min(res[name]), 1)}), flush=True)
+        del eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()

@@ -44,6 +44,10 @@ class StyleGAN2Wrapper(nn.Module):
         w, _ = self.G._mapping_fwd(z, save=False)
         return self.G.synthesis_begin(w, self.G.resolve_precision(precision), pause_res)
 
+    def advance(self, handle):
+        """Enqueue the layers up to the next pause resolution (`pause_res` a tuple): None while paused again, else the image."""
+        return self.G.synthesis_advance(handle)
+
     def finish(self, handle):
         """Enqueue the remaining layers: the image [B, 3, res, res]."""
         return self.G.synthesis_finish(handle)

@@ -195,6 +195,7 @@ class Generator(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self.debug_keep = None   # tests set this to {} to read back the activation gates of a forward
+        self.bwd_tail_hook = None   # (resolution, callable) for the NEXT synthesis backward (trainer.TrainStep: tail stage of the prefetched pass)
         # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES); the reference's is fp32
         self.precision = 'fp32'
         self.mixed_policy = None  # conv.MixedPolicy override of 'mixed' (None: conv.mixed_policy(size))
@@ -338,24 +339,34 @@ class Generator(nn.Module):
         raise L.WgsError("synthesis generator paused without a pause resolution")
 
     def synthesis_begin(self, w, prec, pause_res):
-        """Enqueue the synthesis layers whose output is <= pause_res (nothing saved) and return a handle for synthesis_finish().  The
-        low-resolution layers are latency-bound (a tenth of the FLOPs, a quarter of the pass's time): the training step runs them for
-        the NEXT batch's un-shifted pass next to the same layers of this batch's shifted pass (trainer.TrainStep)."""
+        """Enqueue the synthesis layers whose output is <= pause_res (nothing saved) and return a handle for synthesis_advance() /
+        synthesis_finish().  `pause_res` may be a tuple of ascending resolutions: the pass then pauses before the first layer above
+        each.  The low-resolution layers are latency-bound (a tenth of the FLOPs, a quarter of the pass's time): the training step
+        runs them for the NEXT batch's un-shifted pass next to the same layers of this batch's shifted pass (trainer.TrainStep)."""
         g = self._synthesis_gen(w.contiguous(), False, prec, pause_res)
         next(g)
         return g
 
     @staticmethod
-    def synthesis_finish(handle):
+    def synthesis_advance(handle):
+        """Enqueue the layers up to the next pause resolution: None while the pass is paused again, the image when it is complete."""
         try:
             next(handle)
         except StopIteration as e:
             return e.value[0]
-        raise L.WgsError("synthesis generator paused twice")
+        return None
+
+    @staticmethod
+    def synthesis_finish(handle):
+        """Enqueue everything that is left: the image."""
+        while True:
+            img = Generator.synthesis_advance(handle)
+            if img is not None:
+                return img
 
     def _synthesis_gen(self, w, save, prec, pause_res):
-        """The synthesis pass as a Python generator: yields once, before the first layer whose output exceeds `pause_res` (None: never),
-        and returns (image, saved)."""
+        """The synthesis pass as a Python generator: yields before the first layer whose output exceeds `pause_res` (an int, or a tuple of
+        ascending resolutions with one pause each; None: never; at least once when a pause resolution is given) and returns (image, saved)."""
         P = self._prepare()
         pol = self.mixed_policy or C.mixed_policy(self.size)
         lib, st = L.lib(), L.stream()
@@ -395,12 +406,15 @@ class Generator(nn.Module):
                                            L.c_float(ly['scale']), st), 'demod')
         xplane = None          # (fp16 operand plane, its magnitude bound) of the current layer's input, written by the producing up-conv
         paused = False
+        pauses = [] if pause_res is None else sorted(pause_res if isinstance(pause_res, (tuple, list)) else [pause_res])
         for i, ly in enumerate(P['layers']):
             Ci, Co = ly['Ci'], ly['Co']
             s_view = S[:, ly['off']:]
             demod = demods[i]
             H = (x if x is not None else xplane[0]).shape[1]
-            if pause_res is not None and not paused and (2 * H if ly['up'] else H) > pause_res:
+            if pauses and (2 * H if ly['up'] else H) > pauses[0]:
+                while pauses and (2 * H if ly['up'] else H) > pauses[0]:
+                    pauses.pop(0)
                 paused = True
                 yield None
             lp = C.layer_precision(prec, 2 * H if ly['up'] else H, ly['up'], pol)      # 'mixed': per-layer arithmetic
@@ -499,11 +513,15 @@ class Generator(nn.Module):
         gA, sA_off = None, None                      # un-scaled dgrad of the consumer conv, its style slice
         sg = []                                      # style-gradient reductions of the pass, launched together at the end
         num_next = None
+        hook, self.bwd_tail_hook = self.bwd_tail_hook, None      # (resolution, callable): called once, when the pass reaches a layer of <= resolution
         for i in range(len(layers) - 1, -1, -1):
             ly = layers[i]
             Co = ly['Co']
             out = outs[i]
             Hc = out.shape[1]
+            if hook is not None and Hc <= hook[0]:
+                hook[1]()
+                hook = None
             Pn = Hc * Hc
             has_rgb = (i % 2 == 0)
             r = rgbs[i // 2] if has_rgb else None
@@ -568,6 +586,8 @@ class Generator(nn.Module):
                     gA_amax = None
             del dy
             sA_off, num_next = ly['off'], num
+        if hook is not None:
+            hook[1]()
         # bottom layer: its input is the ConstantInput -> only the style gradient remains
         ly = layers[0]
         ds0 = zeros(B, ly['Ci'])

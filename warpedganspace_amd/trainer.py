@@ -152,6 +152,12 @@ class TrainStep:
         self.eager_wgrad = getattr(TrainStep, 'eager_wgrad_default', False)     # R's weight gradients next to R's own backward (measured: 26.47 -> 26.71 ms, off)
         self.split_pause_res = getattr(TrainStep, 'split_pause_res_default', 32)
         self.split_prefetch = getattr(TrainStep, 'split_prefetch_default', True)           # ... its low-resolution layers already next to this step's shifted forward (StyleGAN2)
+        # ... and its last, chip-filling layers (above tail_pause_res) held back until the generator's BACKWARD reaches its latency-bound
+        # layers (<= tail_hook_res): they fill the chip under the backward's tail, the RBF backward, Adam and the head of the next step
+        # instead of time-sharing it with the backward's own chip-filling layers.  The image is needed by the next step's Reconstructor only.
+        self.tail_prefetch = getattr(TrainStep, 'tail_prefetch_default', True)
+        self.tail_pause_res = getattr(TrainStep, 'tail_pause_res_default', 128)
+        self.tail_hook_res = getattr(TrainStep, 'tail_hook_res_default', 32)
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
         self._cold = True                    # next step builds the generator's weight caches of this arithmetic: single stream
         self._r_precision = r_precision
@@ -268,9 +274,10 @@ class TrainStep:
         lib, st = L.lib(), L.stream()
         auto = z is None
         img = None
+        pre_ev = None
         if auto:
             if self._pre is not None:
-                z, idx, mag, img = self._pre
+                z, idx, mag, img, pre_ev = self._pre
                 self._pre = None
             else:
                 z, idx, mag = self.sample()
@@ -285,8 +292,7 @@ class TrainStep:
         prec = self.precision
         pre_img = img is not None           # G(z) of this batch was generated during the previous step (see below)
         if pre_img:
-            cur.wait_stream(self.pre_stream)
-            img.record_stream(cur)
+            img.record_stream(cur)          # (the wait for it sits in front of the Reconstructor, its only reader)
         elif side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
@@ -306,8 +312,9 @@ class TrainStep:
             handle = None
             if self.split_prefetch and hasattr(G, 'begin') and not self.w_space:
                 self.pre_stream.wait_stream(cur)
+                pauses = (self.split_pause_res, self.tail_pause_res) if self.tail_prefetch else self.split_pause_res
                 with torch.cuda.stream(self.pre_stream), torch.no_grad():
-                    handle = G.begin(zn, precision=prec, pause_res=self.split_pause_res)
+                    handle = G.begin(zn, precision=prec, pause_res=pauses)
                 zn.record_stream(self.pre_stream)
             nxt = (zn, idxn, magn, handle)
         # shift = mag * S(mask, code)   (:235) — fused scale
@@ -331,13 +338,34 @@ class TrainStep:
             img.record_stream(cur)
         # the next batch's un-shifted pass (its remaining, chip-filling layers), gated behind this step's shifted forward.  Same
         # arithmetic, same values as an ordinary call; one generated batch stays unused when training stops.
+        tail = None
         if nxt is not None:
             zn, idxn, magn, handle = nxt
             self.pre_stream.wait_stream(cur)
             with torch.cuda.stream(self.pre_stream), torch.no_grad():
-                imgn = G.finish(handle) if handle is not None else G(zn, precision=prec)
+                if handle is None:
+                    imgn = G(zn, precision=prec)
+                elif self.tail_prefetch:
+                    imgn = G.advance(handle)            # None: paused in front of the tail layers
+                else:
+                    imgn = G.finish(handle)
             zn.record_stream(self.pre_stream)
-            self._pre = (zn, idxn, magn, imgn)
+            if imgn is not None:
+                self._pre = (zn, idxn, magn, imgn, None)
+            else:
+                def tail():
+                    # called from the generator's backward (autograd's device thread: its current stream is the step's stream)
+                    self.pre_stream.wait_stream(torch.cuda.current_stream(self.dev))
+                    with torch.cuda.stream(self.pre_stream), torch.no_grad():
+                        im = G.finish(handle)
+                    ev = torch.cuda.Event()
+                    ev.record(self.pre_stream)
+                    self._pre = (zn, idxn, magn, im, ev)
+        if pre_img:                       # the image generated one step ahead: complete before the Reconstructor reads it
+            if pre_ev is not None:
+                cur.wait_event(pre_ev)
+            else:
+                cur.wait_stream(self.pre_stream)
         logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True, arith=self.r_arith)   # :242
         L.check(lib.wgs_ce_l1_loss(L.ptr(logits), L.ptr(idx, torch.int64), L.ptr(mag_hat.reshape(B)), L.ptr(mag),
                                    L.c_float(p.lambda_cls), L.c_float(p.lambda_reg), L.ptr(self.dlogits), L.ptr(self.dmag),
@@ -371,7 +399,14 @@ class TrainStep:
         elif self.world > 1:
             _, a, b = self.bucket.groups[0]
             pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
+        inner = getattr(G, 'G', None)
+        if tail is not None and hasattr(inner, 'bwd_tail_hook'):
+            inner.bwd_tail_hook = (self.tail_hook_res, tail)
         img_shifted.backward(d_img)                                           # G: d image -> d shift
+        if tail is not None and (not hasattr(inner, 'bwd_tail_hook') or inner.bwd_tail_hook is not None):
+            if hasattr(inner, 'bwd_tail_hook'):
+                inner.bwd_tail_hook = None
+            tail()                        # (a backward that did not pass through the synthesis hook)
         dtable = gb[id(S.SUPPORT_SETS)]
         dlg = gb[id(S.LOGGAMMA)].reshape(-1) if (S.learn_gammas and id(S.LOGGAMMA) in gb) else None
         dal = gb[id(S.ALPHAS)] if (S.learn_alphas and id(S.ALPHAS) in gb) else None
