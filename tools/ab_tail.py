@@ -16,12 +16,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import bench  # noqa: E402
 
 VARIANTS = [
-    ('tail off', dict(tail_prefetch=False)),
-    ('tail 128/32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=32)),
-    ('tail 128/64', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=64)),
-    ('tail 64/32', dict(tail_prefetch=True, tail_pause_res=64, tail_hook_res=32)),
-    ('tail 64/64', dict(tail_prefetch=True, tail_pause_res=64, tail_hook_res=64)),
-    ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16)),
+    ('tail off', dict(tail_prefetch=False, wgrad_hook_res=0)),
+    ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=0)),
+    ('tail 128/16 wgrad 64', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=64)),
+    ('tail 128/16 wgrad 32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=32)),
+    ('tail 128/16 wgrad 16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=16)),
+    ('tail 128/8 wgrad 32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=8, wgrad_hook_res=32)),
+    ('tail off wgrad 32', dict(tail_prefetch=False, wgrad_hook_res=32)),
 ]
 
 
@@ -31,16 +32,18 @@ def main():
     ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--rounds', type=int, default=2)
+    ap.add_argument('--only', default='', help='comma-separated variant names (default: all)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
+    variants = [v for v in VARIANTS if not args.only or v[0] in args.only.split(',')]
     for prec in args.precision.split(','):
         eng = bench.build(dev, 'stylegan2', 128, 32, 32, precision=prec)
         for _ in range(10):
             eng.step()
         torch.cuda.synchronize()
-        res = {name: [] for name, _ in VARIANTS}
+        res = {name: [] for name, _ in variants}
         for _ in range(args.rounds):
-            for name, kw in VARIANTS:
+            for name, kw in variants:
                 for k, v in kw.items():
                     setattr(eng, k, v)
                 for _ in range(args.warmup):
@@ -51,8 +54,8 @@ def main():
                     eng.step()
                 torch.cuda.synchronize()
                 res[name].append(1e3 * (time.perf_counter() - t0) / args.steps)
-        for name, _ in VARIANTS:
-            print(json.dumps({'precision': prec, 'variant': name, 'ms_per_step': [round(v, 3) for v in res[name]],
+        for name, _ in variants:
+            print(json.dumps({'cu_quarters': os.environ.get('WGS_SIDE_CU_QUARTERS', '4'), 'precision': prec, 'variant': name, 'ms_per_step': [round(v, 3) for v in res[name]],
                               'img_per_s': round(32e3 / min(res[name]), 1)}), flush=True)
         del eng
         torch.cuda.empty_cache()

@@ -195,7 +195,8 @@ class Generator(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self.debug_keep = None   # tests set this to {} to read back the activation gates of a forward
-        self.bwd_tail_hook = None   # (resolution, callable) for the NEXT synthesis backward (trainer.TrainStep: tail stage of the prefetched pass)
+        self.bwd_hooks = None       # [(resolution, callable), ...] for the NEXT synthesis backward: each is called once, when the pass reaches a layer
+                                    # of <= resolution (trainer.TrainStep: side work that should run under the backward's latency-bound tail)
         # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES); the reference's is fp32
         self.precision = 'fp32'
         self.mixed_policy = None  # conv.MixedPolicy override of 'mixed' (None: conv.mixed_policy(size))
@@ -513,15 +514,16 @@ class Generator(nn.Module):
         gA, sA_off = None, None                      # un-scaled dgrad of the consumer conv, its style slice
         sg = []                                      # style-gradient reductions of the pass, launched together at the end
         num_next = None
-        hook, self.bwd_tail_hook = self.bwd_tail_hook, None      # (resolution, callable): called once, when the pass reaches a layer of <= resolution
+        hooks, self.bwd_hooks = list(self.bwd_hooks or ()), None
         for i in range(len(layers) - 1, -1, -1):
             ly = layers[i]
             Co = ly['Co']
             out = outs[i]
             Hc = out.shape[1]
-            if hook is not None and Hc <= hook[0]:
-                hook[1]()
-                hook = None
+            while hooks and max(h[0] for h in hooks) >= Hc:
+                h = max(hooks, key=lambda q: q[0])
+                hooks.remove(h)
+                h[1]()
             Pn = Hc * Hc
             has_rgb = (i % 2 == 0)
             r = rgbs[i // 2] if has_rgb else None
@@ -586,8 +588,8 @@ class Generator(nn.Module):
                     gA_amax = None
             del dy
             sA_off, num_next = ly['off'], num
-        if hook is not None:
-            hook[1]()
+        for h in sorted(hooks, key=lambda q: -q[0]):
+            h[1]()
         # bottom layer: its input is the ConstantInput -> only the style gradient remains
         ly = layers[0]
         ds0 = zeros(B, ly['Ci'])

@@ -64,11 +64,33 @@ class _EagerSide:
 _STREAMS = {}
 
 
+def _masked_stream(device, keep_of_4):
+    """A stream whose workgroups may run on `keep_of_4` of every 4 groups of 8 CUs only (hipExtStreamCreateWithCUMask): side work on
+    such a stream never occupies the whole chip, so the critical path's short launches find free CUs at once.  Development switch
+    (WGS_SIDE_CU_QUARTERS = 1..3)."""
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    words = (ctypes.c_uint32 * 8)()
+    for i in range(256):
+        # bit i -> (XCD, CU) is either (i % 8, i // 8) or (i // 32, i % 32): (i // 8) % 4 selects a quarter of every XCD's CUs under both
+        if (i // 8) % 4 < keep_of_4:
+            words[i // 32] |= 1 << (i % 32)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 def _engine_streams(device):
     """(side, prefetch, high-priority main) streams of `device`, created once per process."""
+    import os
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _STREAMS:
-        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device), torch.cuda.Stream(device=device, priority=-1))
+        q = int(os.environ.get('WGS_SIDE_CU_QUARTERS', '0'))
+        mk = (lambda: _masked_stream(device, q)) if 0 < q < 4 else (lambda: torch.cuda.Stream(device=device))
+        _STREAMS[key] = (mk(), mk(), torch.cuda.Stream(device=device, priority=-1))
     return _STREAMS[key]
 
 
@@ -157,7 +179,9 @@ class TrainStep:
         # instead of time-sharing it with the backward's own chip-filling layers.  The image is needed by the next step's Reconstructor only.
         self.tail_prefetch = getattr(TrainStep, 'tail_prefetch_default', True)
         self.tail_pause_res = getattr(TrainStep, 'tail_pause_res_default', 128)
-        self.tail_hook_res = getattr(TrainStep, 'tail_hook_res_default', 32)
+        self.tail_hook_res = getattr(TrainStep, 'tail_hook_res_default', 16)
+        # R's weight gradients likewise (single-GPU runs: with several ranks their all-reduce wants the whole backward to hide behind)
+        self.wgrad_hook_res = getattr(TrainStep, 'wgrad_hook_res_default', 0)
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
         self._cold = True                    # next step builds the generator's weight caches of this arithmetic: single stream
         self._r_precision = r_precision
@@ -351,7 +375,9 @@ class TrainStep:
                     imgn = G.finish(handle)
             zn.record_stream(self.pre_stream)
             if imgn is not None:
-                self._pre = (zn, idxn, magn, imgn, None)
+                ev = torch.cuda.Event()
+                ev.record(self.pre_stream)
+                self._pre = (zn, idxn, magn, imgn, ev)
             else:
                 def tail():
                     # called from the generator's backward (autograd's device thread: its current stream is the step's stream)
@@ -383,8 +409,10 @@ class TrainStep:
         _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred)
         del saved
         pending = []
-        if deferred is not None:
-            side.wait_stream(cur)
+        hooks = []                          # side work enqueued from inside the generator's backward (synthesis hooks)
+
+        def run_wgrads(deferred=deferred):
+            side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
                 if not isinstance(deferred, _EagerSide):
                     for x_, dy_, fn in deferred:
@@ -395,18 +423,29 @@ class TrainStep:
                     # is queued behind them and overlaps the generator's backward (no trainable parameters)
                     _, a, b = self.bucket.groups[0]
                     pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
+        inner = getattr(G, 'G', None)
+        hookable = hasattr(inner, 'bwd_hooks')
+        if deferred is not None:
+            if self.wgrad_hook_res and hookable and self.world == 1:
+                hooks.append((self.wgrad_hook_res, run_wgrads))     # under the backward's latency-bound tail instead of next to its chip-filling layers
+            else:
+                run_wgrads()
             del deferred
         elif self.world > 1:
             _, a, b = self.bucket.groups[0]
             pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
-        inner = getattr(G, 'G', None)
-        if tail is not None and hasattr(inner, 'bwd_tail_hook'):
-            inner.bwd_tail_hook = (self.tail_hook_res, tail)
+        if tail is not None:
+            if hookable:
+                hooks.append((self.tail_hook_res, tail))
+        if hooks:
+            inner.bwd_hooks = hooks
         img_shifted.backward(d_img)                                           # G: d image -> d shift
-        if tail is not None and (not hasattr(inner, 'bwd_tail_hook') or inner.bwd_tail_hook is not None):
-            if hasattr(inner, 'bwd_tail_hook'):
-                inner.bwd_tail_hook = None
-            tail()                        # (a backward that did not pass through the synthesis hook)
+        if hookable and inner.bwd_hooks is not None:      # (a backward that did not pass through the synthesis hooks)
+            for h in sorted(inner.bwd_hooks, key=lambda q: -q[0]):
+                h[1]()
+            inner.bwd_hooks = None
+        elif tail is not None and not hookable:
+            tail()
         dtable = gb[id(S.SUPPORT_SETS)]
         dlg = gb[id(S.LOGGAMMA)].reshape(-1) if (S.learn_gammas and id(S.LOGGAMMA) in gb) else None
         dal = gb[id(S.ALPHAS)] if (S.learn_alphas and id(S.ALPHAS) in gb) else None
