@@ -17,12 +17,11 @@ import bench  # noqa: E402
 
 VARIANTS = [
     ('tail off', dict(tail_prefetch=False, wgrad_hook_res=0)),
+    ('tail 128/32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=32, wgrad_hook_res=0)),
     ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=0)),
-    ('tail 128/16 wgrad 64', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=64)),
+    ('tail 128/8', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=8, wgrad_hook_res=0)),
+    ('tail 64/16', dict(tail_prefetch=True, tail_pause_res=64, tail_hook_res=16, wgrad_hook_res=0)),
     ('tail 128/16 wgrad 32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=32)),
-    ('tail 128/16 wgrad 16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=16)),
-    ('tail 128/8 wgrad 32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=8, wgrad_hook_res=32)),
-    ('tail off wgrad 32', dict(tail_prefetch=False, wgrad_hook_res=32)),
 ]
 
 
@@ -55,7 +54,7 @@ def main():
                 torch.cuda.synchronize()
                 res[name].append(1e3 * (time.perf_counter() - t0) / args.steps)
         for name, _ in variants:
-            print(json.dumps({'cu_quarters': os.environ.get('WGS_SIDE_CU_QUARTERS', '4'), 'precision': prec, 'variant': name, 'ms_per_step': [round(v, 3) for v in res[name]],
+            print(json.dumps({'precision': prec, 'variant': name, 'ms_per_step': [round(v, 3) for v in res[name]],
                               'img_per_s': round(32e3 / min(res[name]), 1)}), flush=True)
         del eng
         torch.cuda.empty_cache()

@@ -64,33 +64,14 @@ class _EagerSide:
 _STREAMS = {}
 
 
-def _masked_stream(device, keep_of_4):
-    """A stream whose workgroups may run on `keep_of_4` of every 4 groups of 8 CUs only (hipExtStreamCreateWithCUMask): side work on
-    such a stream never occupies the whole chip, so the critical path's short launches find free CUs at once.  Development switch
-    (WGS_SIDE_CU_QUARTERS = 1..3)."""
-    import ctypes
-    hip = ctypes.CDLL('libamdhip64.so')
-    words = (ctypes.c_uint32 * 8)()
-    for i in range(256):
-        # bit i -> (XCD, CU) is either (i % 8, i // 8) or (i // 32, i % 32): (i // 8) % 4 selects a quarter of every XCD's CUs under both
-        if (i // 8) % 4 < keep_of_4:
-            words[i // 32] |= 1 << (i % 32)
-    st = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
-    if rc != 0:
-        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
-    return torch.cuda.ExternalStream(st.value, device=device)
-
-
 def _engine_streams(device):
     """(side, prefetch, high-priority main) streams of `device`, created once per process."""
-    import os
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _STREAMS:
-        q = int(os.environ.get('WGS_SIDE_CU_QUARTERS', '0'))
-        mk = (lambda: _masked_stream(device, q)) if 0 < q < 4 else (lambda: torch.cuda.Stream(device=device))
-        _STREAMS[key] = (mk(), mk(), torch.cuda.Stream(device=device, priority=-1))
+        # (CU-masked side streams — hipExtStreamCreateWithCUMask, 3/4 or 1/2 of every XCD's CUs, so that the critical path's short
+        # launches always find free CUs — measured slower both for all side work (auto 25.7 -> 26.7 / 30.0 ms, fp32w 53.7 -> 59.9 / 69.9)
+        # and for the prefetched pass's middle stage alone, the one that runs beside the Reconstructor (auto 25.7 -> 26.5 / 38.9 ms))
+        _STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device), torch.cuda.Stream(device=device, priority=-1))
     return _STREAMS[key]
 
 
