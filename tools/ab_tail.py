@@ -16,12 +16,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import bench  # noqa: E402
 
 VARIANTS = [
-    ('tail off', dict(tail_prefetch=False, wgrad_hook_res=0)),
-    ('tail 128/32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=32, wgrad_hook_res=0)),
-    ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=0)),
-    ('tail 128/8', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=8, wgrad_hook_res=0)),
-    ('tail 64/16', dict(tail_prefetch=True, tail_pause_res=64, tail_hook_res=16, wgrad_hook_res=0)),
-    ('tail 128/16 wgrad 32', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, wgrad_hook_res=32)),
+    ('tail off', dict(tail_prefetch=False, prepare_wt=False)),
+    ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, prepare_wt=False)),
+    ('tail 128/16 + wt ahead', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, prepare_wt=True)),
 ]
 
 

@@ -212,6 +212,22 @@ class Reconstructor(nn.Module):
         w1p[:, :, :2 * c].copy_(_packed(self.features_extractor.conv1))
         return w1p
 
+    # -- transposed weights for the input-gradient convs, ahead of time -----------------------------------------------
+    def prepare_dgrad_weights(self):
+        """[T, Ci, Co] copies of every block conv's weights (what conv2d_dgrad contracts with) into persistent scratch, enqueued on the
+        current stream: {id(conv): tensor} for _backward_impl(wt=...).  The weights of a training step are fixed from the previous
+        Adam update on, so TrainStep issues these 20 small launches at the start of the step on its side stream instead of one by
+        one inside R's backward, where each sits in the critical path's chain of dependent launches."""
+        if self.reconstructor_type != 'ResNet':
+            return None
+        out = {}
+        for blk in self.features_extractor.blocks():
+            for conv in (blk.conv1, blk.conv2) + ((blk.downsample[0],) if blk.downsample is not None else ()):
+                w = _packed(conv)
+                Co, T, Ci = w.shape
+                out[id(conv)] = C.repack_w_t(w, Co, T, Ci, out=self._scratch('wt%d' % id(conv), (T, Ci, Co), torch.float32, w.device))
+        return out
+
     # -- reference signature ---------------------------------------------------------------------------
     def forward(self, x1, x2):
         if not x1.is_cuda:
@@ -288,7 +304,7 @@ class Reconstructor(nn.Module):
                      B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws, arith=arith, s2d=s2d) if save else None
         return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
 
-    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None):
+    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None, wt=None):
         """Returns ({id(param): grad}, d_x1 or None, d_x2 or None).  With `gbuf` ({id(param): zero-initialised
         buffer in the parameter's MEMORY layout, conv weights packed [Co,T,Ci]}) gradients are written /
         accumulated straight into those buffers (the trainer's flat gradient bucket)."""
@@ -313,6 +329,9 @@ class Reconstructor(nn.Module):
                 C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad, precision=prec)
             else:
                 deferred.append((x, dy, lambda: C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad, precision=prec)))
+
+        def w_t(conv, w, Co, T, Ci):          # the conv's weights as [T, Ci, Co]: prepared ahead (prepare_dgrad_weights) or made here
+            return wt[id(conv)] if (wt is not None and id(conv) in wt) else C.repack_w_t(w, Co, T, Ci)
 
         feat = S['feat']
         dmag = dmag.reshape(B, 1)
@@ -340,7 +359,7 @@ class Reconstructor(nn.Module):
             dw2 = gbuf[id(blk.conv2.weight)] if gbuf is not None else torch.zeros_like(w2)
             wgrad(aa, dcb, dw2, 3, 1, 1)
             grads[id(blk.conv2.weight)] = _grad_like(blk.conv2, dw2)
-            daa = C.conv2d_dgrad(dcb, C.repack_w_t(w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=arith.dgrad)
+            daa = C.conv2d_dgrad(dcb, w_t(blk.conv2, w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=arith.dgrad)
             dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train, gbuf=gbuf)
             grads[id(blk.bn1.weight)], grads[id(blk.bn1.bias)] = dg, db_
             w1 = _packed(blk.conv1)
@@ -348,7 +367,7 @@ class Reconstructor(nn.Module):
             dw1 = gbuf[id(blk.conv1.weight)] if gbuf is not None else torch.zeros_like(w1)
             wgrad(xin, dca, dw1, 3, blk.stride, 1)
             grads[id(blk.conv1.weight)] = _grad_like(blk.conv1, dw1)
-            dmain = C.conv2d_dgrad(dca, C.repack_w_t(w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=arith.dgrad)
+            dmain = C.conv2d_dgrad(dca, w_t(blk.conv1, w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=arith.dgrad)
             if blk.downsample is not None:
                 dcd, _, dg, db_ = _BN.bwd(blk.downsample[1], cd, sd, dres, None, None, ws, train=train, gbuf=gbuf)
                 grads[id(blk.downsample[1].weight)], grads[id(blk.downsample[1].bias)] = dg, db_
@@ -357,7 +376,7 @@ class Reconstructor(nn.Module):
                 dwd = gbuf[id(blk.downsample[0].weight)] if gbuf is not None else torch.zeros_like(wd)
                 wgrad(xin, dcd, dwd, 1, blk.stride, 0)
                 grads[id(blk.downsample[0].weight)] = _grad_like(blk.downsample[0], dwd)
-                dside = C.conv2d_dgrad(dcd, C.repack_w_t(wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0, precision=arith.dgrad)
+                dside = C.conv2d_dgrad(dcd, w_t(blk.downsample[0], wd, Co, T, Ci), xin.shape[1:3], 1, stride=blk.stride, pad=0, precision=arith.dgrad)
             else:
                 dside = dres
             dyA, dyB = dmain, dside

@@ -163,6 +163,7 @@ class TrainStep:
         self.tail_hook_res = getattr(TrainStep, 'tail_hook_res_default', 16)
         # R's weight gradients likewise (single-GPU runs: with several ranks their all-reduce wants the whole backward to hide behind)
         self.wgrad_hook_res = getattr(TrainStep, 'wgrad_hook_res_default', 0)
+        self.prepare_wt = getattr(TrainStep, 'prepare_wt_default', True)        # R's transposed weights at the start of the step, off the critical path
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
         self._cold = True                    # next step builds the generator's weight caches of this arithmetic: single stream
         self._r_precision = r_precision
@@ -306,6 +307,15 @@ class TrainStep:
             if img is None:
                 img = G(z, precision=prec)                                                    # :200, nothing saved
             code = G.get_w(z) if self.w_space else z                          # :236
+        # R's transposed weights for its input-gradient convs: fixed since the last Adam update, made now on the side stream
+        wt, wt_ev = None, None
+        if side is not None and self.prepare_wt and hasattr(R, 'prepare_dgrad_weights'):
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), torch.no_grad():
+                wt = R.prepare_dgrad_weights()
+            if wt is not None:
+                wt_ev = torch.cuda.Event()
+                wt_ev.record(side)
         # G(z) has no trainable ancestor (:200), so the NEXT step's un-shifted pass does not depend on this step's update: its batch
         # is drawn now (same order of draws from the sampler's generator as one draw per step) and generated on a third stream.  Its
         # layers up to 32 x 32 — latency-bound: a tenth of the FLOPs, a quarter of a pass's time — are enqueued HERE, so that they run
@@ -387,7 +397,9 @@ class TrainStep:
             # backward instead of next to the generator's backward.  Measured slower — auto 26.47 -> 26.71 ms, fp32w +-0: during R's
             # phases the prefetched pass already fills the chip, a third stream only adds contention.  Off.)
             deferred = _EagerSide(side) if self.eager_wgrad else []
-        _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred)
+        if wt_ev is not None:
+            cur.wait_event(wt_ev)
+        _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred, **({'wt': wt} if wt else {}))
         del saved
         pending = []
         hooks = []                          # side work enqueued from inside the generator's backward (synthesis hooks)
