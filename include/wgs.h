@@ -226,9 +226,10 @@ typedef struct wgs_wgrad_desc {
     int16_t wt[64];
     int32_t precision;   /* 0: exact fp32 MFMA.  1: split-bf16 x3 (operands split into bf16 hi + lo while they are transposed into the
                             [channel][pixel] LDS image, 3 bf16 MFMAs per product, fp32 accumulate: ~2^-16 per product) for
-                            Ci % 64 == 0 and Co % 64 == 0; other shapes use the exact kernel. */
+                            Ci % 64 == 0 and Co % 64 == 0, and for few input channels (Ci <= 32, ntaps * Ci >= 64, Co % 64 == 0, Wo % 8 == 0:
+                            the (tap, channel) pairs flattened into the GEMM columns); other shapes use the exact kernel. */
     int32_t x_s2d;       /* != 0: x is stored space-to-depth, [B, Hi/2, Wi/2, 4*Ci] with channel (py*2 + px)*Ci + c (wgs_pack_pair_s2d);
-                            Ci == 8, precision 0: the ResNet stem's weight gradient without a second copy of its input */
+                            Ci == 8: the ResNet stem's weight gradient without a second copy of its input */
 } wgs_wgrad_desc;
 int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
 

@@ -98,6 +98,30 @@ def test_s2d_conv_equals_the_strided_7x7(dev, B, H, W, expect_halo, prec):
     refw = wd.grad.permute(0, 2, 3, 1).reshape(64, 49, 2 * c)
     assert (dw8[:, :, :2 * c].double() - refw).abs().max() <= 2e-5 * refw.abs().max()
     assert float(dw8[:, :, 2 * c:].abs().max()) == 0.0
+    # ... and the split-bf16 form of it (conv_wgrad16.hip, the 392 (tap, channel) pairs flattened into the GEMM columns): fp32-class
+    dw8b = torch.zeros(64, 49, 8, device=dev)
+    lib.wgs_dev_trace_kernels(1)
+    try:
+        C.conv2d_wgrad(xs, gy, dw8b, 7, stride=2, pad=3, x_s2d=True, precision=1)
+        symw = lib.wgs_dev_last_kernel().decode()
+    finally:
+        lib.wgs_dev_trace_kernels(0)
+    assert symw.startswith('igemm_wgrad16_kernel<64, 128, true>') == ((W // 2) % 8 == 0), symw
+    assert (dw8b[:, :, :2 * c].double() - refw).abs().max() <= 4e-5 * refw.abs().max()
+    assert float(dw8b[:, :, 2 * c:].abs().max()) == 0.0
+    # the gradient taken in the s2d form (4 x 4 window, 32 channels: what the Reconstructor does) and gathered back to 7 x 7 x 2c
+    for p_ in (0, 1):
+        dws = torch.zeros(64, 16, 32, device=dev)
+        C.conv2d_wgrad(xs, gy, dws, 4, stride=1, pad=2, precision=p_)
+        back = torch.empty(64, 49, 2 * c, device=dev)
+        L.check(lib.wgs_stem_weight_s2d(L.ptr(dws), L.ptr(back), 64, 2 * c, 1, st))
+        assert (back.double() - refw).abs().max() <= (4e-5 if p_ else 2e-5) * refw.abs().max()
+    # the same on the plain [B, H, W, 8] input (the gather form of the stem)
+    xg = torch.zeros(B, H, W, 8, device=dev)
+    xg[..., :2 * c] = torch.cat([x1, x2], 1).permute(0, 2, 3, 1)
+    dw8c = torch.zeros(64, 49, 8, device=dev)
+    C.conv2d_wgrad(xg, gy, dw8c, 7, stride=2, pad=3, precision=1)
+    assert (dw8c[:, :, :2 * c].double() - refw).abs().max() <= 4e-5 * refw.abs().max()
 
 
 @pytest.mark.parametrize('arith', ['bf16x3', 'fp32', 'fp32w'])

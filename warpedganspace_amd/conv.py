@@ -551,7 +551,7 @@ def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0, precision=0, x_
             d.dy_t[i], d.dx_t[i], d.wt[i] = ky - pad, kx - pad, i
             i += 1
     flops = 2.0 * B * Ho * Wo * Co * Ci * k * k
-    _timed('wgrad %s %d->%d @%dx%d %d taps B%d' % ('bf16x3' if precision == 1 and Ci % 64 == 0 and Co % 64 == 0 else 'fp32', Ci, Co, Hi, Wi, k * k, B) if PROFILE is not None else None, flops, lambda: L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad'))
+    _timed('wgrad %s %d->%d @%dx%d %d taps B%d' % ('bf16x3' if precision == 1 and Co % 64 == 0 and (Ci % 64 == 0 or (Ci <= 32 and k * k * Ci >= 64 and Wo % 8 == 0)) else 'fp32', Ci, Co, Hi, Wi, k * k, B) if PROFILE is not None else None, flops, lambda: L.check(L.lib().wgs_conv_wgrad(ctypes.byref(d), L.stream()), 'wgs_conv_wgrad'))
     return dw_packed
 
 

@@ -715,8 +715,8 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
     a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
     a.x_s2d = d->x_s2d;
-    WGS_CHECK_ARG(!d->x_s2d || (d->Ci == 8 && d->Hi % 2 == 0 && d->Wi % 2 == 0 && d->precision == 0),
-                  "wgs_conv_wgrad: x_s2d needs Ci == 8, even Hi / Wi and precision 0 (the stem's weight gradient)");
+    WGS_CHECK_ARG(!d->x_s2d || (d->Ci == 8 && d->Hi % 2 == 0 && d->Wi % 2 == 0 && (d->precision == 0 || (d->Co % 64 == 0 && d->Wo % 8 == 0))),
+                  "wgs_conv_wgrad: x_s2d needs Ci == 8 and even Hi / Wi (the stem's weight gradient); in split-bf16 also Co %% 64 == 0, Wo %% 8 == 0");
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
     // reciprocal multiplies are exact while dividend * divisor < 2^32 (wgs_div_magic); divisor 1 needs none
     auto magic_of = [](long n_max, int dv) -> unsigned { return (dv >= 2 && n_max * dv < (1L << 32)) ? wgs_div_magic(dv) : 0u; };
@@ -728,7 +728,7 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
         WGS_CHECK_LAUNCH("igemm_wgrad16_kernel");
         return WGS_OK;
     }
-    if (d->Ci < 32 && d->ntaps * d->Ci >= 64) {
+    if (d->Ci <= 32 && d->ntaps * d->Ci >= 64) {
         // few input channels: flatten (tap, ci) into the GEMM columns — one pass over dy instead of one per tap
         const int ncol = d->ntaps * d->Ci;
         const int tiles = ((d->Co + 63) / 64) * ((ncol + 127) / 128);

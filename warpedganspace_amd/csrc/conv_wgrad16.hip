@@ -28,13 +28,18 @@ struct Wgrad16Args {
     long w_tap_stride, w_row_stride;
     signed char dy_[64], dx_[64];
     short wt[64];
+    int x_s2d;        // FLAT form only: x is the space-to-depth tensor [B, Hi/2, Wi/2, 4 * Ci] (wgs_pack_pair_s2d; Ci == 8)
+    int oct_row;      // Wo % 8 == 0: the 8 pixels of a staging unit share an image row (one pixel -> (b, oy, ox) split per unit and chunk)
 };
 
 constexpr int BK = 32;          // pixels per chunk
 constexpr int ROWB = 80;        // bytes per LDS row: 32 bf16 + 16 B pad
 
-// BM x BN output tile (BM, BN in {64, 128}), 4 waves as 2 x 2
-template <int BM, int BN>
+// BM x BN output tile (BM, BN in {64, 128}), 4 waves as 2 x 2.
+// FLAT (few input channels: the Reconstructor's stem, Ci = 8, 49 taps): the GEMM columns are the flattened (tap, ci) pairs, so one
+// launch reads dy once for all taps (grid.y = 1) — the form of igemm_wgrad_kernel<.., true>, on the bf16 matrix cores.  A staging
+// unit's four columns lie inside one tap (Ci % 4 == 0); the host guarantees Wo % 8 == 0 (a pixel octet never straddles image rows).
+template <int BM, int BN, bool FLAT = false>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
@@ -46,9 +51,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (p.Ci + BN - 1) / BN;
+    const int ncol = FLAT ? p.ntaps * p.Ci : p.Ci;
+    const int ntn = (ncol + BN - 1) / BN;
     const int co0 = (blockIdx.x / ntn) * BM, ci0 = (blockIdx.x % ntn) * BN;
-    const int t = blockIdx.y;
+    const int t = FLAT ? 0 : blockIdx.y;
     const int dyt = p.dy_[t], dxt = p.dx_[t];
     const int nchunks = (p.M + BK - 1) / BK;
     const int per = (nchunks + p.ksplit - 1) / p.ksplit;
@@ -57,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args
 
     // this thread's staging units
     int u_isA[UPT], u_cq[UPT], u_po[UPT];
+    int u_dy[UPT], u_dx[UPT], u_ci[UPT];        // FLAT: tap offsets and first channel of a B unit's column quad
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
         const int e = tid + u * 256;
@@ -66,10 +73,39 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args
         u_isA[u] = e < UT ? (isA ? 1 : 0) : -1;
         u_cq[u] = f % nq;
         u_po[u] = f / nq;
+        u_dy[u] = dyt; u_dx[u] = dxt; u_ci[u] = ci0 + u_cq[u] * 4;
+        if (FLAT && !isA) {
+            const int col = ci0 + u_cq[u] * 4;
+            const int tc = col < ncol ? col / p.Ci : 0;
+            u_dy[u] = p.dy_[tc]; u_dx[u] = p.dx_[tc];
+            u_ci[u] = col < ncol ? col - tc * p.Ci : -1;      // -1: column past the end (zeros)
+        }
     }
     float4 rg[UPT][8];
     auto load_chunk = [&](int c) {
         const int mbase = c * BK;
+        bool o_ok[UPT];
+        const float* o_row[UPT];
+        int o_ix0[UPT];
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+            o_ok[u] = false; o_row[u] = p.x; o_ix0[u] = 0;
+            if (p.oct_row && u_isA[u] == 0) {
+                const int m0 = mbase + u_po[u] * 8, ci = u_ci[u];
+                if (m0 < p.M && ci >= 0 && ci < p.Ci) {
+                    const int ox = m0 % p.Wo;
+                    const int tt = m0 / p.Wo;
+                    const int oy = tt % p.Ho;
+                    const int b = tt / p.Ho;
+                    const int iy = oy * p.isy + u_dy[u];
+                    o_ix0[u] = ox * p.isx + u_dx[u];
+                    o_ok[u] = iy >= 0 && iy < p.Hi;
+                    if (o_ok[u])
+                        o_row[u] = (FLAT && p.x_s2d) ? p.x + (((size_t)(b * (p.Hi >> 1) + (iy >> 1)) * (p.Wi >> 1)) * 4 + (iy & 1) * 2) * p.Ci + ci
+                                                     : p.x + ((size_t)(b * p.Hi + iy) * p.Wi) * p.Ci + ci;
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UPT; ++u) {
             if (u_isA[u] < 0) continue;
@@ -80,16 +116,30 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args
                 if (u_isA[u] == 1) {
                     const int co = co0 + u_cq[u] * 4;
                     if (m < p.M && co < p.Co) v = *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.Co + co);
-                } else {
-                    const int ci = ci0 + u_cq[u] * 4;
-                    if (m < p.M && ci < p.Ci) {
+                } else if (!p.oct_row) {
+                    const int ci = u_ci[u];
+                    if (m < p.M && ci >= 0 && ci < p.Ci) {
                         const int ox = m % p.Wo;
                         const int tt = m / p.Wo;
                         const int oy = tt % p.Ho;
                         const int b = tt / p.Ho;
-                        const int iy = oy * p.isy + dyt, ix = ox * p.isx + dxt;
-                        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
-                            v = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci);
+                        const int iy = oy * p.isy + u_dy[u], ix = ox * p.isx + u_dx[u];
+                        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) {
+                            if (FLAT && p.x_s2d)
+                                v = *reinterpret_cast<const float4*>(p.x + (((size_t)(b * (p.Hi >> 1) + (iy >> 1)) * (p.Wi >> 1) + (ix >> 1)) * 4 + ((iy & 1) * 2 + (ix & 1))) * p.Ci + ci);
+                            else
+                                v = *reinterpret_cast<const float4*>(p.x + ((size_t)(b * p.Hi + iy) * p.Wi + ix) * p.Ci + ci);
+                        }
+                    }
+                } else {
+                    // the octet's row was split once (o_ok / o_row / o_ix0 above): a 32-bit division is ~35 vector instructions, and
+                    // eight of them per staged float4 made this kernel instruction-bound on its gather
+                    const int ix = o_ix0[u] + j * p.isx;
+                    if (o_ok[u] && ix >= 0 && ix < p.Wi) {
+                        if (FLAT && p.x_s2d)
+                            v = *reinterpret_cast<const float4*>(o_row[u] + ((size_t)(ix >> 1) * 4 + (ix & 1)) * p.Ci);
+                        else
+                            v = *reinterpret_cast<const float4*>(o_row[u] + (size_t)ix * p.Ci);
                     }
                 }
                 rg[u][j] = v;
@@ -158,16 +208,19 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad16_kernel(const Wgrad16Args
         if (c + 1 < c_end) store_chunk(cur ^ 1);
         __syncthreads();
     }
-    float* out = p.dw + (size_t)p.wt[t] * p.w_tap_stride;
+    float* out = p.dw + (FLAT ? (size_t)0 : (size_t)p.wt[t] * p.w_tap_stride);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ci = ci0 + wn * WN + j * 32 + l31;
+        const bool cok = ci < ncol;
+        size_t coff = ci;
+        if (FLAT && cok) { const int tc = ci / p.Ci; coff = (size_t)p.wt[tc] * p.w_tap_stride + (ci - tc * p.Ci); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < p.Co && ci < p.Ci) unsafeAtomicAdd(out + (size_t)co * p.w_row_stride + ci, acc[i][j][r]);
+                if (co < p.Co && cok) unsafeAtomicAdd(out + (size_t)co * p.w_row_stride + coff, acc[i][j][r]);
             }
         }
     }
@@ -329,11 +382,11 @@ void launch16_row(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
     WGS_LAUNCH(k, grid, dim3(256), sm, st, a);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool FLAT = false>
 void launch16(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
     const size_t sm = (size_t)2 * (2 * BM + 2 * BN) * ROWB;
-    auto k = igemm_wgrad16_kernel<BM, BN>;
-    wgs_note_kernel("igemm_wgrad16_kernel<%d, %d>", BM, BN);
+    auto k = igemm_wgrad16_kernel<BM, BN, FLAT>;
+    wgs_note_kernel(FLAT ? "igemm_wgrad16_kernel<%d, %d, true>" : "igemm_wgrad16_kernel<%d, %d>", BM, BN);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     WGS_LAUNCH(k, grid, dim3(256), sm, st, a);
 }
@@ -343,13 +396,29 @@ void launch16(const Wgrad16Args& a, dim3 grid, hipStream_t st) {
 // precision-1 form of wgs_conv_wgrad (called from conv_igemm.hip); returns 0 when it took the launch, 1 when the shape is
 // left to the exact kernel (few input channels / flattened taps, channel counts that are not multiples of 64)
 int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st) {
-    if (d->Ci % 64 != 0 || d->Co % 64 != 0 || d->ntaps > 64) return 1;
+    const bool flat = d->Ci <= 32 && d->Ci % 4 == 0 && d->ntaps * d->Ci >= 64 && d->Co % 64 == 0 && d->Wo % 8 == 0 && d->ntaps <= 64;
+    if (!flat && (d->Ci % 64 != 0 || d->Co % 64 != 0 || d->ntaps > 64 || d->x_s2d)) return 1;
     Wgrad16Args a;
     a.x = d->x; a.dy = d->dy; a.dw = d->dw;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
     a.isy = d->isy; a.isx = d->isx; a.ntaps = d->ntaps; a.M = d->B * d->Ho * d->Wo;
     a.w_tap_stride = d->w_tap_stride; a.w_row_stride = d->w_row_stride;
+    a.x_s2d = d->x_s2d;
+    a.oct_row = d->Wo % 8 == 0 ? 1 : 0;
     for (int t = 0; t < d->ntaps; ++t) { a.dy_[t] = d->dy_t[t]; a.dx_[t] = d->dx_t[t]; a.wt[t] = d->wt[t]; }
+    if (flat) {
+        // few input channels (the stem: 49 taps x 8 channels = 392 columns): one pass over dy for all taps; 64 x 128 tiles, K = pixels
+        const int ncol = d->ntaps * d->Ci;
+        const int bm = d->Co >= 128 ? 128 : 64;
+        const int tiles = (d->Co / bm) * ((ncol + 127) / 128);
+        const int nchunks = (a.M + BK - 1) / BK;
+        int ks = d->ksplit;
+        if (ks <= 0) { ks = (1024 + tiles - 1) / tiles; if (ks > nchunks / 8) ks = nchunks / 8; if (ks < 1) ks = 1; }
+        a.ksplit = ks;
+        dim3 grid((unsigned)tiles, 1, (unsigned)ks);
+        if (bm == 128) launch16<128, 128, true>(a, grid, st); else launch16<64, 128, true>(a, grid, st);
+        return 0;
+    }
     // stride-1 convs whose taps come as kernel rows (dy equal, dx consecutive within each group of three): the row kernel
     bool rows = d->isx == 1 && d->isy == 1 && d->ntaps % 3 == 0 && d->Wo % 8 == 0 && a.M % BK == 0 && d->Hi == d->Ho && d->Wi == d->Wo &&
                 !wgs_flags().wgrad_per_tap;

@@ -68,6 +68,7 @@ def r_arith(r_precision='auto', generator_code=None):
 
 # The ResNet stem in space-to-depth form (Reconstructor._forward_impl): taps (dy, dx, weight index r*4 + s) of the 4 x 4 block window
 STEM_S2D = True
+STEM_WGRAD_S2D = True     # ... and its weight gradient in the same form (64 x 16 x 32, gathered back to 64 x 49 x 2c)
 _S2D_TAPS = [(r - 2, s_ - 2, r * 4 + s_) for r in range(4) for s_ in range(4)]
 
 
@@ -391,18 +392,30 @@ class Reconstructor(nn.Module):
         c, Cp = S['c'], S['Cp']
         # the stem's weight gradient is not on the path to the image gradient either (0.45 ms in front of it at 256^2 inputs): with
         # `deferred` it joins the other weight gradients; the caller's flat bucket (gbuf) receives it when that closure runs
-        dw1p = torch.zeros(64, 49, Cp, device=dev)
         x_stem, s2d_stem = S['x'], S['s2d']
+        s2d_form = s2d_stem and STEM_WGRAD_S2D and 2 * c <= 8
+        # s2d input: the gradient is taken in the s2d form too — a 4 x 4-window stride-1 conv over 32 channels, 512 (tap, channel)
+        # columns of which 49 * 2c are live: 30 % more products than the 7 x 7 form, but a pixel's 32 channels are one 128-byte line
+        # instead of 49 scattered 32-byte pieces (the 7 x 7 form was bound by its gather, 54-61 TFLOP/s in fp32 AND in split-bf16)
+        dw1p = torch.zeros(64, 16, 32, device=dev) if s2d_form else torch.zeros(64, 49, Cp, device=dev)
 
         def stem_wgrad():
-            C.conv2d_wgrad(x_stem, dc1, dw1p, 7, stride=2, pad=3, x_s2d=s2d_stem)        # (reads the s2d input in place)
-            if gbuf is not None:
-                gbuf[id(fe.conv1.weight)].copy_(dw1p[:, :, :2 * c])
+            if s2d_form:
+                C.conv2d_wgrad(x_stem, dc1, dw1p, 4, stride=1, pad=2, precision=arith.wgrad)
+                dst = gbuf[id(fe.conv1.weight)] if gbuf is not None else torch.empty(64, 49, 2 * c, device=dev)
+                L.check(L.lib().wgs_stem_weight_s2d(L.ptr(dw1p), L.rawptr(dst), 64, 2 * c, 1, L.stream()), 'stem_weight_s2d(back)')
+                res = dst
+            else:
+                # (reads the s2d input in place; split-bf16 where the arithmetic allows it: 392 flattened (tap, channel) columns)
+                C.conv2d_wgrad(x_stem, dc1, dw1p, 7, stride=2, pad=3, x_s2d=s2d_stem, precision=arith.wgrad)
+                if gbuf is not None:
+                    gbuf[id(fe.conv1.weight)].copy_(dw1p[:, :, :2 * c])
+                res = dw1p[:, :, :2 * c]
             if dw1p.is_cuda:
                 dw1p.record_stream(torch.cuda.current_stream(dw1p.device))     # (allocated on the caller's stream, used on the deferred one)
+            return res
         if deferred is None or gbuf is None:
-            stem_wgrad()
-            grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, dw1p[:, :, :2 * c].contiguous())
+            grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, stem_wgrad().contiguous())
         else:
             deferred.append((x_stem, dc1, stem_wgrad))
             grads[id(fe.conv1.weight)] = _grad_like(fe.conv1, gbuf[id(fe.conv1.weight)].view(64, 49, 2 * c))
