@@ -16,15 +16,19 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import bench  # noqa: E402
 
 VARIANTS = [
-    ('tail off', dict(tail_prefetch=False, prepare_wt=False)),
-    ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, prepare_wt=False)),
-    ('tail 128/16 + wt ahead', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16, prepare_wt=True)),
+    ('tail off', dict(tail_prefetch=False)),
+    ('tail default/16', dict(tail_prefetch=True, tail_pause_res=None, tail_hook_res=16)),
+    ('tail default/32', dict(tail_prefetch=True, tail_pause_res=None, tail_hook_res=32)),
+    ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16)),
+    ('tail 256/16', dict(tail_prefetch=True, tail_pause_res=256, tail_hook_res=16)),
 ]
+CONFIGS = {'cfg3': ('stylegan2', 128, 32, 32, 256), 'cfg5': ('stylegan2', 200, 64, 8, 1024), 'cfg2': ('proggan', 64, 16, 32, 1024)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--precision', default='fp32w,mixed')
+    ap.add_argument('--config', default='cfg3', choices=tuple(CONFIGS))
     ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--rounds', type=int, default=2)
@@ -33,7 +37,8 @@ def main():
     dev = torch.device('cuda:0')
     variants = [v for v in VARIANTS if not args.only or v[0] in args.only.split(',')]
     for prec in args.precision.split(','):
-        eng = bench.build(dev, 'stylegan2', 128, 32, 32, precision=prec)
+        gan, K, N, B, size = CONFIGS[args.config]
+        eng = bench.build(dev, gan, K, N, B, precision=prec, size=size)
         for _ in range(10):
             eng.step()
         torch.cuda.synchronize()
@@ -52,7 +57,7 @@ def main():
                 res[name].append(1e3 * (time.perf_counter() - t0) / args.steps)
         for name, _ in variants:
             print(json.dumps({'precision': prec, 'variant': name, 'ms_per_step': [round(v, 3) for v in res[name]],
-                              'img_per_s': round(32e3 / min(res[name]), 1)}), flush=True)
+                              'config': args.config, 'img_per_s': round(B * 1e3 / min(res[name]), 1)}), flush=True)
         del eng
         torch.cuda.empty_cache()
 

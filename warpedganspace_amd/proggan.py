@@ -64,6 +64,7 @@ class Generator(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         self._prep = None
+        self.bwd_hooks = None        # [(resolution, callable)] for the NEXT backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
         self.debug_keep = None
         self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
 
@@ -121,14 +122,31 @@ class Generator(nn.Module):
 
     def _fwd(self, z, save, prec):
         """z [B,512] (the wrapper reshapes to [B,512,1,1], models/gan_load.py:115-120)."""
+        g = self._fwd_gen(z, save, prec, None)
+        try:
+            next(g)
+        except StopIteration as e:
+            return e.value
+        raise L.WgsError("ProgGAN pass paused without a pause resolution")
+
+    def _fwd_gen(self, z, save, prec, pause_res):
+        """The pass as a Python generator (as stylegan2.Generator._synthesis_gen): yields before the first block whose output exceeds
+        `pause_res` (an int or a tuple of ascending resolutions, one pause each; at least once when one is given); returns (image, saved)."""
         P = self._prepare()
         B = z.shape[0]
         x = z.contiguous().reshape(B, 1, 1, 512)
         saved = []
+        pauses = [] if pause_res is None else sorted(pause_res if isinstance(pause_res, (tuple, list)) else [pause_res])
+        paused = False
         for ly in P['layers']:
-            xn = self._pixelnorm(x)
             H = x.shape[1] << (1 if ly['up'] else 0)
             Ho = H + 2 * ly['pad'] - ly['k'] + 1
+            if pauses and Ho > pauses[0]:
+                while pauses and Ho > pauses[0]:
+                    pauses.pop(0)
+                paused = True
+                yield None
+            xn = self._pixelnorm(x)
             y = torch.empty(B, Ho, Ho, ly['co'], device=z.device)
             k, pad = ly['k'], ly['pad']
             taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
@@ -143,6 +161,8 @@ class Generator(nn.Module):
         y4 = torch.empty(B, Hc, Hc, 8, device=z.device)
         C.launch(xn, o['wp'], y4, [(0, 0, 0)], Hc, Hc, w_tap_stride=o['ci'], w_row_stride=o['ci'], alpha=o['scale'], bias=o['b'], precision=prec)
         img = y4[..., :3].permute(0, 3, 1, 2).contiguous()
+        if pause_res is not None and not paused:
+            yield None
         return img, ((saved, x, xn) if save else None)
 
     def _bwd(self, saved_all, gimg, prec):
@@ -163,7 +183,12 @@ class Generator(nn.Module):
         # separate activation-backward pass over the tensor is gone.
         dpre = self._pixelnorm_bwd(x_last, gxn, act_slope=0.2)
         nl = len(P['layers'])
+        hooks, self.bwd_hooks = list(self.bwd_hooks or ()), None      # [(resolution, callable)]: each called once, at the first block of <= resolution
         for li, (ly, (x, xn, y)) in enumerate(zip(reversed(P['layers']), reversed(saved))):
+            while hooks and max(h[0] for h in hooks) >= y.shape[1]:
+                h = max(hooks, key=lambda q: q[0])
+                hooks.remove(h)
+                h[1]()
             k, pad = ly['k'], ly['pad']
             Hup = x.shape[1] << (1 if ly['up'] else 0)
             dup = torch.empty(B, Hup, Hup, ly['ci'], device=dev)
@@ -177,6 +202,8 @@ class Generator(nn.Module):
                 gxn = dup
             # x = the previous block's activated output (gate folded in), or — first block — the latent code itself
             dpre = self._pixelnorm_bwd(x, gxn, act_slope=0.2 if li + 1 < nl else 1.0)
+        for h in sorted(hooks, key=lambda q: -q[0]):
+            h[1]()
         g = dpre
         return g.reshape(B, 512)
 
@@ -202,6 +229,27 @@ class ProgGANWrapper(nn.Module):
 
     def resolve_precision(self, requested=None):
         return self.G.resolve_precision(requested)
+
+    # -- the un-shifted pass G(z) in stages (extension; trainer.TrainStep, as StyleGAN2Wrapper) ------------------------------
+    def begin(self, z, precision=None, pause_res=32):
+        g = self.G._fwd_gen(z.reshape(z.shape[0], -1), False, self.G.resolve_precision(precision), pause_res)
+        next(g)
+        return g
+
+    @staticmethod
+    def advance(handle):
+        try:
+            next(handle)
+        except StopIteration as e:
+            return e.value[0]
+        return None
+
+    @staticmethod
+    def finish(handle):
+        while True:
+            img = ProgGANWrapper.advance(handle)
+            if img is not None:
+                return img
 
 
 def build_proggan(pretrained_gan_weights=None, num_blocks=18):
