@@ -51,3 +51,35 @@ def test_proggan_truncated_vs_oracle_fp64(dev, nb, B):
     e = rel_err(shd.grad, sh.grad)
     print('ProgGAN %d blocks: shared-gate d/dshift vs fp64 oracle %.3e' % (nb, e))
     assert e < 1e-4
+
+
+@pytest.mark.parametrize('pauses', [16, (8, 32), (4, 8, 16, 32, 64), 256])
+def test_staged_pass_equals_the_plain_pass_and_hooks_fire_in_the_backward(dev, pauses):
+    """ProgGANWrapper.begin / advance / finish (the pass as a generator that pauses above the given resolutions; trainer.TrainStep runs the
+    stages at different points of a training step) enqueue exactly the launches of a plain call: bit-identical image.  Generator.bwd_hooks:
+    each (resolution, callable) is called once, largest resolution first, and the gradient is what it is without hooks."""
+    G = Generator(10)                      # 64 x 64
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 700))
+    wrap = ProgGANWrapper(G).to(dev).eval()
+    z = GI.rt(701, 3, 512).to(dev)
+    with torch.no_grad():
+        ref = wrap(z)
+        h = wrap.begin(z, pause_res=pauses)
+        n, img = 0, None
+        while img is None:
+            img = wrap.advance(h)
+            n += 1
+    assert torch.equal(img, ref)
+    expect = {16: 1, (8, 32): 2, (4, 8, 16, 32, 64): 4, 256: 1}[pauses]      # pauses above 64 never trigger; 64 x 64 is the last block's size
+    assert n == expect, n
+    sh = (GI.rt(702, 3, 512) * 0.1).to(dev)
+    wgt = GI.rt(703, 3, 3, 64, 64).to(dev)
+    grads, fired = [], []
+    for hooks in (None, [(8, lambda: fired.append(8)), (32, lambda: fired.append(32)), (1024, lambda: fired.append(1024))]):
+        s = sh.clone().requires_grad_(True)
+        G.bwd_hooks = hooks
+        (wrap(z, s) * wgt).sum().backward()
+        assert G.bwd_hooks is None
+        grads.append(s.grad.clone())
+    assert fired == [1024, 32, 8]
+    assert rel_err(grads[1], grads[0]) < 1e-5          # (atomic partial sums: the order of additions is not fixed)

@@ -214,3 +214,35 @@ def test_full_size_batch_consistency(dev):
             print('precision %d rows %s: image %.2e grad %.2e' % (prec, sl, e_img, e_g))
             assert e_img < tol
             assert e_g < 5e-2              # free-running gradient: gate flips between two fp32-class evaluations
+
+
+@pytest.mark.parametrize('pauses', [32, (8, 32), (16, 128), 1024])
+@pytest.mark.parametrize('prec', ['fp32', 'auto'])
+def test_staged_pass_equals_the_plain_pass_and_hooks_fire_in_the_backward(dev, pauses, prec):
+    """StyleGAN2Wrapper.begin / advance / finish (the un-shifted pass as a generator that pauses above the given resolutions: trainer.TrainStep
+    runs its stages at different points of a training step) enqueue exactly the launches of a plain call: bit-identical image.
+    Generator.bwd_hooks: each (resolution, callable) is called once, largest resolution first; the gradient is what it is without hooks."""
+    G, _ = build(64, 41, dev)
+    wrap = StyleGAN2Wrapper(G, False).eval()
+    z = GI.rt(42, 4, 512).to(dev)
+    with torch.no_grad():
+        ref = wrap(z, precision=prec)
+        h = wrap.begin(z, precision=prec, pause_res=pauses)
+        n, img = 0, None
+        while img is None:
+            img = wrap.advance(h)
+            n += 1
+        assert torch.equal(wrap.finish(wrap.begin(z, precision=prec, pause_res=pauses)), ref)
+    assert torch.equal(img, ref)
+    assert n == {32: 1, (8, 32): 2, (16, 128): 1, 1024: 1}[pauses], n
+    sh = (GI.rt(43, 4, 512) * 0.1).to(dev)
+    wgt = GI.rt(44, 4, 3, 64, 64).to(dev)
+    grads, fired = [], []
+    for hooks in (None, [(8, lambda: fired.append(8)), (32, lambda: fired.append(32)), (4096, lambda: fired.append(4096))]):
+        s = sh.clone().requires_grad_(True)
+        G.bwd_hooks = hooks
+        (wrap(z, s, precision=prec) * wgt).sum().backward()
+        assert G.bwd_hooks is None
+        grads.append(s.grad.clone())
+    assert fired == [4096, 32, 8]
+    assert rel_err(grads[1], grads[0]) < 1e-5          # (atomic partial sums: the order of additions is not fixed)

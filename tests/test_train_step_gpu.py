@@ -120,15 +120,19 @@ def test_sampler_distribution_matches_reference_quirk(dev):
     assert 0.64 < pos / tot < 0.78
 
 
-def test_prefetched_unshifted_pass_same_trajectory(dev):
+@pytest.mark.parametrize('tail', [False, True])
+def test_prefetched_unshifted_pass_same_trajectory(dev, tail):
     """The next step's un-shifted pass G(z) is drawn and generated one step ahead on a third stream (trainer.py): the
     sampler's draws — hence every batch — are bit-identical to the plain schedule's, the first two steps' statistics agree
-    to rounding, and the trajectory stays inside the run-to-run envelope of the plain schedule itself."""
+    to rounding, and the trajectory stays inside the run-to-run envelope of the plain schedule itself.  tail: the pass in THREE
+    stages, its last layers enqueued from inside the generator's backward (here: pauses above 8^2 and 16^2, hook at <= 8^2)."""
     size, K, N, B = 32, 16, 4, 4
     runs = []
     for prefetch in (False, True):
         eng, _, _ = make(dev, size, K, N, B)
         eng.prefetch = prefetch
+        eng.tail_prefetch = tail
+        eng.split_pause_res, eng.tail_pause_res, eng.tail_hook_res = 8, 16, 8
         drawn, plain_sample = [], eng.sample
 
         def sample(_s=plain_sample, _d=drawn):
