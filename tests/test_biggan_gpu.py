@@ -50,3 +50,33 @@ def test_biggan_wrapper_draws_target_classes(dev):
     with torch.no_grad():
         img = W(torch.randn(3, 120, device=dev))
     assert img.shape == (3, 3, 128, 128) and float(img.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize('pauses', [32, (16, 64), 512])
+def test_staged_pass_equals_the_plain_pass_and_hooks_fire_in_the_backward(dev, pauses):
+    """BigGANWrapper.begin / advance / finish (the pass as a generator that pauses above the given resolutions; trainer.TrainStep runs the stages
+    at different points of a training step): bit-identical image for the same classes.  Generator.bwd_hooks fire once, largest first."""
+    W = _biggan().to(dev).eval()
+    G = W.G
+    z = GI.rt(551, 3, 120).to(dev)
+    cls = torch.tensor([239, 100, 7], device=dev)
+    with torch.no_grad():
+        ref = W(z, classes=cls)
+        h = W.begin(z, pause_res=pauses, classes=cls)
+        n, img = 0, None
+        while img is None:
+            img = W.advance(h)
+            n += 1
+    assert torch.equal(img, ref)
+    assert n == {32: 1, (16, 64): 2, 512: 1}[pauses], n
+    sh = (GI.rt(552, 3, 120) * 0.1).to(dev)
+    wgt = GI.rt(553, 3, 3, 128, 128).to(dev)
+    grads, fired = [], []
+    for hooks in (None, [(8, lambda: fired.append(8)), (64, lambda: fired.append(64)), (1024, lambda: fired.append(1024))]):
+        s = sh.clone().requires_grad_(True)
+        G.bwd_hooks = hooks
+        (W(z, s, classes=cls) * wgt).sum().backward()
+        assert G.bwd_hooks is None
+        grads.append(s.grad.clone())
+    assert fired == [1024, 64, 8]
+    assert rel_err(grads[1], grads[0]) < 1e-5

@@ -152,6 +152,7 @@ class Generator(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         self._prep = None
+        self.bwd_hooks = None        # [(resolution, callable)] for the NEXT backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
         self.debug_keep = None
         self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
 
@@ -407,7 +408,19 @@ class Generator(nn.Module):
 
     # -- forward / backward ----------------------------------------------------------------------------------
     def _fwd(self, z, y, save, prec):
+        g = self._fwd_gen(z, y, save, prec, None)
+        try:
+            next(g)
+        except StopIteration as e:
+            return e.value
+        raise L.WgsError("BigGAN pass paused without a pause resolution")
+
+    def _fwd_gen(self, z, y, save, prec, pause_res):
+        """The pass as a Python generator (as stylegan2.Generator._synthesis_gen): yields before the first block whose output exceeds
+        `pause_res` (an int or a tuple of ascending resolutions, one pause each; at least once when one is given); returns (image, saved)."""
         P = self._prepare()
+        pauses = [] if pause_res is None else sorted(pause_res if isinstance(pause_res, (tuple, list)) else [pause_res])
+        paused = False
         z, y = z.contiguous(), y.contiguous()
         B = z.shape[0]
         cs = self.z_chunk_size
@@ -417,6 +430,11 @@ class Generator(nn.Module):
         h = self._lin(zs[0], P['lin_w'], P['lin_inv'], P['lin_b']).reshape(B, s, s, c0)  # rows pre-permuted to NHWC
         saved = []
         for d, yb in zip(P['blocks'], ys):
+            if pauses and 2 * h.shape[1] > pauses[0]:
+                while pauses and 2 * h.shape[1] > pauses[0]:
+                    pauses.pop(0)
+                paused = True
+                yield None
             s1, t1 = self._ccbn_affine(d['bn1'], yb)
             a1 = self._affine_relu(h, s1, t1)
             h1 = self._conv(a1, d['c1'], prec, ups=1)
@@ -437,6 +455,8 @@ class Generator(nn.Module):
         af = self._affine_relu(h, so, to)
         y8 = self._conv(af, P['out'], prec, act=1)
         img = y8[..., :3].permute(0, 3, 1, 2).contiguous()
+        if pause_res is not None and not paused:
+            yield None
         return img, ((saved, h, af, so, y8, zs, B) if save else None)
 
     def _bwd(self, saved_all, gimg, prec):
@@ -454,9 +474,14 @@ class Generator(nn.Module):
         g, _, _ = self._affine_relu_bwd(h_last, af, gaf, so)
         cs = self.z_chunk_size
         dz = torch.zeros(B, self.dim_z, device=dev)
+        hooks, self.bwd_hooks = list(self.bwd_hooks or ()), None      # [(resolution, callable)]: each called once, at the first block of <= resolution
         for i in range(len(P['blocks']) - 1, -1, -1):
             d = P['blocks'][i]
             h, s1, a1, h1, s2, a2, yb, att_saved = saved[i]
+            while hooks and max(q[0] for q in hooks) >= 2 * h.shape[1]:
+                q = max(hooks, key=lambda t_: t_[0])
+                hooks.remove(q)
+                q[1]()
             if d['att'] is not None:
                 g = self._att_bwd(d['att'], att_saved, g, prec)
             dyb = torch.zeros(B, yb.shape[1], device=dev)
@@ -470,6 +495,8 @@ class Generator(nn.Module):
             gsc = self._up_bwd(self._conv_dgrad(g, d['sc'], prec))
             g = gh + gsc
             dz[:, (i + 1) * cs:(i + 2) * cs] = dyb[:, self.shared_dim:]              # ys[i] = cat(y, zs[i+1])
+        for q in sorted(hooks, key=lambda t_: -t_[0]):
+            q[1]()
         dz0 = torch.empty(B, cs, device=dev)
         self._lin_dgrad(g.reshape(B, -1), P['lin_w'], P['lin_inv'], dz0, accumulate=False)
         dz[:, :cs] = dz0
@@ -511,6 +538,28 @@ class BigGANWrapper(nn.Module):
 
     def resolve_precision(self, requested=None):
         return self.G.resolve_precision(requested)
+
+    # -- the un-shifted pass G(z) in stages (extension; trainer.TrainStep, as StyleGAN2Wrapper) ------------------------------
+    def begin(self, z, precision=None, pause_res=32, classes=None):
+        target_classes = (self.mixed_classes(z.shape[0]) if classes is None else classes).to(z.device)
+        g = self.G._fwd_gen(z, self.G.shared(target_classes), False, self.G.resolve_precision(precision), pause_res)
+        next(g)
+        return g
+
+    @staticmethod
+    def advance(handle):
+        try:
+            next(handle)
+        except StopIteration as e:
+            return e.value[0]
+        return None
+
+    @staticmethod
+    def finish(handle):
+        while True:
+            img = BigGANWrapper.advance(handle)
+            if img is not None:
+                return img
 
 
 def build_biggan(pretrained_gan_weights=None, target_classes=(239,), config_file=None):

@@ -257,6 +257,8 @@ class TrainStep:
             return int(inner.size)
         if hasattr(inner, 'num_blocks'):
             return 4 << ((inner.num_blocks - 2) // 2)
+        if hasattr(inner, 'resolution'):
+            return int(inner.resolution)
         return 256
 
     # -- sampling (lib/trainer.py:195-221), on the device ---------------------------------------------
