@@ -21,8 +21,10 @@ VARIANTS = [
     ('tail default/32', dict(tail_prefetch=True, tail_pause_res=None, tail_hook_res=32)),
     ('tail 128/16', dict(tail_prefetch=True, tail_pause_res=128, tail_hook_res=16)),
     ('tail 256/16', dict(tail_prefetch=True, tail_pause_res=256, tail_hook_res=16)),
+    ('weights inline', dict(prepare_wt=False)),
+    ('weights ahead', dict(prepare_wt=True)),
 ]
-CONFIGS = {'cfg3': ('stylegan2', 128, 32, 32, 256), 'cfg5': ('stylegan2', 200, 64, 8, 1024), 'cfg2': ('proggan', 64, 16, 32, 1024)}
+CONFIGS = {'cfg3': ('stylegan2', 128, 32, 32, 256), 'cfg5': ('stylegan2', 200, 64, 8, 1024), 'cfg2': ('proggan', 64, 16, 32, 1024), 'cfg4': ('biggan', 128, 32, 16, 128)}
 
 
 def main():

@@ -236,6 +236,20 @@ class WinoCache(SplitCache):
         return None
 
 
+class StepWinoCache(WinoCache):
+    """Winograd U operands of a TRAINED weight tensor, owned by a training engine: the launches that built an operand leave their
+    descriptor behind (`recipes`), refresh() rebuilds every operand in place from the tensor's current values — once per optimisation
+    step, after the update and off the critical path (reconstructor.StepWeights), instead of one transform launch in front of every
+    conv.  Valid only while its owner refreshes it: nothing else may hold one across a weight update."""
+
+    def __init__(self):
+        self.w, self.planes, self.recipes = None, {}, {}
+
+    def refresh(self):
+        for key, d in self.recipes.items():
+            L.check(L.lib().wgs_conv_wino_weight(ctypes.byref(d), L.ptr(self.planes[key]), L.stream()), 'wgs_conv_wino_weight')
+
+
 def _timed(kind, flops, fn):
     if PROFILE is None:
         return fn()
@@ -317,6 +331,8 @@ def _wino_weight(d, w, cache):
     L.check(L.lib().wgs_conv_wino_weight(ctypes.byref(d), L.ptr(U), L.stream()), 'wgs_conv_wino_weight')
     if isinstance(cache, SplitCache):
         cache.planes[key] = U
+        if isinstance(cache, StepWinoCache):
+            cache.recipes[key] = ConvDesc.from_buffer_copy(d)
     return U
 
 

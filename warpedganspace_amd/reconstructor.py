@@ -159,6 +159,25 @@ class _BN:
         return dx, dres, dg, db
 
 
+class StepWeights:
+    """Per-step derived forms of the Reconstructor's trained conv weights, owned by a training engine (trainer.TrainStep): the [T, Ci, Co]
+    copies its input-gradient convs contract with and, in 'fp32w', the Winograd U operands of its forward and input-gradient convs.
+    refresh() re-derives all of them from the parameters' current values on the current stream — the engine calls it once per step, after
+    the previous Adam update, on its side stream — so that none of these ~60 small launches sits in the critical chain of R's forward /
+    backward.  Pass the object to _forward_impl / _backward_impl (sw=) ONLY in steps that refreshed it."""
+
+    def __init__(self, R):
+        self.R, self.caches, self.wt = R, {}, {}
+
+    def cache(self, conv, kind):
+        return self.caches.setdefault((id(conv), kind), C.StepWinoCache())
+
+    def refresh(self):
+        self.wt = self.R.prepare_dgrad_weights() or {}
+        for c in self.caches.values():
+            c.refresh()
+
+
 class _RFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, R, x1, x2, *params):
@@ -236,7 +255,7 @@ class Reconstructor(nn.Module):
         return _RFunction.apply(self, x1, x2, *self._param_list())
 
     # -- explicit schedule -------------------------------------------------------------------------------
-    def _forward_impl(self, x1, x2, save=True, arith=None):
+    def _forward_impl(self, x1, x2, save=True, arith=None, sw=None):
         if self.reconstructor_type == 'LeNet':
             from . import lenet
             return lenet.forward_impl(self, x1, x2, save)
@@ -278,11 +297,12 @@ class Reconstructor(nn.Module):
                 'maxpool')
         saved_blocks = []
         h = p1
+        wc = (lambda conv: sw.cache(conv, 'f')) if sw is not None else (lambda conv: None)       # Winograd operands refreshed by the engine (StepWeights)
         for blk in fe.blocks():
             xin = h
-            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=fp)
+            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=fp, w_split=wc(blk.conv1))
             aa, sa = _BN.fwd(blk.bn1, ca, ws, relu=True, train=train)
-            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=fp)
+            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=fp, w_split=wc(blk.conv2))
             if blk.downsample is not None:
                 cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=fp)
                 ad, sd = _BN.fwd(blk.downsample[1], cd, ws, relu=False, train=train)
@@ -305,7 +325,7 @@ class Reconstructor(nn.Module):
                      B=B, c=c, H=H, W=W, Cp=Cp, train=train, ws=ws, arith=arith, s2d=s2d) if save else None
         return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
 
-    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None, wt=None):
+    def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None, wt=None, sw=None):
         """Returns ({id(param): grad}, d_x1 or None, d_x2 or None).  With `gbuf` ({id(param): zero-initialised
         buffer in the parameter's MEMORY layout, conv weights packed [Co,T,Ci]}) gradients are written /
         accumulated straight into those buffers (the trainer's flat gradient bucket)."""
@@ -331,8 +351,14 @@ class Reconstructor(nn.Module):
             else:
                 deferred.append((x, dy, lambda: C.conv2d_wgrad(x, dy, dw, k, stride=stride, pad=pad, precision=prec)))
 
+        if sw is not None and wt is None:
+            wt = sw.wt
+
         def w_t(conv, w, Co, T, Ci):          # the conv's weights as [T, Ci, Co]: prepared ahead (prepare_dgrad_weights) or made here
             return wt[id(conv)] if (wt is not None and id(conv) in wt) else C.repack_w_t(w, Co, T, Ci)
+
+        def wcd(conv):                        # Winograd operand cache of the conv's input-gradient launch: only beside a prepared [T, Ci, Co] copy
+            return sw.cache(conv, 'd') if (sw is not None and wt is not None and id(conv) in wt) else None
 
         feat = S['feat']
         dmag = dmag.reshape(B, 1)
@@ -360,7 +386,7 @@ class Reconstructor(nn.Module):
             dw2 = gbuf[id(blk.conv2.weight)] if gbuf is not None else torch.zeros_like(w2)
             wgrad(aa, dcb, dw2, 3, 1, 1)
             grads[id(blk.conv2.weight)] = _grad_like(blk.conv2, dw2)
-            daa = C.conv2d_dgrad(dcb, w_t(blk.conv2, w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=arith.dgrad)
+            daa = C.conv2d_dgrad(dcb, w_t(blk.conv2, w2, Co, T, Ci), aa.shape[1:3], 3, stride=1, pad=1, precision=arith.dgrad, w_split=wcd(blk.conv2))
             dca, _, dg, db_ = _BN.bwd(blk.bn1, ca, sa, daa, None, aa, ws, train=train, gbuf=gbuf)
             grads[id(blk.bn1.weight)], grads[id(blk.bn1.bias)] = dg, db_
             w1 = _packed(blk.conv1)
@@ -368,7 +394,7 @@ class Reconstructor(nn.Module):
             dw1 = gbuf[id(blk.conv1.weight)] if gbuf is not None else torch.zeros_like(w1)
             wgrad(xin, dca, dw1, 3, blk.stride, 1)
             grads[id(blk.conv1.weight)] = _grad_like(blk.conv1, dw1)
-            dmain = C.conv2d_dgrad(dca, w_t(blk.conv1, w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=arith.dgrad)
+            dmain = C.conv2d_dgrad(dca, w_t(blk.conv1, w1, Co, T, Ci), xin.shape[1:3], 3, stride=blk.stride, pad=1, precision=arith.dgrad, w_split=wcd(blk.conv1))
             if blk.downsample is not None:
                 dcd, _, dg, db_ = _BN.bwd(blk.downsample[1], cd, sd, dres, None, None, ws, train=train, gbuf=gbuf)
                 grads[id(blk.downsample[1].weight)], grads[id(blk.downsample[1].bias)] = dg, db_

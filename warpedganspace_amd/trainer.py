@@ -164,6 +164,7 @@ class TrainStep:
         # R's weight gradients likewise (single-GPU runs: with several ranks their all-reduce wants the whole backward to hide behind)
         self.wgrad_hook_res = getattr(TrainStep, 'wgrad_hook_res_default', 0)
         self.prepare_wt = getattr(TrainStep, 'prepare_wt_default', True)        # R's transposed weights at the start of the step, off the critical path
+        self._sw = None                      # reconstructor.StepWeights of this engine (built with the first multi-stream step)
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
         self._cold = True                    # next step builds the generator's weight caches of this arithmetic: single stream
         self._r_precision = r_precision
@@ -318,15 +319,19 @@ class TrainStep:
             if img is None:
                 img = G(z, precision=prec)                                                    # :200, nothing saved
             code = G.get_w(z) if self.w_space else z                          # :236
-        # R's transposed weights for its input-gradient convs: fixed since the last Adam update, made now on the side stream
-        wt, wt_ev = None, None
-        if side is not None and self.prepare_wt and hasattr(R, 'prepare_dgrad_weights'):
+        # Derived forms of R's trained weights (transposed copies for its input-gradient convs, Winograd operands in 'fp32w'): fixed since
+        # the last Adam update, re-derived now on the side stream instead of launch by launch inside R's forward / backward
+        sw, wt_ev = None, None
+        if side is not None and self.prepare_wt and getattr(R, 'reconstructor_type', None) == 'ResNet':
+            if self._sw is None:
+                from .reconstructor import StepWeights
+                self._sw = StepWeights(R)
+            sw = self._sw
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
-                wt = R.prepare_dgrad_weights()
-            if wt is not None:
-                wt_ev = torch.cuda.Event()
-                wt_ev.record(side)
+                sw.refresh()
+            wt_ev = torch.cuda.Event()
+            wt_ev.record(side)
         # G(z) has no trainable ancestor (:200), so the NEXT step's un-shifted pass does not depend on this step's update: its batch
         # is drawn now (same order of draws from the sampler's generator as one draw per step) and generated on a third stream.  Its
         # layers up to 32 x 32 — latency-bound: a tenth of the FLOPs, a quarter of a pass's time — are enqueued HERE, so that they run
@@ -395,7 +400,9 @@ class TrainStep:
                 cur.wait_event(pre_ev)
             else:
                 cur.wait_stream(self.pre_stream)
-        logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True, arith=self.r_arith)   # :242
+        if wt_ev is not None:
+            cur.wait_event(wt_ev)
+        logits, mag_hat, saved = R._forward_impl(img, img_shifted.detach(), save=True, arith=self.r_arith, **({'sw': sw} if sw else {}))   # :242
         L.check(lib.wgs_ce_l1_loss(L.ptr(logits), L.ptr(idx, torch.int64), L.ptr(mag_hat.reshape(B)), L.ptr(mag),
                                    L.c_float(p.lambda_cls), L.c_float(p.lambda_reg), L.ptr(self.dlogits), L.ptr(self.dmag),
                                    L.ptr(self.stats), L.ptr(self.argmax, torch.int64), L.ptr(self.loss_ws), B, self.K, st),
@@ -409,9 +416,7 @@ class TrainStep:
             # backward instead of next to the generator's backward.  Measured slower — auto 26.47 -> 26.71 ms, fp32w +-0: during R's
             # phases the prefetched pass already fills the chip, a third stream only adds contention.  Off.)
             deferred = _EagerSide(side) if self.eager_wgrad else []
-        if wt_ev is not None:
-            cur.wait_event(wt_ev)
-        _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred, **({'wt': wt} if wt else {}))
+        _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred, **({'sw': sw} if sw else {}))
         del saved
         pending = []
         hooks = []                          # side work enqueued from inside the generator's backward (synthesis hooks)
