@@ -454,6 +454,17 @@ int wgs_ce_l1_loss(const float* logits, const int64_t* target, const float* mag_
 int wgs_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, wgs_stream_t stream);
 
+/* One training step's batch drawn in HBM by ONE launch (replaces the host-side sampling of lib/trainer.py:195-221 and lib/aux.py:39-53;
+ * SURVEY section 8b `sample_step`):
+ *   z [B, d] ~ N(0, 1), truncated to [-trunc, trunc] when 0 < trunc != 1 (inverse CDF; trunc <= 0 or == 1: plain normal);
+ *   idx [B] (int64) ~ U{0 .. K-1};
+ *   mag [B]: B entries of the pool [neg_0 .. neg_{B-1}, pos_0 .. pos_{B-1}] (neg_i = (lo - hi) u - lo, pos_i = (lo - hi) u' + hi) drawn
+ *            WITHOUT replacement with weights 0 .. 2B-1, in torch.multinomial's order (the reference's arange-weighted draw, :218-221).
+ * Counter-based generator (Philox4x32-10): the values are a pure function of (seed, step) — stateless and reproducible; a caller
+ * increments `step` per draw and gives every rank its own seed.  B <= 1024. */
+int wgs_sample_step(float* z, int64_t* idx, float* mag, int B, int d, int K, float lo, float hi, float trunc, uint64_t seed, uint64_t step,
+                    wgs_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BigGAN generator glue (models/BigGAN/layers.py).
  */

@@ -23,6 +23,8 @@ VARIANTS = [
     ('tail 256/16', dict(tail_prefetch=True, tail_pause_res=256, tail_hook_res=16)),
     ('weights inline', dict(prepare_wt=False)),
     ('weights ahead', dict(prepare_wt=True)),
+    ('torch sampler', dict(torch_sampler=True)),
+    ('kernel sampler', dict(torch_sampler=False)),
 ]
 CONFIGS = {'cfg3': ('stylegan2', 128, 32, 32, 256), 'cfg5': ('stylegan2', 200, 64, 8, 1024), 'cfg2': ('proggan', 64, 16, 32, 1024), 'cfg4': ('biggan', 128, 32, 16, 128)}
 

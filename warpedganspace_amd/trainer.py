@@ -22,6 +22,8 @@ import sys
 import time
 
 import numpy as np
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -164,6 +166,8 @@ class TrainStep:
         # R's weight gradients likewise (single-GPU runs: with several ranks their all-reduce wants the whole backward to hide behind)
         self.wgrad_hook_res = getattr(TrainStep, 'wgrad_hook_res_default', 0)
         self.prepare_wt = getattr(TrainStep, 'prepare_wt_default', True)        # R's transposed weights at the start of the step, off the critical path
+        self.torch_sampler = getattr(TrainStep, 'torch_sampler_default', False)       # sample() through torch's generator instead of wgs_sample_step
+        self._draws = 0                      # batches drawn so far: the counter half of the sampler's Philox key
         self._sw = None                      # reconstructor.StepWeights of this engine (built with the first multi-stream step)
         self._pre = None                     # (z, idx, mag, img) drawn and generated one step ahead
         self._cold = True                    # next step builds the generator's weight caches of this arithmetic: single stream
@@ -264,6 +268,23 @@ class TrainStep:
 
     # -- sampling (lib/trainer.py:195-221), on the device ---------------------------------------------
     def sample(self):
+        """(z [B, d], path indices [B] int64, shift magnitudes [B]) of one step, drawn in HBM by ONE launch (wgs_sample_step: the same
+        distributions as lib/trainer.py:195-221 incl. the arange-weighted draw without replacement; Philox stream keyed by this rank's
+        sampler seed and the draw counter).  `torch_sampler` (development / tests): the same draws from torch's generator, ~25 launches."""
+        p, B = self.p, self.B
+        if self.torch_sampler or B > 1024:
+            return self._sample_torch()
+        z = torch.empty(B, self.G.dim_z, device=self.dev)
+        idx = torch.empty(B, dtype=torch.int64, device=self.dev)
+        mag = torch.empty(B, device=self.dev)
+        trunc = getattr(p, 'z_truncation', None)
+        L.check(L.lib().wgs_sample_step(L.ptr(z), L.ptr(idx, torch.int64), L.ptr(mag), B, self.G.dim_z, self.K, L.c_float(p.min_shift_magnitude),
+                                        L.c_float(p.max_shift_magnitude), L.c_float(0.0 if trunc is None else float(trunc)),
+                                        ctypes.c_uint64(self.sampler_seed & 0xFFFFFFFFFFFFFFFF), ctypes.c_uint64(self._draws), L.stream()), 'wgs_sample_step')
+        self._draws += 1
+        return z, idx, mag
+
+    def _sample_torch(self):
         p, B = self.p, self.B
         z = sample_z(B, self.G.dim_z, truncation=getattr(p, 'z_truncation', None), device=self.dev, generator=self.gen)
         idx = torch.randint(0, self.K, (B,), device=self.dev, generator=self.gen)
