@@ -111,7 +111,7 @@ def test_step_loss_and_argmax_fp16_schemes(dev, name):
         assert cos > 0.9
 
 
-@pytest.mark.parametrize('family', ['stylegan2-256', 'proggan-256', 'biggan-128'])
+@pytest.mark.parametrize('family', ['stylegan2-256', 'proggan-256', 'proggan-1024', 'biggan-128'])
 def test_fp16_image_error_distribution(dev, family):
     """Image error (max-norm relative) of the fp16 modes over 6 batches of 32 random latent codes, against the exact-fp32
     kernels (themselves ~1e-6 from the float64 oracle), per batch tensor and per single image: the distribution behind the
@@ -132,12 +132,16 @@ def test_fp16_image_error_distribution(dev, family):
         from warpedganspace_amd.proggan import build_proggan
         G = build_proggan(None, num_blocks=14).to(dev).eval()
         fam, res = 'proggan', 256
+    elif family == 'proggan-1024':                     # cfg2's native network (18 blocks)
+        from warpedganspace_amd.proggan import build_proggan
+        G = build_proggan(None, num_blocks=18).to(dev).eval()
+        fam, res = 'proggan', 1024
     else:
         from warpedganspace_amd.biggan import build_biggan
         G = build_biggan(None, (239,)).to(dev).eval()
         fam, res = 'biggan', 128
     NB = 6                                             # batches of 32 latent codes (the training batch of cfg3)
-    zs = [torch.randn(32, G.dim_z, device=dev) for _ in range(NB)]
+    zs = [torch.randn(32 if res < 1024 else 16, G.dim_z, device=dev) for _ in range(NB)]
     out = {}
     if True:
         with torch.no_grad():

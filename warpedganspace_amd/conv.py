@@ -70,8 +70,8 @@ AUTO, MIXED, FP32W = -1, 4, 5
 DEFAULT_PRECISION = 'auto'
 IMAGE_DEFAULT_PRECISION = 'bf16x3'
 # (generator family, output resolution) -> mode for 'auto'; only entries with a measurement behind them
-# (profiles/r3_precision_schemes.json); everything else falls back to the fp32-class mode.
-AUTO_TABLE = {('stylegan2', 256): 'mixed', ('stylegan2', 1024): 'mixed', ('proggan', 256): 'f16'}
+# (profiles/r4_precision_schemes.json: ProgGAN-256 3.5e-4, ProgGAN-1024 9e-5 per image in f16); everything else falls back to the fp32-class mode.
+AUTO_TABLE = {('stylegan2', 256): 'mixed', ('stylegan2', 1024): 'mixed', ('proggan', 256): 'f16', ('proggan', 1024): 'f16'}
 AUTO_FALLBACK = 'bf16x3'
 
 
