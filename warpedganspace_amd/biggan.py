@@ -38,6 +38,12 @@ def generator_arch(ch=64, attention='64'):
             32: mk([4, 4, 4], [4, 4, 4], [8, 16, 32])}
 
 
+# 'mixed' arithmetic of the generator's forward convs: blocks whose OUTPUT resolution is >= the entry run fp16 x2 (2 MFMAs per product), the
+# others and the image conv split-bf16 x3; measured per resolution (tests/test_precision_schemes_gpu.py), None = no fp16 block passes the gate.
+# The input-gradient convs have no magnitude bound for their fp16 operand and run split-bf16 in every 16-bit mode (conv._desc).
+MIXED_FROM_RES = {}
+
+
 class _SNMixin:
     def _sn_init(self, num_outputs):
         self.register_buffer('u0', torch.randn(1, num_outputs))
@@ -155,6 +161,7 @@ class Generator(nn.Module):
         self.bwd_hooks = None        # [(resolution, callable)] for the NEXT backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
         self.debug_keep = None
         self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
+        self.mixed_from_res = MIXED_FROM_RES.get(resolution)      # 'mixed' (conv.AUTO_TABLE): fp16 x2 from this block resolution up, split-bf16 below
 
     def _apply(self, fn, *a, **k):
         self._prep = None
@@ -429,7 +436,11 @@ class Generator(nn.Module):
         s, c0 = self.bottom_width, P['c0']
         h = self._lin(zs[0], P['lin_w'], P['lin_inv'], P['lin_b']).reshape(B, s, s, c0)  # rows pre-permuted to NHWC
         saved = []
+        mixed_from = self.mixed_from_res      # 'mixed': fp16 x2 in the blocks whose output is >= this resolution, split-bf16 below
+        prec_in = prec
         for d, yb in zip(P['blocks'], ys):
+            if prec_in == C.MIXED:
+                prec = 3 if (mixed_from is not None and 2 * h.shape[1] >= mixed_from) else 1
             if pauses and 2 * h.shape[1] > pauses[0]:
                 while pauses and 2 * h.shape[1] > pauses[0]:
                     pauses.pop(0)
@@ -453,6 +464,8 @@ class Generator(nn.Module):
         so = P['out_scale'].unsqueeze(0).expand(B, -1).contiguous()
         to = P['out_shift'].unsqueeze(0).expand(B, -1).contiguous()
         af = self._affine_relu(h, so, to)
+        if prec_in == C.MIXED:
+            prec = 1          # the image conv (3 output channels, tanh) stays fp32-class
         y8 = self._conv(af, P['out'], prec, act=1)
         img = y8[..., :3].permute(0, 3, 1, 2).contiguous()
         if pause_res is not None and not paused:
