@@ -252,6 +252,9 @@ int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int 
  * (models/ProgGAN/model.py:35-62) the PixelNorm input of a block is the activated output of the previous block, so this replaces that
  * block's separate activation-backward pass over the tensor. */
 int wgs_pixelnorm_bwd_act(const float* x, const float* gy, float* gx, int rows, int d, float eps, float act_slope, wgs_stream_t stream);
+/* ... and raises the device scalar gx_amax (caller-zeroed, atomic max) to max |gx|: the magnitude bound (wgs_conv_desc.a_amax) that lets the
+ * gradient conv consuming gx round it to fp16 under a power-of-two scale (ProgGAN's backward in the f16 modes). */
+int wgs_pixelnorm_bwd_act_amax(const float* x, const float* gy, float* gx, float* gx_amax, int rows, int d, float eps, float act_slope, wgs_stream_t stream);
 
 /* The whole mapping network (model.py:288-295: PixelNorm, then L x EqualLinear(d, d, lr_mul, activation='fused_lrelu')) in ONE
  * launch.  w / bias: host arrays of L device pointers ([d,d] and [d] per layer); acts: device [(L+1), B, d] — acts[0] =

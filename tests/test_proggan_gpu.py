@@ -83,3 +83,50 @@ def test_staged_pass_equals_the_plain_pass_and_hooks_fire_in_the_backward(dev, p
         grads.append(s.grad.clone())
     assert fired == [1024, 32, 8]
     assert rel_err(grads[1], grads[0]) < 1e-5          # (atomic partial sums: the order of additions is not fixed)
+
+
+def test_f16_backward_uses_the_magnitude_chain_and_tracks_fp32(dev):
+    """In the fp16 modes every PixelNorm backward publishes max |dpre| (wgs_pixelnorm_bwd_act_amax) and the gradient conv behind it rounds
+    dpre to fp16 under that bound (before: split-bf16 for want of a bound).  The bound is the tensor's true maximum; the input gradient
+    stays with the exact-fp32 one (different leaky-relu gates on a few pre-activations: direction and size, not bits)."""
+    G = Generator(12)                      # 128 x 128
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 800))
+    wrap = ProgGANWrapper(G).to(dev).eval()
+    z = GI.rt(801, 4, 512).to(dev)
+    sh = (GI.rt(802, 4, 512) * 0.1).to(dev)
+    wgt = GI.rt(803, 4, 3, 128, 128).to(dev)
+    from warpedganspace_amd import proggan as PG
+    grads = {}
+    try:
+        for prec, chain in (('fp32', True), ('bf16x3', True), ('f16', True), ('f16', False), ('f16x2', True), ('f16x2', False)):
+            PG.F16_GRADS = chain
+            s = sh.clone().requires_grad_(True)
+            (wrap(z, s, precision=prec) * wgt).sum().backward()
+            grads[(prec, chain)] = s.grad.double().flatten()
+    finally:
+        PG.F16_GRADS = True
+    ref = grads[('fp32', True)]
+    for prec in ('bf16x3', 'f16', 'f16x2'):
+        g = grads[(prec, True)]
+        cos = float((g * ref).sum() / (g.norm() * ref.norm()))
+        err = float((g - ref).norm() / ref.norm())
+        print('ProgGAN-128 d/dshift %s vs fp32: cosine %.6f, l2 error %.2e' % (prec, cos, err))
+        # (another forward arithmetic = other leaky-relu gates on a few of the 1e7 pre-activations: direction and size, not digits)
+        assert cos > (0.9999 if prec == 'bf16x3' else 0.995) and err < (2e-2 if prec == 'bf16x3' else 0.1), (prec, cos, err)
+    for prec in ('f16', 'f16x2'):
+        # the SAME forward (same gates), gradient convs in fp16 under the published bounds against split-bf16: the new path's own error
+        g, g3 = grads[(prec, True)], grads[(prec, False)]
+        err = float((g - g3).norm() / g3.norm())
+        print('ProgGAN-128 d/dshift %s: fp16 gradient convs vs split-bf16 ones, same forward: l2 error %.2e' % (prec, err))
+        assert 0 < err < 3e-3, (prec, err)
+    # the published bound is the maximum of the tensor
+    x = GI.rt(804, 2, 16, 16, 64).to(dev).contiguous()
+    gy = GI.rt(805, 2, 16, 16, 64).to(dev).contiguous()
+    am = torch.zeros(1, device=dev)
+    gx = G._pixelnorm_bwd(x, gy, act_slope=0.2, amax=am)
+    assert torch.equal(gx, G._pixelnorm_bwd(x, gy, act_slope=0.2))
+    assert float(am) == float(gx.abs().max())
+    x2, gy2 = GI.rt(806, 3, 1, 1, 512).to(dev).contiguous(), GI.rt(807, 3, 1, 1, 512).to(dev).contiguous()      # the scalar kernel (d = 512)
+    am2 = torch.zeros(1, device=dev)
+    gx2 = G._pixelnorm_bwd(x2, gy2, act_slope=1.0, amax=am2)
+    assert float(am2) == float(gx2.abs().max())

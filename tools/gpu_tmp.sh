@@ -1,4 +1,3 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 600 python tools/biggan_mixed_sweep.py 128 2>&1 | grep BigGAN
-timeout 600 python tools/biggan_mixed_sweep.py 256 2>&1 | grep BigGAN
+timeout 900 python -m pytest tests/test_proggan_gpu.py -q -m gpu -x -s -k f16_backward 2>&1 | grep "d/dshift\|passed\|failed\|Error\|assert" | cut -c1-200

@@ -50,8 +50,11 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_vec_kernel(const float* __r
 // y = x * f, f = (mean(x^2)+eps)^-1/2  =>  gx = f*gy - x * f^3 * (x.gy)/d
 // act_slope != 1: the result is also multiplied by the leaky-relu gate of x (x > 0 ? 1 : act_slope) — x is the activated output of
 // the previous block, so this is that block's activation backward folded into the store (ProgGAN, models/ProgGAN/model.py:35-62)
+// gx_amax (optional): device scalar raised (atomic max) to max |gx| of the launch — the magnitude bound of the fp16 operand scale of the
+// gradient conv that consumes gx (wgs_conv_desc.a_amax)
 __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                            float* __restrict__ gx, int rows, int d, float eps, float act_slope) {
+                                                            float* __restrict__ gx, int rows, int d, float eps, float act_slope,
+                                                            float* __restrict__ gx_amax) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + wave;
     if (r >= rows) return;
@@ -62,14 +65,25 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
     s = wave_sum(s); t = wave_sum(t);
     const float f = rsqrtf(s / d + eps);
     const float c = f * f * f * t / d;
-    for (int j = lane; j < d; j += 64) gx[(size_t)r * d + j] = (f * gr[j] - xr[j] * c) * (xr[j] > 0.f ? 1.f : act_slope);
+    float am = 0.f;
+    for (int j = lane; j < d; j += 64) {
+        const float v = (f * gr[j] - xr[j] * c) * (xr[j] > 0.f ? 1.f : act_slope);
+        gx[(size_t)r * d + j] = v;
+        am = fmaxf(am, fabsf(v));
+    }
+    if (gx_amax) {
+        am = wave_max(am);
+        if (lane == 0) raise_amax(gx_amax, am);
+    }
 }
 template <int LPR>
 __global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                float* __restrict__ gx, long rows, float eps, float act_slope) {
+                                                                float* __restrict__ gx, long rows, float eps, float act_slope,
+                                                                float* __restrict__ gx_amax) {
     constexpr int RPB = 256 / LPR;
     const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
     const float inv_d = 1.f / (4 * LPR);
+    float am = 0.f;
     for (long r = (long)blockIdx.x * RPB + rl; r < rows; r += (long)gridDim.x * RPB) {
         const size_t o = (size_t)r * (4 * LPR) + 4 * sub;
         const float4 v = *reinterpret_cast<const float4*>(x + o);
@@ -78,8 +92,14 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_vec_kernel(const float* __r
         const float t = group_sum<LPR>(fmaf(v.x, g.x, fmaf(v.y, g.y, fmaf(v.z, g.z, v.w * g.w))));
         const float f = rsqrtf(s * inv_d + eps);
         const float c = f * f * f * t * inv_d;
-        *reinterpret_cast<float4*>(gx + o) = make_float4((f * g.x - v.x * c) * (v.x > 0.f ? 1.f : act_slope), (f * g.y - v.y * c) * (v.y > 0.f ? 1.f : act_slope),
-                                                         (f * g.z - v.z * c) * (v.z > 0.f ? 1.f : act_slope), (f * g.w - v.w * c) * (v.w > 0.f ? 1.f : act_slope));
+        const float4 o4 = make_float4((f * g.x - v.x * c) * (v.x > 0.f ? 1.f : act_slope), (f * g.y - v.y * c) * (v.y > 0.f ? 1.f : act_slope),
+                                      (f * g.z - v.z * c) * (v.z > 0.f ? 1.f : act_slope), (f * g.w - v.w * c) * (v.w > 0.f ? 1.f : act_slope));
+        *reinterpret_cast<float4*>(gx + o) = o4;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o4.x), fabsf(o4.y))), fmaxf(fabsf(o4.z), fabsf(o4.w)));
+    }
+    if (gx_amax) {      // (every lane of the wave reaches this point: the row loop has no early exit)
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) raise_amax(gx_amax, am);
     }
 }
 
@@ -722,22 +742,26 @@ int wgs_pixelnorm_fwd(const float* x, float* y, int rows, int d, float eps, wgs_
     WGS_CHECK_LAUNCH("pixelnorm_fwd_kernel");
     return WGS_OK;
 }
-static int pixelnorm_bwd_launch(const float* x, const float* gy, float* gx, int rows, int d, float eps, float act_slope, hipStream_t st) {
+static int pixelnorm_bwd_launch(const float* x, const float* gy, float* gx, int rows, int d, float eps, float act_slope, float* gx_amax, hipStream_t st) {
 #define WGS_PN(LPR) { const long nb = ((long)rows + 256 / LPR - 1) / (256 / LPR); \
-        WGS_LAUNCH(pixelnorm_bwd_vec_kernel<LPR>, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, st, x, gy, gx, (long)rows, eps, act_slope); }
+        WGS_LAUNCH(pixelnorm_bwd_vec_kernel<LPR>, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, st, x, gy, gx, (long)rows, eps, act_slope, gx_amax); }
     if (d == 16) WGS_PN(4) else if (d == 32) WGS_PN(8) else if (d == 64) WGS_PN(16) else if (d == 128) WGS_PN(32) else if (d == 256) WGS_PN(64)
-    else WGS_LAUNCH(pixelnorm_bwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, st, x, gy, gx, rows, d, eps, act_slope);
+    else WGS_LAUNCH(pixelnorm_bwd_kernel, dim3(wgs_cdiv(rows, 4)), dim3(256), 0, st, x, gy, gx, rows, d, eps, act_slope, gx_amax);
 #undef WGS_PN
     WGS_CHECK_LAUNCH("pixelnorm_bwd_kernel");
     return WGS_OK;
 }
 int wgs_pixelnorm_bwd(const float* x, const float* gy, float* gx, int rows, int d, float eps, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && gy && gx && rows > 0 && d > 0, "wgs_pixelnorm_bwd: bad arguments");
-    return pixelnorm_bwd_launch(x, gy, gx, rows, d, eps, 1.f, (hipStream_t)stream);
+    return pixelnorm_bwd_launch(x, gy, gx, rows, d, eps, 1.f, nullptr, (hipStream_t)stream);
 }
 int wgs_pixelnorm_bwd_act(const float* x, const float* gy, float* gx, int rows, int d, float eps, float act_slope, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && gy && gx && rows > 0 && d > 0, "wgs_pixelnorm_bwd_act: bad arguments");
-    return pixelnorm_bwd_launch(x, gy, gx, rows, d, eps, act_slope, (hipStream_t)stream);
+    return pixelnorm_bwd_launch(x, gy, gx, rows, d, eps, act_slope, nullptr, (hipStream_t)stream);
+}
+int wgs_pixelnorm_bwd_act_amax(const float* x, const float* gy, float* gx, float* gx_amax, int rows, int d, float eps, float act_slope, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && gy && gx && gx_amax && rows > 0 && d > 0, "wgs_pixelnorm_bwd_act_amax: bad arguments");
+    return pixelnorm_bwd_launch(x, gy, gx, rows, d, eps, act_slope, gx_amax, (hipStream_t)stream);
 }
 
 int wgs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldx,

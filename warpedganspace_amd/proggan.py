@@ -24,6 +24,9 @@ BLOCKS = [(512, 512, 4, 3, False), (512, 512, 3, 1, False), (512, 512, 3, 1, Tru
           (32, 16, 3, 1, True), (16, 16, 3, 1, False)]
 
 
+F16_GRADS = True       # fp16 gradient convs in the fp16 modes (False: split-bf16, as before the magnitude chain existed)
+
+
 class _WScale(nn.Module):
     def __init__(self, size):
         super().__init__()
@@ -113,11 +116,16 @@ class Generator(nn.Module):
         return y
 
     @staticmethod
-    def _pixelnorm_bwd(x, gy, eps=1e-8, act_slope=1.0):
+    def _pixelnorm_bwd(x, gy, eps=1e-8, act_slope=1.0, amax=None):
+        """amax (a zeroed device scalar): raised to max |gx| — the magnitude bound of the fp16 operand scale of the gradient conv behind it."""
         gx = torch.empty_like(x)
         rows, d = x.numel() // x.shape[-1], x.shape[-1]
-        L.check(L.lib().wgs_pixelnorm_bwd_act(L.ptr(x), L.ptr(gy), L.ptr(gx), rows, d, L.c_float(eps), L.c_float(act_slope), L.stream()),
-                'pixelnorm_bwd')
+        if amax is not None:
+            L.check(L.lib().wgs_pixelnorm_bwd_act_amax(L.ptr(x), L.ptr(gy), L.ptr(gx), L.ptr(amax), rows, d, L.c_float(eps), L.c_float(act_slope),
+                                                       L.stream()), 'pixelnorm_bwd_amax')
+        else:
+            L.check(L.lib().wgs_pixelnorm_bwd_act(L.ptr(x), L.ptr(gy), L.ptr(gx), rows, d, L.c_float(eps), L.c_float(act_slope), L.stream()),
+                    'pixelnorm_bwd')
         return gx
 
     def _fwd(self, z, save, prec):
@@ -181,8 +189,13 @@ class Generator(nn.Module):
         # The PixelNorm input of a block is the activated output y of the block before it, so the PixelNorm backward also applies that
         # block's leaky-relu gate (y > 0 ? 1 : 0.2) while it stores: `dpre` below is d loss / d (scale * conv + b) of the block, and the
         # separate activation-backward pass over the tensor is gone.
-        dpre = self._pixelnorm_bwd(x_last, gxn, act_slope=0.2)
+        # fp16 modes: every PixelNorm backward also publishes max |dpre| (one atomic per wave), the magnitude bound under which the
+        # gradient conv behind it rounds dpre to fp16 (power-of-two operand scale, conv_scheme.h) — without a bound those convs ran in
+        # split-bf16 whatever the mode (conv._desc), i.e. a third of cfg2's generator FLOPs at three MFMAs per product
         nl = len(P['layers'])
+        f16_grads = C.is_f16_operand(prec) and F16_GRADS
+        amaxes = torch.zeros(nl + 1, 1, device=dev).unbind(0) if f16_grads else [None] * (nl + 1)
+        dpre = self._pixelnorm_bwd(x_last, gxn, act_slope=0.2, amax=amaxes[0])
         hooks, self.bwd_hooks = list(self.bwd_hooks or ()), None      # [(resolution, callable)]: each called once, at the first block of <= resolution
         for li, (ly, (x, xn, y)) in enumerate(zip(reversed(P['layers']), reversed(saved))):
             while hooks and max(h[0] for h in hooks) >= y.shape[1]:
@@ -194,14 +207,14 @@ class Generator(nn.Module):
             dup = torch.empty(B, Hup, Hup, ly['ci'], device=dev)
             taps = [(pad - ky, pad - kx, ky * k + kx) for ky in range(k) for kx in range(k)]
             C.launch(dpre, ly['wt'], dup, taps, Hup, Hup, w_tap_stride=ly['ci'] * ly['co'], w_row_stride=ly['co'], alpha=ly['scale'],
-                     w_split=ly['wts'], precision=prec, grad_operand=True)
+                     w_split=ly['wts'], precision=prec, grad_operand=True, **(dict(a_amax=amaxes[li], a_bound=1.0) if f16_grads else {}))
             if ly['up']:
                 gxn = torch.empty_like(xn)
                 L.check(lib.wgs_upsample2x_bwd(L.ptr(dup), L.ptr(gxn), B, x.shape[1], x.shape[2], ly['ci'], st), 'upsample_bwd')
             else:
                 gxn = dup
             # x = the previous block's activated output (gate folded in), or — first block — the latent code itself
-            dpre = self._pixelnorm_bwd(x, gxn, act_slope=0.2 if li + 1 < nl else 1.0)
+            dpre = self._pixelnorm_bwd(x, gxn, act_slope=0.2 if li + 1 < nl else 1.0, amax=amaxes[li + 1])
         for h in sorted(hooks, key=lambda q: -q[0]):
             h[1]()
         g = dpre
