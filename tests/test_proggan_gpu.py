@@ -130,3 +130,65 @@ def test_f16_backward_uses_the_magnitude_chain_and_tracks_fp32(dev):
     am2 = torch.zeros(1, device=dev)
     gx2 = G._pixelnorm_bwd(x2, gy2, act_slope=1.0, amax=am2)
     assert float(am2) == float(gx2.abs().max())
+
+
+@pytest.mark.parametrize('ci,co,H,up', [(16, 16, 256, False), (32, 16, 128, True), (32, 32, 256, False)])
+@pytest.mark.parametrize('prec', ['bf16x3', 'f16', 'f16x2'])
+def test_pixelnorm_inside_the_few_channel_kernel_is_bit_identical(dev, ci, co, H, up, prec):
+    """wgs_conv_desc.a_pixelnorm_eps: the conv's operand PixelNorm(x) formed while conv_halo16.hip stages its input patch gives the bits of
+    wgs_pixelnorm_fwd followed by the conv (same fma chain, same lane tree, same rounded product) — and the generator takes the route."""
+    from warpedganspace_amd import conv as C
+    from warpedganspace_amd import _lib as L
+    B = 8
+    x = (GI.rt(900 + ci, B, H, H, ci) * 3.0).to(dev).contiguous()
+    w = (GI.rt(901 + co, co, 9, ci) / (9 * ci) ** 0.5).to(dev).contiguous()
+    bias = GI.rt(902, co).to(dev)
+    Ho = 2 * H if up else H
+    taps = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    m = C.precision_code(prec)
+    kw = dict(w_tap_stride=ci, w_row_stride=9 * ci, ups=1 if up else 0, alpha=0.7, bias=bias, act_slope=0.2, gain=1.0, w_split=C.SplitCache(w), precision=m)
+    y0, y1 = torch.empty(B, Ho, Ho, co, device=dev), torch.empty(B, Ho, Ho, co, device=dev)
+    assert C.pixelnorm_fused_ok(x, w, y1, taps, Ho, Ho, **kw)
+    xn = Generator._pixelnorm(x)
+    lib = L.lib()
+    lib.wgs_dev_trace_kernels(1)
+    try:
+        C.launch(xn, w, y0, taps, Ho, Ho, **kw)
+        s0 = lib.wgs_dev_last_kernel().decode()
+        C.launch(x, w, y1, taps, Ho, Ho, pixelnorm_eps=1e-8, **kw)
+        s1 = lib.wgs_dev_last_kernel().decode()
+    finally:
+        lib.wgs_dev_trace_kernels(0)
+    assert s0 == s1 and s0.startswith('halo3x3_kernel'), (s0, s1)
+    assert torch.equal(y0, y1)
+    # shapes the kernel does not cover are refused by the query and by the launch
+    x64 = torch.randn(2, 64, 64, 64, device=dev)
+    w64 = torch.randn(64, 9, 64, device=dev)
+    y64 = torch.empty(2, 64, 64, 64, device=dev)
+    kw64 = dict(w_tap_stride=64, w_row_stride=9 * 64, w_split=C.SplitCache(w64), precision=m)
+    assert not C.pixelnorm_fused_ok(x64, w64, y64, taps, 64, 64, **kw64)
+    with pytest.raises(L.WgsError):
+        C.launch(x64, w64, y64, taps, 64, 64, pixelnorm_eps=1e-8, **kw64)
+
+
+def test_generator_with_and_without_the_fused_pixelnorm(dev):
+    from warpedganspace_amd import proggan as PG
+    G = Generator(18)
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 950))
+    wrap = ProgGANWrapper(G).to(dev).eval()
+    z = GI.rt(951, 2, 512).to(dev)
+    sh = (GI.rt(952, 2, 512) * 0.1).to(dev)
+    out = {}
+    try:
+        for fused in (True, False):
+            PG.PN_FUSED = fused
+            G._pn_fused = {}
+            s = sh.clone().requires_grad_(True)
+            img = wrap(z, s, precision='f16')
+            img.square().mean().backward()
+            out[fused] = (img.detach().clone(), s.grad.clone(), sum(bool(v) for v in G._pn_fused.values()))
+    finally:
+        PG.PN_FUSED = True
+    assert out[True][2] == 3 and out[False][2] == 0        # the 32 -> 32 @512^2, 32 -> 16 @1024^2 and 16 -> 16 @1024^2 blocks
+    assert torch.equal(out[True][0], out[False][0])
+    assert rel_err(out[True][1], out[False][1]) < 1e-5

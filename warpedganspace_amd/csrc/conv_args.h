@@ -35,6 +35,7 @@ struct ConvArgs {
     const float* a_amax2;           // ... times this optional second device scalar (bound of |a_scale| in forward launches)
     float* y_amax;                  // optional device scalar raised (atomic max) to max |y| of this launch: the next layer's a_amax
     float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int rgb_ld;      // ToRGB in the epilogue (wgs_conv_desc.rgb_out)
+    float pn_eps;                   // > 0: the operand is PixelNorm(x) (wgs_conv_desc.a_pixelnorm_eps; conv_halo16.hip only)
     const unsigned short* a_hi;     // split (and style-modulated) activation planes: set by launch_bf16x3 (LDS-DMA path)
     const unsigned short* a_lo;
     float* ws;          // split-K workspace or null
@@ -100,7 +101,7 @@ void split_f16(const float* x, const float* s, int s_ld, unsigned short* hi, uns
 void launch_dma_bf16x3(const ConvArgs& a, int bn, int nblocks, hipStream_t st);
 
 // few-channel 3x3 stride-1 convs on large maps (conv_halo16.hip): 0 = launch taken.  Needs x_bytes / w_bytes and the tap tables.
-int launch_halo16(const ConvArgs& a, hipStream_t st);
+int launch_halo16(const ConvArgs& a, hipStream_t st, bool dry = false);     // dry: decide only, launch nothing
 
 // patch form for stride-1 convs (conv_igemm_patch.hip); 0 = launch taken.  Needs x_bytes / w_bytes (fp32 extents) and the
 // 64-entry tap tables filled.

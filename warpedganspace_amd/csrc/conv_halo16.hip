@@ -152,6 +152,16 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO, WIN>::WGS_PER_CU)) void 
             float4 v = make_float4(__uint_as_float(pr_[j].x), __uint_as_float(pr_[j].y), __uint_as_float(pr_[j].z), __uint_as_float(pr_[j].w));
             v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
             asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep the rounded product (the roundings of the other 16-bit kernels)
+            if (p.pn_eps > 0.f) {
+                // PixelNorm of the pixel's Ci = KC channels (its EP consecutive lanes hold them): the arithmetic of pixelnorm_fwd_vec_kernel
+                // (stylegan2_ops.hip) — per-lane fma chain, xor tree over the lanes, rsqrt(mean + eps), one rounded product per value
+                float s2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, v.w * v.w)));
+#pragma unroll
+                for (int off = EP / 2; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+                const float fn = rsqrtf(s2 * (1.f / KC) + p.pn_eps);
+                v.x = __fmul_rn(v.x, fn); v.y = __fmul_rn(v.y, fn); v.z = __fmul_rn(v.z, fn); v.w = __fmul_rn(v.w, fn);
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            }
             if (SCH != 0) { v.x *= op_mult; v.y *= op_mult; v.z *= op_mult; v.w *= op_mult; }
             const f32x4 f = {v.x, v.y, v.z, v.w};
             uint2 h, l;
@@ -243,10 +253,12 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO, WIN>::WGS_PER_CU)) void 
 }
 
 template <int SCH, int KC, int CO, int WIN>
-int launch_halo_k(const ConvArgs& a, const HaloGeom& g, int nblocks, hipStream_t st) {
+int launch_halo_k(const ConvArgs& a, const HaloGeom& g, int nblocks, hipStream_t st, bool dry) {
     typedef HaloCfg<SCH, KC, CO, WIN> CF;
     const long wfb = CF::wfrag_bytes(a.Ci / KC);
     if (!a.ws || a.ws_bytes < wfb) return 1;            // needs the caller's workspace for the fragment-ordered weights (<= 150 KB)
+    if (a.pn_eps > 0.f && a.Ci != KC) return 1;         // a PixelNorm operand: the whole channel vector of a pixel in one chunk
+    if (dry) return 0;
     unsigned short* wf = reinterpret_cast<unsigned short*>(a.ws);
     const int total = (int)(wfb / 16);
     WGS_LAUNCH((halo_wfrag_kernel<SCH, KC, CO, WIN>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, wf, total);
@@ -258,14 +270,14 @@ int launch_halo_k(const ConvArgs& a, const HaloGeom& g, int nblocks, hipStream_t
 }
 
 template <int SCH>
-int launch_halo_s(const ConvArgs& a, const HaloGeom& g, int nblocks, int win, hipStream_t st) {
+int launch_halo_s(const ConvArgs& a, const HaloGeom& g, int nblocks, int win, hipStream_t st, bool dry) {
     const bool k16 = a.Ci % 32 != 0;
     if (win == 4) {       // the stem's space-to-depth form: 32 -> 64 (forward) and 64 -> 32 (input gradient) channels
         if (k16) return 1;
-        return a.Co > 32 ? launch_halo_k<SCH, 32, 64, 4>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 32, 4>(a, g, nblocks, st);
+        return a.Co > 32 ? launch_halo_k<SCH, 32, 64, 4>(a, g, nblocks, st, dry) : launch_halo_k<SCH, 32, 32, 4>(a, g, nblocks, st, dry);
     }
-    if (a.Co > 32) return k16 ? launch_halo_k<SCH, 16, 64, 3>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 64, 3>(a, g, nblocks, st);
-    return k16 ? launch_halo_k<SCH, 16, 32, 3>(a, g, nblocks, st) : launch_halo_k<SCH, 32, 32, 3>(a, g, nblocks, st);
+    if (a.Co > 32) return k16 ? launch_halo_k<SCH, 16, 64, 3>(a, g, nblocks, st, dry) : launch_halo_k<SCH, 32, 64, 3>(a, g, nblocks, st, dry);
+    return k16 ? launch_halo_k<SCH, 16, 32, 3>(a, g, nblocks, st, dry) : launch_halo_k<SCH, 32, 32, 3>(a, g, nblocks, st, dry);
 }
 
 }  // namespace
@@ -273,7 +285,7 @@ int launch_halo_s(const ConvArgs& a, const HaloGeom& g, int nblocks, int win, hi
 namespace wgsconv {
 
 // 0 = launch taken.  Needs pre-split weight planes, the extents (set_extents) and the tap tables.
-int launch_halo16(const ConvArgs& a, hipStream_t st) {
+int launch_halo16(const ConvArgs& a, hipStream_t st, bool dry) {
     if (wgs_flags().no_halo || (a.w_hi && !a.w_lo && a.sch != 1) || a.a_hi || a.ups > 1 || a.isy != 1 || a.isx != 1 || a.osy != 1 || a.osx != 1 ||
         a.oy0 || a.ox0 || a.ntaps < 9 || a.ntaps > 16)
         return 1;
@@ -303,9 +315,9 @@ int launch_halo16(const ConvArgs& a, hipStream_t st) {
     const int nblocks = a.B * g.tiles_per_img;
     ConvArgs b = a;
     b.w_bytes = a.w_bytes / 2;          // extents of the 16-bit weight planes
-    if (a.sch == 0) return launch_halo_s<0>(b, g, nblocks, win, st);
-    if (a.sch == 1) return launch_halo_s<1>(b, g, nblocks, win, st);
-    return launch_halo_s<2>(b, g, nblocks, win, st);
+    if (a.sch == 0) return launch_halo_s<0>(b, g, nblocks, win, st, dry);
+    if (a.sch == 1) return launch_halo_s<1>(b, g, nblocks, win, st, dry);
+    return launch_halo_s<2>(b, g, nblocks, win, st, dry);
 }
 
 }  // namespace wgsconv

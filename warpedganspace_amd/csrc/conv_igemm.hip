@@ -592,6 +592,9 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
     a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = d->x_f16; a.a_lo = nullptr;
     a.rgb_out = d->rgb_out; a.rgb_s = d->rgb_s; a.rgb_w = d->rgb_w; a.rgb_scale = d->rgb_scale; a.rgb_ld = d->rgb_ld;
+    a.pn_eps = d->a_pixelnorm_eps > 0.f ? d->a_pixelnorm_eps : 0.f;
+    WGS_CHECK_ARG(!(a.pn_eps > 0.f) || (d->precision >= 1 && !d->a_scale && !d->x_f16 && (d->Ci == 16 || d->Ci == 32)),
+                  "wgs_conv_igemm: a_pixelnorm_eps needs a 16-bit precision, no a_scale / x_f16 and Ci in {16, 32}");
     WGS_CHECK_ARG(d->precision >= 0 && d->precision <= 3, "wgs_conv_igemm: precision=%d (0 fp32, 1 bf16x3, 2 f16, 3 f16x2)", d->precision);
     a.sch = d->precision > 0 ? d->precision - 1 : 4;      // conv_scheme.h: 0..2 the 16-bit schemes, 4 exact fp32
     a.a_amax = d->precision >= 2 ? d->a_amax : nullptr;
@@ -600,6 +603,25 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     a.y_amax = d->y_amax;
     wgsconv::fill_tap_tables(a);
     return WGS_OK;
+}
+
+int wgs_conv_pixelnorm_supported(const wgs_conv_desc* d) {
+    if (!d || d->precision < 1 || d->a_scale || d->x_f16 || (d->Ci != 16 && d->Ci != 32) || !d->x || !d->w || !d->y) return 0;
+    wgs_conv_desc c = *d;
+    if (!(c.a_pixelnorm_eps > 0.f)) c.a_pixelnorm_eps = 1e-8f;
+    // (a launch beyond 2 GiB is issued per sample range, wgs_conv_igemm: the decision is the one for a single sample)
+    const long xs = (long)c.Hi * c.Wi * c.Ci * 4, ys = (long)c.Ho * c.Wo * c.Co * 4, lim = 0x7fffffffL;
+    if ((long)c.B * xs > lim || (long)c.B * ys > lim) {
+        if (xs > lim || ys > lim) return 0;
+        long nb = lim / (xs > ys ? xs : ys);
+        c.B = (int)(nb < 1 ? 1 : (nb < c.B ? nb : c.B));
+    }
+    ConvArgs a;
+    if (build_conv_args(&c, a) != WGS_OK) return 0;
+    int wt_max = 0;
+    for (int t = 0; t < a.ntaps; ++t) wt_max = a.wt[t] > wt_max ? a.wt[t] : wt_max;
+    if (!wgsconv::set_extents(a, wt_max)) return 0;
+    return wgsconv::launch_halo16(a, nullptr, true) == 0 ? 1 : 0;
 }
 
 int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
@@ -640,6 +662,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         WGS_CHECK_LAUNCH("igemm_nt16_kernel");
         return WGS_OK;
     }
+    WGS_CHECK_ARG(!(a.pn_eps > 0.f), "wgs_conv_igemm: a_pixelnorm_eps: the launch is not one the few-channel kernel takes (wgs_conv_pixelnorm_supported)");
     // exact fp32: the slot-interleaved kernel (conv_igemm_f32.hip) where it covers the shape, else the plain kernel below
     a.sch = 4;
     if (!wgs_flags().f32_old && wgsconv::launch_f32(a, st) == 0) {

@@ -24,6 +24,7 @@ BLOCKS = [(512, 512, 4, 3, False), (512, 512, 3, 1, False), (512, 512, 3, 1, Tru
           (32, 16, 3, 1, True), (16, 16, 3, 1, False)]
 
 
+PN_FUSED = True        # PixelNorm of the few-channel layers' operand inside the conv kernel (False: the separate pass everywhere)
 F16_GRADS = True       # fp16 gradient convs in the fp16 modes (False: split-bf16, as before the magnitude chain existed)
 
 
@@ -67,6 +68,7 @@ class Generator(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         self._prep = None
+        self._pn_fused = {}
         self.bwd_hooks = None        # [(resolution, callable)] for the NEXT backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
         self.debug_keep = None
         self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
@@ -105,7 +107,7 @@ class Generator(nn.Module):
             b = torch.zeros(8, device=dev)
             b[:3] = self.output.wscale.b
             P['out'] = dict(wp=wp, wt=C.repack_w_t(wp, 8, 1, ci), ci=ci, scale=float(self.output.wscale.scale.item()), b=b)
-        self._prep = P
+        self._prep, self._pn_fused = P, {}
         return P
 
     @staticmethod
@@ -154,12 +156,22 @@ class Generator(nn.Module):
                     pauses.pop(0)
                 paused = True
                 yield None
-            xn = self._pixelnorm(x)
             y = torch.empty(B, Ho, Ho, ly['co'], device=z.device)
             k, pad = ly['k'], ly['pad']
             taps = [(ky - pad, kx - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
-            C.launch(xn, ly['wp'], y, taps, Ho, Ho, w_tap_stride=ly['ci'], w_row_stride=k * k * ly['ci'], ups=1 if ly['up'] else 0,
-                     alpha=ly['scale'], bias=ly['b'], act_slope=0.2, gain=1.0, w_split=ly['ws'], precision=prec)
+            kw = dict(w_tap_stride=ly['ci'], w_row_stride=k * k * ly['ci'], ups=1 if ly['up'] else 0, alpha=ly['scale'], bias=ly['b'], act_slope=0.2,
+                      gain=1.0, w_split=ly['ws'], precision=prec)
+            # the 16- / 32-channel layers at 512^2 / 1024^2 in the 16-bit modes: PixelNorm of the operand inside the conv kernel (no
+            # normalised tensor: 1 - 2 GB written and read back per layer at B = 32); decided once per (layer, batch, arithmetic)
+            key = (id(ly), B, prec)
+            if key not in self._pn_fused:
+                self._pn_fused[key] = PN_FUSED and C.is_reduced(prec) and ly['ci'] in (16, 32) and C.pixelnorm_fused_ok(x, ly['wp'], y, taps, Ho, Ho, **kw)
+            if self._pn_fused[key]:
+                xn = None
+                C.launch(x, ly['wp'], y, taps, Ho, Ho, pixelnorm_eps=1e-8, **kw)
+            else:
+                xn = self._pixelnorm(x)
+                C.launch(xn, ly['wp'], y, taps, Ho, Ho, **kw)
             if save:
                 saved.append((x, xn, y))
             x = y
@@ -209,7 +221,7 @@ class Generator(nn.Module):
             C.launch(dpre, ly['wt'], dup, taps, Hup, Hup, w_tap_stride=ly['ci'] * ly['co'], w_row_stride=ly['co'], alpha=ly['scale'],
                      w_split=ly['wts'], precision=prec, grad_operand=True, **(dict(a_amax=amaxes[li], a_bound=1.0) if f16_grads else {}))
             if ly['up']:
-                gxn = torch.empty_like(xn)
+                gxn = torch.empty_like(x)
                 L.check(lib.wgs_upsample2x_bwd(L.ptr(dup), L.ptr(gxn), B, x.shape[1], x.shape[2], ly['ci'], st), 'upsample_bwd')
             else:
                 gxn = dup
