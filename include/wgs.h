@@ -185,7 +185,8 @@ typedef struct wgs_conv_desc {
        With rgb_out given y may be NULL (a pass that keeps nothing: the 1 GB output of StyleGAN2-256's last layer is neither written nor
        read back).  Supported for the launches the generators use it for — x_f16 operand, precision 2, stride-1 3 x 3, and either Co == 128 with
        Ci <= 128 (igemm_patch_kernel's 128 x 128 tile) or Co == 256 with Hg * Wg % 256 == 0 (igemm_dma16_kernel's 256 x 256 tile): one tile then
-       holds all output channels of its pixels — otherwise WGS_EINVAL. */
+       holds all output channels of its pixels — or, without x_f16, a 16-bit precision with Co == 32 or 64 where wgs_conv_rgb_supported() says so
+       (the few-channel kernel: StyleGAN2-1024's layers at 512^2 / 1024^2) — otherwise WGS_EINVAL. */
     float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int32_t rgb_ld;
     /* > 0: the activation operand is PixelNorm(x) (models/ProgGAN/model.py:12-18: x * rsqrt(mean_c x^2 + eps), eps = this field), applied
        while the few-channel kernel stages its input patch — the normalised tensor is never written or read (ProgGAN's 16- / 32-channel
@@ -196,6 +197,9 @@ typedef struct wgs_conv_desc {
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
 /* 1 when a launch of `desc` with a_pixelnorm_eps > 0 is covered (the operand normalised inside the few-channel kernel), else 0. */
 int wgs_conv_pixelnorm_supported(const wgs_conv_desc* desc);
+/* 1 when a launch of `desc` WITHOUT an x_f16 operand may carry rgb_out (ToRGB in the few-channel kernel's epilogue: a 16-bit precision,
+ * Co == 32 or 64, a launch conv_halo16.hip takes), else 0. */
+int wgs_conv_rgb_supported(const wgs_conv_desc* desc);
 /* n launches that share every operand and differ only in (Hg, Wg, oy0, ox0, taps) — the 4 sub-pixel phases of a
  * stride-2 transposed conv (models/StyleGAN2/model.py:201-212).  Same results as n wgs_conv_igemm calls; when the
  * split-bf16 8-wave kernel covers the shape they run as ONE launch (short-K phases fill the chip together). */

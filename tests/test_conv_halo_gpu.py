@@ -158,3 +158,52 @@ def test_shapes_the_kernel_declines(dev, halo_everywhere):
         assert lib.wgs_dev_last_kernel().decode().startswith('halo3x3_kernel<0, 32, 32, 3>')
     finally:
         lib.wgs_dev_trace_kernels(0)
+
+
+@pytest.mark.parametrize('Ci,Co,H,prec,with_y', [(64, 64, 256, 'f16x2', True), (32, 32, 256, 'f16x2', False), (64, 32, 256, 'f16', True), (32, 64, 256, 'bf16x3', True)])
+def test_torgb_in_the_few_channel_kernel_epilogue(dev, Ci, Co, H, prec, with_y):
+    """wgs_conv_desc.rgb_out without an fp16 operand plane: ToRGB's channel sums from the epilogue of the few-channel kernel (StyleGAN2-1024's
+    64- / 32-channel layers at 512^2 / 1024^2) against wgs_sg2_torgb_fwd on the stored output; y bit-identical to the launch without it."""
+    import torch
+    from warpedganspace_amd import _lib as L, conv as C
+    torch.manual_seed(Ci + Co + H)
+    lib, st = L.lib(), L.stream()
+    B = 4
+    x = torch.randn(B, H, H, Ci, device=dev)
+    S = (torch.randn(B, Ci + Co + 20, device=dev) + 1.0).contiguous()
+    s_in, s_rgb = S[:, 4:], S[:, Ci + 10:]
+    w = torch.randn(Co, 9, Ci, device=dev) / (9 * Ci) ** 0.5
+    m = C.precision_code(prec)
+    demod = torch.rand(B, Co, device=dev) + 0.5
+    noise, nw, bias = torch.randn(H * H, device=dev), torch.full((1,), 0.3, device=dev), torch.randn(Co, device=dev) * 0.2
+    am_in = (x.abs().amax()).reshape(1)
+    smax = s_in.abs().amax().reshape(1)
+    epi = dict(a_scale=s_in, a_ld=S.shape[1], col_scale=demod, noise=noise, noise_w=nw, bias=bias, act_slope=0.2, gain=2 ** 0.5, w_split=C.SplitCache(w),
+               **(dict(a_amax=am_in, a_amax2=smax) if m in (2, 3) else {}))
+    assert C.rgb_halo_ok(x, w, m, **epi)
+    ref = C.conv2d(x, w, 3, pad=1, precision=m, **epi)
+    w_rgb = torch.randn(3, Co, device=dev).contiguous()
+    rgbp = torch.full((B, H, H, 4), float('nan'), device=dev)
+    am = torch.zeros(1, device=dev)
+    out = torch.empty(B, H, H, Co, device=dev) if with_y else C.NoOutput(B, H, H, Co)
+    lib.wgs_dev_trace_kernels(1)
+    try:
+        got = C.conv2d(x, w, 3, pad=1, precision=m, out=out, y_amax=am, rgb=dict(out=rgbp, s=s_rgb, ld=S.shape[1], w=w_rgb, scale=0.37), **epi)
+        sym = lib.wgs_dev_last_kernel().decode()
+    finally:
+        lib.wgs_dev_trace_kernels(0)
+    assert sym.startswith('halo3x3_kernel') and sym.endswith('true>'), sym
+    if with_y:
+        assert torch.equal(got, ref)
+    assert am.item() == ref.abs().max().item()
+    want = torch.empty(B, 3, H * H, device=dev)
+    s_c, b0 = s_rgb[:, :Co].contiguous(), torch.zeros(3, device=dev)
+    L.check(lib.wgs_sg2_torgb_fwd(L.ptr(ref), L.ptr(s_c), L.ptr(w_rgb), L.ptr(b0), None, L.ptr(want), B, H * H, Co, L.c_float(0.37), st), 'torgb')
+    gotc = rgbp.view(B, H * H, 4)
+    assert float(gotc[..., 3].abs().max()) == 0.0
+    assert (gotc[..., :3].permute(0, 2, 1) - want).abs().max() <= 3e-6 * want.abs().max()
+    # a launch the kernel does not take may not carry rgb_out
+    x2, w2 = torch.randn(2, 16, 16, 64, device=dev), torch.randn(64, 9, 64, device=dev)
+    assert not C.rgb_halo_ok(x2, w2, m, w_split=C.SplitCache(w2))
+    with pytest.raises(L.WgsError):
+        C.conv2d(x2, w2, 3, pad=1, precision=m, w_split=C.SplitCache(w2), rgb=dict(out=torch.empty(2, 16, 16, 4, device=dev), s=s_rgb, ld=S.shape[1], w=w_rgb, scale=1.0))

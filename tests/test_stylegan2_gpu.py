@@ -246,3 +246,29 @@ def test_staged_pass_equals_the_plain_pass_and_hooks_fire_in_the_backward(dev, p
         grads.append(s.grad.clone())
     assert fired == [4096, 32, 8]
     assert rel_err(grads[1], grads[0]) < 1e-5          # (atomic partial sums: the order of additions is not fixed)
+
+
+def test_stylegan2_1024_torgb_in_the_few_channel_kernel(dev):
+    """StyleGAN2-1024 in its default arithmetic: the ToRGBs of the 64- / 32-channel layers at 512^2 / 1024^2 run in their conv's epilogue
+    (conv.rgb_halo_ok); same image and gradient as with the separate ToRGB launches."""
+    from warpedganspace_amd import conv as C
+    G, _ = build(1024, 77, dev)
+    wrap = StyleGAN2Wrapper(G, False).eval()
+    z = GI.rt(78, 2, 512).to(dev)
+    sh = (GI.rt(79, 2, 512) * 0.1).to(dev)
+    out = {}
+    try:
+        for fused in (True, False):
+            C.RGB_FUSED = fused
+            G._route = {}
+            s = sh.clone().requires_grad_(True)
+            img = wrap(z, s, precision='auto')
+            img.square().mean().backward()
+            with torch.no_grad():
+                img0 = wrap(z, precision='auto')             # the pass that keeps nothing (its last layer's output is never stored)
+            out[fused] = (img.detach().clone(), s.grad.clone(), img0.clone(), sum(bool(v) for k, v in G._route.items() if k[0] == 'rgb_halo'))
+    finally:
+        C.RGB_FUSED = True
+    assert out[True][3] >= 2 and out[False][3] == 0
+    assert rel_err(out[True][0], out[False][0]) < 1e-5 and rel_err(out[True][2], out[False][2]) < 1e-5
+    assert rel_err(out[True][1], out[False][1]) < 1e-4

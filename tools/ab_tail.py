@@ -39,6 +39,9 @@ def main():
     ap.add_argument('--only', default='', help='comma-separated variant names (default: all)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
+    if os.environ.get('WGS_RGB') == '0':            # development A/B: ToRGB as its own launch everywhere
+        from warpedganspace_amd import conv as _C
+        _C.RGB_FUSED = False
     variants = [v for v in VARIANTS if not args.only or v[0] in args.only.split(',')]
     for prec in args.precision.split(','):
         gan, K, N, B, size = CONFIGS[args.config]

@@ -467,6 +467,18 @@ def rgb_fused_ok(B, H, Ci, Co, lp, has_plane):
     return Co == 256 and B * H * H // 256 >= 200            # the LDS-DMA kernel's 256 x 256 tile
 
 
+def rgb_halo_ok(x, w_packed, lp, **epi):
+    """ToRGB may run in the epilogue of this stride-1 3x3 launch WITHOUT an fp16 operand plane: the few-channel kernel (32 / 64 output
+    channels on the 512^2 / 1024^2 maps of StyleGAN2-1024) holds all output channels of its pixels (wgs_conv_rgb_supported)."""
+    B, H, W, Ci = x.shape
+    Co = w_packed.shape[0]
+    if not (RGB_FUSED and lp in (1, 2, 3) and Co in (32, 64)):
+        return False
+    taps = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    d, _ = _desc(x, w_packed, NoOutput(B, H, W, Co), taps, H, W, w_tap_stride=Ci, w_row_stride=9 * Ci, precision=lp, **epi)
+    return bool(L.lib().wgs_conv_rgb_supported(ctypes.byref(d)))
+
+
 def fwd_plane_ok(B, Hout, C, Co_next, lp_next):
     """the up-conv's output [B,Hout,Hout,C] may be handed to the next (stride-1, plain fp16) conv as its operand plane"""
     return FWD_PLANE and lp_next == 2 and C % 32 == 0 and Co_next % 128 == 0 and _plane_fits(B, Hout, Hout, C) and \

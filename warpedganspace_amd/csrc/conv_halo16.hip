@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void halo_wfrag_kernel(const ConvArgs p, unsig
     *reinterpret_cast<uint4*>(dst + (size_t)e * 8) = v;
 }
 
-template <int SCH, int KC, int CO, int WIN>
+// RGB: ToRGB in the epilogue (wgs_conv_desc.rgb_out; the workgroup holds all Cout = CO channels of its pixels) — its own instantiation
+template <int SCH, int KC, int CO, int WIN, bool RGB = false>
 __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO, WIN>::WGS_PER_CU)) void halo3x3_kernel(const ConvArgs p, const HaloGeom g, const unsigned short* __restrict__ wfrag, int wfrag_bytes) {
     typedef HaloCfg<SCH, KC, CO, WIN> CF;
     constexpr int NT = CF::NT, PW = CF::PW, NPIX = CF::NPIX;
@@ -249,7 +250,11 @@ __global__ __launch_bounds__(256, (HaloCfg<SCH, KC, CO, WIN>::WGS_PER_CU)) void 
         r_add[tid] = (b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups);
     }
     __syncthreads();
-    wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, 0, wm, 0, l31, lh, op_inv);
+    if constexpr (RGB) {
+        static_assert(CF::SMEM >= (4 * BM + 2 * BM * 4) * 4, "the ToRGB partial sums live behind the row arrays");
+        wgsconv::conv_epilogue_rgb<BM, TM, TN, WM, WN, 1>(p, acc, smem_b, wm, 0, l31, lh, tid, op_inv);
+    } else
+        wgsconv::conv_epilogue_apply<BM, TM, TN, WM, WN>(p, acc, smem_b, 0, wm, 0, l31, lh, op_inv);
 }
 
 template <int SCH, int KC, int CO, int WIN>
@@ -258,10 +263,20 @@ int launch_halo_k(const ConvArgs& a, const HaloGeom& g, int nblocks, hipStream_t
     const long wfb = CF::wfrag_bytes(a.Ci / KC);
     if (!a.ws || a.ws_bytes < wfb) return 1;            // needs the caller's workspace for the fragment-ordered weights (<= 150 KB)
     if (a.pn_eps > 0.f && a.Ci != KC) return 1;         // a PixelNorm operand: the whole channel vector of a pixel in one chunk
+    if (a.rgb_out && (a.Co != CO || WIN != 3)) return 1;    // ToRGB in the epilogue: every column of the tile is an output channel
     if (dry) return 0;
     unsigned short* wf = reinterpret_cast<unsigned short*>(a.ws);
     const int total = (int)(wfb / 16);
     WGS_LAUNCH((halo_wfrag_kernel<SCH, KC, CO, WIN>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, wf, total);
+    if constexpr (WIN == 3) {
+        if (a.rgb_out) {
+            auto kr = halo3x3_kernel<SCH, KC, CO, WIN, true>;
+            wgs_note_kernel("halo3x3_kernel<%d, %d, %d, %d, true>", SCH, KC, CO, WIN);
+            (void)hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+            WGS_LAUNCH(kr, dim3((unsigned)nblocks), dim3(256), CF::SMEM, st, a, g, (const unsigned short*)wf, (int)wfb);
+            return 0;
+        }
+    }
     auto k = halo3x3_kernel<SCH, KC, CO, WIN>;
     wgs_note_kernel("halo3x3_kernel<%d, %d, %d, %d>", SCH, KC, CO, WIN);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);

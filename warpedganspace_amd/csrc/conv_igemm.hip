@@ -563,8 +563,11 @@ int wgs_repack_w_t(const float* src, float* dst, int Co, int T, int Ci, wgs_stre
 
 static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     WGS_CHECK_ARG(d && (d->x || d->x_f16) && d->w && (d->y || d->rgb_out), "wgs_conv_igemm: null pointer");
-    WGS_CHECK_ARG(!d->rgb_out || (d->x_f16 && d->rgb_s && d->rgb_w && ((d->Co == 128 && d->Ci <= 128) || d->Co == 256) && d->ntaps == 9 && d->rgb_ld >= d->Co && !d->addend && d->act == 0),
-                  "wgs_conv_igemm: rgb_out needs an x_f16 operand, Co == 128, Ci <= 128, 9 taps, rgb_s / rgb_w / rgb_ld >= Co, leaky-relu epilogue");
+    WGS_CHECK_ARG(!d->rgb_out || (d->rgb_s && d->rgb_w && d->ntaps == 9 && d->rgb_ld >= d->Co && !d->addend && d->act == 0 &&
+                                  ((d->x_f16 && ((d->Co == 128 && d->Ci <= 128) || d->Co == 256)) ||
+                                   (!d->x_f16 && d->precision >= 1 && (d->Co == 32 || d->Co == 64)))),
+                  "wgs_conv_igemm: rgb_out needs 9 taps, rgb_s / rgb_w / rgb_ld >= Co, the leaky-relu epilogue and either an x_f16 operand with Co == 128 "
+                  "(Ci <= 128) or 256, or a 16-bit precision with Co == 32 or 64 (the few-channel kernel)");
     WGS_CHECK_ARG(!d->x_f16 || (d->precision == 2 && !d->a_scale && !d->ups && d->w_hi && d->Ci % 32 == 0 && d->Co % 128 == 0 && d->ntaps <= 16),
                   "wgs_conv_igemm: x_f16 needs precision 2, no a_scale / ups, pre-split weights, Ci %% 32 == 0, Co %% 128 == 0, <= 16 taps");
     WGS_CHECK_ARG(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Hg > 0 && d->Wg > 0 && d->Ho > 0 && d->Wo > 0,
@@ -624,6 +627,21 @@ int wgs_conv_pixelnorm_supported(const wgs_conv_desc* d) {
     return wgsconv::launch_halo16(a, nullptr, true) == 0 ? 1 : 0;
 }
 
+int wgs_conv_rgb_supported(const wgs_conv_desc* d) {
+    if (!d || d->x_f16 || d->precision < 1 || (d->Co != 32 && d->Co != 64) || !d->x || !d->w) return 0;
+    wgs_conv_desc c = *d;
+    if (!c.rgb_out) { c.rgb_out = const_cast<float*>(d->x); c.rgb_s = d->x; c.rgb_w = d->x; c.rgb_ld = d->Co; c.rgb_scale = 1.f; }
+    if (!c.y) c.y = const_cast<float*>(d->x);
+    const long xs = (long)c.Hi * c.Wi * c.Ci * 4, ys = (long)c.Ho * c.Wo * c.Co * 4, lim = 0x7fffffffL;
+    if ((long)c.B * xs > lim || (long)c.B * ys > lim) return 0;       // (a launch split over sample ranges would need rgb_out split too)
+    ConvArgs a;
+    if (build_conv_args(&c, a) != WGS_OK) return 0;
+    int wt_max = 0;
+    for (int t = 0; t < a.ntaps; ++t) wt_max = a.wt[t] > wt_max ? a.wt[t] : wt_max;
+    if (!wgsconv::set_extents(a, wt_max)) return 0;
+    return wgsconv::launch_halo16(a, nullptr, true) == 0 ? 1 : 0;
+}
+
 int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
     // Tensors beyond 2 GiB (ProgGAN's 512^2 / 1024^2 feature maps at batch 32: 2.1 - 4.3 GB): the fast kernels address their
     // operands through buffer descriptors with 31-bit byte offsets and would decline the launch (-> the plain fp32 kernel with
@@ -663,6 +681,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         return WGS_OK;
     }
     WGS_CHECK_ARG(!(a.pn_eps > 0.f), "wgs_conv_igemm: a_pixelnorm_eps: the launch is not one the few-channel kernel takes (wgs_conv_pixelnorm_supported)");
+    WGS_CHECK_ARG(!a.rgb_out, "wgs_conv_igemm: rgb_out without an x_f16 operand: the launch is not one the few-channel kernel takes (wgs_conv_rgb_supported)");
     // exact fp32: the slot-interleaved kernel (conv_igemm_f32.hip) where it covers the shape, else the plain kernel below
     a.sch = 4;
     if (!wgs_flags().f32_old && wgsconv::launch_f32(a, st) == 0) {

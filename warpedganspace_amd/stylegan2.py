@@ -195,6 +195,7 @@ class Generator(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self.debug_keep = None   # tests set this to {} to read back the activation gates of a forward
+        self._route = {}            # cached kernel-route decisions of this generator's launches (queries of the library, per shape)
         self.bwd_hooks = None       # [(resolution, callable), ...] for the NEXT synthesis backward: each is called once, when the pass reaches a layer
                                     # of <= resolution (trainer.TrainStep: side work that should run under the backward's latency-bound tail)
         # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES); the reference's is fp32
@@ -456,9 +457,23 @@ class Generator(nn.Module):
                                                         2 * H, Co, st), 'blur_nba')
                 del t
             else:
-                y = C.conv2d(x, ly['wp'], 3, pad=1, a_scale=s_view, a_ld=sumC, col_scale=demod, noise=ly['noise'],
-                             noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2, gain=SQRT2, w_split=ly['wp_s'], precision=lp,
-                             y_amax=ymax, **sc_kw)
+                ckw = dict(a_scale=s_view, a_ld=sumC, col_scale=demod, noise=ly['noise'], noise_w=ly['noise_w'], bias=ly['bias'], act_slope=0.2,
+                           gain=SQRT2, w_split=ly['wp_s'], y_amax=ymax, **sc_kw)
+                rgb_kw, keep = {}, True
+                key = ('rgb_halo', i, B, lp)
+                if i % 2 == 0 and Co <= 64:
+                    # StyleGAN2-1024's 64- / 32-channel layers at 512^2 / 1024^2: ToRGB in the few-channel kernel's epilogue (decided once per
+                    # (layer, batch, arithmetic)); without a backward to feed, the last layer's output is not stored at all
+                    if key not in self._route:
+                        self._route[key] = C.rgb_halo_ok(x, ly['wp'], lp, **ckw)
+                    if self._route[key]:
+                        r_ = P['rgbs'][i // 2]
+                        rgbp = torch.empty(B, H, H, 4, device=dev)
+                        rgb_kw = dict(rgb=dict(out=rgbp, s=S[:, r_['off']:], ld=sumC, w=r_['w'], scale=r_['scale']))
+                        keep = save or i + 1 < len(P['layers'])
+                y = C.conv2d(x, ly['wp'], 3, pad=1, precision=lp, out=None if keep else C.NoOutput(B, H, H, Co), **ckw, **rgb_kw)
+                if not keep:
+                    y = None
             outs.append(y)
             x = y
             if i % 2 == 0:
