@@ -48,7 +48,7 @@ def layer_f64(xs, w, demod, kern, noise, nw, bias):
 
 
 @pytest.mark.parametrize('prec', [2, 3])
-@pytest.mark.parametrize('B,Ci,Co,H', [(2, 32, 64, 16), (1, 64, 128, 14), (2, 64, 64, 20), (1, 96, 64, 33), (3, 32, 128, 5)])
+@pytest.mark.parametrize('B,Ci,Co,H', [(2, 32, 64, 16), (1, 64, 128, 14), (2, 64, 64, 20), (1, 96, 64, 33), (3, 32, 128, 5), (2, 64, 32, 24), (1, 32, 32, 40)])
 def test_upconv_fused_vs_float64(dev, prec, B, Ci, Co, H):
     torch.manual_seed(Ci * 7 + Co + H + prec)
     x = torch.randn(B, Ci, H, H, dtype=torch.float64)

@@ -446,7 +446,7 @@ UPCONV_FUSED_MIN_H = {2: 16, 3: 16}
 
 
 def upconv_fused_ok(H, Ci, Co, precision):
-    return precision in (2, 3) and H >= UPCONV_FUSED_MIN_H[precision] and Ci % 32 == 0 and Co % 64 == 0
+    return precision in (2, 3) and H >= UPCONV_FUSED_MIN_H[precision] and Ci % 32 == 0 and (Co % 64 == 0 or Co == 32)
 
 
 # Forward planes: the fused up-sampling kernel writes the fp16 operand plane of the stride-1 conv that follows it (that conv's style

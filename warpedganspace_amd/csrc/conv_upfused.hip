@@ -115,7 +115,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave;
-    const int ntn = p.Co / BN;
+    const int ntn = (p.Co + BN - 1) / BN;       // Co = 32 (StyleGAN2-1024's last up-sampling layer): one half-filled column tile
     int bid;
     {
         const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -287,9 +287,10 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             aux_nz[e] = (p.noise && oy < Ho && ox < Ho) ? nw * p.noise[oy * Ho + ox] : 0.f;
         }
         if (tid < BN) {
-            aux_bias[tid] = p.bias[n0 + tid];
-            aux_cs[tid] = p.col_scale[(size_t)b * p.col_ld + n0 + tid];
-            aux_sn[tid] = p.y_f16 ? p.y_f16_scale[(size_t)b * p.y_f16_ld + n0 + tid] : 0.f;
+            const bool cok = n0 + tid < p.Co;           // (columns past Cout: their weight rows read as zeros, their outputs are not stored)
+            aux_bias[tid] = cok ? p.bias[n0 + tid] : 0.f;
+            aux_cs[tid] = cok ? p.col_scale[(size_t)b * p.col_ld + n0 + tid] : 0.f;
+            aux_sn[tid] = (p.y_f16 && cok) ? p.y_f16_scale[(size_t)b * p.y_f16_ld + n0 + tid] : 0.f;
         }
     };
 
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     float vmax = 0.f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        if (n0 + half * 32 >= p.Co) break;               // a half-filled column tile (Co = 32)
         {
             const float cs = aux_cs[half * 32 + l31];
             const float al = p.alpha * op_inv;
@@ -489,7 +491,7 @@ void launch_up(const UpArgs& a0, hipStream_t st) {
     UpArgs a = a0;
     a.tiles_x = (a.H + CF::CX - 1) / CF::CX;
     a.tiles_per_img = a.tiles_x * ((a.H + CF::CY - 1) / CF::CY);
-    const int nblocks = a.B * a.tiles_per_img * (a.Co / BN);
+    const int nblocks = a.B * a.tiles_per_img * ((a.Co + BN - 1) / BN);
     auto k = upconv_blur_kernel<SCH, GH>;
     wgs_note_kernel("upconv_blur_kernel<%d, %d>", SCH, GH);
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
@@ -504,8 +506,8 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     WGS_CHECK_ARG(!d->y_f16 || (d->y_f16_scale && d->a_amax && d->y_f16_ld >= d->Co && d->y_f16_mul > 0.f && d->y_f16_add >= 0.f),
                   "wgs_sg2_upconv_blur_act: y_f16 needs y_f16_scale, y_f16_ld >= Co, a_amax and the bound coefficients y_f16_mul > 0, y_f16_add >= 0");
     WGS_CHECK_ARG(d->precision == 2 || d->precision == 3, "wgs_sg2_upconv_blur_act: precision %d (fp16 schemes 2 / 3 only)", d->precision);
-    WGS_CHECK_ARG(d->B > 0 && d->H >= 4 && d->Ci % 32 == 0 && d->Ci > 0 && d->Co % 64 == 0 && d->Co > 0,
-                  "wgs_sg2_upconv_blur_act: B=%d H=%d Ci=%d (%%32) Co=%d (%%64)", d->B, d->H, d->Ci, d->Co);
+    WGS_CHECK_ARG(d->B > 0 && d->H >= 4 && d->Ci % 32 == 0 && d->Ci > 0 && (d->Co % 64 == 0 || d->Co == 32) && d->Co > 0,
+                  "wgs_sg2_upconv_blur_act: B=%d H=%d Ci=%d (%%32) Co=%d (%%64, or 32)", d->B, d->H, d->Ci, d->Co);
     WGS_CHECK_ARG(!d->noise || d->noise_w, "wgs_sg2_upconv_blur_act: noise needs noise_w");
     const long xb = (long)d->B * d->H * d->H * d->Ci * 4, yb = (long)d->B * 4 * d->H * d->H * d->Co * 4;
     const long wb = (long)d->Co * 9 * d->Ci * 2, sb = ((long)(d->B - 1) * d->a_ld + d->Ci) * 4;
@@ -526,7 +528,7 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     // 16 x 12-cell tiles (one 8-wave workgroup per CU) unless they would leave the chip short of workgroups: then 14 x 6-cell
     // tiles, two 4-wave workgroups per CU (they re-fetch the weights twice as often, which is what bounds the large layers)
     const long big_tiles = (long)((d->H + 15) / 16) * ((d->H + 11) / 12);        // 16 x 12-cell tiles of the 8-wave form
-    const bool gh16 = wgs_flags().up_gh16 || (long)d->B * big_tiles * (d->Co / BN) >= 1536;
+    const bool gh16 = wgs_flags().up_gh16 || (long)d->B * big_tiles * ((d->Co + BN - 1) / BN) >= 1536;
     // precision 3 (fp16 x2) splits the ACTIVATION operand here (Scheme<3>: same two MFMAs, same error class as the weight split of
     // the GEMM kernels): the second weight plane would double the LDS-DMA traffic that bounds this kernel.  w_lo is not read.
     if (d->precision == 2) { if (gh16) launch_up<1, 16>(a, (hipStream_t)stream); else launch_up<1, 8>(a, (hipStream_t)stream); }
