@@ -371,7 +371,21 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
     const float* gt = gate ? gate + (size_t)m * ldg : nullptr;
     double acc = 0.0;
     if (k < K) {
-        for (int n = ng; n < N; n += 16) {
+        // eight loads in flight per lane (the fp64 chain itself is short: the loop was bound by one exposed load latency per trip);
+        // same order of additions
+        int n = ng;
+        for (; n + 7 * 16 < N; n += 8 * 16) {
+            float gv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                gv[u] = g[n + u * 16];
+                if (gt) gv[u] *= (gt[n + u * 16] > 0.f ? gain : gain * slope);
+                wv[u] = w[(size_t)(n + u * 16) * K + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma((double)gv[u], (double)wv[u], acc);
+        }
+        for (; n < N; n += 16) {
             float gv = g[n];
             if (gt) gv *= (gt[n] > 0.f ? gain : gain * slope);
             acc = fma((double)gv, (double)w[(size_t)n * K + k], acc);
