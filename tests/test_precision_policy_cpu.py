@@ -72,7 +72,8 @@ def test_fused_upconv_selection():
     assert not C.upconv_fused_ok(128, 256, 128, 1)          # split-bf16 keeps the phase GEMMs + blur kernel
     assert not C.upconv_fused_ok(128, 256, 128, 0)
     assert not C.upconv_fused_ok(8, 512, 512, 2)            # maps below 16 x 16
-    assert not C.upconv_fused_ok(512, 64, 32, 2)            # 32 output channels: not a multiple of the 64-column tile
+    assert C.upconv_fused_ok(512, 64, 32, 2)                # 32 output channels: one half-filled 64-column tile (StyleGAN2-1024's last up-sampling layer)
+    assert not C.upconv_fused_ok(512, 32, 16, 2) and not C.upconv_fused_ok(512, 64, 96, 2)
     assert not C.upconv_fused_ok(64, 24, 64, 2)
 
 
