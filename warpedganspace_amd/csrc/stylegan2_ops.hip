@@ -671,6 +671,22 @@ __global__ __launch_bounds__(256) void sg2_style_grad_kernel(const float* __rest
     double acc0 = 0.0, acc1 = 0.0;
     if (demod && i < Ci) {
         int o = part;
+        // four trips' loads in flight (same two chains, same order of additions): one exposed load latency per trip bound the loop
+        for (; o + 28 < Co; o += 32) {
+            float dv[8], nv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                dv[u] = demod[(size_t)b * Co + o + 4 * u];
+                nv[u] = num[(size_t)b * Co + o + 4 * u];
+                wv[u] = wsq[(size_t)(o + 4 * u) * Ci + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const double d0 = dv[u], d1 = dv[u + 1];
+                acc0 = fma((double)nv[u] * d0 * d0, (double)wv[u], acc0);
+                acc1 = fma((double)nv[u + 1] * d1 * d1, (double)wv[u + 1], acc1);
+            }
+        }
         for (; o + 4 < Co; o += 8) {
             const double d0 = demod[(size_t)b * Co + o], d1 = demod[(size_t)b * Co + o + 4];
             acc0 = fma((double)num[(size_t)b * Co + o] * d0 * d0, (double)wsq[(size_t)o * Ci + i], acc0);
@@ -712,6 +728,22 @@ __global__ __launch_bounds__(256) void sg2_style_grad_batch_kernel(const StyleGr
     double acc0 = 0.0, acc1 = 0.0;
     if (demod && i < Ci) {
         int o = part;
+        // four trips' loads in flight (same two chains, same order of additions): one exposed load latency per trip bound the loop
+        for (; o + 28 < Co; o += 32) {
+            float dv[8], nv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                dv[u] = demod[(size_t)b * Co + o + 4 * u];
+                nv[u] = num[(size_t)b * Co + o + 4 * u];
+                wv[u] = wsq[(size_t)(o + 4 * u) * Ci + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                const double d0 = dv[u], d1 = dv[u + 1];
+                acc0 = fma((double)nv[u] * d0 * d0, (double)wv[u], acc0);
+                acc1 = fma((double)nv[u + 1] * d1 * d1, (double)wv[u + 1], acc1);
+            }
+        }
         for (; o + 4 < Co; o += 8) {
             const double d0 = demod[(size_t)b * Co + o], d1 = demod[(size_t)b * Co + o + 4];
             acc0 = fma((double)num[(size_t)b * Co + o] * d0 * d0, (double)wsq[(size_t)o * Ci + i], acc0);
