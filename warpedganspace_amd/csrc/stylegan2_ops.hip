@@ -979,27 +979,49 @@ int wgs_sg2_act_bwd_f16(const float* out, const float* gA, const float* sA, cons
 
 // bound[0] = sqrt(2) * max_{b,c} post_scale[b,c] * ( |sA[b,c]| * gA_amax + |sR[b,c]| * rscale * drgb_amax * drgb_factor * sum_o |wR[o,c]| )
 // >= max |dy * post_scale| of the sg2_act_bwd launch with the same operands (|lrelu'| * sqrt(2) <= sqrt(2)): one workgroup.
-__global__ __launch_bounds__(256) void sg2_dy_bound_kernel(const float* __restrict__ gA_amax, const float* __restrict__ sA,
-                                                           const float* __restrict__ drgb_amax, float drgb_factor,
-                                                           const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
-                                                           const float* __restrict__ post_scale, float* __restrict__ bound,
-                                                           int B, int C, int s_ld) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void sg2_dy_bound_kernel(const float* __restrict__ gA_amax, const float* __restrict__ sA,
+                                                            const float* __restrict__ drgb_amax, float drgb_factor,
+                                                            const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
+                                                            const float* __restrict__ post_scale, float* __restrict__ bound,
+                                                            int B, int C, int s_ld) {
+    // one workgroup of 16 waves, four elements per lane and trip with their loads issued together: the kernel sits in the generator
+    // backward's dependent chain three times per step, and with 256 lanes taking one element per trip (64 trips of 3 - 6 dependent
+    // loads at B = 32, C = 512) it took 50 - 95 us.  A maximum: any order gives the same value.
+    __shared__ float red[16];
     const float a = gA_amax ? gA_amax[0] : 0.f;
     const float r = drgb_amax ? drgb_amax[0] * drgb_factor * rscale : 0.f;
+    const int n = B * C;
     float m = 0.f;
-    for (int e = threadIdx.x; e < B * C; e += 256) {
-        const int b = e / C, c = e - b * C;
-        float v = 0.f;
-        if (gA_amax) v += fabsf(sA[(size_t)b * s_ld + c]) * a;
-        if (drgb_amax) v += fabsf(sR[(size_t)b * s_ld + c]) * r * (fabsf(wR[c]) + fabsf(wR[C + c]) + fabsf(wR[2 * C + c]));
-        if (post_scale) v *= fabsf(post_scale[(size_t)b * C + c]);
-        m = fmaxf(m, v);
+    for (int e0 = threadIdx.x; e0 < n; e0 += 4 * 1024) {
+        float va[4], vr[4], vw[4], vp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 1024;
+            const bool ok = e < n;
+            const int b = ok ? e / C : 0, c = ok ? e - b * C : 0;
+            va[u] = (ok && gA_amax) ? fabsf(sA[(size_t)b * s_ld + c]) : 0.f;
+            vr[u] = (ok && drgb_amax) ? fabsf(sR[(size_t)b * s_ld + c]) : 0.f;
+            vw[u] = (ok && drgb_amax) ? fabsf(wR[c]) + fabsf(wR[C + c]) + fabsf(wR[2 * C + c]) : 0.f;
+            vp[u] = (ok && post_scale) ? fabsf(post_scale[(size_t)b * C + c]) : (ok ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = 0.f;
+            if (gA_amax) v += va[u] * a;
+            if (drgb_amax) v += vr[u] * r * vw[u];
+            v *= vp[u];
+            m = fmaxf(m, v);
+        }
     }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) bound[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * SQRT2;
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t = fmaxf(t, red[i]);
+        bound[0] = t * SQRT2;
+    }
 }
 
 int wgs_sg2_dy_bound(const float* gA_amax, const float* sA, const float* drgb_amax, float drgb_factor, const float* wR,
@@ -1009,7 +1031,7 @@ int wgs_sg2_dy_bound(const float* gA_amax, const float* sA, const float* drgb_am
     WGS_CHECK_ARG(!gA_amax || sA, "wgs_sg2_dy_bound: gA_amax needs sA");
     WGS_CHECK_ARG(!drgb_amax || (wR && sR), "wgs_sg2_dy_bound: drgb_amax needs wR and sR");
     WGS_CHECK_ARG(B > 0 && C > 0, "wgs_sg2_dy_bound: bad sizes");
-    WGS_LAUNCH(sg2_dy_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gA_amax, sA, drgb_amax, drgb_factor, wR, sR,
+    WGS_LAUNCH(sg2_dy_bound_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, gA_amax, sA, drgb_amax, drgb_factor, wR, sR,
                        rscale, post_scale, bound, B, C, s_ld > 0 ? s_ld : C);
     WGS_CHECK_LAUNCH("sg2_dy_bound_kernel");
     return WGS_OK;
