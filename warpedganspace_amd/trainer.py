@@ -470,7 +470,12 @@ class TrainStep:
                 hooks.append((self.tail_hook_res, tail))
         if hooks:
             inner.bwd_hooks = hooks
-        img_shifted.backward(d_img)                                           # G: d image -> d shift
+        try:
+            img_shifted.backward(d_img)                                       # G: d image -> d shift
+        except BaseException:
+            if hookable:
+                inner.bwd_hooks = None      # (a failed backward must not leave this step's closures for the generator's next one)
+            raise
         if hookable and inner.bwd_hooks is not None:      # (a backward that did not pass through the synthesis hooks)
             for h in sorted(inner.bwd_hooks, key=lambda q: -q[0]):
                 h[1]()
