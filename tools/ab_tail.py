@@ -23,6 +23,9 @@ VARIANTS = [
     ('tail 256/16', dict(tail_prefetch=True, tail_pause_res=256, tail_hook_res=16)),
     ('weights inline', dict(prepare_wt=False)),
     ('weights ahead', dict(prepare_wt=True)),
+    ('split 16', dict(split_pause_res=16)),
+    ('split 32', dict(split_pause_res=32)),
+    ('split 64', dict(split_pause_res=64)),
     ('torch sampler', dict(torch_sampler=True)),
     ('kernel sampler', dict(torch_sampler=False)),
 ]
