@@ -61,7 +61,8 @@ FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf16,f16}, dense (no sparsity)
 MFMA_PER_PRODUCT = {'fp32': 1.0, 'fp32w': 16.0 / 36.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}        # per launch label (a 'mixed' run has all three 16-bit kinds)
 DTYPE = {'fp32': 'fp32', 'fp32w': 'fp32', 'bf16x3': 'bf16x3 (split-bf16, fp32-class)', 'f16': 'fp16 operands, fp32 accumulate',
-         'f16x2': 'fp16 x2 operands, fp32 accumulate', 'mixed': 'mixed fp16 / split-bf16 per layer, fp32 accumulate'}
+         'f16x2': 'fp16 x2 operands, fp32 accumulate', 'mixed': 'mixed fp16 / split-bf16 per layer, fp32 accumulate',
+         'mixed-strict': 'mixed fp16 x2 / split-bf16 per layer (strict table), fp32 accumulate'}
 DTYPE_TEXT = {
     'fp32': "fp32 everywhere (the reference's arithmetic): every conv of G and R, forward and backward, is f32-input MFMA "
             "(v_mfma_f32_32x32x2_f32) with fp32 accumulate; everything else fp32 VALU",
@@ -76,6 +77,7 @@ DTYPE_TEXT = {
              "3.2): fp16 operands (1 or 2 MFMAs per product) in the layers at >= 64x64, split-bf16 x3 (fp32-class) below; fp32 accumulate / "
              "demodulation / epilogue everywhere; dynamic power-of-two scale on every fp16 operand",
 }
+DTYPE_TEXT['mixed-strict'] = DTYPE_TEXT['mixed'] + " — the STRICT table (conv.MIXED_STRICT_POLICIES): no single image of the 2 304-image sample over 1e-3"
 R_TEXT = {(5, 5, 0): "; reconstructor (trained): fp32 MFMA, Winograd form of the 3x3 stride-1 forward / input-gradient convs, direct exact "
                      "fp32 for the rest and for every weight gradient; BatchNorm statistics in fp64 partials",
           (0, 0, 0): "; reconstructor (trained): exact fp32 MFMA forward, input-gradient and weight-gradient convs; BatchNorm statistics in fp64 partials",
@@ -92,7 +94,7 @@ def make_params(w_space=False):
 ENGINE_KW = {}      # --single-stream: TrainStep(two_streams=False), so that a rocprofv3 kernel table adds up to the step
 
 
-def build(dev, gan, K, N, B, rank=0, w_space=False, size=256, precision='fp32', r_precision='auto'):
+def build(dev, gan, K, N, B, rank=0, w_space=False, size=256, precision='fp32', r_precision='auto', world=None):
     """gan: 'stylegan2' (size 256 / 1024), 'proggan' (size 1024 native or 256 = first 14 blocks), 'biggan' (size 128 / 256)."""
     from warpedganspace_amd.reconstructor import Reconstructor
     from warpedganspace_amd.support_sets import SupportSets
@@ -112,7 +114,8 @@ def build(dev, gan, K, N, B, rank=0, w_space=False, size=256, precision='fp32', 
         raise ValueError(gan)
     S = SupportSets(K, N, G.dim_z, learn_alphas=False, learn_gammas=True, gamma=1.0 / G.dim_z)
     R = Reconstructor('ResNet', K, channels=3)
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
     return TrainStep(G.to(dev).eval(), S.to(dev).train(), R.to(dev).train(), make_params(w_space), B, dev, world=world, seed=0,
                      rank=rank, precision=precision, r_precision=r_precision, **ENGINE_KW)
 
@@ -347,6 +350,23 @@ def hbm_subpaths(eng, dev, B):
     return out
 
 
+def physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs of the allowed logical CPUs (sysfs topology);
+    falls back to the allowed logical CPUs."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in allowed:
+        try:
+            base = '/sys/devices/system/cpu/cpu%d/topology/' % c
+            cores.add((open(base + 'physical_package_id').read().strip(), open(base + 'core_id').read().strip()))
+        except OSError:
+            return len(allowed)
+    return max(1, len(cores))
+
+
 def cpu_baseline(size, K, N, b, steps, threads):
     """The reference step AS WRITTEN (incl. the generator's unused weight gradients) replayed by the oracle
     with plain PyTorch-CPU ops on this box's host cores.  Bounded sample."""
@@ -387,6 +407,7 @@ EXTRA = [
     ("cfg3 StyleGAN2-256 bf16x3", 'stylegan2', 256, 128, 32, 32, 'bf16x3', 'auto', False, 10, 'stylegan2-256', 'cfg3_bf16x3'),
     ("cfg3 StyleGAN2-256 f16", 'stylegan2', 256, 128, 32, 32, 'f16', 'auto', False, 10, 'stylegan2-256', 'cfg3_f16'),
     ("cfg3 StyleGAN2-256 f16x2", 'stylegan2', 256, 128, 32, 32, 'f16x2', 'auto', False, 10, 'stylegan2-256', 'cfg3_f16x2'),
+    ("cfg3 StyleGAN2-256 mixed-strict (no single image of the sample over the 1e-3 gate)", 'stylegan2', 256, 128, 32, 32, 'mixed-strict', 'auto', False, 30, 'stylegan2-256', 'cfg3_mixed_strict'),
     ("cfg3 StyleGAN2-256 auto, reconstructor convs in exact fp32 [R fp32]", 'stylegan2', 256, 128, 32, 32, 'auto', 'fp32', False, 20, 'stylegan2-256', 'cfg3_auto_Rfp32'),
     ("cfg3 StyleGAN2-256 auto, W-space", 'stylegan2', 256, 128, 32, 32, 'auto', 'auto', True, 10, 'stylegan2-256', 'cfg3_auto_Wspace'),
     ("cfg2 ProgGAN native 1024, K=64 N=16 B=32, auto", 'proggan', 1024, 64, 16, 32, 'auto', 'auto', False, 10, 'proggan-1024', 'cfg2_proggan1024_auto'),
@@ -400,11 +421,27 @@ EXTRA = [
 ]
 
 
-def run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, warmup, gkey, world=1, rank=0, full=False):
-    """Build an engine, time `steps` steps after `warmup`, profile the conv launches; `full` adds the roofline and host sections."""
+PRECISION_CHECK_IMAGES = 2304       # DESIGN.md section 3.2's sample size (there: 4 weight fills x 576 codes; here: THIS engine's weights)
+
+
+def precision_check(eng, images=PRECISION_CHECK_IMAGES):
+    """TrainStep.check_precision() on the timed engine: the measured image error of the arithmetic the run was timed in,
+    against the exact-fp32 kernels on the same weights — max-norm relative, per batch tensor and per single image."""
+    r = eng.check_precision(batches=max(1, min(72, images // eng.B)))
+    if r is None:
+        return None
+    return {"batch_max": float('%.3g' % r['batch']), "image_median": float('%.3g' % r['per_image_median']), "image_p99": float('%.3g' % r['per_image_p99']),
+            "image_max": float('%.3g' % r['per_image_max']), "over_gate_frac": round(r['over_gate_frac'], 5), "gate": r['gate'], "n": r['n']}
+
+
+def run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, warmup, gkey, world=1, rank=0, full=False, check=False, eng_world=None):
+    """Build an engine, time `steps` steps after `warmup`, profile the conv launches; `full` adds the roofline and host sections;
+    `check` the measured image error of the engine's arithmetic; eng_world=1 inside an N > 1 job: a single-rank engine (no collectives)."""
     from warpedganspace_amd import conv as C
-    eng = build(dev, gan, K, N, B, rank=rank, w_space=w_space, size=size, precision=prec, r_precision=r_prec)
+    eng = build(dev, gan, K, N, B, rank=rank, w_space=w_space, size=size, precision=prec, r_precision=r_prec, world=eng_world)
     name = C.precision_name(eng.precision)
+    if eng_world is not None:
+        world = eng_world
     dt = timed_steps(eng, steps, warmup, world, dev)
     recs = conv_profile(eng, 2 if full else 1)
     a_fl, a_ms = sum(r[2] for r in recs), sum(r[3] for r in recs)
@@ -417,6 +454,11 @@ def run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, warmup, gkey,
         rec["dtype_detail"] = DTYPE_TEXT[name] + R_TEXT.get(tuple(eng.r_arith), "; reconstructor arithmetic (forward, dgrad, wgrad; 0 exact fp32, 1 split-bf16 x3): %s" % (tuple(eng.r_arith),))
         rec["roofline"] = roofline_of(recs, B * steps / dt, GFLOP_PER_IMG.get(gkey))
         rec["host"] = host_overheads(eng)
+    if check:
+        try:
+            rec["precision_check"] = precision_check(eng)
+        except Exception as e:  # noqa: BLE001
+            rec["precision_check"] = {"error": repr(e)[:200]}
     return rec, eng
 
 
@@ -424,7 +466,7 @@ def run_extra(dev):
     out = []
     for name, gan, size, K, N, B, prec, r_prec, w_space, steps, gkey, short in EXTRA:
         try:
-            rec, eng = run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, 6, gkey)
+            rec, eng = run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, 6, gkey, check=(prec == 'mixed-strict'))
             out.append(dict({"config": name, "key": short}, **rec))
             del eng
         except Exception as e:  # noqa: BLE001
@@ -446,7 +488,7 @@ def spawn_ranks(n, argv, backend):
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
 
 
-def comm_section(eng, backend):
+def comm_section(eng, backend, value=None):
     eng.comm_events = []
     for _ in range(5):
         eng.step()
@@ -456,8 +498,27 @@ def comm_section(eng, backend):
     return {"backend": "RCCL (torch.distributed 'nccl')" if backend == 'nccl' else "gloo (development switch: ranks may share one device)",
             "world_size_observed": dist.get_world_size(), "allreduce_bytes_per_step": eng.allreduce_bytes, "collectives_per_step": 2,
             "exposed_wait_ms_per_step": round(sum(waits) / len(waits), 3),
+            "per_gpu_images_per_sec": round(value / dist.get_world_size(), 2) if value else None,
             "note": "main-stream time between reaching the wait for the two all-reduces (R group, queued behind R's weight gradients on "
                     "the side stream; S group, after the RBF backward) and their completion, mean of 5 extra steps on rank 0"}
+
+
+def n1_reference(dev, args, prec, r_prec, gkey, rank, world):
+    """Inside an N > 1 job: the same workload on ONE rank with a single-rank engine while the other ranks idle at a barrier
+    (VERDICT r4 #6c: the N = 1 rate of the same process, box and build beside the N > 1 one)."""
+    out = None
+    dist.barrier()
+    if rank == 0:
+        try:
+            rec, eng = run_one(dev, args.gan, args.size, args.K, args.N, args.batch, prec, r_prec, args.w_space,
+                               min(args.steps, 30), min(args.warmup, 10), gkey, rank=0, eng_world=1)
+            out = {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"]}
+            del eng
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            out = {"error": repr(e)[:200]}
+    dist.barrier()
+    return out
 
 
 def full_record(args, world, head, stats, comm, hbm, extra, cpu, gkey):
@@ -491,6 +552,10 @@ def _short_run(e):
     c = e.get("comm")
     if c:
         out["exposed_wait_ms_per_step"] = c.get("exposed_wait_ms_per_step")
+        out["per_gpu_images_per_sec"] = c.get("per_gpu_images_per_sec")
+        out["n1_same_job"] = c.get("n1_same_job")
+    if e.get("precision_check"):
+        out["precision_check"] = e["precision_check"]
     return out
 
 
@@ -511,7 +576,7 @@ def final_line(full, extra_file):
     line["cpu_baseline"] = c
     cm = full.get("comm")
     line["comm"] = {k: cm.get(k) for k in ("backend", "world_size_observed", "allreduce_bytes_per_step", "collectives_per_step",
-                                           "exposed_wait_ms_per_step")} if cm else None
+                                           "exposed_wait_ms_per_step", "per_gpu_images_per_sec", "n1_same_job")} if cm else None
     h = full.get("host")
     if h:
         line["host"] = {k: h.get(k) for k in ("library_launches_per_step", "host_enqueue_ms_per_step")}
@@ -522,6 +587,11 @@ def final_line(full, extra_file):
     others = {}
     for e in extra:
         if e in same:
+            continue
+        if e.get("key") == "cfg3_mixed_strict" and "product" in line and "error" not in e:
+            pc = e.get("precision_check") or {}
+            line["product"]["strict"] = {"precision": e.get("precision"), "value": e.get("value"), "ms_per_step": e.get("ms_per_step"),
+                                         "precision_check": {k: pc.get(k) for k in ("batch_max", "image_p99", "image_max", "over_gate_frac", "n")} if pc else None}
             continue
         others[str(e.get("key") or e.get("config", "?"))[:40]] = e.get("value") if "error" not in e else "error"
     line["others_images_per_sec"] = others or None
@@ -553,7 +623,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=3)
-    ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--cpu-threads', type=int, default=0, help="threads of the CPU baseline (0 = every physical core this process may run on)")
     ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default='fp32w',
                     help="arithmetic of the HEADLINE run's generator convs (default: fp32w = fp32, Winograd form of the 3x3 stride-1 convs)")
     ap.add_argument('--no-direct-run', action='store_true', help="skip extra[1] (the direct-form exact-fp32 run with the same steps / warmup)")
@@ -564,6 +634,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--single-stream', action='store_true', help='no side streams (profiling: kernel times then add up to the step)')
     ap.add_argument('--no-product-run', action='store_true', help='skip extra[0] (the default-arithmetic run with the same steps / warmup)')
+    ap.add_argument('--no-n1-reference', action='store_true', help="N > 1: skip the single-rank reference runs on rank 0 (comm.n1_same_job)")
     ap.add_argument('--no-extra', action='store_true', help='skip the short runs of the other arithmetic modes / configs')
     ap.add_argument('--extra-out', default=os.path.join('gpurun_out', 'bench_extra.json'),
                     help="side file for everything the < 4 KB stdout line leaves out (relative to the repo root)")
@@ -630,7 +701,7 @@ def main():
     head, eng = run_one(dev, args.gan, args.size, args.K, args.N, args.batch, args.precision, args.r_precision, args.w_space,
                         args.steps, args.warmup, gkey, world=world, rank=rank, full=full)
     stats = eng.pop_stats()
-    comm = comm_section(eng, args.dist_backend) if world > 1 else None
+    comm = comm_section(eng, args.dist_backend, head["value"]) if world > 1 else None
     hbm = None
     if rank == 0 and world == 1 and full:
         try:
@@ -639,19 +710,23 @@ def main():
             hbm = {"error": repr(e)}
     del eng
     torch.cuda.empty_cache()
+    if world > 1 and not args.no_n1_reference:
+        comm["n1_same_job"] = n1_reference(dev, args, args.precision, args.r_precision, gkey, rank, world)
 
     extra = []
     if not args.no_product_run:
         # the same workload, steps and warm-up in the product's default arithmetic, with its own roofline (every rank takes part)
         prod, eng = run_one(dev, args.gan, args.size, args.K, args.N, args.batch, args.product_precision, 'auto', args.w_space,
-                            args.steps, args.warmup, gkey, world=world, rank=rank, full=full)
+                            args.steps, args.warmup, gkey, world=world, rank=rank, full=full, check=True)
         prod["last_stats"] = eng.pop_stats()
         if world > 1:
-            prod["comm"] = comm_section(eng, args.dist_backend)
-        extra.append(dict({"config": "headline workload in the product's default arithmetic (--precision %s), same steps / warmup"
-                                     % args.product_precision}, **prod))
+            prod["comm"] = comm_section(eng, args.dist_backend, prod["value"])
         del eng
         torch.cuda.empty_cache()
+        if world > 1 and not args.no_n1_reference:
+            prod["comm"]["n1_same_job"] = n1_reference(dev, args, args.product_precision, 'auto', gkey, rank, world)
+        extra.append(dict({"config": "headline workload in the product's default arithmetic (--precision %s), same steps / warmup"
+                                     % args.product_precision}, **prod))
     if not args.no_direct_run and not args.no_product_run and args.precision == 'fp32w':
         dirr, eng = run_one(dev, args.gan, args.size, args.K, args.N, args.batch, 'fp32', 'fp32', args.w_space,
                             args.steps, args.warmup, gkey, world=world, rank=rank, full=full)
@@ -665,13 +740,16 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.gan == 'stylegan2':
         try:
-            cpu = cpu_baseline(args.size, args.K, args.N, args.cpu_batch, args.cpu_steps, min(os.cpu_count() or 1, args.cpu_threads))
+            cpu = cpu_baseline(args.size, args.K, args.N, args.cpu_batch, args.cpu_steps, args.cpu_threads or physical_cores())
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
 
     if rank == 0:
         doc = full_record(args, world, head, stats, comm, hbm, extra, cpu, gkey)
         doc["host_pinning_rank0"] = pin
+        if world > 1:
+            from warpedganspace_amd.hostpin import plan_all
+            doc["host_pinning_plan"] = plan_all(int(os.environ.get('LOCAL_WORLD_SIZE', world)))
         path = args.extra_out if os.path.isabs(args.extra_out) else os.path.join(REPO, args.extra_out)
         try:
             os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -426,7 +426,9 @@ int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, 
  * save_mean / save_invstd [C] are written for the backward; ws = WGS_BN_WS_DOUBLES(C) doubles of scratch: 32 replicas of the 2*C
  * partial sums (so that the reduction's fp64 atomics do not all hit the same addresses).  ws MUST BE ZERO ON ENTRY and is left zero
  * on exit (zero it once when allocating it; one buffer serves any sequence of wgs_bn_fwd / wgs_bn_bwd / wgs_colsum calls on one
- * stream, with any C): the launch that sums the replicas zeroes them again, so no reduction needs a memset.  C % 4 == 0. */
+ * stream, with any C): the launch that sums the replicas zeroes them again, so no reduction needs a memset.  A buffer that is NOT zero
+ * (never zeroed, a call cut short, two streams sharing it) gives wrong statistics without an error; WGS_CHECK_WS=1 in the environment
+ * makes every call verify it first (synchronously: debugging only).  C % 4 == 0. */
 #define WGS_BN_WS_DOUBLES(C) (64 * (C))
 int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
@@ -434,8 +436,9 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
 /* Backward: g = (dyA + (dyB ? dyB : 0)) * (out ? out > 0 : 1)   [out = the saved post-ReLU output]
  *   dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) (train) ;  dgamma = sum g*xhat ; dbeta = sum g ;
  *   dres (optional) = g  (gradient of the residual branch).
- * dgamma and dbeta are REQUIRED in train mode (the reduction launch writes the two sums there and the input-gradient launch reads them
- * back); in eval mode pass both or neither (neither: no reduction is launched).  ws as in wgs_bn_fwd. */
+ * dgamma and dbeta are REQUIRED in train mode: the reduction launch OVERWRITES them with the two sums (fp64 partials rounded to fp32;
+ * they cannot be accumulate-into buffers) and the input-gradient launch reads them back; in eval mode pass both or neither (neither: no
+ * reduction is launched).  ws as in wgs_bn_fwd. */
 int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* out, const float* save_mean,
                const float* save_invstd, const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta,
                double* ws, int64_t N, int C, int train, wgs_stream_t stream);

@@ -105,19 +105,25 @@ def _canned_full(bench, world=1):
             "by_symbol": [{"symbol": "igemm_nt16_kernel<4, 256, 256, 2, 4, 2, false>" + str(i), "ms_per_step": 1.0, "frac": 0.5} for i in range(10)],
             "method": "y" * 400, "step_achieved_TFLOPs": 116.0, "step_frac": 0.74, "step_direct_equiv_TFLOPs": 163.0}
     comm = {"backend": "RCCL (torch.distributed 'nccl')", "world_size_observed": world, "allreduce_bytes_per_step": 63800000, "collectives_per_step": 2,
-            "exposed_wait_ms_per_step": 0.123, "note": "z" * 300} if world > 1 else None
+            "exposed_wait_ms_per_step": 0.123, "per_gpu_images_per_sec": 71.59, "n1_same_job": {"value": 590.12, "ms_per_step": 54.23, "steps": 30},
+            "note": "z" * 300} if world > 1 else None
     host = {"library_launches_per_step": 426.0, "host_enqueue_ms_per_step": 6.6, "host_enqueue_ms_per_step_mean": 7.0, "note": "n" * 200}
     same = [dict({"config": "headline workload in the product's default arithmetic (--precision auto), same steps / warmup"}, precision='mixed', value=1145.0,
                  ms_per_step=27.9, dtype=bench.DTYPE['mixed'], dtype_detail='d' * 500, roofline=dict(roof, kernel='igemm_patch_kernel<0, 256, 256, 2, 4, 1, 0>'),
-                 host=host, comm=comm, last_stats={}, n_gpus=world, steps=100),
+                 host=host, comm=comm, last_stats={}, n_gpus=world, steps=100,
+                 precision_check={"batch_max": 5.9e-4, "image_median": 4.1e-4, "image_p99": 8.4e-4, "image_max": 1.06e-3, "over_gate_frac": 0.0013, "gate": 1e-3, "n": 2304}),
             dict({"config": "headline workload in direct-form exact fp32 (--precision fp32: no Winograd), same steps / warmup"}, precision='fp32', value=410.0,
                  ms_per_step=78.0, dtype='fp32', dtype_detail='d' * 500, roofline=roof, host=host, last_stats={}, n_gpus=world, steps=100)]
     others = [dict({"config": e[0], "key": e[-1]}, precision=e[6], value=123.45, ms_per_step=1.0, r_arith=[1, 1, 1]) for e in bench.EXTRA]
-    others[3] = {"config": bench.EXTRA[3][0], "key": bench.EXTRA[3][-1], "precision": bench.EXTRA[3][6], "error": "RuntimeError('" + "e" * 300 + "')"}
+    for o in others:
+        if o["key"] == "cfg3_mixed_strict":
+            o["precision_check"] = {"batch_max": 4.5e-4, "image_median": 3.5e-4, "image_p99": 6.5e-4, "image_max": 8.4e-4, "over_gate_frac": 0.0, "gate": 1e-3, "n": 2304}
+    assert bench.EXTRA[4][-1] == 'cfg3_auto_Rfp32'
+    others[4] = {"config": bench.EXTRA[4][0], "key": bench.EXTRA[4][-1], "precision": bench.EXTRA[4][6], "error": "RuntimeError('" + "e" * 300 + "')"}
     args = types.SimpleNamespace(size=256, gan='stylegan2', K=128, N=32, batch=32, w_space=False, steps=100, warmup=20, precision='fp32w')
     head = {"value": 572.7, "ms_per_step": 55.9, "dtype": "fp32", "dtype_detail": bench.DTYPE_TEXT['fp32w'], "precision": "fp32w", "r_arith": [5, 5, 0],
             "roofline": roof, "host": host}
-    cpu = {"value": 0.393, "unit": "images/sec", "cores": 32, "kind": "port", "sample": "s" * 600}
+    cpu = {"value": 0.393, "unit": "images/sec", "cores": 128, "kind": "port", "sample": "s" * 600}
     hbm = {k: {"bytes": 1, "us": 1.0, "GB/s": 1.0, "note": "h" * 80} for k in ('rbf_fwd', 'rbf_bwd', 'adam', 'blur', 'torgb', 'bn')}
     return bench.full_record(args, world, head, {"accuracy": 0.1, "classification_loss": 4.8, "regression_loss": 0.3, "total_loss": 4.9}, comm, hbm,
                              same + (others if world == 1 else []), cpu if world == 1 else None, 'stylegan2-256')
@@ -143,11 +149,18 @@ def test_final_line_is_under_4kb_and_round_trips(bench, world):
     assert d['product']['value'] == 1145.0 and d['direct_fp32']['value'] == 410.0 and d['extra_file'] == 'gpurun_out/bench_extra.json'
     if world == 1:
         c = d['cpu_baseline']
-        assert c['value'] == 0.393 and c['cores'] == 32 and c['kind'] == 'port' and len(c['sample']) <= 300
-        assert len(d['others_images_per_sec']) == len(bench.EXTRA) and 'error' in d['others_images_per_sec'].values()
+        assert c['value'] == 0.393 and c['cores'] == 128 and c['kind'] == 'port' and len(c['sample']) <= 300
+        assert len(d['others_images_per_sec']) == len(bench.EXTRA) - 1 and 'error' in d['others_images_per_sec'].values()
         assert d['comm'] is None
+        # the measured image error of the timed arithmetic, and the strict policy's rate + error beside it
+        pc = d['product']['precision_check']
+        assert pc['n'] == 2304 and pc['image_max'] == 1.06e-3 and pc['over_gate_frac'] == 0.0013 and pc['batch_max'] == 5.9e-4 and pc['image_p99'] == 8.4e-4
+        st = d['product']['strict']
+        assert st['precision'] == 'mixed-strict' and st['value'] == 123.45 and st['precision_check']['over_gate_frac'] == 0.0
     else:
         assert d['comm']['world_size_observed'] == 8 and d['comm']['exposed_wait_ms_per_step'] == 0.123 and d['product']['exposed_wait_ms_per_step'] == 0.123
+        # VERDICT r4 #6c: the N = 1 rate of the same job beside the per-GPU rate and the exposed wait
+        assert d['comm']['per_gpu_images_per_sec'] == 71.59 and d['comm']['n1_same_job']['value'] == 590.12 and d['product']['n1_same_job']['steps'] == 30
 
 
 def test_no_gpu_means_a_loud_failure(bench, monkeypatch):

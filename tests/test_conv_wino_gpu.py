@@ -171,3 +171,34 @@ def test_one_weight_cache_serves_launches_of_different_layouts(dev):
         layouts.add(L.lib().wgs_conv_wino_layout(ctypes.byref(d)))
     assert len(layouts) == 2, layouts                                   # the two batch sizes really straddle the shape threshold
     assert sum(1 for k in cache.planes if isinstance(k, tuple) and k[0] == 'wino') == 2
+
+
+def test_step_cache_follows_its_weight_tensor(dev):
+    """a StepWinoCache recipe keeps the weight tensor it was recorded from.  refresh() rebuilds U from the tensor's CURRENT
+    values; a launch whose weights live at another address by now (parameters re-homed, R.to(), a re-allocated transposed copy) does not
+    hit the stale operand — it rebuilds from its own tensor and the recipe follows it."""
+    torch.manual_seed(5)
+    ci = co = 64
+    x = torch.randn(2, 32, 32, ci, device=dev)
+
+    def ref(w):
+        return torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().reshape(co, 3, 3, ci).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+
+    def err(y, w):
+        r = ref(w)
+        return float((y.double() - r).abs().max() / r.abs().max())
+    cache = C.StepWinoCache()
+    w1 = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
+    assert err(C.conv2d(x, w1, 3, pad=1, precision=C.FP32W, w_split=cache), w1) < 3e-6
+    assert len(cache.recipes) == 1
+    w1.mul_(-0.5)                                   # an optimiser update in place: stale until refresh() ...
+    assert err(C.conv2d(x, w1, 3, pad=1, precision=C.FP32W, w_split=cache), w1) > 0.1
+    cache.refresh()                                 # ... which re-reads the tensor
+    assert err(C.conv2d(x, w1, 3, pad=1, precision=C.FP32W, w_split=cache), w1) < 3e-6
+    w2 = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5          # the same layer's weights at ANOTHER address
+    assert err(C.conv2d(x, w2, 3, pad=1, precision=C.FP32W, w_split=cache), w2) < 3e-6
+    assert len(cache.recipes) == 1 and next(iter(cache.recipes.values()))[1] is w2
+    del w1
+    w2.add_(0.01)
+    cache.refresh()
+    assert err(C.conv2d(x, w2, 3, pad=1, precision=C.FP32W, w_split=cache), w2) < 3e-6

@@ -112,3 +112,66 @@ def test_host_pinning_plan_gives_disjoint_slices():
     assert len(HP.plan({0}, {0}, 8, 5)) == 1                                      # more ranks than CPUs: still one CPU each
     r = HP.pin_rank(0, 1)                                                         # no GPU here: reports why, changes nothing
     assert r['pinned'] is False and r['why']
+    # the affinity covers the whole process (RCCL proxy, autograd's device thread): slices below MIN_CPUS_PER_RANK are not applied
+    cpus, why = HP.choose(set(range(0, 48)), set(range(0, 96)), 4, 1)
+    assert cpus == set(range(12, 24)) and 'own slice' in why
+    cpus, why = HP.choose(set(range(0, 8)), set(range(0, 16)), 4, 1)              # 2 CPUs each: the whole node instead, shared
+    assert cpus == set(range(0, 8)) and 'confined to the NUMA node' in why
+    cpus, why = HP.choose(set(range(0, 8)), set(range(0, 8)), 8, 3)               # 8 ranks on 8 CPUs, one node: leave it alone
+    assert cpus is None and 'left alone' in why
+    os.environ['WGS_NO_PIN'] = '1'
+    try:
+        assert HP._plan_rank(0, 2, set(range(64)), [(0, 'a'), (0, 'b')])['why'] == 'WGS_NO_PIN=1'
+    finally:
+        del os.environ['WGS_NO_PIN']
+    assert len(HP.plan_all(8)) == 8
+
+
+class _FakeWriter:
+    def __init__(self):
+        self.n = 0
+
+    def add_scalar(self, *a):
+        self.n += 1
+
+
+def _tb_worker(rank, world, port, root, q):
+    """The statistics branch of Trainer.train's loop as every rank takes it (with --tensorboard the writer exists on
+    rank 0 only, and pop_stats() is a collective)."""
+    import types
+    from warpedganspace_amd.trainer import Trainer
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    p = types.SimpleNamespace(tensorboard=False, log_freq=3, max_iter=6, batch_size=4)
+    tr = Trainer(params=p, exp_dir='exp', use_cuda=False, root=os.path.join(root, 'r%d' % rank))
+    if rank == 0:
+        tr.tb_writer = _FakeWriter()            # as `--tensorboard` leaves it: a writer on rank 0, none elsewhere
+    before = tr.tb_writer is not None           # what the old loop condition looked at: differs between the ranks
+    tr.agree_tensorboard()
+    n_coll = 0
+    for it in range(1, 2 * p.log_freq + 1):
+        if tr.stats_due(it):                    # pop_stats(): one all-reduce per call
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert float(t) == world
+            n_coll += 1
+    dist.barrier()
+    q.put((rank, before, tr.tb_active, n_coll))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_every_rank_pops_statistics_in_the_same_iterations(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_tb_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(90)
+        assert p.exitcode == 0                  # a mismatched collective would hang until the join times out
+    res = sorted(q.get() for _ in range(world))
+    assert [r[1] for r in res] == [True, False]           # only rank 0 owns a writer ...
+    assert [r[2] for r in res] == [True, True]            # ... every rank knows it after agree_tensorboard()
+    assert [r[3] for r in res] == [6, 6]                  # statistics popped in every iteration, on BOTH ranks

@@ -203,3 +203,97 @@ def test_bench_two_ranks_end_to_end_over_rccl(tmp_path):
     never RCCL's first contact with this code."""
     d = _bench_two_ranks('nccl', tmp_path)
     assert d['comm']['backend'].startswith('RCCL')
+
+
+class _FakeWriter:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, key, value, it):
+        self.rows.append((key, it))
+
+
+def _train_worker(rank, world, port, root, q):
+    try:
+        from warpedganspace_amd.gan_load import build_stylegan2
+        from warpedganspace_amd.reconstructor import Reconstructor
+        from warpedganspace_amd.support_sets import SupportSets
+        from warpedganspace_amd.trainer import Trainer
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        log_freq = 3
+        p = types.SimpleNamespace(reconstructor_lr=1e-4, support_set_lr=1e-4, min_shift_magnitude=0.25, max_shift_magnitude=0.45,
+                                  lambda_cls=1.0, lambda_reg=0.25, z_truncation=None, shift_in_w_space=False, tensorboard=False,
+                                  log_freq=log_freq, ckp_freq=1000, max_iter=2 * log_freq, batch_size=4, seed=3, precision='fp32')
+        torch.manual_seed(0)
+        G = build_stylegan2(None, resolution=32)
+        S = SupportSets(8, 4, 512, learn_alphas=False, learn_gammas=True, gamma=1.0 / 512)
+        R = Reconstructor('ResNet', 8)
+        tr = Trainer(params=p, exp_dir='exp', use_cuda=True, root=os.path.join(root, 'r%d' % rank))
+        n_pop = [0]
+        if rank == 0:
+            tr.tb_writer = _FakeWriter()         # `--tensorboard` as it lands: rank 0 owns the only writer
+        eng = tr.train(G, S, R)
+        flat = eng.bucket.flat.clone()
+        other = flat.clone()
+        dist.broadcast(other, 0)
+        q.put((rank, tr.tb_active, len(tr.tb_writer.rows) if rank == 0 else 0, bool(torch.equal(flat, other)), eng.steps_done, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, None, None, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(900)
+def test_trainer_loop_with_a_rank0_only_tensorboard_writer(dev, tmp_path):
+    """Trainer.train over two ranks for 2 x log_freq iterations with a TensorBoard writer on rank 0 only (lib/trainer.py:127-131 builds it
+    in every process of the reference; here rank 0's alone): pop_stats() all-reduces, so both ranks must pop in EVERY iteration — the
+    loop used to test `self.tb_writer`, which differs between the ranks (mismatched collectives)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    torch.cuda.empty_cache()
+    port = _free_port()
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive, "ranks hung: mismatched collectives"
+    res = sorted(q.get() for _ in range(world))
+    for r in res:
+        assert r[-1] is None, r[-1]
+    assert [r[1] for r in res] == [True, True]
+    assert res[0][2] == 4 * 6                      # four scalars in each of the 2 x log_freq iterations
+    assert all(r[3] for r in res) and all(r[4] == 6 for r in res)      # replicas identical after the run
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_eight_ranks_end_to_end_over_gloo(tmp_path):
+    """`bench.py --gpus 8 --dist-backend gloo` on ONE device with a small batch: the launcher path, eight per-rank engines, barrier +
+    max-over-ranks timing and the N = 8 line (< 4 KB, comm.world_size_observed == 8, the N = 1 reference value beside the exposed wait)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    side = str(tmp_path / 'bench_extra.json')
+    cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8', '--dist-backend', 'gloo', '--steps', '2', '--warmup', '1', '--batch', '2',
+           '--size', '32', '-K', '16', '-N', '4', '--no-cpu-baseline', '--no-extra', '--no-direct-run', '--extra-out', side]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, PYTHONPATH=repo))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 16 and d['config']['parallelism'] == 'dp8'
+    c = d['comm']
+    assert c['world_size_observed'] == 8 and c['collectives_per_step'] == 2 and c['exposed_wait_ms_per_step'] >= 0
+    assert c['per_gpu_images_per_sec'] > 0 and abs(c['per_gpu_images_per_sec'] * 8 - d['value']) < 0.01 * d['value'] + 0.1
+    assert d['product']['value'] > 0
+    full = json.load(open(side))
+    assert full['host_pinning_plan'] and len(full['host_pinning_plan']) == 8          # the plan every rank would take under RCCL

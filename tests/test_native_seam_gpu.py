@@ -59,3 +59,35 @@ def test_upfirdn2d_autograd_nchw(dev):
         (yd * p.to(dev)).sum().backward()
         assert rel_err(yd, y) < 1e-6
         assert rel_err(xd.grad, x.grad) < 1e-6
+
+
+def test_bn_scratch_contract_is_checkable(dev):
+    """wgs_bn_fwd / wgs_bn_bwd / wgs_colsum rely on their fp64 scratch being zero on entry (include/wgs.h); a dirty buffer gives
+    wrong statistics silently — unless WGS_CHECK_WS=1, which makes every call verify it first and fail with WGS_EINVAL."""
+    import os
+    from warpedganspace_amd import _lib as L
+    lib = L.lib()
+    N, C = 512, 8
+    x = torch.randn(N, C, device=dev)
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    y, mean, invstd = torch.empty_like(x), torch.empty(C, device=dev), torch.empty(C, device=dev)
+
+    def bn(ws):
+        return lib.wgs_bn_fwd(L.ptr(x), L.ptr(g), L.ptr(b), None, L.ptr(y), L.ptr(mean), L.ptr(invstd), None, None, None, L.rawptr(ws),
+                              L.c_int64(N), C, L.c_float(1e-5), L.c_float(0.1), 0, 1, L.stream())
+    ws = torch.zeros(64 * C, dtype=torch.float64, device=dev)
+    assert bn(ws) == 0 and bn(ws) == 0                     # left zero on exit: the second call needs no memset
+    torch.cuda.synchronize()
+    assert float(ws.abs().max()) == 0.0 and float((mean - x.mean(0)).abs().max()) < 1e-6
+    os.environ['WGS_CHECK_WS'] = '1'
+    lib.wgs_dev_reload_flags()
+    try:
+        assert bn(ws) == 0
+        dirty = torch.zeros(64 * C, dtype=torch.float64, device=dev)
+        dirty[5] = 1.0
+        assert bn(dirty) == -22 and b'not zero on entry' in lib.wgs_last_error()
+        out = torch.empty(C, device=dev)
+        assert lib.wgs_colsum(L.ptr(x), L.ptr(out), L.rawptr(dirty), L.c_int64(N), C, L.stream()) == -22
+    finally:
+        del os.environ['WGS_CHECK_WS']
+        lib.wgs_dev_reload_flags()

@@ -6,6 +6,7 @@ import torch.nn.functional as F
 from oracle import wgs_oracle as O
 from tests import golden_inputs as GI
 from tests.util import rel_err, l2_rel
+from warpedganspace_amd import _lib as L
 from warpedganspace_amd.gan_load import StyleGAN2Wrapper
 from warpedganspace_amd.stylegan2 import Generator
 
@@ -272,3 +273,30 @@ def test_stylegan2_1024_torgb_in_the_few_channel_kernel(dev):
     assert out[True][3] >= 2 and out[False][3] == 0
     assert rel_err(out[True][0], out[False][0]) < 1e-5 and rel_err(out[True][2], out[False][2]) < 1e-5
     assert rel_err(out[True][1], out[False][1]) < 1e-4
+
+
+def test_backward_hooks_belong_to_one_forward_and_stages_to_one_stream(dev):
+    """the hook list set before a differentiable forward is bound to THAT forward's autograd node — entries appended after the
+    forward fire in its backward, and another forward / backward of the same generator in between neither sees nor consumes them.  A
+    staged pass captured its launch stream at begin(): resuming it under another stream raises instead of enqueueing there."""
+    G, _ = build(32, 41, dev)
+    wrap = StyleGAN2Wrapper(G, False).eval()
+    z = GI.rt(42, 2, 512).to(dev)
+    wgt = GI.rt(44, 2, 3, 32, 32).to(dev)
+    fired, carrier = [], []
+    s1 = (GI.rt(43, 2, 512) * 0.1).to(dev).requires_grad_(True)
+    G.bwd_hooks = carrier
+    out1 = wrap(z, s1)
+    assert G.bwd_hooks is None                       # taken by the forward
+    carrier.append((8, lambda: fired.append('mine')))
+    s2 = (GI.rt(45, 2, 512) * 0.1).to(dev).requires_grad_(True)
+    (wrap(z, s2) * wgt).sum().backward()             # an unrelated forward / backward of the same generator
+    assert fired == [] and len(carrier) == 1
+    (out1 * wgt).sum().backward()
+    assert fired == ['mine'] and carrier == []
+    with torch.no_grad():
+        h = wrap.begin(z, pause_res=8)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            with pytest.raises(L.WgsError):
+                wrap.advance(h)
+        assert torch.equal(wrap.finish(h), wrap(z))

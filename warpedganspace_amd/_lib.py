@@ -76,6 +76,35 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class StagedPass:
+    """A generator pass enqueued in stages (a Python generator that yields at its pause points).  The pass captured its launch stream
+    when it was created, so every stage must be resumed under THAT stream: advance() checks it instead of silently enqueueing one
+    stage's launches on another stream than the tensors they read were produced on."""
+
+    def __init__(self, gen):
+        self.stream_id = torch.cuda.current_stream().cuda_stream
+        self.gen = gen
+        next(gen)                      # the first stage
+
+    def advance(self):
+        """Enqueue the next stage: None while the pass is paused again, the image when it is complete."""
+        if torch.cuda.current_stream().cuda_stream != self.stream_id:
+            raise WgsError("a staged generator pass must be resumed under the stream it was begun on (begun on %#x, resumed on %#x)"
+                           % (self.stream_id, torch.cuda.current_stream().cuda_stream))
+        try:
+            next(self.gen)
+        except StopIteration as e:
+            return e.value[0]
+        return None
+
+    def finish(self):
+        """Enqueue everything that is left: the image."""
+        while True:
+            img = self.advance()
+            if img is not None:
+                return img
+
+
 def ptr(t, dtype=torch.float32, name="tensor"):
     """Device pointer of a contiguous tensor (None -> NULL)."""
     if t is None:

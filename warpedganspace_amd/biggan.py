@@ -115,6 +115,9 @@ class _BG(torch.autograd.Function):
         ctx.prec = prec
         img, saved = G._fwd(z, y, ctx.needs_input_grad[1], prec)
         ctx.G, ctx.saved = G, saved
+        ctx.hooks = None
+        if ctx.needs_input_grad[1]:              # bound to THIS forward's autograd node (stylegan2._Synthesis)
+            ctx.hooks, G.bwd_hooks = G.bwd_hooks, None
         if G.debug_keep is not None and saved is not None:     # ReLU gates in execution order, NCHW (tests)
             gates = []
             for (_, _, a1, _, _, a2, _, _) in saved[0]:
@@ -124,7 +127,8 @@ class _BG(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gimg):
-        return None, ctx.G._bwd(ctx.saved, gimg.contiguous(), ctx.prec), None, None
+        hooks, ctx.hooks = ctx.hooks, None
+        return None, ctx.G._bwd(ctx.saved, gimg.contiguous(), ctx.prec, hooks), None, None
 
 
 class Generator(nn.Module):
@@ -158,7 +162,7 @@ class Generator(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
         self._prep = None
-        self.bwd_hooks = None        # [(resolution, callable)] for the NEXT backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
+        self.bwd_hooks = None        # hook list for the next differentiable forward's backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
         self.debug_keep = None
         self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
         self.mixed_from_res = MIXED_FROM_RES.get(resolution)      # 'mixed' (conv.AUTO_TABLE): fp16 x2 from this block resolution up, split-bf16 below
@@ -439,7 +443,7 @@ class Generator(nn.Module):
         mixed_from = self.mixed_from_res      # 'mixed': fp16 x2 in the blocks whose output is >= this resolution, split-bf16 below
         prec_in = prec
         for d, yb in zip(P['blocks'], ys):
-            if prec_in == C.MIXED:
+            if C.is_mixed(prec_in):
                 prec = 3 if (mixed_from is not None and 2 * h.shape[1] >= mixed_from) else 1
             if pauses and 2 * h.shape[1] > pauses[0]:
                 while pauses and 2 * h.shape[1] > pauses[0]:
@@ -464,7 +468,7 @@ class Generator(nn.Module):
         so = P['out_scale'].unsqueeze(0).expand(B, -1).contiguous()
         to = P['out_shift'].unsqueeze(0).expand(B, -1).contiguous()
         af = self._affine_relu(h, so, to)
-        if prec_in == C.MIXED:
+        if C.is_mixed(prec_in):
             prec = 1          # the image conv (3 output channels, tanh) stays fp32-class
         y8 = self._conv(af, P['out'], prec, act=1)
         img = y8[..., :3].permute(0, 3, 1, 2).contiguous()
@@ -472,7 +476,7 @@ class Generator(nn.Module):
             yield None
         return img, ((saved, h, af, so, y8, zs, B) if save else None)
 
-    def _bwd(self, saved_all, gimg, prec):
+    def _bwd(self, saved_all, gimg, prec, hooks=None):
         P = self._prepare()
         lib, st = L.lib(), L.stream()
         saved, h_last, af, so, y8, zs, B = saved_all
@@ -487,7 +491,9 @@ class Generator(nn.Module):
         g, _, _ = self._affine_relu_bwd(h_last, af, gaf, so)
         cs = self.z_chunk_size
         dz = torch.zeros(B, self.dim_z, device=dev)
-        hooks, self.bwd_hooks = list(self.bwd_hooks or ()), None      # [(resolution, callable)]: each called once, at the first block of <= resolution
+        carrier, hooks = hooks, list(hooks or ())      # [(resolution, callable)]: each called once, at the first block of <= resolution
+        if carrier is not None:
+            del carrier[:]
         for i in range(len(P['blocks']) - 1, -1, -1):
             d = P['blocks'][i]
             h, s1, a1, h1, s2, a2, yb, att_saved = saved[i]
@@ -555,24 +561,15 @@ class BigGANWrapper(nn.Module):
     # -- the un-shifted pass G(z) in stages (extension; trainer.TrainStep, as StyleGAN2Wrapper) ------------------------------
     def begin(self, z, precision=None, pause_res=32, classes=None):
         target_classes = (self.mixed_classes(z.shape[0]) if classes is None else classes).to(z.device)
-        g = self.G._fwd_gen(z, self.G.shared(target_classes), False, self.G.resolve_precision(precision), pause_res)
-        next(g)
-        return g
+        return L.StagedPass(self.G._fwd_gen(z, self.G.shared(target_classes), False, self.G.resolve_precision(precision), pause_res))
 
     @staticmethod
     def advance(handle):
-        try:
-            next(handle)
-        except StopIteration as e:
-            return e.value[0]
-        return None
+        return handle.advance()
 
     @staticmethod
     def finish(handle):
-        while True:
-            img = BigGANWrapper.advance(handle)
-            if img is not None:
-                return img
+        return handle.finish()
 
 
 def build_biggan(pretrained_gan_weights=None, target_classes=(239,), config_file=None):

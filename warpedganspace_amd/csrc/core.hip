@@ -43,6 +43,7 @@ static WgsFlags read_flags() {
     g.halo_min_tiles = getenv("WGS_HALO_MIN_TILES") ? atoi(getenv("WGS_HALO_MIN_TILES")) : 512;      // (tests: 1 = every covered shape)
     g.rbf_split = getenv("WGS_RBF_SPLIT") != nullptr;      // RBF forward as two launches (support vectors split over workgroups + finish)
     g.no_halo = getenv("WGS_NO_HALO") != nullptr;      // few-channel 3x3 convs on large maps through the GEMM-tiled kernels (conv_halo16.hip off)
+    g.check_ws = getenv("WGS_CHECK_WS") != nullptr;      // debug: verify (synchronously) that the BatchNorm / column-sum scratch is zero on entry
     g.f32_old = getenv("WGS_F32_OLD") != nullptr;      // exact fp32: the plain three-phase kernel of conv_igemm.hip everywhere
     // producer-written fp16 activation planes (x_f16): stride-1 3x3 launches with fewer output columns than this take the patch form,
     // the others the LDS-DMA kernel (development: WGS_PLANE_PATCH_MAX_CO=0 pins the LDS-DMA kernel, 100000 the patch form)

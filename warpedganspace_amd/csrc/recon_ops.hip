@@ -533,6 +533,26 @@ int wgs_unpack_pair_grad(const float* dy, float* d1, float* d2, int B, int c, in
     return WGS_OK;
 }
 
+// WGS_CHECK_WS=1 (debug): the zero-on-entry contract of the BatchNorm / column-sum scratch, checked synchronously before the reduction
+// (a dirty buffer — a client following the old per-call-memset contract, an interrupted call, two streams sharing one ws — otherwise
+// gives wrong statistics silently; include/wgs.h)
+static int ws_is_zero(const double* ws, int C, hipStream_t st, const char* who) {
+    if (!wgs_flags().check_ws) return WGS_OK;
+    const size_t n = (size_t)WGS_BN_WS_DOUBLES(C);
+    double* h = (double*)malloc(n * sizeof(double));
+    if (!h) return WGS_OK;
+    hipError_t e = hipMemcpyAsync(h, ws, n * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    size_t bad = n;
+    if (e == hipSuccess)
+        for (size_t i = 0; i < n; ++i)
+            if (h[i] != 0.0) { bad = i; break; }
+    free(h);
+    if (e != hipSuccess) { wgs_set_error("%s: WGS_CHECK_WS copy failed: %s", who, hipGetErrorString(e)); return WGS_ELAUNCH; }
+    if (bad != n) { wgs_set_error("%s: ws is not zero on entry (double %zu of %zu): zero it once when allocating it, one stream per buffer", who, bad, n); return WGS_EINVAL; }
+    return WGS_OK;
+}
+
 static int reduce_rows_per_block(int64_t N, int C) {
     const int c4n = C >> 2;
     const int tpr = c4n < 256 ? c4n : 256;
@@ -550,6 +570,7 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
     WGS_CHECK_ARG(train || (running_mean && running_var), "wgs_bn_fwd: eval mode needs running stats");
     hipStream_t st = (hipStream_t)stream;
     if (train) {
+        if (int rc = ws_is_zero(ws, C, st, "wgs_bn_fwd")) return rc;
         const int rpb = reduce_rows_per_block(N, C);
         WGS_LAUNCH(chan_reduce_kernel<0>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                            nullptr, nullptr, ws, N, C, rpb);
@@ -575,6 +596,7 @@ int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* 
     hipStream_t st = (hipStream_t)stream;
     const int rpb = reduce_rows_per_block(N, C);
     if (dgamma) {        // (eval mode without parameter gradients — a frozen generator's BatchNorm — needs no reduction at all)
+        if (int rc = ws_is_zero(ws, C, st, "wgs_bn_bwd")) return rc;
         WGS_LAUNCH(chan_reduce_kernel<1>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, dyA, dyB, out, save_mean,
                            save_invstd, ws, N, C, rpb);
         WGS_LAUNCH(ws_collapse_kernel, dim3(wgs_cdiv(2 * C, 256)), dim3(256), 0, st, ws, C, dbeta, dgamma);
@@ -629,6 +651,7 @@ int wgs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, w
 int wgs_colsum(const float* x, float* out, double* ws, int64_t N, int C, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && out && ws && N > 0 && C >= 4 && C % 4 == 0, "wgs_colsum: bad arguments (C %% 4)");
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = ws_is_zero(ws, C, st, "wgs_colsum")) return rc;
     const int rpb = reduce_rows_per_block(N, C);
     WGS_LAUNCH(chan_reduce_kernel<2>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                        nullptr, ws, N, C, rpb);

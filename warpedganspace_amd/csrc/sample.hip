@@ -29,9 +29,12 @@ __device__ __forceinline__ u4 philox4x32_10(u4 c, unsigned k0, unsigned k1) {
     }
     return c;
 }
-// uniform in (0, 1): never 0 (logarithms below), never 1
-__device__ __forceinline__ float u01(unsigned v) { return ((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-__device__ __forceinline__ double u01d(unsigned a, unsigned b) { return ((double)(((unsigned long long)a << 21) ^ (unsigned long long)(b >> 11)) + 0.5) * (1.0 / 9007199254740992.0); }
+// uniform in (0, 1): never 0 (logarithms below), never 1.  For the largest draw (2^24 - 1, resp. 2^53 - 1) the "+ 0.5" rounds up to the
+// next power of two and the product would be exactly 1 (probability 2^-24 / 2^-53 per draw): clamped to the largest value below 1.
+__device__ __forceinline__ float u01(unsigned v) { return fminf(((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f), 0x1.fffffep-1f); }
+__device__ __forceinline__ double u01d(unsigned a, unsigned b) {
+    return fmin(((double)(((unsigned long long)a << 21) ^ (unsigned long long)(b >> 11)) + 0.5) * (1.0 / 9007199254740992.0), 0x1.fffffffffffffp-1);
+}
 
 // counter = (element, 0, stream id, step_hi); key = seed.  stream id: 0 = z, 1 = idx, 2 = pool magnitudes, 3 = exponential race
 __device__ __forceinline__ u4 draw(unsigned long long seed, unsigned long long step, unsigned sid, unsigned elem) {
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void sample_step_kernel(float* __restrict__ z,
         const u4 r = draw(seed, step, 2u, (unsigned)i);
         const float u = u01(r.x);
         pool[i] = i < B ? (lo - hi) * u - lo : (lo - hi) * u + hi;
-        const float e = -__logf(u01(draw(seed, step, 3u, (unsigned)i).x));
+        const float e = fmaxf(-__logf(u01(draw(seed, step, 3u, (unsigned)i).x)), 1.17549435e-38f);     // > 0: no 0 / 0 for entry 0, no inf key
         key[i] = (float)i / e;                     // weight i: entry 0 has key 0 and is never among the B largest
     }
     __syncthreads();

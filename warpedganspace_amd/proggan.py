@@ -48,13 +48,17 @@ class _PG(torch.autograd.Function):
         ctx.prec = prec
         img, saved = G._fwd(z, ctx.needs_input_grad[1], prec)
         ctx.G, ctx.saved = G, saved
+        ctx.hooks = None
+        if ctx.needs_input_grad[1]:              # bound to THIS forward's autograd node (stylegan2._Synthesis)
+            ctx.hooks, G.bwd_hooks = G.bwd_hooks, None
         if G.debug_keep is not None and saved is not None:     # leaky-relu gates, NCHW (tests)
             G.debug_keep['gates'] = [(y > 0).permute(0, 3, 1, 2) for (_, _, y) in saved[0]]
         return img
 
     @staticmethod
     def backward(ctx, gimg):
-        return None, ctx.G._bwd(ctx.saved, gimg.contiguous(), ctx.prec), None
+        hooks, ctx.hooks = ctx.hooks, None
+        return None, ctx.G._bwd(ctx.saved, gimg.contiguous(), ctx.prec, hooks), None
 
 
 class Generator(nn.Module):
@@ -69,7 +73,7 @@ class Generator(nn.Module):
             p.requires_grad_(False)
         self._prep = None
         self._pn_fused = {}
-        self.bwd_hooks = None        # [(resolution, callable)] for the NEXT backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
+        self.bwd_hooks = None        # hook list for the next differentiable forward's backward (trainer.TrainStep, as stylegan2.Generator.bwd_hooks)
         self.debug_keep = None
         self.precision = 'fp32'      # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES)
 
@@ -185,7 +189,7 @@ class Generator(nn.Module):
             yield None
         return img, ((saved, x, xn) if save else None)
 
-    def _bwd(self, saved_all, gimg, prec):
+    def _bwd(self, saved_all, gimg, prec, hooks=None):
         # fp16 modes: gradient operands without a magnitude bound run in split-bf16 (grad_operand=True)
         P = self._prepare()
         lib, st = L.lib(), L.stream()
@@ -208,7 +212,9 @@ class Generator(nn.Module):
         f16_grads = C.is_f16_operand(prec) and F16_GRADS
         amaxes = torch.zeros(nl + 1, 1, device=dev).unbind(0) if f16_grads else [None] * (nl + 1)
         dpre = self._pixelnorm_bwd(x_last, gxn, act_slope=0.2, amax=amaxes[0])
-        hooks, self.bwd_hooks = list(self.bwd_hooks or ()), None      # [(resolution, callable)]: each called once, at the first block of <= resolution
+        carrier, hooks = hooks, list(hooks or ())      # [(resolution, callable)]: each called once, at the first block of <= resolution
+        if carrier is not None:
+            del carrier[:]
         for li, (ly, (x, xn, y)) in enumerate(zip(reversed(P['layers']), reversed(saved))):
             while hooks and max(h[0] for h in hooks) >= y.shape[1]:
                 h = max(hooks, key=lambda q: q[0])
@@ -257,24 +263,15 @@ class ProgGANWrapper(nn.Module):
 
     # -- the un-shifted pass G(z) in stages (extension; trainer.TrainStep, as StyleGAN2Wrapper) ------------------------------
     def begin(self, z, precision=None, pause_res=32):
-        g = self.G._fwd_gen(z.reshape(z.shape[0], -1), False, self.G.resolve_precision(precision), pause_res)
-        next(g)
-        return g
+        return L.StagedPass(self.G._fwd_gen(z.reshape(z.shape[0], -1), False, self.G.resolve_precision(precision), pause_res))
 
     @staticmethod
     def advance(handle):
-        try:
-            next(handle)
-        except StopIteration as e:
-            return e.value[0]
-        return None
+        return handle.advance()
 
     @staticmethod
     def finish(handle):
-        while True:
-            img = ProgGANWrapper.advance(handle)
-            if img is not None:
-                return img
+        return handle.finish()
 
 
 def build_proggan(pretrained_gan_weights=None, num_blocks=18):

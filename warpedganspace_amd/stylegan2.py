@@ -147,13 +147,19 @@ class _Synthesis(torch.autograd.Function):
         ctx.prec = prec                                      # the backward runs in the arithmetic its forward ran in
         img, saved = G._synthesis_fwd(w, ctx.needs_input_grad[1], prec)
         ctx.G, ctx.saved = G, saved
+        # side work for THIS forward's backward (Generator.bwd_hooks): the list object is bound to this autograd node and taken off the
+        # generator, so that another forward / backward of the same generator in between neither sees nor consumes it
+        ctx.hooks = None
+        if ctx.needs_input_grad[1]:
+            ctx.hooks, G.bwd_hooks = G.bwd_hooks, None
         if G.debug_keep is not None and saved is not None:   # leaky-relu gates of every StyledConv, NCHW (tests)
             G.debug_keep['synthesis'] = [(o > 0).permute(0, 3, 1, 2) for o in saved[1]]
         return img
 
     @staticmethod
     def backward(ctx, gimg):
-        return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous(), ctx.prec), None
+        hooks, ctx.hooks = ctx.hooks, None
+        return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous(), ctx.prec, hooks), None
 
 
 class Generator(nn.Module):
@@ -196,8 +202,10 @@ class Generator(nn.Module):
         self._prep = None
         self.debug_keep = None   # tests set this to {} to read back the activation gates of a forward
         self._route = {}            # cached kernel-route decisions of this generator's launches (queries of the library, per shape)
-        self.bwd_hooks = None       # [(resolution, callable), ...] for the NEXT synthesis backward: each is called once, when the pass reaches a layer
-                                    # of <= resolution (trainer.TrainStep: side work that should run under the backward's latency-bound tail)
+        # A LIST set here before a differentiable forward is bound to that forward's autograd node (and taken off the generator); the
+        # (resolution, callable) entries it holds when THAT forward's backward runs — they may be appended after the forward — are each
+        # called once, when the pass reaches a layer of <= resolution (trainer.TrainStep: side work under the backward's latency-bound tail)
+        self.bwd_hooks = None
         # arithmetic of the convs when forward() is not told otherwise (conv.PRECISION_NAMES); the reference's is fp32
         self.precision = 'fp32'
         self.mixed_policy = None  # conv.MixedPolicy override of 'mixed' (None: conv.mixed_policy(size))
@@ -345,32 +353,23 @@ class Generator(nn.Module):
         synthesis_finish().  `pause_res` may be a tuple of ascending resolutions: the pass then pauses before the first layer above
         each.  The low-resolution layers are latency-bound (a tenth of the FLOPs, a quarter of the pass's time): the training step
         runs them for the NEXT batch's un-shifted pass next to the same layers of this batch's shifted pass (trainer.TrainStep)."""
-        g = self._synthesis_gen(w.contiguous(), False, prec, pause_res)
-        next(g)
-        return g
+        return L.StagedPass(self._synthesis_gen(w.contiguous(), False, prec, pause_res))
 
     @staticmethod
     def synthesis_advance(handle):
         """Enqueue the layers up to the next pause resolution: None while the pass is paused again, the image when it is complete."""
-        try:
-            next(handle)
-        except StopIteration as e:
-            return e.value[0]
-        return None
+        return handle.advance()
 
     @staticmethod
     def synthesis_finish(handle):
         """Enqueue everything that is left: the image."""
-        while True:
-            img = Generator.synthesis_advance(handle)
-            if img is not None:
-                return img
+        return handle.finish()
 
     def _synthesis_gen(self, w, save, prec, pause_res):
         """The synthesis pass as a Python generator: yields before the first layer whose output exceeds `pause_res` (an int, or a tuple of
         ascending resolutions with one pause each; None: never; at least once when a pause resolution is given) and returns (image, saved)."""
         P = self._prepare()
-        pol = self.mixed_policy or C.mixed_policy(self.size)
+        pol = self.mixed_policy or C.mixed_policy(self.size, prec)
         lib, st = L.lib(), L.stream()
         w = w.contiguous()
         B = w.shape[0]
@@ -501,10 +500,10 @@ class Generator(nn.Module):
             yield None                    # (a generator smaller than the pause resolution: everything ran in the first stage)
         return skip, saved
 
-    def _synthesis_bwd(self, saved, dimg, prec):
+    def _synthesis_bwd(self, saved, dimg, prec, hooks=None):
         """d image [B,3,S,S] -> d latent [B, style_dim] (all n_latent copies of w summed)."""
         P = self._prepare()
-        pol = self.mixed_policy or C.mixed_policy(self.size)
+        pol = self.mixed_policy or C.mixed_policy(self.size, prec)
         lib, st = L.lib(), L.stream()
         S, outs, demods, B = saved
         dev = dimg.device
@@ -529,7 +528,9 @@ class Generator(nn.Module):
         gA, sA_off = None, None                      # un-scaled dgrad of the consumer conv, its style slice
         sg = []                                      # style-gradient reductions of the pass, launched together at the end
         num_next = None
-        hooks, self.bwd_hooks = list(self.bwd_hooks or ()), None
+        carrier, hooks = hooks, list(hooks or ())
+        if carrier is not None:
+            del carrier[:]                       # consumed: the step sees an empty list when every hook has been taken over by this pass
         for i in range(len(layers) - 1, -1, -1):
             ly = layers[i]
             Co = ly['Co']

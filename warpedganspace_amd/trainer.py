@@ -228,32 +228,39 @@ class TrainStep:
         self.r_arith = r_arith(self._r_precision, self.precision)
         self._pre, self._cold = None, True
 
-    def check_precision(self, gate=1e-3):
+    def check_precision(self, gate=1e-3, batches=1):
         """Run-time guard of a 16-bit generator mode (the per-architecture policy tables were calibrated on random-init weights):
-        image error of this engine's arithmetic against the exact-fp32 kernels on a fresh batch of latent codes, with THIS
-        generator's weights.  Max-norm relative error, of the batch tensor (how the parity tests apply the north_star's 1e-3 gate)
+        image error of this engine's arithmetic against the exact-fp32 kernels on `batches` fresh batches of latent codes, with THIS
+        generator's weights.  Max-norm relative error, of each batch tensor (how the parity tests apply the north_star's 1e-3 gate)
         and per single image.  Draws from its own generator (identical on every rank): the training sample stream is untouched.  None for fp32 engines."""
         if not C.is_reduced(self.precision):
             return None
         g = torch.Generator(device=self.dev)
         g.manual_seed(0x5DEECE66D + self.steps_done)       # the same codes on every rank: every rank takes the same decision
-        z = sample_z(self.B, self.G.dim_z, truncation=getattr(self.p, 'z_truncation', None), device=self.dev, generator=g)
-        # a class-conditional wrapper draws its class ids per call (numpy RNG, different on every rank): both passes must render the
-        # SAME classes, and every rank the same ones — drawn here from the check's own generator (ADVICE r3)
-        kw = {}
-        tc = getattr(self.G, 'target_classes', None)
-        if tc is not None and hasattr(self.G, 'mixed_classes'):
-            pool = tc.detach().reshape(-1).to(self.dev)
-            kw['classes'] = pool[torch.randint(0, pool.numel(), (self.B,), device=self.dev, generator=g)]
-        with torch.no_grad():
-            ref = self.G(z, precision='fp32', **kw)
-            img = self.G(z, precision=self.precision, **kw)
-            d, m = (img - ref).abs().flatten(1).amax(1), ref.abs().flatten(1).amax(1)
-            per = (d / m.clamp_min(1e-30)).cpu()
-            batch = float(d.max() / m.max().clamp_min(1e-30))
+        per, bat = [], []
+        for _ in range(max(1, int(batches))):
+            z = sample_z(self.B, self.G.dim_z, truncation=getattr(self.p, 'z_truncation', None), device=self.dev, generator=g)
+            # a class-conditional wrapper draws its class ids per call (numpy RNG, different on every rank): both passes must render the
+            # SAME classes, and every rank the same ones — drawn here from the check's own generator (ADVICE r3)
+            kw = {}
+            tc = getattr(self.G, 'target_classes', None)
+            if tc is not None and hasattr(self.G, 'mixed_classes'):
+                pool = tc.detach().reshape(-1).to(self.dev)
+                kw['classes'] = pool[torch.randint(0, pool.numel(), (self.B,), device=self.dev, generator=g)]
+            with torch.no_grad():
+                ref = self.G(z, precision='fp32', **kw)
+                img = self.G(z, precision=self.precision, **kw)
+                d, m = (img - ref).abs().flatten(1).amax(1), ref.abs().flatten(1).amax(1)
+                per.append(d / m.clamp_min(1e-30))
+                bat.append(d.max() / m.max().clamp_min(1e-30))
+                del ref, img
+        per, bat = torch.cat(per).cpu(), torch.stack(bat).cpu()
+        batch = float(bat.max())
         self._cold = True       # the fp32 pass may have built weight caches on this stream: keep the next step single-stream
-        return {'precision': C.precision_name(self.precision), 'batch': batch, 'per_image_median': float(per.median()),
-                'per_image_max': float(per.max()), 'gate': gate, 'ok': bool(batch < gate and batch == batch), 'n': int(per.numel())}
+        return {'precision': C.precision_name(self.precision), 'batch': batch, 'batch_median': float(bat.median()),
+                'per_image_median': float(per.median()), 'per_image_p99': float(per.quantile(0.99)), 'per_image_max': float(per.max()),
+                'over_gate_frac': float((per > gate).float().mean()), 'gate': gate, 'ok': bool(batch < gate and batch == batch),
+                'n': int(per.numel())}
 
     def _out_size(self):
         """Output resolution of the generator (StyleGAN2: .size; ProgGAN: from its block count); 256 when it cannot be told."""
@@ -385,7 +392,19 @@ class TrainStep:
         if pad:
             shift = shift[:, :self.d].contiguous()
         shift.requires_grad_(True)
-        img_shifted = G(z, shift, precision=prec)                                             # :239, input-gradient only
+        # side work to be enqueued from inside THIS forward's backward (the prefetched pass's tail, deferred weight gradients): the list
+        # is bound to the forward's autograd node by the generator (Generator.bwd_hooks) — entries are appended below, once they exist;
+        # no other forward / backward of the generator sees them
+        inner = getattr(G, 'G', None)
+        hookable = hasattr(inner, 'bwd_hooks')
+        hooks = []
+        if hookable:
+            inner.bwd_hooks = hooks
+        try:
+            img_shifted = G(z, shift, precision=prec)                                         # :239, input-gradient only
+        finally:
+            if hookable:
+                inner.bwd_hooks = None      # (taken by the forward; cleared here if it failed or kept nothing)
         if side is not None and not pre_img:
             cur.wait_stream(side)
             img.record_stream(cur)
@@ -440,7 +459,6 @@ class TrainStep:
         _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred, **({'sw': sw} if sw else {}))
         del saved
         pending = []
-        hooks = []                          # side work enqueued from inside the generator's backward (synthesis hooks)
 
         def run_wgrads(deferred=deferred):
             side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -454,8 +472,6 @@ class TrainStep:
                     # is queued behind them and overlaps the generator's backward (no trainable parameters)
                     _, a, b = self.bucket.groups[0]
                     pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
-        inner = getattr(G, 'G', None)
-        hookable = hasattr(inner, 'bwd_hooks')
         if deferred is not None:
             if self.wgrad_hook_res and hookable and self.world == 1:
                 hooks.append((self.wgrad_hook_res, run_wgrads))     # under the backward's latency-bound tail instead of next to its chip-filling layers
@@ -466,22 +482,13 @@ class TrainStep:
             _, a, b = self.bucket.groups[0]
             pending.append(dist.all_reduce(self.bucket.grad[a:b], async_op=True))
         if tail is not None:
-            if hookable:
-                hooks.append((self.tail_hook_res, tail))
-        if hooks:
-            inner.bwd_hooks = hooks
+            hooks.append((self.tail_hook_res, tail))      # (a generator without hooks: run after its backward, below)
         try:
             img_shifted.backward(d_img)                                       # G: d image -> d shift
-        except BaseException:
-            if hookable:
-                inner.bwd_hooks = None      # (a failed backward must not leave this step's closures for the generator's next one)
-            raise
-        if hookable and inner.bwd_hooks is not None:      # (a backward that did not pass through the synthesis hooks)
-            for h in sorted(inner.bwd_hooks, key=lambda q: -q[0]):
-                h[1]()
-            inner.bwd_hooks = None
-        elif tail is not None and not hookable:
-            tail()
+        finally:
+            left, hooks[:] = list(hooks), []    # consumed by the synthesis backward (it empties the list it was handed); what is left did not
+        for h in sorted(left, key=lambda q: -q[0]):                          # pass through it (no hook support, a backward that kept nothing): run now
+            h[1]()
         dtable = gb[id(S.SUPPORT_SETS)]
         dlg = gb[id(S.LOGGAMMA)].reshape(-1) if (S.learn_gammas and id(S.LOGGAMMA) in gb) else None
         dal = gb[id(S.ALPHAS)] if (S.learn_alphas and id(S.ALPHAS) in gb) else None
@@ -557,6 +564,9 @@ class Trainer(object):
                 self.tb_writer = SummaryWriter(log_dir=self.tb_dir)
             except Exception as e:  # noqa: BLE001
                 print("#. TensorBoard unavailable ({}); continuing without it".format(e))
+        # Whether statistics are popped EVERY iteration (TensorBoard scalars) — a collective when world > 1 (TrainStep.pop_stats
+        # all-reduces), so the decision must be the same on every rank although only rank 0 owns a writer: agreed on in train().
+        self.tb_active = self.tb_writer is not None
         self.iter_times = np.array([])
         self.stat_tracker = TrainingStatTracker()
 
@@ -606,6 +616,24 @@ class Trainer(object):
         print("         ===================================================================")
         if sys.stdout.isatty():
             update_stdout(10)
+
+    def agree_tensorboard(self, device=None):
+        """Rank 0's "a TensorBoard writer exists" broadcast to every rank (the writer is rank 0's alone, and creating it can fail there:
+        the other ranks cannot derive it from --tensorboard).  pop_stats() contains an all-reduce: every rank must enter it in the
+        same iterations."""
+        flag = 1 if self.tb_writer is not None else 0
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            on_dev = dist.get_backend() == 'nccl' and device is not None
+            t = torch.tensor([flag], dtype=torch.int64, device=device if on_dev else 'cpu')
+            dist.broadcast(t, 0)
+            flag = int(t.item())
+        self.tb_active = bool(flag)
+        return self.tb_active
+
+    def stats_due(self, iteration):
+        """True in the iterations whose statistics are popped (one device sync + one all-reduce when world > 1): a function of
+        rank-invariant state only."""
+        return bool(self.tb_active or iteration % self.params.log_freq == 0)
 
     def precision_check(self, engine, iteration):
         """--check-precision: measure the generator arithmetic's image error on the current weights; a mode that misses the
@@ -657,6 +685,7 @@ class Trainer(object):
             print("#. Restored Adam moments (step {}) from the checkpoint".format(engine.bucket.step_count))
         if self.rank == 0:
             print("#. Start training from iteration {}".format(starting_iter))
+        self.agree_tensorboard(dev)
         check_every = int(getattr(p, 'check_precision', 0) or 0)
         if C.is_f16_operand(engine.precision):      # an fp16-operand mode: check it once against the exact-fp32 kernels on THESE weights
             self.precision_check(engine, starting_iter - 1)
@@ -668,8 +697,8 @@ class Trainer(object):
             engine.step()
             if check_every and C.is_reduced(engine.precision) and iteration % check_every == 0:
                 self.precision_check(engine, iteration)
-            if self.tb_writer is not None or iteration % p.log_freq == 0:
-                stats = engine.pop_stats()           # one device sync
+            if self.stats_due(iteration):
+                stats = engine.pop_stats()           # one device sync (+ one all-reduce: every rank takes this branch in the same iterations)
                 now = time.time()
                 self.iter_times = np.append(self.iter_times, np.full(iteration - mark_iter, (now - mark_t) / (iteration - mark_iter)))
                 mark_t, mark_iter = now, iteration
