@@ -77,7 +77,7 @@ DTYPE_TEXT = {
              "3.2): fp16 operands (1 or 2 MFMAs per product) in the layers at >= 64x64, split-bf16 x3 (fp32-class) below; fp32 accumulate / "
              "demodulation / epilogue everywhere; dynamic power-of-two scale on every fp16 operand",
 }
-DTYPE_TEXT['mixed-strict'] = DTYPE_TEXT['mixed'] + " — the STRICT table (conv.MIXED_STRICT_POLICIES): no single image of the 2 304-image sample over 1e-3"
+DTYPE_TEXT['mixed-strict'] = DTYPE_TEXT['mixed'] + " — per-layer table CALIBRATED on the engine's own generator (conv.STRICT_LADDER): the cheapest rung with no single image of a 2 304-code sample over 0.95e-3"
 R_TEXT = {(5, 5, 0): "; reconstructor (trained): fp32 MFMA, Winograd form of the 3x3 stride-1 forward / input-gradient convs, direct exact "
                      "fp32 for the rest and for every weight gradient; BatchNorm statistics in fp64 partials",
           (0, 0, 0): "; reconstructor (trained): exact fp32 MFMA forward, input-gradient and weight-gradient convs; BatchNorm statistics in fp64 partials",
@@ -385,20 +385,29 @@ def cpu_baseline(size, K, N, b, steps, threads):
     sd_s = O.support_sets_init(K, N, 512, 1.0 / 512)
     sd_r = {k: v.detach().clone().contiguous() for k, v in Reconstructor('ResNet', K).state_dict().items()}
     ref = O.ReferenceStep(sd_g, sd_s, sd_r, size, learn_gammas=True, gamma=1.0 / 512, g_requires_grad=True)
+    # all physical cores first; on a 2 x 64-core host PyTorch-CPU's convolutions at batch 4 run SLOWER on 128 threads than
+    # on 32 (27.5 s against 10.6 s per step, round 5), so the same step is also timed on min(32, cores) threads and the better rate is the
+    # baseline — both are stated
+    counts = [threads] + ([32] if threads > 32 else [])
     g = torch.Generator().manual_seed(1)
-    times = []
-    for it in range(steps):
-        z = torch.randn(b, 512, generator=g)
-        idx = torch.randint(0, K, (b,), generator=g)
-        mag = (torch.rand(b, generator=g) * 0.2 + 0.25)
-        t0 = time.time()
-        ref.step(z, idx, mag)
-        times.append(time.time() - t0)
-    dt = sum(times) / len(times)
-    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d step(s) of batch %d (after a 32x32 warm-up step), StyleGAN2-%d K=%d N=%d ResNet-18, reference step as written "
-                      "(lib/trainer.py:190-254) replayed by oracle/wgs_oracle.py on PyTorch-CPU; per-step seconds %s"
-                      % (steps, b, size, K, N, [round(t, 2) for t in times])}
+    z = torch.randn(b, 512, generator=g)
+    idx = torch.randint(0, K, (b,), generator=g)
+    mag = (torch.rand(b, generator=g) * 0.2 + 0.25)
+    by = {}
+    for n in counts:
+        torch.set_num_threads(n)
+        ts = []
+        for it in range(steps):
+            t0 = time.time()
+            ref.step(z, idx, mag)
+            ts.append(time.time() - t0)
+        by[n] = ts
+    best = min(by, key=lambda n: sum(by[n]) / len(by[n]))
+    dt = sum(by[best]) / len(by[best])
+    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": best, "kind": "port", "physical_cores": threads,
+            "sample": "%d step(s) of batch %d per thread count (after a 32x32 warm-up step), StyleGAN2-%d K=%d N=%d ResNet-18, reference step as written "
+                      "(lib/trainer.py:190-254) replayed by oracle/wgs_oracle.py on PyTorch-CPU; per-step seconds by threads: %s"
+                      % (steps, b, size, K, N, {n: [round(t, 2) for t in v] for n, v in by.items()})}
 
 
 # Short runs of the other arithmetic modes and BASELINE configs (N = 1 only).
@@ -454,6 +463,8 @@ def run_one(dev, gan, size, K, N, B, prec, r_prec, w_space, steps, warmup, gkey,
         rec["dtype_detail"] = DTYPE_TEXT[name] + R_TEXT.get(tuple(eng.r_arith), "; reconstructor arithmetic (forward, dgrad, wgrad; 0 exact fp32, 1 split-bf16 x3): %s" % (tuple(eng.r_arith),))
         rec["roofline"] = roofline_of(recs, B * steps / dt, GFLOP_PER_IMG.get(gkey))
         rec["host"] = host_overheads(eng)
+    if getattr(eng, 'strict_calibration', None):
+        rec["strict_calibration"] = eng.strict_calibration
     if check:
         try:
             rec["precision_check"] = precision_check(eng)
@@ -590,7 +601,8 @@ def final_line(full, extra_file):
             continue
         if e.get("key") == "cfg3_mixed_strict" and "product" in line and "error" not in e:
             pc = e.get("precision_check") or {}
-            line["product"]["strict"] = {"precision": e.get("precision"), "value": e.get("value"), "ms_per_step": e.get("ms_per_step"),
+            line["product"]["strict"] = {"precision": e.get("precision"), "table": (e.get("strict_calibration") or {}).get("table"),
+                                         "value": e.get("value"), "ms_per_step": e.get("ms_per_step"),
                                          "precision_check": {k: pc.get(k) for k in ("batch_max", "image_p99", "image_max", "over_gate_frac", "n")} if pc else None}
             continue
         others[str(e.get("key") or e.get("config", "?"))[:40]] = e.get("value") if "error" not in e else "error"
@@ -622,7 +634,7 @@ def main():
     ap.add_argument('--w-space', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=4)
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=1)
     ap.add_argument('--cpu-threads', type=int, default=0, help="threads of the CPU baseline (0 = every physical core this process may run on)")
     ap.add_argument('--precision', choices=tuple(C.PRECISION_NAMES), default='fp32w',
                     help="arithmetic of the HEADLINE run's generator convs (default: fp32w = fp32, Winograd form of the 3x3 stride-1 convs)")

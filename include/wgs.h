@@ -241,6 +241,12 @@ typedef struct wgs_wgrad_desc {
                             the (tap, channel) pairs flattened into the GEMM columns); other shapes use the exact kernel. */
     int32_t x_s2d;       /* != 0: x is stored space-to-depth, [B, Hi/2, Wi/2, 4*Ci] with channel (py*2 + px)*Ci + c (wgs_pack_pair_s2d);
                             Ci == 8: the ResNet stem's weight gradient without a second copy of its input */
+    void* ws;            /* (ABI 8) optional scratch, ws_bytes long, 16-byte aligned, private to the stream.  With it, stride-1 3 x 3 'same'
+                            launches with Co % 64 == 0, Ci % 64 == 0, Wo % 8 == 0, pixels % 16 == 0 take the direct-fragment kernel
+                            (conv_wgrad_direct.hip): operand fragments straight from global memory, no LDS staging, partial tiles of the
+                            pixel-range splits written here and added in split order — no atomics, bit-reproducible.  One split needs
+                            Co * Ci * 9 * 4 bytes; NULL: the staged kernels (split-K atomics). */
+    int64_t ws_bytes;
 } wgs_wgrad_desc;
 int wgs_conv_wgrad(const wgs_wgrad_desc* desc, wgs_stream_t stream);
 

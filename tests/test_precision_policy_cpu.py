@@ -69,7 +69,8 @@ def test_mixed_policy_per_layer():
 
 def test_fused_upconv_selection():
     assert C.upconv_fused_ok(128, 256, 128, 3) and C.upconv_fused_ok(32, 512, 512, 2)
-    assert not C.upconv_fused_ok(128, 256, 128, 1)          # split-bf16 keeps the phase GEMMs + blur kernel
+    assert C.upconv_fused_ok(128, 256, 128, 1) and C.upconv_fused_ok(32, 512, 512, 1)       # round 5: split-bf16 through the fused kernel from 32 x 32 inputs
+    assert not C.upconv_fused_ok(16, 512, 512, 1)           # ... below that the phase GEMMs + blur kernel
     assert not C.upconv_fused_ok(128, 256, 128, 0)
     assert not C.upconv_fused_ok(8, 512, 512, 2)            # maps below 16 x 16
     assert C.upconv_fused_ok(512, 64, 32, 2)                # 32 output channels: one half-filled 64-column tile (StyleGAN2-1024's last up-sampling layer)

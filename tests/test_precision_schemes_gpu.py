@@ -40,40 +40,45 @@ def test_image_and_shared_gate_gradient_per_scheme(dev, size, B):
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     z = GI.rt(11 + size, B, 512)
     rows = {}
-    if True:
-        for name in ('fp32', 'fp32w', 'bf16x3', 'f16', 'f16x2', 'mixed'):
-            res = {}
-            for w_space in (True, False):
-                G.debug_keep = {}
-                sh = (GI.rt(12 + size, B, 512) * 0.1).to(dev).requires_grad_(True)
-                img = StyleGAN2Wrapper(G, w_space)(z.to(dev), sh, precision=name)
-                probe = GI.rt(13 + size, *img.shape)
-                (img * probe.to(dev)).sum().backward()
-                gates = ([] if w_space else [g.cpu() for g in G.debug_keep['mapping']]) + [g.cpu() for g in G.debug_keep['synthesis']]
-                G.debug_keep = None
-                sho = (GI.rt(12 + size, B, 512) * 0.1).double().requires_grad_(True)
-                if w_space:
-                    w = O.sg2_mapping(sd64, z.double()).detach()
-                    O.GATE_OVERRIDE = iter(gates)
-                    img_o = O.sg2_synthesis(sd64, w + sho, size)
-                else:
-                    O.GATE_OVERRIDE = iter(gates)
-                    img_o = O.sg2_generate(sd64, z.double(), size, sho)
-                O.GATE_OVERRIDE = None
-                (img_o * probe.double()).sum().backward()
-                tag = 'W' if w_space else 'Z'
-                res['img_' + tag] = rel_err(img, img_o.detach())
-                res['grad_' + tag] = rel_err(sh.grad, sho.grad)
-                del img_o, sho
-            rows[name] = res
-            print('StyleGAN2-%d %-7s image err W %.2e Z %.2e | shared-gate gradient err W %.2e Z %.2e' % (
-                size, name, res['img_W'], res['img_Z'], res['grad_W'], res['grad_Z']))
-    _record('stylegan2_%d' % size, rows)
+    # Every evaluation is one float64 forward + backward of the oracle on the CPU (15 - 30 s at these sizes): the suite runs what it ASSERTS
+    # on — the three fp32-class modes in W space, the architecture's default in W and Z space (5 evaluations); WGS_FULL_SCHEMES=1 (the round's
+    # profile run, tools/run_round.sh) adds the reported-only fp16 modes and the Z-space rows of every mode (12) for profiles/r*_precision_schemes.json
+    full = os.environ.get('WGS_FULL_SCHEMES') == '1'
+    default = C.AUTO_TABLE.get(('stylegan2', size), C.AUTO_FALLBACK)
+    for name in (('fp32', 'fp32w', 'bf16x3', 'f16', 'f16x2', 'mixed') if full else ('fp32', 'fp32w', 'bf16x3', default)):
+        res = {}
+        for w_space in ((True, False) if (full or name == default) else (True,)):
+            G.debug_keep = {}
+            sh = (GI.rt(12 + size, B, 512) * 0.1).to(dev).requires_grad_(True)
+            img = StyleGAN2Wrapper(G, w_space)(z.to(dev), sh, precision=name)
+            probe = GI.rt(13 + size, *img.shape)
+            (img * probe.to(dev)).sum().backward()
+            gates = ([] if w_space else [g.cpu() for g in G.debug_keep['mapping']]) + [g.cpu() for g in G.debug_keep['synthesis']]
+            G.debug_keep = None
+            sho = (GI.rt(12 + size, B, 512) * 0.1).double().requires_grad_(True)
+            if w_space:
+                w = O.sg2_mapping(sd64, z.double()).detach()
+                O.GATE_OVERRIDE = iter(gates)
+                img_o = O.sg2_synthesis(sd64, w + sho, size)
+            else:
+                O.GATE_OVERRIDE = iter(gates)
+                img_o = O.sg2_generate(sd64, z.double(), size, sho)
+            O.GATE_OVERRIDE = None
+            (img_o * probe.double()).sum().backward()
+            tag = 'W' if w_space else 'Z'
+            res['img_' + tag] = rel_err(img, img_o.detach())
+            res['grad_' + tag] = rel_err(sh.grad, sho.grad)
+            del img_o, sho
+        rows[name] = res
+        print('StyleGAN2-%d %-7s ' % (size, name) + ' | '.join('%s %.2e' % kv for kv in sorted(res.items())))
+    if full:
+        _record('stylegan2_%d' % size, rows)
     for name, res in rows.items():
-        ok = res['img_W'] < GATE and res['img_Z'] < GATE and res['grad_W'] < GATE and res['grad_Z'] < GATE
+        ok = all(v < GATE for v in res.values())
         if name in ('fp32', 'fp32w', 'bf16x3'):
             assert res['img_W'] < 1e-4 and res['grad_W'] < 2e-4, (name, res)
-        default = C.AUTO_TABLE.get(('stylegan2', size), C.AUTO_FALLBACK)
+        if name == default:
+            assert set(res) == {'img_W', 'img_Z', 'grad_W', 'grad_Z'}
         if not ok:
             assert name != default, "default arithmetic %s of StyleGAN2-%d misses the 1e-3 gate: %r" % (name, size, res)
         elif name == default:

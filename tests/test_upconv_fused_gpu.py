@@ -138,3 +138,41 @@ def test_upconv_fused_rejects_bad_shapes(dev):
     with pytest.raises(L.WgsError):
         C.upconv_blur_act(x, C.split_weight(wp, 2), blur_kernel().float().to(dev), torch.ones(1, 24, device=dev), 24,
                           torch.ones(1, 64, device=dev), None, None, torch.zeros(64, device=dev), 2)
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(2, 32, 64, 16), (1, 64, 128, 14), (1, 96, 64, 33), (32, 64, 64, 32), (3, 32, 128, 5)])
+def test_upconv_fused_split_bf16_is_fp32_class(dev, B, Ci, Co, H):
+    """Round 5: the fused kernel in split-bf16 (precision 1: hi + lo planes of BOTH operands, three MFMAs per product) — the arithmetic
+    StyleGAN2-256's 32 -> 64 up-sampling layer runs in under the default policy.  fp32-class against the float64 layer, and next to the
+    unfused launches (phase GEMMs + blur kernel) of the same arithmetic; both tile shapes (B = 32 at 32 x 32 fills the chip: 8-wave tiles)."""
+    torch.manual_seed(Ci * 5 + Co + H)
+    x = torch.randn(B, Ci, H, H, dtype=torch.float64)
+    w = torch.randn(Co, Ci, 3, 3, dtype=torch.float64) / (Ci * 9) ** 0.5
+    sc = (torch.randn(B, Ci) + 1.0).double()
+    demod = (torch.rand(B, Co) + 0.5).double()
+    noise = torch.randn(2 * H, 2 * H, dtype=torch.float64)
+    nw, bias, kern = 0.3, torch.randn(Co, dtype=torch.float64) * 0.2, blur_kernel()
+    xs = (x.float() * sc.float()[:, :, None, None]).double()
+    y_x = layer_f64(xs, w.float().double(), demod.float().double(), kern.float().double(), noise.float().double(), nw, bias.float().double())
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    wp = C.pack_weight(w.float()).to(dev)
+    ws = C.split_weight(wp, 1)
+    S = sc.float().to(dev).contiguous()
+    dm_d, k_d, nz_d = demod.float().to(dev), kern.float().to(dev), noise.float().reshape(-1).to(dev)
+    nw_d, b_d = torch.tensor([nw], device=dev), bias.float().to(dev)
+    amax = torch.zeros(1, device=dev)
+    L.lib().wgs_dev_trace_kernels(1)
+    y = C.upconv_blur_act(xd, ws, k_d, S, Ci, dm_d, nz_d, nw_d, b_d, 1, y_amax=amax)
+    sym = L.lib().wgs_dev_last_kernel().decode()
+    L.lib().wgs_dev_trace_kernels(0)
+    assert sym.startswith('upconv_blur_kernel<0, '), sym
+    e = rel_err(y.permute(0, 3, 1, 2), y_x)
+    assert e < 3e-5, e                                              # split-bf16: ~2^-16 per product
+    assert abs(amax.item() - y.abs().max().item()) <= 1e-6 * amax.item()
+    t = C.conv_transpose2d_s2(xd, wp, a_scale=S, a_ld=Ci, col_scale=dm_d, w_split=ws, precision=1)
+    y2 = torch.empty_like(y)
+    L.check(L.lib().wgs_sg2_blur_noise_bias_act(L.ptr(t), L.ptr(k_d), L.ptr(nz_d), L.ptr(nw_d), L.ptr(b_d), L.ptr(y2), None,
+                                                B, 2 * H, 2 * H, Co, L.stream()), 'blur_nba')
+    assert rel_err(y, y2) < 3e-5
+    with pytest.raises(L.WgsError):                                  # one plane only: refused
+        C.upconv_blur_act(xd, (ws[0], None), k_d, S, Ci, dm_d, nz_d, nw_d, b_d, 1)

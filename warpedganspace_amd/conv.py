@@ -57,8 +57,8 @@ class WgradDesc(ctypes.Structure):
 #   2 'f16'    fp16 operands, 1 MFMA per product, fp32 accumulate (image error ~8e-4 at 256^2: ON the 1e-3 gate, reported only)
 #   3 'f16x2'  fp16 activations x (hi + lo) fp16 weights, 2 MFMAs (image error ~5e-4)
 #   4 'mixed'  StyleGAN2 only: per-layer arithmetic from an error budget, see MixedPolicy
-#   6 'mixed-strict'  as 'mixed' with the STRICT per-layer table (MIXED_STRICT_POLICIES): no single image of the 2 304-image sample over the
-#              1e-3 gate (the default table holds the gate per batch tensor with 38 % margin and per image at the 99.9th percentile)
+#   6 'mixed-strict'  as 'mixed' with a per-layer table CALIBRATED on the generator's own weights so that no single image of a 2 304-image
+#              sample is over the 1e-3 gate (STRICT_LADDER; the default table holds the gate per batch tensor and per image at p99 - p99.9)
 #   5 'fp32w'  fp32 with the 3x3 stride-1 convs in Winograd F(2x2,3x3) form on the fp32 matrix cores (2.25x fewer multiplies, ~1e-6
 #              against the direct form, 3e-6 against fp64: no wider than the direct fp32 kernel); the rest as 'fp32'
 #  -1 'auto'   per generator: the cheapest mode whose measured image error stays inside the north_star's 1e-3 gate for that
@@ -115,11 +115,29 @@ MIXED_256 = MixedPolicy({128: (2, 3), 256: (2, 3)}, bwd_table={64: (2, 2)})
 # measured image within 1e-3 (max 8.5e-4).  fp16 in the 64^2 .. 256^2 layers as well measures 1.1e-3 .. 1.4e-3 at this depth.
 MIXED_1024 = MixedPolicy({512: (3, 3), 1024: (3, 3)}, bwd_table={64: (2, 2), 128: (2, 2), 256: (2, 2)})
 MIXED_POLICIES = {256: MIXED_256, 1024: MIXED_1024}
-# 'mixed-strict' (VERDICT r4 #7): the cheapest measured table with NO single image over 1e-3 in the 2 304-image sample (4 weight fills x
-# 576 codes, tools/policy_sweep.py; profiles/r5_policy_sweep.md).  StyleGAN2-256: the two 128^2 / 256^2 stride-1 convs in fp16 x2 as well
-# (activation rounding only: ~1.7e-4 per layer instead of 2.5e-4).  StyleGAN2-1024: the default table already measures max 9.2e-4 over its sample.
-MIXED_256_STRICT = MixedPolicy({128: (3, 3), 256: (3, 3)}, bwd_table={64: (2, 2), 128: (2, 2), 256: (2, 2)})
-MIXED_STRICT_POLICIES = {256: MIXED_256_STRICT, 1024: MIXED_1024}
+# 'mixed-strict' (VERDICT r4 #7): NO single image over the 1e-3 gate.  Which table achieves that depends on the weights: the sweep's
+# well-conditioned fills (profiles/r5_policy_sweep.md: 4 fills x 576 codes) put the default table at max 1.06e-3 / 0.1 % over and table `f`
+# below at 9.3e-4 / none over, but on bench.py's raw constructor initialisation (a mapping network that collapses every z onto nearly one
+# w) the same tables measure 1.27e-3 / 1.0 % and 1.11e-3 / 0.09 %.  So the strict mode is CALIBRATED: a step engine built with
+# 'mixed-strict' measures the ladder below on its own generator (trainer.TrainStep.calibrate_strict: 2 304 codes against the exact-fp32
+# kernels) and takes the first — cheapest — table whose worst single image stays under 0.95 x the gate; the last rung is split-bf16
+# everywhere.  Backward arithmetic is the default table's on every rung (the gradient has its own gate, section 3.2 of DESIGN.md).
+_BWD_256 = {64: (2, 2), 128: (2, 2), 256: (2, 2)}
+_BWD_1024 = {64: (2, 2), 128: (2, 2), 256: (2, 2), 512: (3, 2), 1024: (3, 2)}
+STRICT_LADDER = {
+    256: [('default 128:2,3;256:2,3', MIXED_256),
+          ('k 128:2,3;256:3,3', MixedPolicy({128: (2, 3), 256: (3, 3)}, bwd_table=_BWD_256)),
+          ('f 128:3,3;256:3,3', MixedPolicy({128: (3, 3), 256: (3, 3)}, bwd_table=_BWD_256)),
+          ('e 256:2,3', MixedPolicy({256: (2, 3)}, bwd_table=_BWD_256)),
+          ('256:3,3', MixedPolicy({256: (3, 3)}, bwd_table=_BWD_256)),
+          ('bf16x3 everywhere', MixedPolicy({}, bwd_table=_BWD_256))],
+    1024: [('default 512:3,3;1024:3,3', MIXED_1024),
+           ('1024:3,3', MixedPolicy({1024: (3, 3)}, bwd_table=_BWD_1024)),
+           ('bf16x3 everywhere', MixedPolicy({}, bwd_table=_BWD_1024))],
+}
+# before an engine has calibrated (a bare generator call with precision='mixed-strict'): the most conservative fp16 rung
+MIXED_256_STRICT = STRICT_LADDER[256][4][1]
+MIXED_STRICT_POLICIES = {256: MIXED_256_STRICT, 1024: STRICT_LADDER[1024][1][1]}
 
 
 def is_mixed(code):
@@ -466,11 +484,11 @@ class UpconvDesc(ctypes.Structure):
 
 # The fused up-sampling layer (conv_upfused.hip) is taken for the fp16 modes from this input size up (below it a 14 x 14-cell
 # tile wastes most of its GEMM rows on the image border; tools/bench_upfused.py).
-UPCONV_FUSED_MIN_H = {2: 16, 3: 16}
+UPCONV_FUSED_MIN_H = {1: 32, 2: 16, 3: 16}      # (split-bf16: from 32 x 32 inputs, where the 8-wave tile fills the chip at B = 32)
 
 
 def upconv_fused_ok(H, Ci, Co, precision):
-    return precision in (2, 3) and H >= UPCONV_FUSED_MIN_H[precision] and Ci % 32 == 0 and (Co % 64 == 0 or Co == 32)
+    return precision in UPCONV_FUSED_MIN_H and H >= UPCONV_FUSED_MIN_H[precision] and Ci % 32 == 0 and (Co % 64 == 0 or Co == 32)
 
 
 # Forward planes: the fused up-sampling kernel writes the fp16 operand plane of the stride-1 conv that follows it (that conv's style
@@ -592,6 +610,9 @@ def blur_bwd_f16(dy, blur_f, a_amax, a_bound):
     return dt
 
 
+WGRAD_DIRECT = True      # stride-1 3x3 weight gradients through conv_wgrad_direct.hip (no LDS staging, no atomics) where the shape allows
+
+
 def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0, precision=0, x_s2d=False):
     """Accumulate the weight gradient into the zero-initialised dw_packed [Co, k*k, Ci] memory.
     precision 0: exact fp32 MFMA; 1: split-bf16 x3 (fp32-class) where the shape allows it.
@@ -607,6 +628,9 @@ def conv2d_wgrad(x, dy, dw_packed, k, stride=1, pad=0, ksplit=0, precision=0, x_
     d.isy, d.isx, d.ntaps, d.ksplit = stride, stride, k * k, ksplit
     d.precision = precision
     d.x_s2d = int(bool(x_s2d))
+    if WGRAD_DIRECT and k == 3 and stride == 1 and not x_s2d:
+        ws = _workspace(x.device)          # partial tiles of the direct-fragment kernel's pixel-range splits (private to the stream)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     d.w_tap_stride, d.w_row_stride = Ci, k * k * Ci
     i = 0
     for ky in range(k):

@@ -536,6 +536,7 @@ __global__ __launch_bounds__(256) void repack_w_t_kernel(const float* __restrict
 }  // namespace
 
 int wgs_conv_wgrad16(const wgs_wgrad_desc* d, hipStream_t st);      // conv_wgrad16.hip
+int wgs_conv_wgrad_direct(const wgs_wgrad_desc* d, hipStream_t st);      // conv_wgrad_direct.hip
 
 extern "C" {
 
@@ -766,6 +767,11 @@ int wgs_conv_wgrad(const wgs_wgrad_desc* d, wgs_stream_t stream) {
     a.magic_ho = magic_of((long)d->B * d->Ho + 64, d->Ho);
     a.magic_ci = magic_of((long)d->ntaps * d->Ci + 256, d->Ci);
     hipStream_t st = (hipStream_t)stream;
+    WGS_CHECK_ARG(!d->ws || (d->ws_bytes > 0 && ((uintptr_t)d->ws & 15) == 0), "wgs_conv_wgrad: ws needs ws_bytes > 0 and 16-byte alignment");
+    if ((d->precision == 0 || d->precision == 1) && wgs_conv_wgrad_direct(d, st) == 0) {
+        WGS_CHECK_LAUNCH("wgrad_direct_kernel");
+        return WGS_OK;
+    }
     if (d->precision == 1 && wgs_conv_wgrad16(d, st) == 0) {
         WGS_CHECK_LAUNCH("igemm_wgrad16_kernel");
         return WGS_OK;

@@ -1,4 +1,4 @@
-// StyleGAN2 up-sampling layer in ONE kernel (fp16 operand schemes): modulated stride-2 transposed 3x3 conv, demodulation,
+// StyleGAN2 up-sampling layer in ONE kernel (fp16 operand schemes and split-bf16): modulated stride-2 transposed 3x3 conv, demodulation,
 // 4x4 blur, noise, bias, leaky-relu*sqrt(2)   (models/StyleGAN2/model.py:201-212 conv_transpose2d + Blur, :231-241, :264).
 //
 // The unfused path runs the transposed conv as four sub-pixel phase GEMMs that write a (2H+1)^2 intermediate t (1.08 GB at
@@ -79,7 +79,8 @@ struct UpCfg {
     static constexpr int PW = GX + 1, PH = GY + 1, NPIX = PW * PH, PALLOC = (NPIX + 7) / 8 * 8;
     static constexpr int TW = 2 * GX, TH = 2 * GY;                     // t tile positions
     static constexpr int OW = 2 * CX, OR = 2 * CY;                     // output block
-    static constexpr int TS = GH == 16 ? (NA * NB == 1 ? 9 : 5) : (NA * NB == 1 ? 5 : 3);   // products per weight stage
+    // products per weight stage (split-bf16: two planes of BOTH operands — three products fit beside the patch planes, one in the two-per-CU form)
+    static constexpr int TS = GH == 16 ? (NA * NB == 1 ? 9 : (NA * NB == 2 ? 5 : 3)) : (NA * NB == 1 ? 5 : (NA * NB == 2 ? 3 : 1));
     static constexpr int NSTEP = (9 + TS - 1) / TS;
     static constexpr int P_BYTES = PALLOC * PROW;
     static constexpr int B_BYTES = BN * ROW, B_TAP = NB * B_BYTES, B_STAGE = TS * B_TAP;
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         p_goff[j] = v ? (((b * p.H + iy) * p.H + ix) * p.Ci + q * 4) * 4 : OOB;
     }
     const int p_lbase = (tid >> 3) * PROW + q * 8;
-    float op_mult, op_inv;
-    wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);
+    float op_mult = 1.f, op_inv = 1.f;
+    if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);      // (bf16 has fp32's exponent range: no operand scale)
     const int cpt = p.Ci / BK;
     float4 pr_[NPL];
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -505,7 +506,8 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
                   "wgs_sg2_upconv_blur_act: null pointer");
     WGS_CHECK_ARG(!d->y_f16 || (d->y_f16_scale && d->a_amax && d->y_f16_ld >= d->Co && d->y_f16_mul > 0.f && d->y_f16_add >= 0.f),
                   "wgs_sg2_upconv_blur_act: y_f16 needs y_f16_scale, y_f16_ld >= Co, a_amax and the bound coefficients y_f16_mul > 0, y_f16_add >= 0");
-    WGS_CHECK_ARG(d->precision == 2 || d->precision == 3, "wgs_sg2_upconv_blur_act: precision %d (fp16 schemes 2 / 3 only)", d->precision);
+    WGS_CHECK_ARG(d->precision >= 1 && d->precision <= 3, "wgs_sg2_upconv_blur_act: precision %d (split-bf16 1, fp16 schemes 2 / 3)", d->precision);
+    WGS_CHECK_ARG(d->precision != 1 || d->w_lo, "wgs_sg2_upconv_blur_act: split-bf16 needs both weight planes (w_lo)");
     WGS_CHECK_ARG(d->B > 0 && d->H >= 4 && d->Ci % 32 == 0 && d->Ci > 0 && (d->Co % 64 == 0 || d->Co == 32) && d->Co > 0,
                   "wgs_sg2_upconv_blur_act: B=%d H=%d Ci=%d (%%32) Co=%d (%%64, or 32)", d->B, d->H, d->Ci, d->Co);
     WGS_CHECK_ARG(!d->noise || d->noise_w, "wgs_sg2_upconv_blur_act: noise needs noise_w");
@@ -531,7 +533,9 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     const bool gh16 = wgs_flags().up_gh16 || (long)d->B * big_tiles * ((d->Co + BN - 1) / BN) >= 1536;
     // precision 3 (fp16 x2) splits the ACTIVATION operand here (Scheme<3>: same two MFMAs, same error class as the weight split of
     // the GEMM kernels): the second weight plane would double the LDS-DMA traffic that bounds this kernel.  w_lo is not read.
-    if (d->precision == 2) { if (gh16) launch_up<1, 16>(a, (hipStream_t)stream); else launch_up<1, 8>(a, (hipStream_t)stream); }
+    // precision 1 (split-bf16 x3, fp32-class): both operands as hi + lo planes, three MFMAs per product (Scheme<0>); no operand scale
+    if (d->precision == 1) { if (gh16) launch_up<0, 16>(a, (hipStream_t)stream); else launch_up<0, 8>(a, (hipStream_t)stream); }
+    else if (d->precision == 2) { if (gh16) launch_up<1, 16>(a, (hipStream_t)stream); else launch_up<1, 8>(a, (hipStream_t)stream); }
     else { if (gh16) launch_up<3, 16>(a, (hipStream_t)stream); else launch_up<3, 8>(a, (hipStream_t)stream); }
     WGS_CHECK_LAUNCH("upconv_blur_kernel");
     return WGS_OK;

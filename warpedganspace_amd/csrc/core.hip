@@ -43,6 +43,7 @@ static WgsFlags read_flags() {
     g.halo_min_tiles = getenv("WGS_HALO_MIN_TILES") ? atoi(getenv("WGS_HALO_MIN_TILES")) : 512;      // (tests: 1 = every covered shape)
     g.rbf_split = getenv("WGS_RBF_SPLIT") != nullptr;      // RBF forward as two launches (support vectors split over workgroups + finish)
     g.no_halo = getenv("WGS_NO_HALO") != nullptr;      // few-channel 3x3 convs on large maps through the GEMM-tiled kernels (conv_halo16.hip off)
+    g.wgrad_staged = getenv("WGS_WGRAD_STAGED") != nullptr;      // weight gradients: the LDS-staged kernels everywhere (conv_wgrad_direct.hip off)
     g.check_ws = getenv("WGS_CHECK_WS") != nullptr;      // debug: verify (synchronously) that the BatchNorm / column-sum scratch is zero on entry
     g.f32_old = getenv("WGS_F32_OLD") != nullptr;      // exact fp32: the plain three-phase kernel of conv_igemm.hip everywhere
     // producer-written fp16 activation planes (x_f16): stride-1 3x3 launches with fewer output columns than this take the patch form,
@@ -58,7 +59,7 @@ const WgsFlags& wgs_flags() { return flags_storage(); }
 
 extern "C" {
 const char* wgs_last_error(void) { return g_err; }
-int wgs_abi_version(void) { return 7; }      // 7: wgs_sample_step; split-bf16 weight gradients with few input channels.  6: wgs_conv_wino_layout; fp16 activation planes
+int wgs_abi_version(void) { return 8; }      // 8: wgs_wgrad_desc.ws / ws_bytes (direct-fragment weight gradients); split-bf16 in wgs_sg2_upconv_blur_act.  7: wgs_sample_step; split-bf16 weight gradients with few input channels.  6: wgs_conv_wino_layout; fp16 activation planes
 void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
 int64_t wgs_dev_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 void wgs_dev_trace_kernels(int on) { g_trace.store(on ? 1 : 0, std::memory_order_relaxed); g_kernel[0] = 0; }

@@ -199,6 +199,9 @@ class TrainStep:
         self.argmax = torch.empty(local_batch, dtype=torch.int64, device=device)
         self.loss_ws = torch.empty(2 * local_batch, device=device)
         self.w_space = bool(getattr(params, 'shift_in_w_space', False))
+        self.strict_calibration = None
+        if self.precision == C.MIXED_STRICT:
+            self.calibrate_strict()
         self.comm_events = None      # set to a list to collect (start, end) HIP events around the all-reduce waits
         self.allreduce_bytes = 4 * self.bucket.flat.numel()     # payload of the step's collectives (R group + S group)
 
@@ -227,6 +230,8 @@ class TrainStep:
             self._r_precision = r_precision
         self.r_arith = r_arith(self._r_precision, self.precision)
         self._pre, self._cold = None, True
+        if self.precision == C.MIXED_STRICT:
+            self.calibrate_strict()
 
     def check_precision(self, gate=1e-3, batches=1):
         """Run-time guard of a 16-bit generator mode (the per-architecture policy tables were calibrated on random-init weights):
@@ -261,6 +266,39 @@ class TrainStep:
                 'per_image_median': float(per.median()), 'per_image_p99': float(per.quantile(0.99)), 'per_image_max': float(per.max()),
                 'over_gate_frac': float((per > gate).float().mean()), 'gate': gate, 'ok': bool(batch < gate and batch == batch),
                 'n': int(per.numel())}
+
+    def calibrate_strict(self, images=2304, margin=0.95, gate=1e-3, seed=0x51C7):
+        """'mixed-strict': measure conv.STRICT_LADDER on THIS generator's weights (per-image max-norm error against the exact-fp32 kernels over
+        `images` latent codes, identical on every rank) and adopt the first — cheapest — table whose worst single image is under
+        margin * gate.  Returns the calibration record (also kept as self.strict_calibration)."""
+        inner = getattr(self.G, 'G', None)
+        ladder = C.STRICT_LADDER.get(getattr(inner, 'size', None))
+        if self.precision != C.MIXED_STRICT or ladder is None or not hasattr(inner, 'mixed_policy'):
+            return None
+        nb = max(1, images // self.B)
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(seed)
+        zs = [sample_z(self.B, self.G.dim_z, truncation=getattr(self.p, 'z_truncation', None), device=self.dev, generator=g) for _ in range(nb)]
+        tried, chosen = [], None
+        with torch.no_grad():
+            refs = [self.G(z, precision='fp32') for z in zs]
+            mx = [r.abs().flatten(1).amax(1).clamp_min(1e-30) for r in refs]
+            for name, pol in ladder:
+                inner.mixed_policy = pol
+                worst = torch.zeros((), device=self.dev)
+                for z, r, m in zip(zs, refs, mx):
+                    worst = torch.maximum(worst, ((self.G(z, precision=self.precision) - r).abs().flatten(1).amax(1) / m).max())
+                w = float(worst)
+                tried.append((name, w))
+                if w == w and w < margin * gate:
+                    chosen = name
+                    break
+        if chosen is None:       # (cannot happen with a split-bf16 last rung unless the generator overflows: keep it anyway)
+            chosen = ladder[-1][0]
+            inner.mixed_policy = ladder[-1][1]
+        self._pre, self._cold = None, True
+        self.strict_calibration = {'table': chosen, 'tried': [(n, float('%.3g' % w)) for n, w in tried], 'images': nb * self.B, 'margin': margin, 'gate': gate}
+        return self.strict_calibration
 
     def _out_size(self):
         """Output resolution of the generator (StyleGAN2: .size; ProgGAN: from its block count); 256 when it cannot be told."""
