@@ -39,3 +39,45 @@ def test_prebuilt_library_matches_the_sources_beside_it():
     robustness).  __graft_entry__.build() rebuilds from scratch on a mismatch."""
     from warpedganspace_amd import _lib
     assert _lib.library_matches_sources() is True, "run `python -c 'import __graft_entry__ as g; g.build()'`"
+
+
+def test_ctypes_mirrors_match_the_header_structs(tmp_path):
+    """The Python host layer fills ctypes mirrors of include/wgs.h's descriptor structs: size and the offset of every field must equal what a
+    C compiler lays out from the header (round 5: a field added to the header but not to its mirror is silently dropped — ctypes accepts
+    assignment to unknown attribute names)."""
+    import ctypes
+    import re
+    import subprocess
+    from warpedganspace_amd import conv as C
+    from warpedganspace_amd import stylegan2 as SG
+    pairs = [('wgs_conv_desc', C.ConvDesc), ('wgs_wgrad_desc', C.WgradDesc), ('wgs_upconv_desc', C.UpconvDesc),
+             ('wgs_linear_batch', SG.LinearBatch), ('wgs_style_grad_batch', SG.StyleGradBatch)]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(repo, 'include', 'wgs.h')).read()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wgs.h"', 'int main(void) {']
+    for cname, mirror in pairs:
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        names = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for piece in decl.split(','):
+                m = re.search(r'(\w+)\s*(\[\s*\w+\s*\])?\s*$', piece.strip())
+                names.append(m.group(1))
+        assert names == [f[0] for f in mirror._fields_], (cname, names, [f[0] for f in mirror._fields_])
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for n in names:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, n))
+        lines.append('printf("\\n");')
+    lines += ['return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = str(tmp_path / 'layout')
+    subprocess.run(['gcc', '-I', os.path.join(repo, 'include'), str(src), '-o', exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    for (cname, mirror), row in zip(pairs, out):
+        vals = row.split()
+        assert vals[0] == cname and int(vals[1]) == ctypes.sizeof(mirror), (row, ctypes.sizeof(mirror))
+        assert [int(v) for v in vals[2:]] == [getattr(mirror, f[0]).offset for f in mirror._fields_], cname

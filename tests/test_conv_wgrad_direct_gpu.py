@@ -36,7 +36,7 @@ def _run(xd, gd, Co, Ci, precision, ksplit=0, into=None):
     return dw, sym
 
 
-@pytest.mark.parametrize('precision,tol', [(1, 3e-5), (0, 3e-6)])
+@pytest.mark.parametrize('precision,tol', [(1, 3e-5), (0, 6e-6)])      # (one split = one fp32 chain over up to 131 072 pixels per wave)
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(4, 64, 64, 16, 16), (2, 128, 64, 24, 8), (3, 64, 128, 8, 32), (32, 64, 64, 64, 64), (2, 512, 512, 8, 8),
                                          (1, 256, 128, 16, 16), (5, 64, 192, 16, 40)])
 def test_direct_wgrad_vs_float64(dev, precision, tol, B, Ci, Co, H, W):

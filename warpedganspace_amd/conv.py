@@ -48,7 +48,7 @@ class WgradDesc(ctypes.Structure):
                                               'ksplit')] + \
                [('w_tap_stride', ctypes.c_int64), ('w_row_stride', ctypes.c_int64),
                 ('dy_t', ctypes.c_int8 * 64), ('dx_t', ctypes.c_int8 * 64), ('wt', ctypes.c_int16 * 64),
-                ('precision', ctypes.c_int32), ('x_s2d', ctypes.c_int32)]
+                ('precision', ctypes.c_int32), ('x_s2d', ctypes.c_int32), ('ws', ctypes.c_void_p), ('ws_bytes', ctypes.c_int64)]
 
 
 # Arithmetic of a generator's implicit-GEMM launches (wgs_conv_desc.precision, include/wgs.h):
@@ -488,6 +488,8 @@ UPCONV_FUSED_MIN_H = {1: 32, 2: 16, 3: 16}      # (split-bf16: from 32 x 32 inpu
 
 
 def upconv_fused_ok(H, Ci, Co, precision):
+    if precision == 1 and H == 64:      # split-bf16 512 -> 256 @64 -> 128: 1.26 ms fused against 1.21 ms unfused (tools/bench_upfused.py, round 5); 32 -> 64: 0.66 / 0.85, 128 -> 256: 1.36 / 1.71
+        return False
     return precision in UPCONV_FUSED_MIN_H and H >= UPCONV_FUSED_MIN_H[precision] and Ci % 32 == 0 and (Co % 64 == 0 or Co == 32)
 
 

@@ -39,7 +39,7 @@ constexpr int OOB = (int)0x80000000;
 
 struct WDArgs {
     const float* x; const float* dy; float* part; float* dw;
-    int Co, Ci, Ho, Wo, M, nsteps, ksplit, ntn;
+    int Co, Ci, Ho, Wo, M, nsteps, ksplit, ntn, tiles;
     int x_bytes, dy_bytes;
     unsigned magic_w, magic_h;
     long w_tap_stride, w_row_stride;
@@ -65,11 +65,19 @@ __global__ __launch_bounds__(256, TN == 1 ? 2 : 1) void wgrad_direct_kernel(cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, g = lane >> 5;
-    const int tile = blockIdx.x, krow = blockIdx.y;
+    // work item = (pixel-range split, kernel row, tile), tiles fastest: the items of one split read the same dy / x pixels.  Workgroups are
+    // dealt to the 8 XCDs round-robin (each XCD has its own L2): XCD x takes a CONTIGUOUS range of items, so that a split's items share an L2
+    int item;
+    {
+        const int nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int qn = nb >> 3, rn = nb & 7;
+        item = xcd * qn + min(xcd, rn) + slot;
+    }
+    const int tile = item % p.tiles, krow = (item / p.tiles) % 3, split = item / (3 * p.tiles);
     const int co0 = (tile / p.ntn) * 64, ci0 = (tile % p.ntn) * (32 * TN);
     const int dyt = p.dy_t[krow * 3];
     const int per = (p.nsteps + p.ksplit - 1) / p.ksplit;
-    const int s_begin = blockIdx.z * per, s_end = min(p.nsteps, s_begin + per);
+    const int s_begin = split * per, s_end = min(p.nsteps, s_begin + per);
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
@@ -181,24 +189,31 @@ __global__ __launch_bounds__(256, TN == 1 ? 2 : 1) void wgrad_direct_kernel(cons
         }
     };
 
-    // ---- main loop: this wave's k-steps s_begin + wave, + 4, ...; the next step's 18 loads are in flight while the current one multiplies.
-    // Straight-line body (two steps per trip, no branch around the loads: hipcc's wait counts stay exact — with the loads under an `if` it
-    // waited for all but 6 of the NEXT step's loads in front of every conversion block); steps past the range load zeros.
+    // ---- main loop: this wave's k-steps s_begin + wave, + 4, ...; the loads of the next TWO steps (36 instructions, ~13 KB per wave) are in
+    // flight while the current one multiplies: one step ahead left the loop latency-bound (Little: 8 waves x 6.5 KB per CU at ~2 us under
+    // load = 6.6 TB/s chip-wide, measured 5.5).  Straight-line body (three steps per trip, no branch around the loads: hipcc's wait counts
+    // stay exact — with the loads under an `if` it waited for all but 6 of the NEXT step's loads in front of every conversion block);
+    // steps past the range load zeros.
     {
-        Raw w0, w1;
+        Raw w0, w1, w2;
         int s = s_begin + wave;
         issue(s, w0);
+        issue(s + 4, w1);
         __builtin_amdgcn_sched_barrier(0);       // (without the fences hipcc sinks a step's loads down to their first use: no prefetch left)
-        const int trips = s < s_end ? (s_end - s + 7) >> 3 : 0;
+        const int trips = s < s_end ? (s_end - s + 11) / 12 : 0;
 #pragma clang loop unroll(disable)
-        for (int it = 0; it < trips; ++it, s += 8) {
-            issue(s + 4, w1);
+        for (int it = 0; it < trips; ++it, s += 12) {
+            issue(s + 8, w2);
             __builtin_amdgcn_sched_barrier(0);
             consume(w0);
             __builtin_amdgcn_sched_barrier(0);
-            issue(s + 8, w0);
+            issue(s + 12, w0);
             __builtin_amdgcn_sched_barrier(0);
             consume(w1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(s + 16, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(w2);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 2 : 1) void wgrad_direct_kernel(cons
         __syncthreads();
     }
     if (wave == 0) {
-        float* part = p.part + (long)blockIdx.z * p.part_stride;
+        float* part = p.part + (long)split * p.part_stride;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -289,21 +304,25 @@ int wgs_conv_wgrad_direct(const wgs_wgrad_desc* d, hipStream_t st) {
     a.ntaps = 9;
     for (int t = 0; t < 9; ++t) { a.dy_t[t] = d->dy_t[t]; a.wt[t] = d->wt[t]; }
     const int tiles = (d->Co / 64) * a.ntn;
+    a.tiles = tiles;
     a.part_stride = (long)tiles * 9 * 2048 * TN;
     const long cap = d->ws_bytes / (a.part_stride * 4);
     if (cap < 1) return 1;
-    // pixel-range splits: about four workgroups per CU over the launch (two resident per CU), at least 8 k-steps per wave, never more
-    // than the workspace holds
+    // pixel-range splits (tools/bench_wgrad_direct.py ksweep, round 5): one round of workgroups — about 384 of the 512 resident slots (two per
+    // CU) — is best on every layer shape of the Reconstructor at 256^2 inputs (more splits only grow the partial-tile traffic of the second
+    // launch); launches with a lot of work per wave (1024^2 inputs) take twice or four times as many while the grid stays <= 1024
     int ks = d->ksplit;
     if (ks <= 0) {
-        ks = (1024 + tiles * 3 - 1) / (tiles * 3);
-        if (ks > a.nsteps / 32) ks = a.nsteps / 32;
+        ks = 384 / (tiles * 3);
+        if (ks < 1) ks = 1;
+        while (a.nsteps / (ks * 4) > 48 && (long)tiles * 3 * ks * 2 <= 1024) ks *= 2;
+        if (ks > a.nsteps / 16) ks = a.nsteps / 16;
     }
     if (ks > cap) ks = (int)cap;
     if (ks > a.nsteps) ks = a.nsteps;
     if (ks < 1) ks = 1;
     a.ksplit = ks;
-    dim3 grid((unsigned)tiles, 3, (unsigned)ks);
+    dim3 grid((unsigned)(tiles * 3 * ks));
     if (d->precision == 1) {
         auto k = wgrad_direct_kernel<0, TN>;
         wgs_note_kernel("wgrad_direct_kernel<0>");
