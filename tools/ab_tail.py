@@ -28,6 +28,15 @@ VARIANTS = [
     ('split 64', dict(split_pause_res=64)),
     ('torch sampler', dict(torch_sampler=True)),
     ('kernel sampler', dict(torch_sampler=False)),
+    # round 5: module-level routing switches ('conv.<NAME>' keys are set on warpedganspace_amd.conv instead of the engine)
+    ('wgrad staged', {'conv.WGRAD_DIRECT': False}),
+    ('wgrad direct', {'conv.WGRAD_DIRECT': True}),
+    ('up bf16 unfused', {'conv.UPCONV_FUSED_MIN_H': {1: 1 << 30, 2: 16, 3: 16}}),
+    ('up bf16 fused', {'conv.UPCONV_FUSED_MIN_H': {1: 32, 2: 16, 3: 16}}),
+    ('baseline', dict(debug_static_unshifted=False, mid_after_r=False)),
+    ('chain only (static un-shifted batch: NOT training)', dict(debug_static_unshifted=True, mid_after_r=False)),
+    ('mid stage behind R', dict(debug_static_unshifted=False, mid_after_r=True)),
+    ('baseline again', dict(debug_static_unshifted=False, mid_after_r=False)),
 ]
 CONFIGS = {'cfg3': ('stylegan2', 128, 32, 32, 256), 'cfg5': ('stylegan2', 200, 64, 8, 1024), 'cfg2': ('proggan', 64, 16, 32, 1024), 'cfg4': ('biggan', 128, 32, 16, 128)}
 
@@ -56,7 +65,11 @@ def main():
         for _ in range(args.rounds):
             for name, kw in variants:
                 for k, v in kw.items():
-                    setattr(eng, k, v)
+                    if k.startswith('conv.'):
+                        from warpedganspace_amd import conv as _CC
+                        setattr(_CC, k[5:], v)
+                    else:
+                        setattr(eng, k, v)
                 for _ in range(args.warmup):
                     eng.step()
                 torch.cuda.synchronize()

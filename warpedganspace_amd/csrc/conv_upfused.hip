@@ -32,7 +32,7 @@ namespace {
 
 #ifndef WGS_UABL
 #define WGS_UABL 0   // development ablations (tools/build_abl.sh uabl): 1 no epilogue, 2 no MFMA, 3 no patch global loads,
-                     // 4 no weight DMA, 5 no K loop, 6 no blur arithmetic, 7 no output stores
+                     // 4 no weight DMA, 5 no K loop, 6 no blur arithmetic, 7 no output stores, 8 no patch conversion + LDS stores, 9 = 3 + 8
 #endif
 
 constexpr int BK = 32;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (WGS_UABL != 3) v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
+            if (WGS_UABL != 3 && WGS_UABL != 9) v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((unsigned)p_goff[j] + (unsigned)cbyte), 0, 0);
             else asm volatile("" : "+v"(v));
             pr_[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         if (c < cpt) sc = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     };
     auto store_patch = [&](int buf) {
+        if (WGS_UABL == 8 || WGS_UABL == 9) { asm volatile("" :: "v"(pr_[0].x), "v"(pr_[NPL - 1].w)); return; }
         unsigned char* pb = patch + buf * NA * P_BYTES;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {

@@ -166,6 +166,7 @@ class TrainStep:
         # R's weight gradients likewise (single-GPU runs: with several ranks their all-reduce wants the whole backward to hide behind)
         self.wgrad_hook_res = getattr(TrainStep, 'wgrad_hook_res_default', 0)
         self.prepare_wt = getattr(TrainStep, 'prepare_wt_default', True)        # R's transposed weights at the start of the step, off the critical path
+        self.mid_after_r = getattr(TrainStep, 'mid_after_r_default', False)      # development: the prefetched pass's middle stage behind R's backward instead of beside R
         self.torch_sampler = getattr(TrainStep, 'torch_sampler_default', False)       # sample() through torch's generator instead of wgs_sample_step
         self._draws = 0                      # batches drawn so far: the counter half of the sampler's Philox key
         self._sw = None                      # reconstructor.StepWeights of this engine (built with the first multi-stream step)
@@ -404,7 +405,10 @@ class TrainStep:
         # next to the same layers of this batch's shifted pass (two latency-bound chains side by side); the chip-filling rest is
         # gated behind the shifted forward (below), where it fills the CUs that the Reconstructor's short launches leave idle.
         nxt = None
-        if auto and side is not None and self.prefetch:
+        static = getattr(self, 'debug_static_unshifted', False)       # development (tools/ab_tail.py): re-use ONE un-shifted batch for ever — the
+        if static and auto and pre_img:                               # step without its side work, i.e. the critical chain's own time.  NOT training.
+            self._pre = (z, idx, mag, img, None)
+        elif auto and side is not None and self.prefetch:
             zn, idxn, magn = self.sample()
             handle = None
             if self.split_prefetch and hasattr(G, 'begin') and not self.w_space:
@@ -448,10 +452,11 @@ class TrainStep:
             img.record_stream(cur)
         # the next batch's un-shifted pass (its remaining, chip-filling layers), gated behind this step's shifted forward.  Same
         # arithmetic, same values as an ordinary call; one generated batch stays unused when training stops.
-        tail = None
-        if nxt is not None:
+        tail_box = [None]
+
+        def run_mid():
             zn, idxn, magn, handle = nxt
-            self.pre_stream.wait_stream(cur)
+            self.pre_stream.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(self.pre_stream), torch.no_grad():
                 if handle is None:
                     imgn = G(zn, precision=prec)
@@ -473,6 +478,9 @@ class TrainStep:
                     ev = torch.cuda.Event()
                     ev.record(self.pre_stream)
                     self._pre = (zn, idxn, magn, im, ev)
+                tail_box[0] = tail
+        if nxt is not None and not self.mid_after_r:
+            run_mid()
         if pre_img:                       # the image generated one step ahead: complete before the Reconstructor reads it
             if pre_ev is not None:
                 cur.wait_event(pre_ev)
@@ -496,6 +504,9 @@ class TrainStep:
             deferred = _EagerSide(side) if self.eager_wgrad else []
         _, _, d_img = R._backward_impl(saved, self.dlogits, self.dmag, need_x=(False, True), gbuf=gb, deferred=deferred, **({'sw': sw} if sw else {}))
         del saved
+        if nxt is not None and self.mid_after_r:
+            run_mid()
+        tail = tail_box[0]
         pending = []
 
         def run_wgrads(deferred=deferred):
