@@ -193,6 +193,12 @@ typedef struct wgs_conv_desc {
        layers at 512^2 / 1024^2: 1 - 2 GB each).  Same bits as wgs_pixelnorm_fwd followed by the conv.  Supported where
        wgs_conv_pixelnorm_supported() says so (precision >= 1, no a_scale / x_f16, Ci in {16, 32}, a launch conv_halo16.hip takes); else WGS_EINVAL. */
     float a_pixelnorm_eps;
+    double* col_stats;       /* (ABI 8) optional: the launch also accumulates the per-channel sums of its OUTPUT, sum y and sum y^2 over every
+                                output pixel, into this BatchNorm scratch (WGS_BN_WS_DOUBLES(Co) doubles in wgs_bn_fwd's replica layout, zero
+                                on entry): the statistics pass of the train-mode BatchNorm behind the conv comes out of the conv's epilogue
+                                (wgs_bn_fwd_sums finishes it) instead of re-reading the tensor.  fp32 partial sums over <= 64 rows per lane,
+                                fp64 atomics from there.  Precisions 0 / 1 / 2 / 3 through the tiled kernels; a launch that would fall to a
+                                kernel without the epilogue fails with WGS_EINVAL.  Not with rgb_out / x_f16. */
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);
 /* 1 when a launch of `desc` with a_pixelnorm_eps > 0 is covered (the operand normalised inside the few-channel kernel), else 0. */
@@ -439,6 +445,12 @@ int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, 
 int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
                int64_t N, int C, float eps, float momentum, int relu, int train, wgs_stream_t stream);
+/* Train-mode wgs_bn_fwd whose statistics pass has ALREADY run: ws holds sum x and sum x^2 of x's N rows in the replica layout, written
+ * by the epilogue of the conv that produced x (wgs_conv_desc.col_stats = ws).  Two launches (finalise, apply) instead of three, and x is
+ * read once instead of twice.  ws is left zero as by wgs_bn_fwd. */
+int wgs_bn_fwd_sums(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
+                    float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
+                    int64_t N, int C, float eps, float momentum, int relu, wgs_stream_t stream);
 /* Backward: g = (dyA + (dyB ? dyB : 0)) * (out ? out > 0 : 1)   [out = the saved post-ReLU output]
  *   dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) (train) ;  dgamma = sum g*xhat ; dbeta = sum g ;
  *   dres (optional) = g  (gradient of the residual branch).

@@ -33,6 +33,11 @@ VARIANTS = [
     ('wgrad direct', {'conv.WGRAD_DIRECT': True}),
     ('up bf16 unfused', {'conv.UPCONV_FUSED_MIN_H': {1: 1 << 30, 2: 16, 3: 16}}),
     ('up bf16 fused', {'conv.UPCONV_FUSED_MIN_H': {1: 32, 2: 16, 3: 16}}),
+    ('BN stats pass', {'rr.BN_EPILOGUE_STATS': False}),
+    ('BN stats in epilogue', {'rr.BN_EPILOGUE_STATS': True}),
+    ('R +0 launches', {'bn.debug_extra_launches': 0}),
+    ('R +40 empty launches', {'bn.debug_extra_launches': 2}),
+    ('R +80 empty launches', {'bn.debug_extra_launches': 4}),
     ('baseline', dict(debug_static_unshifted=False, mid_after_r=False)),
     ('chain only (static un-shifted batch: NOT training)', dict(debug_static_unshifted=True, mid_after_r=False)),
     ('mid stage behind R', dict(debug_static_unshifted=False, mid_after_r=True)),
@@ -65,7 +70,13 @@ def main():
         for _ in range(args.rounds):
             for name, kw in variants:
                 for k, v in kw.items():
-                    if k.startswith('conv.'):
+                    if k.startswith('rr.'):
+                        from warpedganspace_amd import reconstructor as _RR2
+                        setattr(_RR2, k[3:], v)
+                    elif k.startswith('bn.'):
+                        from warpedganspace_amd import reconstructor as _RR
+                        setattr(_RR._BN, k[3:], v)
+                    elif k.startswith('conv.'):
                         from warpedganspace_amd import conv as _CC
                         setattr(_CC, k[5:], v)
                     else:

@@ -26,7 +26,7 @@ class ConvDesc(ctypes.Structure):
                 ('a_amax', ctypes.c_void_p), ('a_bound', ctypes.c_float), ('a_amax2', ctypes.c_void_p), ('y_amax', ctypes.c_void_p),
                 ('x_f16', ctypes.c_void_p),
                 ('rgb_out', ctypes.c_void_p), ('rgb_s', ctypes.c_void_p), ('rgb_w', ctypes.c_void_p), ('rgb_scale', ctypes.c_float), ('rgb_ld', ctypes.c_int32),
-                ('a_pixelnorm_eps', ctypes.c_float)]
+                ('a_pixelnorm_eps', ctypes.c_float), ('col_stats', ctypes.c_void_p)]
 
 
 class NoOutput:
@@ -304,7 +304,7 @@ def _timed(kind, flops, fn):
 def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, w_row_stride=None,
           a_scale=None, col_scale=None, bias=None, noise=None, noise_w=None, act_slope=1.0, gain=1.0,
           a_ld=0, col_ld=0, ups=0, alpha=1.0, addend=None, add_ups=0, act=0, precision=None, into=None, w_split=None,
-          a_amax=None, a_bound=1.0, grad_operand=False, a_amax2=None, y_amax=None, x_f16=False, rgb=None, pixelnorm_eps=0.0):
+          a_amax=None, a_bound=1.0, grad_operand=False, a_amax2=None, y_amax=None, x_f16=False, rgb=None, pixelnorm_eps=0.0, col_stats=None):
     """Fill a wgs_conv_desc.  taps: list of (dy, dx, weight_tap_index).  x [B,Hi,Wi,Ci], y [B,Ho,Wo,Co] (NHWC, contiguous).
     x_f16: x is the int16 tensor holding the operand's fp16 plane (wgs_conv_desc.x_f16), written by the producing kernel."""
     if not (x.is_cuda and x.is_contiguous() and y.is_contiguous() and x.dtype == (torch.int16 if x_f16 else torch.float32)):
@@ -337,6 +337,7 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
         prec = 1
     d.precision = prec
     d.a_amax, d.a_bound, d.a_amax2, d.y_amax = _p(a_amax), a_bound, _p(a_amax2), _p(y_amax)
+    d.col_stats = col_stats.data_ptr() if col_stats is not None else None      # BatchNorm scratch (float64): sum y / sum y^2 of the output from the epilogue
     d.a_pixelnorm_eps = pixelnorm_eps       # > 0: the operand is PixelNorm(x), normalised inside the few-channel kernel (pixelnorm_fused_ok)
     if isinstance(w_split, SplitCache):
         w_split = w_split.get(prec)

@@ -36,6 +36,7 @@ struct ConvArgs {
     float* y_amax;                  // optional device scalar raised (atomic max) to max |y| of this launch: the next layer's a_amax
     float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int rgb_ld;      // ToRGB in the epilogue (wgs_conv_desc.rgb_out)
     float pn_eps;                   // > 0: the operand is PixelNorm(x) (wgs_conv_desc.a_pixelnorm_eps; conv_halo16.hip only)
+    double* col_stats;              // per-channel sum y / sum y^2 of the output into BatchNorm scratch (wgs_conv_desc.col_stats), or null
     const unsigned short* a_hi;     // split (and style-modulated) activation planes: set by launch_bf16x3 (LDS-DMA path)
     const unsigned short* a_lo;
     float* ws;          // split-K workspace or null

@@ -8,6 +8,20 @@ namespace wgsconv {
 
 typedef float epi_f32x16 __attribute__((ext_vector_type(16)));
 
+// Column statistics of a launch's output for the train-mode BatchNorm behind it (wgs_conv_desc.col_stats): a lane's partial sums of
+// column n over its rows (<= 64 values, fp32) -> the two half-waves hold the same columns: combined with one cross-half shuffle -> one
+// fp64 atomic per column and wave into replica blockIdx.x % 32 of the scratch [32][2][Co] (the layout of recon_ops.hip's chan_reduce).
+constexpr int STATS_REP = 32;
+__device__ __forceinline__ void col_stats_flush(double* ws, int Co, int n, bool nok, float s1, float s2, int lh) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lh == 0 && nok) {
+        double* wr = ws + (size_t)(blockIdx.x % STATS_REP) * 2 * Co;
+        unsafeAtomicAdd(wr + n, (double)s1);
+        unsafeAtomicAdd(wr + Co + n, (double)s2);
+    }
+}
+
 // second half: the staged row arrays (r_pix / r_b / r_nz / r_add in LDS, filled by the caller and published with a
 // barrier) -> every accumulator gets alpha, demodulation, noise, bias, addend, activation and is stored
 template <int BM, int TM, int TN, int WM, int WN>
@@ -43,6 +57,10 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
             const int rowbytes = p.Co * 4;
             const float slope = p.act_slope, gain = p.gain;
             float vmax = 0.f;
+            float st1[TN], st2[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+            const bool stats = p.col_stats != nullptr;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -59,8 +77,13 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
                         v = fmaxf(v, v * slope) * gain;           // == (v > 0 ? v : v * slope) * gain for slope in [0, 1]
                         vmax = fmaxf(vmax, pix >= 0 ? fabsf(v) : 0.f);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)((unsigned)ro + (unsigned)noff[j]), 0, 0);
+                        if (stats) { const float u = pix >= 0 ? v : 0.f; st1[j] += u; st2[j] = fmaf(u, u, st2[j]); }
                     }
                 }
+            }
+            if (stats) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) col_stats_flush(p.col_stats, p.Co, n0 + wn * WN + j * 32 + l31, true, st1[j], st2[j], lh);
             }
             if (p.y_amax) {      // magnitude bound for the next layer's fp16 operand scale: one atomic per wave
                 vmax = wave_max(vmax);
@@ -81,6 +104,7 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
             cs0 = p.col_scale[(size_t)b_lo * p.col_ld + n];
             cs1 = p.col_scale[(size_t)b_hi2 * p.col_ld + n];
         }
+        float st1 = 0.f, st2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -95,9 +119,11 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
                     v = (p.act == 1) ? tanhf(v) : (v > 0.f ? v : v * p.act_slope) * p.gain;
                     vmax_s = fmaxf(vmax_s, fabsf(v));
                     p.y[(size_t)pix * p.Co + n] = v;
+                    st1 += v; st2 = fmaf(v, v, st2);
                 }
             }
         }
+        if (p.col_stats) col_stats_flush(p.col_stats, p.Co, n, nok, st1, st2, lh);
     }
     if (p.y_amax) raise_amax(p.y_amax, vmax_s);
 }

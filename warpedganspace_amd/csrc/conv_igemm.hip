@@ -596,6 +596,9 @@ static int build_conv_args(const wgs_conv_desc* d, ConvArgs& a) {
     a.ws = d->ws; a.ws_bytes = d->ws ? d->ws_bytes : 0; a.ksplit = 1;
     a.w_hi = d->w_hi; a.w_lo = d->w_lo; a.a_hi = d->x_f16; a.a_lo = nullptr;
     a.rgb_out = d->rgb_out; a.rgb_s = d->rgb_s; a.rgb_w = d->rgb_w; a.rgb_scale = d->rgb_scale; a.rgb_ld = d->rgb_ld;
+    a.col_stats = d->col_stats;
+    WGS_CHECK_ARG(!d->col_stats || (!d->rgb_out && !d->x_f16 && d->Co % 4 == 0 && d->y),
+                  "wgs_conv_igemm: col_stats needs a stored output, Co %% 4 == 0, and neither rgb_out nor x_f16");
     a.pn_eps = d->a_pixelnorm_eps > 0.f ? d->a_pixelnorm_eps : 0.f;
     WGS_CHECK_ARG(!(a.pn_eps > 0.f) || (d->precision >= 1 && !d->a_scale && !d->x_f16 && (d->Ci == 16 || d->Ci == 32)),
                   "wgs_conv_igemm: a_pixelnorm_eps needs a 16-bit precision, no a_scale / x_f16 and Ci in {16, 32}");
@@ -689,6 +692,7 @@ int wgs_conv_igemm(const wgs_conv_desc* d, wgs_stream_t stream) {
         WGS_CHECK_LAUNCH("igemm_nt16_kernel<4>");
         return WGS_OK;
     }
+    WGS_CHECK_ARG(!a.col_stats, "wgs_conv_igemm: col_stats: the launch falls to a kernel without the shared epilogue (Ci %% 32 != 0, > 16 taps or > 2 GiB operands)");
     // (64 -> <= 8 channels, the image gradient of ResNet conv1: the template's 128 x 32 tiles measure 1.07 ms against this kernel's
     // 1.47 ms at B = 32, so it is the fallback now — WGS_F32_OLD, or operands the template declines)
     if (d->precision == 0 && d->Co <= 8 && d->Ci == 64 && d->ntaps <= 16 && (long)d->B * d->Hi * d->Wi * 64 < (1L << 31) && !d->ups && !d->a_scale && !d->col_scale && !d->noise && !d->addend &&

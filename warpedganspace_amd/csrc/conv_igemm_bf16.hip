@@ -28,35 +28,50 @@ namespace {
 
 // Second pass of a split-K launch: y[pix(m)][n] = epilogue(sum_s ws[s][m][n]) — the same epilogue as above
 // (alpha, demod, noise, bias, addend, activation).  One thread per 4 output channels.
+// A thread finishes SK_ROWS consecutive GEMM rows of its 4 channels (a wave's lanes = adjacent channel quads of the same rows: coalesced
+// as before) — so that the output's column statistics (wgs_conv_desc.col_stats) leave a thread as 8 atomics per SK_ROWS rows.
+constexpr int SK_ROWS = 8;
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArgs p) {
     const int c4 = p.Co / 4;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)p.M * c4) return;
-    const int m = (int)(e / c4), n = (int)(e % c4) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < p.ksplit; ++s) {
-        const float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)s * p.M + m) * p.Co + n);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
-    const int b = m / p.Mimg, pq = m - b * p.Mimg;
-    if (pq >= p.HW) return;            // padding row of a sample (see launch_bf16x3)
-    const int gy = pq / p.Wg, gx = pq - gy * p.Wg;
-    const int oy = gy * p.osy + p.oy0, ox = gx * p.osx + p.ox0;
-    const int hw = oy * p.Wo + ox;
-    const float nz = (p.noise && p.noise_w) ? p.noise_w[0] * p.noise[hw] : 0.f;
-    float o[4] = {v.x, v.y, v.z, v.w};
+    const int groups = (p.M + SK_ROWS - 1) / SK_ROWS;
+    if (e >= (long)groups * c4) return;
+    const int m_begin = (int)(e / c4) * SK_ROWS, n = (int)(e % c4) * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float am = 0.f;
+    for (int m = m_begin; m < min(p.M, m_begin + SK_ROWS); ++m) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)s * p.M + m) * p.Co + n);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int b = m / p.Mimg, pq = m - b * p.Mimg;
+        if (pq >= p.HW) continue;            // padding row of a sample (see launch_bf16x3)
+        const int gy = pq / p.Wg, gx = pq - gy * p.Wg;
+        const int oy = gy * p.osy + p.oy0, ox = gx * p.osx + p.ox0;
+        const int hw = oy * p.Wo + ox;
+        const float nz = (p.noise && p.noise_w) ? p.noise_w[0] * p.noise[hw] : 0.f;
+        float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float u = o[k] * p.alpha;
-        if (p.col_scale) u *= p.col_scale[(size_t)b * p.col_ld + n + k];
-        u += nz + (p.bias ? p.bias[n + k] : 0.f);
-        if (p.addend) u += p.addend[((size_t)(b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups)) * p.Co + n + k];
-        o[k] = (p.act == 1) ? tanhf(u) : (u > 0.f ? u : u * p.act_slope) * p.gain;
+        for (int k = 0; k < 4; ++k) {
+            float u = o[k] * p.alpha;
+            if (p.col_scale) u *= p.col_scale[(size_t)b * p.col_ld + n + k];
+            u += nz + (p.bias ? p.bias[n + k] : 0.f);
+            if (p.addend) u += p.addend[((size_t)(b * (p.Ho >> p.add_ups) + (oy >> p.add_ups)) * (p.Wo >> p.add_ups) + (ox >> p.add_ups)) * p.Co + n + k];
+            o[k] = (p.act == 1) ? tanhf(u) : (u > 0.f ? u : u * p.act_slope) * p.gain;
+            s1[k] += o[k]; s2[k] = fmaf(o[k], o[k], s2[k]);
+        }
+        *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + hw) * p.Co + n) = make_float4(o[0], o[1], o[2], o[3]);
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
-    *reinterpret_cast<float4*>(p.y + ((size_t)b * p.Ho * p.Wo + hw) * p.Co + n) = make_float4(o[0], o[1], o[2], o[3]);
-    if (p.y_amax) {     // magnitude bound for the next layer's fp16 operand scale
-        const float am = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
-        raise_amax(p.y_amax, am);
+    if (p.y_amax) raise_amax(p.y_amax, am);     // magnitude bound for the next layer's fp16 operand scale
+    if (p.col_stats) {
+        double* wr = p.col_stats + (size_t)(blockIdx.x % wgsconv::STATS_REP) * 2 * p.Co;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsafeAtomicAdd(wr + n + k, (double)s1[k]);
+            unsafeAtomicAdd(wr + p.Co + n + k, (double)s2[k]);
+        }
     }
 }
 
@@ -79,7 +94,7 @@ void launch_big(ConvArgs& a, hipStream_t st, int nblocks = 0) {
 namespace wgsconv {
 
 void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st) {
-    const long work = (long)a.M * (a.Co / 4);
+    const long work = (long)((a.M + SK_ROWS - 1) / SK_ROWS) * (a.Co / 4);
     WGS_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
 }
 

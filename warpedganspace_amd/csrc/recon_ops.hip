@@ -586,6 +586,21 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
     return WGS_OK;
 }
 
+int wgs_bn_fwd_sums(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
+                    float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
+                    int64_t N, int C, float eps, float momentum, int relu, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws, "wgs_bn_fwd_sums: null pointer");
+    WGS_CHECK_ARG(N > 0 && C >= 4 && C % 4 == 0, "wgs_bn_fwd_sums: C=%d must be a multiple of 4", C);
+    hipStream_t st = (hipStream_t)stream;
+    // (ws holds the sums the producing conv's epilogue accumulated — wgs_conv_desc.col_stats — in chan_reduce's replica layout)
+    WGS_LAUNCH(bn_finalize_kernel, dim3(wgs_cdiv(C, 256)), dim3(256), 0, st, ws, save_mean, save_invstd,
+                       running_mean, running_var, num_batches_tracked, N, C, eps, momentum);
+    WGS_LAUNCH(bn_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta,
+                       residual, y, N, C, relu);
+    WGS_CHECK_LAUNCH("bn_fwd_sums");
+    return WGS_OK;
+}
+
 int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* out, const float* save_mean,
                const float* save_invstd, const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta,
                double* ws, int64_t N, int C, int train, wgs_stream_t stream) {

@@ -67,6 +67,7 @@ def r_arith(r_precision='auto', generator_code=None):
 
 
 # The ResNet stem in space-to-depth form (Reconstructor._forward_impl): taps (dy, dx, weight index r*4 + s) of the 4 x 4 block window
+BN_EPILOGUE_STATS = True      # round 5: BatchNorm statistics from the producing conv's epilogue (wgs_conv_desc.col_stats), see _forward_impl
 STEM_S2D = True
 STEM_WGRAD_S2D = True     # ... and its weight gradient in the same form (64 x 16 x 32, gathered back to 64 x 49 x 2c)
 _S2D_TAPS = [(r - 2, s_ - 2, r * 4 + s_) for r in range(4) for s_ in range(4)]
@@ -134,17 +135,37 @@ class _BN:
     """One fused BatchNorm launch pair + what its backward needs."""
 
     @staticmethod
-    def fwd(bn, x, ws, residual=None, relu=True, train=True):
+    def fwd(bn, x, ws, residual=None, relu=True, train=True, sums_ready=False):
+        """sums_ready: the conv that produced x accumulated its column sums into ws from its epilogue (col_stats=ws): no statistics launch."""
         N, Cn = x.numel() // x.shape[-1], x.shape[-1]
         y = torch.empty_like(x)
         mean = torch.empty(Cn, device=x.device)
         invstd = torch.empty(Cn, device=x.device)
+        if sums_ready and train:
+            L.check(L.lib().wgs_bn_fwd_sums(L.ptr(x), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(residual), L.ptr(y), L.ptr(mean),
+                                            L.ptr(invstd), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                            L.ptr(bn.num_batches_tracked, torch.int64), L.rawptr(ws), L.c_int64(N), Cn,
+                                            L.c_float(bn.eps), L.c_float(bn.momentum if bn.momentum is not None else 0.1),
+                                            int(relu), L.stream()), 'wgs_bn_fwd_sums')
+            return y, (mean, invstd)
         L.check(L.lib().wgs_bn_fwd(L.ptr(x), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(residual), L.ptr(y), L.ptr(mean),
                                    L.ptr(invstd), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                                    L.ptr(bn.num_batches_tracked, torch.int64), L.rawptr(ws), L.c_int64(N), Cn,
                                    L.c_float(bn.eps), L.c_float(bn.momentum if bn.momentum is not None else 0.1),
                                    int(relu), int(train), L.stream()), 'wgs_bn_fwd')
+        for _ in range(_BN.debug_extra_launches):      # development (tools/ab_tail.py): what does a launch in R's chain cost by itself?
+            L.check(L.lib().wgs_split_bf16(L.ptr(mean[:4]), L.ptr(_BN._dummy(x.device), torch.int16), L.ptr(_BN._dummy(x.device)[4:], torch.int16),
+                                           L.c_int64(4), L.stream()), 'dummy')
         return y, (mean, invstd)
+
+    debug_extra_launches = 0
+    _dummy_buf = {}
+
+    @staticmethod
+    def _dummy(dev):
+        if dev not in _BN._dummy_buf:
+            _BN._dummy_buf[dev] = torch.zeros(8, dtype=torch.int16, device=dev)
+        return _BN._dummy_buf[dev]
 
     @staticmethod
     def bwd(bn, x, stats, dyA, dyB, out, ws, want_res=False, train=True, gbuf=None):
@@ -269,6 +290,11 @@ class Reconstructor(nn.Module):
         Cp = 8
         arith = arith or self.arith
         fp = arith.forward
+        # train-mode BatchNorm statistics out of the producing conv's epilogue (wgs_conv_desc.col_stats) wherever the conv runs a tiled
+        # kernel with the shared epilogue: every conv of the direct fp32 and split-bf16 arithmetics (the Winograd launches of 'fp32w' keep
+        # the separate statistics pass).  One scratch: a conv's sums are consumed (and the scratch left zero) by the BatchNorm right behind it.
+        est = BN_EPILOGUE_STATS and train and fp in (0, 1)
+        cs = dict(col_stats=ws) if est else {}
         # The stem (7 x 7, stride 2, 2c = 6 input channels): SPACE-TO-DEPTH.  The image pair is packed as
         # [B, H/2, W/2, 32] (2 x 2 pixel block x 8 channels) and the 7 x 7 / 2 conv becomes a 4 x 4-window stride-1 conv 32 -> 64 channels
         # over it (zeros where a tap falls outside the 7 x 7: 49 * 6 of 16 * 32 weights live) — a shape the few-channel halo kernel
@@ -282,14 +308,14 @@ class Reconstructor(nn.Module):
             w1s = self._scratch('w1s', (64, 16, 32), torch.float32, dev)
             L.check(lib.wgs_stem_weight_s2d(L.rawptr(_packed(fe.conv1)), L.ptr(w1s), 64, 2 * c, 0, st), 'stem_weight_s2d')
             c1 = torch.empty(B, H // 2, W // 2, 64, device=dev)
-            C.launch(x, w1s, c1, _S2D_TAPS, H // 2, W // 2, w_tap_stride=32, w_row_stride=16 * 32, precision=fp)
+            C.launch(x, w1s, c1, _S2D_TAPS, H // 2, W // 2, w_tap_stride=32, w_row_stride=16 * 32, precision=fp, **cs)
         else:
             x = torch.empty(B, H, W, Cp, device=dev)
             L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
             # stem: conv1 weights padded from 2c to Cp input channels
             w1p = self._conv1_padded(c, Cp, dev)
             c1 = C.conv2d(x, w1p, 7, stride=2, pad=3, precision=fp)
-        a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train)
+        a1, st1 = _BN.fwd(fe.bn1, c1, ws, relu=True, train=train, sums_ready=est and s2d)
         Hp = (a1.shape[1] + 2 - 3) // 2 + 1
         p1 = torch.empty(B, Hp, Hp, 64, device=dev)
         idx = torch.empty(B, Hp, Hp, 64, dtype=torch.uint8, device=dev)
@@ -300,16 +326,16 @@ class Reconstructor(nn.Module):
         wc = (lambda conv: sw.cache(conv, 'f')) if sw is not None else (lambda conv: None)       # Winograd operands refreshed by the engine (StepWeights)
         for blk in fe.blocks():
             xin = h
-            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=fp, w_split=wc(blk.conv1))
-            aa, sa = _BN.fwd(blk.bn1, ca, ws, relu=True, train=train)
-            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=fp, w_split=wc(blk.conv2))
-            if blk.downsample is not None:
-                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=fp)
-                ad, sd = _BN.fwd(blk.downsample[1], cd, ws, relu=False, train=train)
+            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=fp, w_split=wc(blk.conv1), **cs)
+            aa, sa = _BN.fwd(blk.bn1, ca, ws, relu=True, train=train, sums_ready=est)
+            if blk.downsample is not None:       # (before conv2: one scratch, consumed by the BatchNorm right behind each conv)
+                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=fp, **cs)
+                ad, sd = _BN.fwd(blk.downsample[1], cd, ws, relu=False, train=train, sums_ready=est)
                 ident = ad
             else:
                 cd, sd, ident = None, None, xin
-            o, sb = _BN.fwd(blk.bn2, cb, ws, residual=ident, relu=True, train=train)
+            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=fp, w_split=wc(blk.conv2), **cs)
+            o, sb = _BN.fwd(blk.bn2, cb, ws, residual=ident, relu=True, train=train, sums_ready=est)
             saved_blocks.append((xin, ca, aa, sa, cb, sb, cd, sd, o))
             h = o
         P = h.shape[1] * h.shape[2]
