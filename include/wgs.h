@@ -436,7 +436,7 @@ int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, 
  * train != 0: batch statistics (biased variance), running stats updated with `momentum` and the unbiased
  * variance, num_batches_tracked += 1 (all three may be NULL); else running statistics are used.
  * save_mean / save_invstd [C] are written for the backward; ws = WGS_BN_WS_DOUBLES(C) doubles of scratch: 32 replicas of the 2*C
- * partial sums (so that the reduction's fp64 atomics do not all hit the same addresses).  ws MUST BE ZERO ON ENTRY and is left zero
+ * partial sums (so that the reduction's fp64 atomics do not all hit the same addresses; min(32, 2048 / C) of them are used).  ws MUST BE ZERO ON ENTRY and is left zero
  * on exit (zero it once when allocating it; one buffer serves any sequence of wgs_bn_fwd / wgs_bn_bwd / wgs_colsum calls on one
  * stream, with any C): the launch that sums the replicas zeroes them again, so no reduction needs a memset.  A buffer that is NOT zero
  * (never zeroed, a call cut short, two streams sharing it) gives wrong statistics without an error; WGS_CHECK_WS=1 in the environment
@@ -451,6 +451,14 @@ int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const floa
 int wgs_bn_fwd_sums(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
                     float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,
                     int64_t N, int C, float eps, float momentum, int relu, wgs_stream_t stream);
+/* The same in ONE launch over a PAIR of scratch buffers (round 5): every workgroup of the apply kernel finishes the statistics from
+ * ws_sums (<= 32 KB: the replica count shrinks with C) in its prologue, workgroup 0 writes save_mean / save_invstd / the running
+ * statistics, and ws_zero — the other buffer of the pair, the one the NEXT producer will accumulate into — is left zero.  ws_sums itself
+ * stays as it is: it is the ws_zero of the next call.  Contract for the caller: alternate the two buffers producer by producer, both zero
+ * before the first one (warpedganspace_amd/reconstructor.py: _BNScratch). */
+int wgs_bn_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
+                     float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const double* ws_sums,
+                     double* ws_zero, int64_t N, int C, float eps, float momentum, int relu, wgs_stream_t stream);
 /* Backward: g = (dyA + (dyB ? dyB : 0)) * (out ? out > 0 : 1)   [out = the saved post-ReLU output]
  *   dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) (train) ;  dgamma = sum g*xhat ; dbeta = sum g ;
  *   dres (optional) = g  (gradient of the residual branch).
@@ -460,6 +468,11 @@ int wgs_bn_fwd_sums(const float* x, const float* gamma, const float* beta, const
 int wgs_bn_bwd(const float* x, const float* dyA, const float* dyB, const float* out, const float* save_mean,
                const float* save_invstd, const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta,
                double* ws, int64_t N, int C, int train, wgs_stream_t stream);
+/* Train-mode wgs_bn_bwd in two launches over the scratch pair of wgs_bn_fwd_fused: the reduction accumulates into ws (zero on entry), the
+ * input-gradient launch finishes the sums in its prologue (workgroup 0 writes dgamma / dbeta) and leaves ws_zero zero; ws stays dirty. */
+int wgs_bn_bwd_fused(const float* x, const float* dyA, const float* dyB, const float* out, const float* save_mean,
+                     const float* save_invstd, const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta,
+                     double* ws, double* ws_zero, int64_t N, int C, wgs_stream_t stream);
 
 /* nn.MaxPool2d(k, stride s, padding p) on NHWC; idx [B,Ho,Wo,C] bytes = window position of the first
  * maximum (torch tie-breaking); backward gathers through idx. */

@@ -43,11 +43,21 @@ def test_conv_epilogue_column_sums(dev, precision, B, Ci, Co, H, k, s, p):
     # the BatchNorm behind it: finalise + apply from the sums == the three-launch form, and the scratch is left zero
     g, b = torch.rand(Co, device=dev) + 0.5, torch.randn(Co, device=dev)
     outs = []
-    for mode in ('sums', 'full'):
+    for mode in ('sums', 'fused', 'full'):
         rm, rv, nb = torch.zeros(Co, device=dev), torch.ones(Co, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
         o, mean, invstd = torch.empty_like(y), torch.empty(Co, device=dev), torch.empty(Co, device=dev)
         N = y.numel() // Co
-        if mode == 'sums':
+        if mode == 'fused':
+            # (the conv's sums again, into a fresh buffer: the fused launch reads it, leaves it as it is and zeroes the OTHER buffer)
+            ws_a = torch.zeros(64 * Co, dtype=torch.float64, device=dev)
+            ws_b = torch.full((64 * Co,), 3.0, dtype=torch.float64, device=dev)
+            C.conv2d(x, w, k, stride=s, pad=p, precision=precision, col_stats=ws_a)
+            L.check(L.lib().wgs_bn_fwd_fused(L.ptr(y), L.ptr(g), L.ptr(b), None, L.ptr(o), L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv),
+                                             L.ptr(nb, torch.int64), L.rawptr(ws_a), L.rawptr(ws_b), L.c_int64(N), Co, L.c_float(1e-5), L.c_float(0.1), 1,
+                                             L.stream()), 'bn_fused')
+            nrep = max(1, min(32, 2048 // Co))
+            assert float(ws_b[:nrep * 2 * Co].abs().max()) == 0.0 and float(ws_a.abs().max()) > 0.0
+        elif mode == 'sums':
             L.check(L.lib().wgs_bn_fwd_sums(L.ptr(y), L.ptr(g), L.ptr(b), None, L.ptr(o), L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv),
                                             L.ptr(nb, torch.int64), L.rawptr(ws), L.c_int64(N), Co, L.c_float(1e-5), L.c_float(0.1), 1, L.stream()), 'bn_sums')
         else:
@@ -55,9 +65,10 @@ def test_conv_epilogue_column_sums(dev, precision, B, Ci, Co, H, k, s, p):
                                        L.ptr(nb, torch.int64), L.rawptr(ws), L.c_int64(N), Co, L.c_float(1e-5), L.c_float(0.1), 1, 1, L.stream()), 'bn')
         assert float(ws.abs().max()) == 0.0
         outs.append((o, mean, invstd, rm, rv, int(nb)))
-    for a_, b_ in zip(outs[0][:5], outs[1][:5]):
-        assert rel_err(a_, b_) < 2e-5
-    assert outs[0][5] == outs[1][5] == 1
+    for other in outs[:2]:
+        for a_, b_ in zip(other[:5], outs[2][:5]):
+            assert rel_err(a_, b_) < 2e-5
+    assert outs[0][5] == outs[1][5] == outs[2][5] == 1
 
 
 def test_col_stats_argument_checks(dev):
@@ -68,8 +79,9 @@ def test_col_stats_argument_checks(dev):
         C.conv2d(x, w, 3, pad=1, precision=0, col_stats=ws)
 
 
+@pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('arith', ['fp32', 'bf16x3'])
-def test_reconstructor_with_and_without_epilogue_statistics(dev, monkeypatch, arith):
+def test_reconstructor_with_and_without_epilogue_statistics(dev, monkeypatch, arith, fused):
     """The whole Reconstructor: logits, magnitude, image gradient, every parameter gradient and the BatchNorm running statistics agree
     between the two routes (same values up to the order of fp32 / fp64 additions)."""
     from warpedganspace_amd import reconstructor as RR
@@ -78,6 +90,7 @@ def test_reconstructor_with_and_without_epilogue_statistics(dev, monkeypatch, ar
     res = []
     for on in (True, False):
         monkeypatch.setattr(RR, 'BN_EPILOGUE_STATS', on)
+        monkeypatch.setattr(RR, 'BN_FUSED_APPLY', fused)
         torch.manual_seed(2)
         R = RR.Reconstructor('ResNet', 16).to(dev).train()
         ar = RR.r_arith(arith, 1 if arith == 'bf16x3' else 0)
@@ -89,7 +102,8 @@ def test_reconstructor_with_and_without_epilogue_statistics(dev, monkeypatch, ar
         grads, _, d2 = R._backward_impl(saved, dl, dm, need_x=(False, True))
         res.append((logits, mag, d2, [grads[id(p)].clone() for n, p in R.named_parameters() if id(p) in grads],
                     [b.clone() for b in R.buffers() if b.is_floating_point()], n_launch))
-    assert res[0][5] <= res[1][5] - 20, (res[0][5], res[1][5])          # one launch fewer per BatchNorm (20 of them)
+    n_bwd = None
+    assert res[0][5] <= res[1][5] - (40 if fused else 20), (res[0][5], res[1][5])          # one / two launches fewer per BatchNorm forward (20 of them)
     assert rel_err(res[0][0], res[1][0]) < 2e-5 and rel_err(res[0][1], res[1][1]) < 2e-5
     for a_, b_ in zip(res[0][4], res[1][4]):          # running statistics
         assert rel_err(a_, b_) < 1e-5
@@ -102,3 +116,28 @@ def test_reconstructor_with_and_without_epilogue_statistics(dev, monkeypatch, ar
     assert cos(res[0][2], res[1][2]) > 0.9999
     for a_, b_ in zip(res[0][3], res[1][3]):
         assert cos(a_, b_) > 0.999
+
+
+def test_bn_backward_over_the_scratch_pair(dev):
+    """wgs_bn_bwd_fused == wgs_bn_bwd (reduction, then the apply kernel sums the replicas itself), with and without the residual branch; the
+    scratch it accumulated into stays dirty, the other one is left zero; a second call with the roles swapped gives the same result."""
+    torch.manual_seed(3)
+    for N, Cn in ((4096, 64), (700, 128), (64, 512)):
+        x, dyA, dyB = torch.randn(N, Cn, device=dev), torch.randn(N, Cn, device=dev), torch.randn(N, Cn, device=dev)
+        out = torch.randn(N, Cn, device=dev)
+        mean, invstd = x.mean(0), 1.0 / (x.var(0, unbiased=False) + 1e-5).sqrt()
+        g = torch.rand(Cn, device=dev) + 0.5
+        ref = [torch.empty_like(x), torch.empty_like(x), torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)]
+        ws = torch.zeros(64 * Cn, dtype=torch.float64, device=dev)
+        L.check(L.lib().wgs_bn_bwd(L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr(out), L.ptr(mean), L.ptr(invstd), L.ptr(g), L.ptr(ref[0]), L.ptr(ref[1]),
+                                   L.ptr(ref[2]), L.ptr(ref[3]), L.rawptr(ws), L.c_int64(N), Cn, 1, L.stream()), 'bn_bwd')
+        a, b = torch.zeros(64 * Cn, dtype=torch.float64, device=dev), torch.full((64 * Cn,), 7.0, dtype=torch.float64, device=dev)
+        for _ in range(2):
+            got = [torch.empty_like(x), torch.empty_like(x), torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)]
+            L.check(L.lib().wgs_bn_bwd_fused(L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr(out), L.ptr(mean), L.ptr(invstd), L.ptr(g), L.ptr(got[0]),
+                                             L.ptr(got[1]), L.ptr(got[2]), L.ptr(got[3]), L.rawptr(a), L.rawptr(b), L.c_int64(N), Cn, L.stream()), 'bn_bwd_fused')
+            nrep = max(1, min(32, 2048 // Cn))
+            assert float(b[:nrep * 2 * Cn].abs().max()) == 0.0 and float(a.abs().max()) > 0.0
+            for u, v in zip(got, ref):
+                assert rel_err(u, v) < 1e-5
+            a, b = b, a

@@ -33,8 +33,9 @@ VARIANTS = [
     ('wgrad direct', {'conv.WGRAD_DIRECT': True}),
     ('up bf16 unfused', {'conv.UPCONV_FUSED_MIN_H': {1: 1 << 30, 2: 16, 3: 16}}),
     ('up bf16 fused', {'conv.UPCONV_FUSED_MIN_H': {1: 32, 2: 16, 3: 16}}),
-    ('BN stats pass', {'rr.BN_EPILOGUE_STATS': False}),
-    ('BN stats in epilogue', {'rr.BN_EPILOGUE_STATS': True}),
+    ('BN stats pass', {'rr.BN_EPILOGUE_STATS': False, 'rr.BN_FUSED_APPLY': False}),
+    ('BN stats in epilogue', {'rr.BN_EPILOGUE_STATS': True, 'rr.BN_FUSED_APPLY': False}),
+    ('BN stats in epilogue + fused apply', {'rr.BN_EPILOGUE_STATS': True, 'rr.BN_FUSED_APPLY': True}),
     ('R +0 launches', {'bn.debug_extra_launches': 0}),
     ('R +40 empty launches', {'bn.debug_extra_launches': 2}),
     ('R +80 empty launches', {'bn.debug_extra_launches': 4}),

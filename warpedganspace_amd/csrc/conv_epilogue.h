@@ -10,13 +10,12 @@ typedef float epi_f32x16 __attribute__((ext_vector_type(16)));
 
 // Column statistics of a launch's output for the train-mode BatchNorm behind it (wgs_conv_desc.col_stats): a lane's partial sums of
 // column n over its rows (<= 64 values, fp32) -> the two half-waves hold the same columns: combined with one cross-half shuffle -> one
-// fp64 atomic per column and wave into replica blockIdx.x % 32 of the scratch [32][2][Co] (the layout of recon_ops.hip's chan_reduce).
-constexpr int STATS_REP = 32;
+// fp64 atomic per column and wave into replica blockIdx.x % nrep of the scratch [nrep][2][Co] (the layout of recon_ops.hip's chan_reduce).
 __device__ __forceinline__ void col_stats_flush(double* ws, int Co, int n, bool nok, float s1, float s2, int lh) {
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lh == 0 && nok) {
-        double* wr = ws + (size_t)(blockIdx.x % STATS_REP) * 2 * Co;
+        double* wr = ws + (size_t)(blockIdx.x % (unsigned)wgs_bn_nrep(Co)) * 2 * Co;
         unsafeAtomicAdd(wr + n, (double)s1);
         unsafeAtomicAdd(wr + Co + n, (double)s2);
     }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArg
     }
     if (p.y_amax) raise_amax(p.y_amax, am);     // magnitude bound for the next layer's fp16 operand scale
     if (p.col_stats) {
-        double* wr = p.col_stats + (size_t)(blockIdx.x % wgsconv::STATS_REP) * 2 * p.Co;
+        double* wr = p.col_stats + (size_t)(blockIdx.x % (unsigned)wgs_bn_nrep(p.Co)) * 2 * p.Co;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             unsafeAtomicAdd(wr + n + k, (double)s1[k]);

@@ -105,15 +105,14 @@ __global__ __launch_bounds__(256) void unpack_pair_kernel(const float* __restric
 // MODE 0: s1 = sum x, s2 = sum x^2                                   (BN forward statistics)
 // MODE 1: g = (dyA + dyB) * (out > 0),  s1 = sum g, s2 = sum g*xhat    (BN backward statistics)
 // MODE 2: s1 = sum x                                                  (bias gradient)
-// ws: double[WS_REP][2*C], ZERO ON ENTRY AND LEFT ZERO ON EXIT (the caller zeroes it once, when it allocates it); workgroup b
-// accumulates into replica b % WS_REP with fp64 atomics (hundreds of workgroups adding to the same 2*C addresses serialise in the L2
+// ws: double[wgs_bn_nrep(C)][2*C], ZERO ON ENTRY AND LEFT ZERO ON EXIT (the caller zeroes it once, when it allocates it); workgroup b
+// accumulates into replica b % nrep with fp64 atomics (hundreds of workgroups adding to the same 2*C addresses serialise in the L2
 // atomic units: replicas cut that 32x); the small second launch (bn_finalize_kernel / ws_collapse_kernel) sums the replicas, writes what
 // the consumer needs (mean / invstd / running statistics, or dbeta / dgamma) and ZEROES the replicas again — no memset launch per
 // reduction (40 per training step over the Reconstructor's 20 BatchNorms).
 // (Tried and dropped, round 4: the whole reduction in ONE launch, the last workgroup to finish — ticket counter — finalising.  The
 // agent-scope fence every workgroup needs in front of its ticket writes back its XCD's L2 on this 8-XCD part: 112 us instead of 72 us
 // for the stem's BatchNorm forward, the training step 27.4 -> 29.5 ms.  Kernel boundaries do that write-back once.)
-constexpr int WS_REP = 32;
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dyA,
                                                           const float* __restrict__ dyB, const float* __restrict__ out,
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
                 for (int q = 0; q < 4; ++q) { t1[q] += red[0][s * tpr + cl][q]; t2[q] += red[1][s * tpr + cl][q]; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                double* wr = ws + (size_t)(blockIdx.x % WS_REP) * 2 * C;
+                double* wr = ws + (size_t)(blockIdx.x % (unsigned)wgs_bn_nrep(C)) * 2 * C;
                 unsafeAtomicAdd(wr + c + q, t1[q]);
                 if (MODE != 2) unsafeAtomicAdd(wr + C + c + q, t2[q]);
             }
@@ -195,8 +194,8 @@ __global__ __launch_bounds__(256) void ws_collapse_kernel(double* __restrict__ w
     const int n = 2 * C;
     if (i >= n) return;
     double t = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < WS_REP; ++r) { t += ws[(size_t)r * n + i]; ws[(size_t)r * n + i] = 0.0; }
+    const int nrep = wgs_bn_nrep(C);
+    for (int r = 0; r < nrep; ++r) { t += ws[(size_t)r * n + i]; ws[(size_t)r * n + i] = 0.0; }
     if (i < C) { if (out1) out1[i] = (float)t; }
     else if (out2) out2[i - C] = (float)t;
 }
@@ -209,10 +208,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, float* __restr
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) nbt[0] += 1;
     if (c >= C) return;
-    // sums the WS_REP replicas itself (same order as ws_collapse_kernel): one launch less per BatchNorm forward
+    // sums the replicas itself (same order as ws_collapse_kernel): one launch less per BatchNorm forward
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < WS_REP; ++r) {
+    const int nrep = wgs_bn_nrep(C);
+    for (int r = 0; r < nrep; ++r) {
         double* pr = const_cast<double*>(ws) + (size_t)r * 2 * C;
         s1 += pr[c]; s2 += pr[C + c];
         pr[c] = 0.0; pr[C + c] = 0.0;               // left zero for the next reduction (no memset launch)
@@ -260,6 +259,114 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[e] = o;
+    }
+}
+
+// ---- round 5: the statistics are finished in the PROLOGUE of the apply kernels (every workgroup sums the <= 32 KB of replicas for all C
+// channels into LDS; workgroup 0 also writes what the finalise / collapse launches wrote), and the scratch is a PAIR: this launch reads
+// `ws`, and leaves the OTHER scratch `wz` zero for the next producer (it was dirtied two producers ago; nothing else touches it now) —
+// so neither a finalise / collapse launch nor a memset sits between a reduction and its apply.
+__global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ ws, double* __restrict__ wz,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ res, float* __restrict__ y,
+                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             int64_t* __restrict__ nbt, int64_t N, int C, float eps, float momentum, int relu) {
+    extern __shared__ float bn_sm[];            // [C] scale = invstd * gamma | [C] shift = beta - mean * scale
+    float* sc = bn_sm;
+    float* sh = bn_sm + C;
+    const int nrep = wgs_bn_nrep(C);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < nrep; ++r) { s1 += ws[(size_t)r * 2 * C + c]; s2 += ws[(size_t)r * 2 * C + C + c]; }
+        const double m = s1 / (double)N;
+        double var = s2 / (double)N - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+        sc[c] = isf; sh[c] = mf;
+        if (blockIdx.x == 0) {
+            save_mean[c] = mf; save_invstd[c] = isf;
+            if (running_mean) {
+                const double unb = N > 1 ? var * (double)N / (double)(N - 1) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && nbt) nbt[0] += 1;
+        for (int i = threadIdx.x; i < nrep * 2 * C; i += 256) wz[i] = 0.0;
+    }
+    __syncthreads();
+    const int c4n = C >> 2;
+    const int64_t total = N * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % c4n) * 4;
+        const float4 v = reinterpret_cast<const float4*>(x)[e];
+        const float4 is = *reinterpret_cast<const float4*>(sc + c);
+        const float4 mu = *reinterpret_cast<const float4*>(sh + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float4 o;      // (the same expression, in the same order, as bn_apply_kernel)
+        o.x = (v.x - mu.x) * is.x * ga.x + be.x; o.y = (v.y - mu.y) * is.y * ga.y + be.y;
+        o.z = (v.z - mu.z) * is.z * ga.z + be.z; o.w = (v.w - mu.w) * is.w * ga.w + be.w;
+        if (res) {
+            const float4 r = reinterpret_cast<const float4*>(res)[e];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[e] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __restrict__ x, const float* __restrict__ dyA,
+                                                                 const float* __restrict__ dyB, const float* __restrict__ out,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const double* __restrict__ ws, double* __restrict__ wz,
+                                                                 float* __restrict__ dx, float* __restrict__ dres,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t N, int C) {
+    extern __shared__ float bn_sm[];            // [C] mean of g | [C] mean of g * xhat
+    float* m1 = bn_sm;
+    float* m2 = bn_sm + C;
+    const int nrep = wgs_bn_nrep(C);
+    const double invN = 1.0 / (double)N;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < nrep; ++r) { s1 += ws[(size_t)r * 2 * C + c]; s2 += ws[(size_t)r * 2 * C + C + c]; }
+        // (the separate collapse launch rounds the sums to fp32 — they are dbeta / dgamma — and the apply kernel divides those: same here)
+        const float f1 = (float)s1, f2 = (float)s2;
+        m1[c] = (float)(f1 * invN); m2[c] = (float)(f2 * invN);
+        if (blockIdx.x == 0) { dbeta[c] = f1; dgamma[c] = f2; }
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nrep * 2 * C; i += 256) wz[i] = 0.0;
+    __syncthreads();
+    const int c4n = C >> 2;
+    const int64_t total = N * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % c4n) * 4;
+        float4 g = reinterpret_cast<const float4*>(dyA)[e];
+        if (dyB) {
+            const float4 g2 = reinterpret_cast<const float4*>(dyB)[e];
+            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+        }
+        if (out) {
+            const float4 o = reinterpret_cast<const float4*>(out)[e];
+            g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
+            g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+        }
+        if (dres) reinterpret_cast<float4*>(dres)[e] = g;
+        const float4 v = reinterpret_cast<const float4*>(x)[e];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 a1 = *reinterpret_cast<const float4*>(m1 + c), a2 = *reinterpret_cast<const float4*>(m2 + c);
+        float4 d;
+        d.x = ga.x * is.x * (g.x - a1.x - (v.x - mu.x) * is.x * a2.x);
+        d.y = ga.y * is.y * (g.y - a1.y - (v.y - mu.y) * is.y * a2.y);
+        d.z = ga.z * is.z * (g.z - a1.z - (v.z - mu.z) * is.z * a2.z);
+        d.w = ga.w * is.w * (g.w - a1.w - (v.w - mu.w) * is.w * a2.w);
+        reinterpret_cast<float4*>(dx)[e] = d;
     }
 }
 
@@ -491,6 +598,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// the fused BatchNorm apply kernels pay a prologue per workgroup (<= 32 KB of replica sums): fewer, fatter workgroups
+int grid_fused(int64_t work) {
+    int g = wgs_cdiv(work, 1024);
+    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
+
 int grid_for(int64_t work) {
     int g = wgs_cdiv(work, 256);
     return g > 8192 ? 8192 : (g < 1 ? 1 : g);
@@ -598,6 +711,33 @@ int wgs_bn_fwd_sums(const float* x, const float* gamma, const float* beta, const
     WGS_LAUNCH(bn_apply_kernel, dim3(grid_for(N * (C / 4))), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta,
                        residual, y, N, C, relu);
     WGS_CHECK_LAUNCH("bn_fwd_sums");
+    return WGS_OK;
+}
+
+int wgs_bn_fwd_fused(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
+                     float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, const double* ws_sums,
+                     double* ws_zero, int64_t N, int C, float eps, float momentum, int relu, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && gamma && beta && y && save_mean && save_invstd && ws_sums && ws_zero && ws_sums != ws_zero, "wgs_bn_fwd_fused: null pointer (or one scratch passed twice)");
+    WGS_CHECK_ARG(N > 0 && C >= 4 && C % 4 == 0 && C <= 8192, "wgs_bn_fwd_fused: C=%d must be a multiple of 4 (<= 8192)", C);
+    WGS_LAUNCH(bn_apply_fused_kernel, dim3(grid_fused(N * (C / 4))), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream, x, ws_sums, ws_zero,
+               gamma, beta, residual, y, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, N, C, eps, momentum, relu);
+    WGS_CHECK_LAUNCH("bn_apply_fused_kernel");
+    return WGS_OK;
+}
+
+int wgs_bn_bwd_fused(const float* x, const float* dyA, const float* dyB, const float* out, const float* save_mean,
+                     const float* save_invstd, const float* gamma, float* dx, float* dres, float* dgamma, float* dbeta,
+                     double* ws, double* ws_zero, int64_t N, int C, wgs_stream_t stream) {
+    WGS_CHECK_ARG(x && dyA && save_mean && save_invstd && gamma && dx && dgamma && dbeta && ws && ws_zero && ws != ws_zero,
+                  "wgs_bn_bwd_fused: null pointer (or one scratch passed twice)");
+    WGS_CHECK_ARG(N > 0 && C >= 4 && C % 4 == 0 && C <= 8192, "wgs_bn_bwd_fused: C=%d must be a multiple of 4 (<= 8192)", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = ws_is_zero(ws, C, st, "wgs_bn_bwd_fused")) return rc;
+    const int rpb = reduce_rows_per_block(N, C);
+    WGS_LAUNCH(chan_reduce_kernel<1>, dim3(wgs_cdiv(N, rpb)), dim3(256), 0, st, x, dyA, dyB, out, save_mean, save_invstd, ws, N, C, rpb);
+    WGS_LAUNCH(bn_bwd_apply_fused_kernel, dim3(grid_fused(N * (C / 4))), dim3(256), (size_t)2 * C * sizeof(float), st, x, dyA, dyB, out, save_mean,
+               save_invstd, gamma, ws, ws_zero, dx, dres, dgamma, dbeta, N, C);
+    WGS_CHECK_LAUNCH("bn_bwd_fused");
     return WGS_OK;
 }
 

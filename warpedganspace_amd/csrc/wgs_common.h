@@ -45,6 +45,12 @@ void wgs_count_launch();
 void wgs_note_kernel(const char* fmt, ...);
 #define WGS_LAUNCH(...) do { wgs_count_launch(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+// Replicas of the BatchNorm / column-sum scratch (double [nrep][2 * C], include/wgs.h WGS_BN_WS_DOUBLES): workgroup b adds into replica
+// b % nrep so that hundreds of workgroups do not serialise on the same 2 * C fp64 addresses.  32 replicas up to 64 channels, fewer for wide
+// layers (whose reductions have few workgroups): every launch that SUMS the replicas then reads at most 32 KB — cheap enough for every
+// workgroup of the BatchNorm apply kernels to do it in its prologue (bn_apply_fused_kernel: no finalise / collapse launch in between).
+__host__ __device__ __forceinline__ int wgs_bn_nrep(int C) { const int r = 2048 / (C > 0 ? C : 1); return r < 1 ? 1 : (r > 32 ? 32 : r); }
+
 static inline int wgs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // n / d for a launch-uniform divisor d >= 2 as one multiply-high: magic = ceil(2^32 / d), exact for n * d < 2^32
 // (a 32-bit integer division is ~35 VALU instructions on gfx950; the short-K conv tiles do a dozen of them per lane).

@@ -67,6 +67,7 @@ def r_arith(r_precision='auto', generator_code=None):
 
 
 # The ResNet stem in space-to-depth form (Reconstructor._forward_impl): taps (dy, dx, weight index r*4 + s) of the 4 x 4 block window
+BN_FUSED_APPLY = True         # round 5: ... and the finalise / collapse launches folded into the apply kernels' prologues (_BNScratch)
 BN_EPILOGUE_STATS = True      # round 5: BatchNorm statistics from the producing conv's epilogue (wgs_conv_desc.col_stats), see _forward_impl
 STEM_S2D = True
 STEM_WGRAD_S2D = True     # ... and its weight gradient in the same form (64 x 16 x 32, gathered back to 64 x 49 x 2c)
@@ -131,6 +132,31 @@ def _grad_like(conv, dw_packed):
     return dw_packed.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
 
 
+class _BNScratch:
+    """The PAIR of fp64 scratch buffers of the fused BatchNorm launches (wgs_bn_fwd_fused / wgs_bn_bwd_fused): a producer (a conv's
+    epilogue, the backward's reduction) accumulates into cur(), the fused apply launch behind it reads that buffer and leaves the OTHER
+    one zero, and the roles swap.  Both zero at the start; the index persists across steps (the buffer a step leaves dirty is the one its
+    successor's first apply launch zeroes)."""
+
+    def __init__(self, dev, C=512):
+        self.buf = [torch.zeros(64 * C, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.k = 0
+
+    def cur(self):
+        return self.buf[self.k]
+
+    def consume(self):
+        """(buffer holding the producer's sums, buffer to leave zero); swaps the roles."""
+        a, b = self.buf[self.k], self.buf[self.k ^ 1]
+        self.k ^= 1
+        return a, b
+
+    def reset(self):
+        for b in self.buf:
+            b.zero_()
+        self.k = 0
+
+
 class _BN:
     """One fused BatchNorm launch pair + what its backward needs."""
 
@@ -142,12 +168,22 @@ class _BN:
         mean = torch.empty(Cn, device=x.device)
         invstd = torch.empty(Cn, device=x.device)
         if sums_ready and train:
+            if isinstance(ws, _BNScratch):      # one launch: statistics finished in the apply kernel's prologue, scratch pair
+                a, b = ws.consume()
+                L.check(L.lib().wgs_bn_fwd_fused(L.ptr(x), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(residual), L.ptr(y), L.ptr(mean),
+                                                 L.ptr(invstd), L.ptr(bn.running_mean), L.ptr(bn.running_var),
+                                                 L.ptr(bn.num_batches_tracked, torch.int64), L.rawptr(a), L.rawptr(b), L.c_int64(N), Cn,
+                                                 L.c_float(bn.eps), L.c_float(bn.momentum if bn.momentum is not None else 0.1),
+                                                 int(relu), L.stream()), 'wgs_bn_fwd_fused')
+                return y, (mean, invstd)
             L.check(L.lib().wgs_bn_fwd_sums(L.ptr(x), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(residual), L.ptr(y), L.ptr(mean),
                                             L.ptr(invstd), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                                             L.ptr(bn.num_batches_tracked, torch.int64), L.rawptr(ws), L.c_int64(N), Cn,
                                             L.c_float(bn.eps), L.c_float(bn.momentum if bn.momentum is not None else 0.1),
                                             int(relu), L.stream()), 'wgs_bn_fwd_sums')
             return y, (mean, invstd)
+        if isinstance(ws, _BNScratch):
+            ws = ws.cur()                       # (no sums from an epilogue: the three-launch form on the buffer that is zero, left zero)
         L.check(L.lib().wgs_bn_fwd(L.ptr(x), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(residual), L.ptr(y), L.ptr(mean),
                                    L.ptr(invstd), L.ptr(bn.running_mean), L.ptr(bn.running_var),
                                    L.ptr(bn.num_batches_tracked, torch.int64), L.rawptr(ws), L.c_int64(N), Cn,
@@ -174,6 +210,14 @@ class _BN:
         dres = torch.empty_like(x) if want_res else None
         dg = gbuf[id(bn.weight)] if gbuf is not None else torch.empty(Cn, device=x.device)
         db = gbuf[id(bn.bias)] if gbuf is not None else torch.empty(Cn, device=x.device)
+        if isinstance(ws, _BNScratch):
+            if train:                           # two launches instead of three: reduction, then the apply kernel finishes the sums itself
+                a, b = ws.consume()
+                L.check(L.lib().wgs_bn_bwd_fused(L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr(out), L.ptr(stats[0]), L.ptr(stats[1]),
+                                                 L.ptr(bn.weight), L.ptr(dx), L.ptr(dres), L.ptr(dg), L.ptr(db), L.rawptr(a), L.rawptr(b),
+                                                 L.c_int64(N), Cn, L.stream()), 'wgs_bn_bwd_fused')
+                return dx, dres, dg, db
+            ws = ws.cur()                       # (eval-mode backward: the three-launch form on the buffer that is zero)
         L.check(L.lib().wgs_bn_bwd(L.ptr(x), L.ptr(dyA), L.ptr(dyB), L.ptr(out), L.ptr(stats[0]), L.ptr(stats[1]),
                                    L.ptr(bn.weight), L.ptr(dx), L.ptr(dres), L.ptr(dg), L.ptr(db), L.rawptr(ws),
                                    L.c_int64(N), Cn, int(train), L.stream()), 'wgs_bn_bwd')
@@ -294,7 +338,14 @@ class Reconstructor(nn.Module):
         # kernel with the shared epilogue: every conv of the direct fp32 and split-bf16 arithmetics (the Winograd launches of 'fp32w' keep
         # the separate statistics pass).  One scratch: a conv's sums are consumed (and the scratch left zero) by the BatchNorm right behind it.
         est = BN_EPILOGUE_STATS and train and fp in (0, 1)
-        cs = dict(col_stats=ws) if est else {}
+        if est and BN_FUSED_APPLY:
+            # ... and finished in the apply kernel's prologue over a scratch PAIR (_BNScratch): conv -> apply, one BatchNorm launch instead of
+            # three; the backward's three launches become two the same way
+            pair = self.__dict__.get('_bn_pair')
+            if pair is None or pair.buf[0].device != dev:
+                pair = self.__dict__['_bn_pair'] = _BNScratch(dev)
+            ws = pair
+        cs = (lambda: dict(col_stats=ws.cur() if isinstance(ws, _BNScratch) else ws)) if est else (lambda: {})
         # The stem (7 x 7, stride 2, 2c = 6 input channels): SPACE-TO-DEPTH.  The image pair is packed as
         # [B, H/2, W/2, 32] (2 x 2 pixel block x 8 channels) and the 7 x 7 / 2 conv becomes a 4 x 4-window stride-1 conv 32 -> 64 channels
         # over it (zeros where a tap falls outside the 7 x 7: 49 * 6 of 16 * 32 weights live) — a shape the few-channel halo kernel
@@ -308,7 +359,7 @@ class Reconstructor(nn.Module):
             w1s = self._scratch('w1s', (64, 16, 32), torch.float32, dev)
             L.check(lib.wgs_stem_weight_s2d(L.rawptr(_packed(fe.conv1)), L.ptr(w1s), 64, 2 * c, 0, st), 'stem_weight_s2d')
             c1 = torch.empty(B, H // 2, W // 2, 64, device=dev)
-            C.launch(x, w1s, c1, _S2D_TAPS, H // 2, W // 2, w_tap_stride=32, w_row_stride=16 * 32, precision=fp, **cs)
+            C.launch(x, w1s, c1, _S2D_TAPS, H // 2, W // 2, w_tap_stride=32, w_row_stride=16 * 32, precision=fp, **cs())
         else:
             x = torch.empty(B, H, W, Cp, device=dev)
             L.check(lib.wgs_pack_pair_nhwc(L.ptr(x1), L.ptr(x2), L.ptr(x), B, c, H * W, Cp, st), 'pack_pair')
@@ -326,15 +377,15 @@ class Reconstructor(nn.Module):
         wc = (lambda conv: sw.cache(conv, 'f')) if sw is not None else (lambda conv: None)       # Winograd operands refreshed by the engine (StepWeights)
         for blk in fe.blocks():
             xin = h
-            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=fp, w_split=wc(blk.conv1), **cs)
+            ca = C.conv2d(xin, _packed(blk.conv1), 3, stride=blk.stride, pad=1, precision=fp, w_split=wc(blk.conv1), **cs())
             aa, sa = _BN.fwd(blk.bn1, ca, ws, relu=True, train=train, sums_ready=est)
             if blk.downsample is not None:       # (before conv2: one scratch, consumed by the BatchNorm right behind each conv)
-                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=fp, **cs)
+                cd = C.conv2d(xin, _packed(blk.downsample[0]), 1, stride=blk.stride, pad=0, precision=fp, **cs())
                 ad, sd = _BN.fwd(blk.downsample[1], cd, ws, relu=False, train=train, sums_ready=est)
                 ident = ad
             else:
                 cd, sd, ident = None, None, xin
-            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=fp, w_split=wc(blk.conv2), **cs)
+            cb = C.conv2d(aa, _packed(blk.conv2), 3, stride=1, pad=1, precision=fp, w_split=wc(blk.conv2), **cs())
             o, sb = _BN.fwd(blk.bn2, cb, ws, residual=ident, relu=True, train=train, sums_ready=est)
             saved_blocks.append((xin, ca, aa, sa, cb, sb, cd, sd, o))
             h = o
