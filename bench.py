@@ -233,6 +233,7 @@ def roofline_of(recs, img_per_s_per_gpu, gflop_per_img, pmc_files=None):
     out = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
            "direct_equiv_TFLOPs": round(d['fl'] / d['ms'] / 1e9, 2),
            "traffic": tr["traffic"] if tr else None, "traffic_algorithmic": tr["traffic_algorithmic"] if tr else None,
+           "traffic_source": ("static: " + tr["source"]) if tr else None,
            "traffic_note": ("GB per launch, launch-weighted mean over %d of the symbol's %d shapes; STATIC, from the committed rocprofv3 --pmc passes %s "
                             "(FETCH_SIZE x2 on gfx950 + WRITE_SIZE)" % (tr["shapes_measured"], tr["shapes_in_step"], tr["source"])) if tr else
                            "not measured for this symbol (PMC counters need separate rocprofv3 --pmc passes: profiles/)",
@@ -245,7 +246,7 @@ def roofline_of(recs, img_per_s_per_gpu, gflop_per_img, pmc_files=None):
            "by_symbol": by_symbol[:10],
            "method": "HIP events on the launch stream around every conv launch of 2 extra single-stream steps; per symbol: sum of the MFMA FLOPs "
                      "the launches execute (direct form: 2 * pixels * Cout * Cin * taps; Winograd F(2x2,3x3): 16/36 of that) / sum of their "
-                     "durations; rocprofv3 tables of the same build: profiles/r4_step_*_kernel_stats.md"}
+                     "durations; rocprofv3 tables of the same build: profiles/r5_step_*_kernel_stats.md"}
     if gflop_per_img:
         # the step's FLOPs: SURVEY.md section 8(d)'s algorithmic count, scaled by executed / algorithmic of the profiled conv launches
         alg = img_per_s_per_gpu * gflop_per_img / 1e3
@@ -549,7 +550,7 @@ def full_record(args, world, head, stats, comm, hbm, extra, cpu, gkey):
             "extra": extra or None, "cpu_baseline": cpu}
 
 
-ROOFLINE_LINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic", "direct_equiv_TFLOPs",
+ROOFLINE_LINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic", "traffic_source", "direct_equiv_TFLOPs",
                       "kernel_launches_per_step", "kernel_avg_launch_ms", "step_achieved_TFLOPs", "step_frac", "step_direct_equiv_TFLOPs")
 LINE_LIMIT = 4096
 

@@ -20,7 +20,9 @@ SHAPES = [('conv fp32w 512->512 @64x64 9 taps B32', 'conv', 'fp32w', 512, 512, 6
           # round 4: producer-written fp16 plane through the patch kernel's XF16 form, and the few-channel halo kernel (StyleGAN2-1024, B = 8)
           ('conv f16 128->128 @256x256 9 taps B32 (fp16 plane)', 'plane', 'f16', 128, 128, 256),
           ('conv f16x2 32->32 @1024x1024 9 taps B8', 'halo', 'f16x2', 32, 32, 1024),
-          ('conv f16x2 64->64 @512x512 9 taps B8', 'halo', 'f16x2', 64, 64, 512)]
+          ('conv f16x2 64->64 @512x512 9 taps B8', 'halo', 'f16x2', 64, 64, 512),
+          # round 5: the fused up-sampling kernel in split-bf16 (StyleGAN2-256's 32 -> 64 layer under the default policy)
+          ('conv bf16x3 512->512 @32x32 up-conv + blur fused B32', 'up', 'bf16x3', 512, 512, 32)]
 
 
 def run():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash tools/run_round.sh <tag> [notests] — GPU test suite, default bench line (+ side file), rocprofv3 kernel tables and phase
 # breakdowns of the fp32w / fp32 / auto step, PMC passes of the dominant conv kernels, host-enqueue measurement with 8 processes
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 if [ "$2" != "notests" ]; then
@@ -27,3 +27,14 @@ done
 find gpurun_out/pmc_${TAG} -name "*kernel_trace.csv" -delete
 python tools/pmc_r3.py --summarise gpurun_out/pmc_${TAG} gpurun_out/${TAG}_conv_pmc | tail -16 | cut -c1-220
 timeout 900 python tools/host_enqueue_n.py 8 auto | tail -1 > gpurun_out/${TAG}_host_enqueue_8.json
+# round 5: weight-gradient kernels (micro-benchmark + PMC passes), the reported-only rows of the precision table
+timeout 600 python tools/bench_wgrad_direct.py ksweep > gpurun_out/${TAG}_wgrad_bench.txt 2>&1
+i=0
+for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmcw_${TAG}/p$i -o p -- python tools/pmc_wgrad16.py > gpurun_out/pmcw_${TAG}_p$i.log 2>&1
+done
+find gpurun_out/pmcw_${TAG} -name "*kernel_trace.csv" -delete
+python tools/pmc_wgrad16.py --summarise gpurun_out/pmcw_${TAG} > gpurun_out/${TAG}_wgrad_pmc.txt 2>&1
+WGS_FULL_SCHEMES=1 timeout 1500 python -m pytest tests/test_precision_schemes_gpu.py -q -x -k per_scheme > gpurun_out/${TAG}_schemes.log 2>&1; tail -2 gpurun_out/${TAG}_schemes.log
+cp gpurun_out/precision_schemes.json gpurun_out/${TAG}_precision_schemes.json 2>/dev/null
