@@ -197,7 +197,7 @@ typedef struct wgs_conv_desc {
                                 output pixel, into this BatchNorm scratch (WGS_BN_WS_DOUBLES(Co) doubles in wgs_bn_fwd's replica layout, zero
                                 on entry): the statistics pass of the train-mode BatchNorm behind the conv comes out of the conv's epilogue
                                 (wgs_bn_fwd_sums finishes it) instead of re-reading the tensor.  fp32 partial sums over <= 64 rows per lane,
-                                fp64 atomics from there.  Precisions 0 / 1 / 2 / 3 through the tiled kernels; a launch that would fall to a
+                                fp64 atomics from there.  Precisions 0 / 1 / 2 / 3 through the tiled kernels, and wgs_conv_wino; a launch that would fall to a
                                 kernel without the epilogue fails with WGS_EINVAL.  Not with rgb_out / x_f16. */
 } wgs_conv_desc;
 int wgs_conv_igemm(const wgs_conv_desc* desc, wgs_stream_t stream);

@@ -21,7 +21,7 @@ def _sums(ws, Co):
     return r[0], r[1]
 
 
-@pytest.mark.parametrize('precision', [0, 1])
+@pytest.mark.parametrize('precision', [0, 1, C.FP32W])
 @pytest.mark.parametrize('B,Ci,Co,H,k,s,p', CASES)
 def test_conv_epilogue_column_sums(dev, precision, B, Ci, Co, H, k, s, p):
     torch.manual_seed(Ci + Co + H + k)
@@ -80,7 +80,7 @@ def test_col_stats_argument_checks(dev):
 
 
 @pytest.mark.parametrize('fused', [True, False])
-@pytest.mark.parametrize('arith', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('arith', ['fp32', 'bf16x3', 'fp32w'])
 def test_reconstructor_with_and_without_epilogue_statistics(dev, monkeypatch, arith, fused):
     """The whole Reconstructor: logits, magnitude, image gradient, every parameter gradient and the BatchNorm running statistics agree
     between the two routes (same values up to the order of fp32 / fp64 additions)."""
@@ -93,7 +93,7 @@ def test_reconstructor_with_and_without_epilogue_statistics(dev, monkeypatch, ar
         monkeypatch.setattr(RR, 'BN_FUSED_APPLY', fused)
         torch.manual_seed(2)
         R = RR.Reconstructor('ResNet', 16).to(dev).train()
-        ar = RR.r_arith(arith, 1 if arith == 'bf16x3' else 0)
+        ar = RR.r_arith(arith, {'bf16x3': 1, 'fp32w': 5}.get(arith, 0))
         lib = L.lib()
         c0 = lib.wgs_dev_launch_count()
         logits, mag, saved = R._forward_impl(x1, x2, save=True, arith=ar)

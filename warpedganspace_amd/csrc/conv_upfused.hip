@@ -38,6 +38,9 @@ namespace {
 constexpr int BK = 32;
 constexpr int ROW = 64;                  // bytes per LDS row of a weight plane (DMA: unpadded, XOR-swizzled 16-B slots)
 constexpr int PROW = 80;                 // bytes per LDS row of the patch (padded, linear)
+// (round 5, measured and reverted: unpadded 64-byte rows with an XOR swizzle make room for all nine products of an fp16 x2 chunk in ONE weight
+//  stage — one full-drain barrier per chunk instead of two: 0.940 -> 0.936 ms at 512 -> 256 @64, 1.034 -> 1.055 ms at 256 -> 128 @128.  The barriers
+//  are not what the kernel waits for either; neither are the 4-wave tiles at two workgroups per CU (WGS_UP_GH8: 1.05 / 1.24 ms).)
 constexpr int OOB = (int)0x80000000;
 constexpr int BN = 64;
 
@@ -531,7 +534,7 @@ extern "C" int wgs_sg2_upconv_blur_act(const wgs_upconv_desc* d, wgs_stream_t st
     // 16 x 12-cell tiles (one 8-wave workgroup per CU) unless they would leave the chip short of workgroups: then 14 x 6-cell
     // tiles, two 4-wave workgroups per CU (they re-fetch the weights twice as often, which is what bounds the large layers)
     const long big_tiles = (long)((d->H + 15) / 16) * ((d->H + 11) / 12);        // 16 x 12-cell tiles of the 8-wave form
-    const bool gh16 = wgs_flags().up_gh16 || (long)d->B * big_tiles * ((d->Co + BN - 1) / BN) >= 1536;
+    const bool gh16 = !wgs_flags().up_gh8 && (wgs_flags().up_gh16 || (long)d->B * big_tiles * ((d->Co + BN - 1) / BN) >= 1536);
     // precision 3 (fp16 x2) splits the ACTIVATION operand here (Scheme<3>: same two MFMAs, same error class as the weight split of
     // the GEMM kernels): the second weight plane would double the LDS-DMA traffic that bounds this kernel.  w_lo is not read.
     // precision 1 (split-bf16 x3, fp32-class): both operands as hi + lo planes, three MFMAs per product (Scheme<0>); no operand scale

@@ -58,6 +58,7 @@ struct WinoArgs {
     const float* noise;
     const float* noise_w;
     float* y_amax;
+    double* col_stats;           // wgs_conv_desc.col_stats: sum y / sum y^2 per output channel into the BatchNorm scratch (conv_epilogue.h), or null
     int B, H, W, Ci, Co, a_ld, col_ld;
     float alpha, act_slope, gain;
 };
@@ -348,6 +349,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wino_f32_kernel(cons
     }
     __syncthreads();
     float vmax = 0.f;
+    float st1 = 0.f, st2 = 0.f;          // column statistics: a thread finishes ONE channel (NT % BN == 0: the same one in every trip), 16 outputs per trip
+    static_assert(NT % BN == 0, "a thread's channel must not change between trips");
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int tq = (tid + it * NT) / BN;
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wino_f32_kernel(cons
                     float v = __builtin_fmaf(yv[j2][k], cs, __builtin_fmaf(nw, nz[it][i2][2 * k + j2], bs[it]));
                     v = fmaxf(v, v * slope) * gain;
                     if (p.y_amax) vmax = fmaxf(vmax, fabsf(v));
+                    if (p.col_stats) { st1 += v; st2 = __builtin_fmaf(v, v, st2); }
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, y_voff, ((i2 * p.W + 2 * k + j2) * p.Co) * 4, 0);
                 }
         }
@@ -377,6 +381,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wino_f32_kernel(cons
     if (p.y_amax) {
         vmax = wave_max(vmax);
         if (lane == 0) raise_amax(p.y_amax, vmax);
+    }
+    if (p.col_stats) {
+        double* wr = p.col_stats + (size_t)(blockIdx.x % (unsigned)wgs_bn_nrep(p.Co)) * 2 * p.Co + nb0 * BN + n_l[0];
+        unsafeAtomicAdd(wr, (double)st1);
+        unsafeAtomicAdd(wr + p.Co, (double)st2);
     }
 }
 
@@ -443,7 +452,7 @@ int wgs_conv_wino(const wgs_conv_desc* d, const float* U, wgs_stream_t stream) {
     WGS_CHECK_ARG(wino_ok(d) && U, "wgs_conv_wino: not a 3x3 stride-1 'same' launch the Winograd kernel covers (wgs_conv_wino_supported)");
     WinoArgs a;
     a.x = d->x; a.U = U; a.y = d->y; a.a_scale = d->a_scale; a.col_scale = d->col_scale; a.bias = d->bias; a.noise = d->noise; a.noise_w = d->noise_w;
-    a.y_amax = d->y_amax;
+    a.y_amax = d->y_amax; a.col_stats = d->col_stats;
     a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.Ci = d->Ci; a.Co = d->Co;
     a.a_ld = d->a_ld > 0 ? d->a_ld : d->Ci; a.col_ld = d->col_ld > 0 ? d->col_ld : d->Co;
     a.alpha = d->alpha != 0.f ? d->alpha : 1.f; a.act_slope = d->act_slope; a.gain = d->gain;

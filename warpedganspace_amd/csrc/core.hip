@@ -34,6 +34,7 @@ static WgsFlags read_flags() {
     g.patch_bm256 = getenv("WGS_PATCH_BM256") != nullptr;
     g.patch_tps1 = getenv("WGS_PATCH_TPS1") != nullptr;
     g.up_gh16 = getenv("WGS_UP_GH16") != nullptr;
+    g.up_gh8 = getenv("WGS_UP_GH8") != nullptr;      // fused up-sampling kernel: the 4-wave 14 x 6-cell tiles (two workgroups per CU) whatever the launch size
     g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
     g.wgrad_per_tap = getenv("WGS_WGRAD_PER_TAP") != nullptr;
     g.patch_wide = getenv("WGS_PATCH_WIDE") != nullptr;

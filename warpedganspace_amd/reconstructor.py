@@ -335,9 +335,8 @@ class Reconstructor(nn.Module):
         arith = arith or self.arith
         fp = arith.forward
         # train-mode BatchNorm statistics out of the producing conv's epilogue (wgs_conv_desc.col_stats) wherever the conv runs a tiled
-        # kernel with the shared epilogue: every conv of the direct fp32 and split-bf16 arithmetics (the Winograd launches of 'fp32w' keep
-        # the separate statistics pass).  One scratch: a conv's sums are consumed (and the scratch left zero) by the BatchNorm right behind it.
-        est = BN_EPILOGUE_STATS and train and fp in (0, 1)
+        # kernel with the shared epilogue or the Winograd kernel: every conv of the direct fp32, 'fp32w' and split-bf16 arithmetics.  One scratch: a conv's sums are consumed (and the scratch left zero) by the BatchNorm right behind it.
+        est = BN_EPILOGUE_STATS and train and fp in (0, 1, C.FP32W)
         if est and BN_FUSED_APPLY:
             # ... and finished in the apply kernel's prologue over a scratch PAIR (_BNScratch): conv -> apply, one BatchNorm launch instead of
             # three; the backward's three launches become two the same way
