@@ -566,20 +566,19 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
         const float4 ps = post_scale ? *reinterpret_cast<const float4*>(post_scale + (size_t)b * C + c) : make_float4(1.f, 1.f, 1.f, 1.f);
         // fp64 partial sums: these reductions run over up to 65536 pixels with heavy cancellation
         double r_num[4] = {0, 0, 0, 0}, r_a[4] = {0, 0, 0, 0}, r_r[4] = {0, 0, 0, 0};
-        for (int p = p_begin + sub; p < p_end; p += ppi) {
+        // one pixel: (o, ga, raw drgb triple, raw noise) -> dy store + the three partial sums.  Layers WITH a ToRGB branch (five dependent-free
+        // loads per pixel, three of them 4-byte broadcasts) keep FOUR pixels' loads in flight per thread and finish them in order — the same
+        // additions in the same order as the one-pixel loop: 580 -> 533 us at 128 ch @256^2, 197 -> 182 us at 512 ch @64^2 (tools/bench_actbwd.py);
+        // layers without it are at 5.0 - 5.5 TB/s with one pixel per trip and lose 1 - 4 % to the larger register footprint: they keep it
+        auto body = [&](int p, const float4 o, const float4 ga, float e0, float e1, float e2, float nzr) {
             const size_t off = ((size_t)b * P + p) * C + c;
-            const float4 o = *reinterpret_cast<const float4*>(out + off);
-            float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gA) ga = *reinterpret_cast<const float4*>(gA + off);
             float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
             if (drgb) {
-                const float d0 = drgb[((size_t)b * 3 + 0) * P + p] * rscale;
-                const float d1 = drgb[((size_t)b * 3 + 1) * P + p] * rscale;
-                const float d2 = drgb[((size_t)b * 3 + 2) * P + p] * rscale;
+                const float d0 = e0 * rscale, d1 = e1 * rscale, d2 = e2 * rscale;
                 gr.x = d0 * w0.x + d1 * w1.x + d2 * w2.x; gr.y = d0 * w0.y + d1 * w1.y + d2 * w2.y;
                 gr.z = d0 * w0.z + d1 * w1.z + d2 * w2.z; gr.w = d0 * w0.w + d1 * w1.w + d2 * w2.w;
             }
-            const float nz = noise ? nw * noise[p] : 0.f;
+            const float nz = noise ? nw * nzr : 0.f;
             float4 d;
 #define WGS_ONE(f, q)                                                               \
     {                                                                               \
@@ -603,6 +602,31 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
                 wgsconv::Scheme<1>::cvt4(f, h, l);
                 *reinterpret_cast<uint2*>(dy_h + off) = h;
             } else *reinterpret_cast<float4*>(dy + off) = d;
+        };
+        auto fetch = [&](int p, float4& o, float4& ga, float& e0, float& e1, float& e2, float& nzr) {
+            const size_t off = ((size_t)b * P + p) * C + c;
+            o = *reinterpret_cast<const float4*>(out + off);
+            ga = gA ? *reinterpret_cast<const float4*>(gA + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            e0 = e1 = e2 = 0.f;
+            if (drgb) {
+                e0 = drgb[((size_t)b * 3 + 0) * P + p]; e1 = drgb[((size_t)b * 3 + 1) * P + p]; e2 = drgb[((size_t)b * 3 + 2) * P + p];
+            }
+            nzr = noise ? noise[p] : 0.f;
+        };
+        int p = p_begin + sub;
+        for (; drgb && p + 3 * ppi < p_end; p += 4 * ppi) {
+            float4 o[4], ga[4];
+            float e0[4], e1[4], e2[4], nzr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fetch(p + u * ppi, o[u], ga[u], e0[u], e1[u], e2[u], nzr[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(p + u * ppi, o[u], ga[u], e0[u], e1[u], e2[u], nzr[u]);
+        }
+        for (; p < p_end; p += ppi) {
+            float4 o, ga;
+            float e0, e1, e2, nzr;
+            fetch(p, o, ga, e0, e1, e2, nzr);
+            body(p, o, ga, e0, e1, e2, nzr);
         }
         // combine the `ppi` pixel sub-streams that share this channel group
         __syncthreads();
