@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void torgb_fwd_kernel(const float* __restrict_
 //   dsA[b,c]  += sum_p out*gA       (direct style gradient of the consumer conv)
 //   dsR[b,c]  += sum_p out*gR       (direct style gradient of the ToRGB)
 // grid = (pixel chunks, B); thread -> fixed float4 channel group, strides over the chunk's pixels.
+template <bool UNR4>      // UNR4: four pixels' loads in flight per thread (the launches with a ToRGB branch), see the loop
 __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
     const float* __restrict__ out, const float* __restrict__ gA, const float* __restrict__ sA,
     const float* __restrict__ drgb, const float* __restrict__ wR, const float* __restrict__ sR, float rscale,
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(256) void sg2_act_bwd_kernel(
             nzr = noise ? noise[p] : 0.f;
         };
         int p = p_begin + sub;
-        for (; drgb && p + 3 * ppi < p_end; p += 4 * ppi) {
+        for (; UNR4 && p + 3 * ppi < p_end; p += 4 * ppi) {
             float4 o[4], ga[4];
             float e0[4], e1[4], e2[4], nzr[4];
 #pragma unroll
@@ -976,9 +977,14 @@ static int sg2_act_bwd_launch(const char* name, const float* out, const float* g
     int chunk = wgs_cdiv(P, chunks);
     if (chunk < 16) chunk = 16;
     chunks = wgs_cdiv(P, chunk);
-    WGS_LAUNCH(sg2_act_bwd_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
-                       rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk, s_ld > 0 ? s_ld : C,
-                       reinterpret_cast<unsigned short*>(dy_h), dy_bound);
+    if (drgb)
+        WGS_LAUNCH(sg2_act_bwd_kernel<true>, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
+                   rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk, s_ld > 0 ? s_ld : C,
+                   reinterpret_cast<unsigned short*>(dy_h), dy_bound);
+    else
+        WGS_LAUNCH(sg2_act_bwd_kernel<false>, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, out, gA, sA, drgb, wR, sR,
+                   rscale, noise, noise_w, bias, dy, num, dsA, dsR, post_scale, dy_amax, P, C, chunk, s_ld > 0 ? s_ld : C,
+                   reinterpret_cast<unsigned short*>(dy_h), dy_bound);
     WGS_CHECK_LAUNCH("sg2_act_bwd_kernel");
     return WGS_OK;
 }
