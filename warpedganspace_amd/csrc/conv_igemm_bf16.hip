@@ -29,8 +29,10 @@ namespace {
 // Second pass of a split-K launch: y[pix(m)][n] = epilogue(sum_s ws[s][m][n]) — the same epilogue as above
 // (alpha, demod, noise, bias, addend, activation).  One thread per 4 output channels.
 // A thread finishes SK_ROWS consecutive GEMM rows of its 4 channels (a wave's lanes = adjacent channel quads of the same rows: coalesced
-// as before) — so that the output's column statistics (wgs_conv_desc.col_stats) leave a thread as 8 atomics per SK_ROWS rows.
-constexpr int SK_ROWS = 8;
+// either way).  One row per thread without column statistics — the form every generator launch takes (eight rows per thread, tried for all
+// launches, doubled this kernel's time: 11.5 -> 21.4 us per launch, +0.45 ms per step: it is latency-bound and wants the threads) — four
+// with them (wgs_conv_desc.col_stats: 8 atomics per thread and four rows).
+template <int SK_ROWS>
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArgs p) {
     const int c4 = p.Co / 4;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -94,8 +96,13 @@ void launch_big(ConvArgs& a, hipStream_t st, int nblocks = 0) {
 namespace wgsconv {
 
 void launch_splitk_epilogue(const ConvArgs& a, hipStream_t st) {
-    const long work = (long)((a.M + SK_ROWS - 1) / SK_ROWS) * (a.Co / 4);
-    WGS_LAUNCH(conv_splitk_epilogue_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    if (a.col_stats) {
+        const long work = (long)((a.M + 3) / 4) * (a.Co / 4);
+        WGS_LAUNCH(conv_splitk_epilogue_kernel<4>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    } else {
+        const long work = (long)a.M * (a.Co / 4);
+        WGS_LAUNCH(conv_splitk_epilogue_kernel<1>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    }
 }
 
 // operand extents for the buffer descriptors; every stream must be addressable with a 31-bit byte offset
