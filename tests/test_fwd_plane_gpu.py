@@ -105,6 +105,8 @@ def test_conv_fed_with_the_plane_returns_the_same_bits(dev, B, C1, C2, H, route)
         os.environ.pop('WGS_PLANE_PATCH_MAX_CO', None)
         lib.wgs_dev_reload_flags()
     want = {'patch': 'igemm_patch_kernel', 'dma': 'igemm_dma16_kernel', 'auto': 'igemm_dma16_kernel'}[route]       # auto: Cout >= 256 -> LDS-DMA
+    if route == 'patch' and C2 == 128:
+        want = 'patch_dma_kernel'            # the 128 x 128 tile of a plane in plain fp16: every operand by LDS-DMA (conv_patch_dma.hip)
     assert sym.startswith(want) and ((', true>' in sym) if want == 'igemm_patch_kernel' else True), sym
     if route == 'patch':
         assert torch.equal(got, ref)              # same kernel family, same tile, same MFMA order: same bits
@@ -167,12 +169,12 @@ def test_the_route_is_taken_in_the_default_policy(dev):
     finally:
         L.lib().wgs_dev_trace_kernels(0)
         C.PROFILE = None
-    # the 128-column launch through the patch kernel's XF16 form, the 256-column one through the LDS-DMA kernel: neither stages fp32
-    assert len(syms) == 2 and sorted(s.split('<')[0] for s in syms) == ['igemm_dma16_kernel', 'igemm_patch_kernel'] and \
-        all(s.endswith(', true>') for s in syms if s.startswith('igemm_patch')), syms
+    # the 128-column launch through the all-DMA patch kernel, the 256-column one through the LDS-DMA kernel: neither stages fp32
+    assert len(syms) == 2 and sorted(s.split('<')[0] for s in syms) == ['igemm_dma16_kernel', 'patch_dma_kernel'], syms
 
 
-@pytest.mark.parametrize('B,Ci,Co,H,with_y', [(8, 128, 128, 64, True), (8, 128, 128, 64, False), (7, 64, 128, 64, True), (16, 256, 256, 64, True), (13, 128, 256, 64, False)])
+@pytest.mark.parametrize('B,Ci,Co,H,with_y', [(13, 128, 128, 64, True), (13, 128, 128, 64, False), (14, 64, 128, 64, True), (8, 128, 128, 64, True), (8, 128, 128, 64, False),
+                                               (16, 256, 256, 64, True), (13, 128, 256, 64, False)])
 def test_torgb_in_the_conv_epilogue(dev, B, Ci, Co, H, with_y):
     """wgs_conv_desc.rgb_out: ToRGB's channel sums (models/StyleGAN2/model.py:270-282) from the epilogue of the 128-channel conv that
     produces its input — against wgs_sg2_torgb_fwd on that conv's stored output (fp32 summation order), with and without storing y;
@@ -202,7 +204,10 @@ def test_torgb_in_the_conv_epilogue(dev, B, Ci, Co, H, with_y):
         got = C.conv2d(plane, w, 3, pad=1, out=out, y_amax=am, rgb=dict(out=rgbp, s=s_rgb, ld=S.shape[1], w=w_rgb, scale=0.37), **epi)
         sym = lib.wgs_dev_last_kernel().decode()
         lib.wgs_dev_trace_kernels(0)
-        assert sym.startswith('igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0, true, true>' if Co == 128 else 'igemm_dma16_kernel<1, 256, 256, 2, 4, true>'), sym
+        # Cout = 128: the all-DMA patch kernel when its 256-pixel tiles fill the chip (>= 200 of them), else the register-staged one
+        want = 'igemm_dma16_kernel<1, 256, 256, 2, 4, true>' if Co != 128 else \
+            ('patch_dma_kernel<256, true>' if B * (H // 16) ** 2 >= 200 else 'igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0, true, true>')
+        assert sym.startswith(want), sym
         if with_y:
             assert torch.equal(got, ref)
         assert am.item() == ref.abs().max().item()

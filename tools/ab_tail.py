@@ -39,6 +39,10 @@ VARIANTS = [
     ('R +0 launches', {'bn.debug_extra_launches': 0}),
     ('R +40 empty launches', {'bn.debug_extra_launches': 2}),
     ('R +80 empty launches', {'bn.debug_extra_launches': 4}),
+    # library development flags ('env.<NAME>': set / unset in the environment, then wgs_dev_reload_flags())
+    ('patch regs', {'env.WGS_PATCH_NODMA': '1', 'env.WGS_PATCH_DMA_BM': None}),
+    ('patch dma 128', {'env.WGS_PATCH_NODMA': None, 'env.WGS_PATCH_DMA_BM': '128'}),
+    ('patch dma 256', {'env.WGS_PATCH_NODMA': None, 'env.WGS_PATCH_DMA_BM': '256'}),
     ('baseline', dict(debug_static_unshifted=False, mid_after_r=False)),
     ('chain only (static un-shifted batch: NOT training)', dict(debug_static_unshifted=True, mid_after_r=False)),
     ('mid stage behind R', dict(debug_static_unshifted=False, mid_after_r=True)),
@@ -80,6 +84,13 @@ def main():
                     elif k.startswith('conv.'):
                         from warpedganspace_amd import conv as _CC
                         setattr(_CC, k[5:], v)
+                    elif k.startswith('env.'):
+                        from warpedganspace_amd import _lib as _LL
+                        if v is None:
+                            os.environ.pop(k[4:], None)
+                        else:
+                            os.environ[k[4:]] = v
+                        _LL.lib().wgs_dev_reload_flags()
                     else:
                         setattr(eng, k, v)
                 for _ in range(args.warmup):

@@ -32,7 +32,10 @@ def flags(**env):
 
 
 am = torch.ones(1, device=dev) * 4.0
+ONLY = int(os.environ.get('ONLY', 0))      # ONLY=128: the 128 -> 128 @256^2 layer alone
 for ci, co, h in [(512, 512, 64), (256, 256, 128), (128, 128, 256)]:
+    if ONLY and ci != ONLY:
+        continue
     x = torch.randn(B, h, h, ci, device=dev)
     w = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
     s = torch.randn(B, ci, device=dev); dm = torch.rand(B, co, device=dev)

@@ -107,5 +107,8 @@ int launch_halo16(const ConvArgs& a, hipStream_t st, bool dry = false);     // d
 // patch form for stride-1 convs (conv_igemm_patch.hip); 0 = launch taken.  Needs x_bytes / w_bytes (fp32 extents) and the
 // 64-entry tap tables filled.
 int launch_patch_bf16x3(const ConvArgs& a, hipStream_t st);
+// ... its 128 x 128 tile for a producer-written fp16 plane in plain fp16, every operand by LDS-DMA (conv_patch_dma.hip); 0 = launch taken.
+// a.w_bytes: extent of the 16-bit weight plane.
+int launch_patch_dma(const ConvArgs& a, hipStream_t st);
 
 }  // namespace wgsconv

@@ -481,7 +481,14 @@ int launch_patch_bf16x3(const ConvArgs& a0, hipStream_t st) {
         bm = tbm; bn = tbn; nblocks = nb; g = t;
         for (int i = 0; i < 16; ++i) g.tapoff[i] = i < a.ntaps ? ((a.dy[i] - dy0) * t.PW + (a.dx[i] - dx0)) * PROW : 0;
     };
-    if (a.Co == 128 && a.Ci <= 128 && (!wgs_flags().patch_bm256 || a.rgb_out)) try_shape(128, 128);
+    if (a.Co == 128 && a.Ci <= 128 && (!wgs_flags().patch_bm256 || a.rgb_out)) {
+        if (a.a_hi && a.sch == 1 && !wgs_flags().patch_nodma) {     // fp16 plane in plain fp16: the all-DMA form of the 128 x 128 tile
+            ConvArgs b = a;
+            b.w_bytes = a.w_bytes / 2;
+            if (!launch_patch_dma(b, st)) return 0;
+        }
+        try_shape(128, 128);
+    }
     if (a.rgb_out && !(bm == 128 && bn == 128 && a.a_hi && a.sch == 1)) return 1;      // ToRGB epilogue: the 128 x 128 fp16-plane tile only
     try_shape(256, 256);
     try_shape(256, 128);
