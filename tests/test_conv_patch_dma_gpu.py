@@ -3,7 +3,7 @@ plain fp16 (StyleGAN2's 128 -> 128 layers at 256^2; the reference's op is models
 style product and the rounding to fp16 having been done by the producing kernel).
 
   * same bits as the register-staged patch kernel it replaces (WGS_PATCH_NODMA=1: same tile, same order of the MFMA sums), for one to
-    four 32-channel chunks, maps 16 .. 128 wide (one tile column, image borders on every side of a tile), odd batch sizes;
+    four 32-channel chunks, maps 16 .. 256 wide (one tile column, image borders on every side of a tile), odd batch sizes, both tile shapes;
   * against the convolution in fp64 within the plain-fp16 scheme's tolerance;
   * launches the library declines for this kernel (too few tiles, Cout = 256) still run, through the other kernels."""
 import os
@@ -60,6 +60,8 @@ def _run(plane, w, epi, B, H, Co, dev):
 @pytest.mark.parametrize('B,Ci,H', [(32, 128, 64), (52, 32, 32), (4, 96, 128), (13, 64, 64), (200, 128, 16), (2, 128, 256)])
 def test_same_bits_as_the_register_staged_patch_kernel_and_close_to_fp64(dev, B, Ci, H, bm):
     Co = 128
+    if bm == 256 and H < 32:
+        pytest.skip('the 256-row tile is 8 x 32 pixels')
     x, plane, w, demod, noise, bias, epi = _case(dev, B, Ci, Co, H, 7 * B + Ci + H)
     try:
         _flags(WGS_PLANE_PATCH_MAX_CO=100000, WGS_PATCH_DMA_BM=bm)

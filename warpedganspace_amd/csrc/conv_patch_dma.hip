@@ -22,6 +22,9 @@
 // 0.611, no patch DMAs 0.629, no MFMAs 0.511, no fragment reads 0.539, no barriers 0.745, no epilogue 0.605 — the stages now add up instead
 // of hiding behind one another's latency; what is left is the LDS traffic of 64 x 64 wave tiles (1 KB of fragment reads per MFMA, the
 // reason the 256-row tile with its 128 x 64 wave tiles is faster) and the epilogue's share of a K = 1152 tile.
+// Also tried on the 256-row tile, both bit-identical and both without effect (0.725-0.733 vs 0.720-0.737 ms): a ring of four weight stages;
+// fragment reads running half a step ahead of the MFMAs (the k-step-0 registers refilled for step s + 1 behind a mid-step barrier, under
+// the MFMAs of k-step 1, and vice versa) — neither the DMAs' nor the LDS's latency is what is left.
 #include "wgs_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
@@ -45,8 +48,6 @@ using wgsconv::ConvArgs;
 
 constexpr int BN = 128, NW = 4, NT = 64 * NW;
 constexpr int WN = 64, TN = 2, WAVES_N = 2;
-constexpr int TW = 16;                              // tile: TH rows x 16 pixels of one sample
-constexpr int PW = TW + 2;
 constexpr int ROW = 64;                             // bytes per LDS row (32 fp16 channels), patch and weights
 constexpr int WST = BN * ROW;                       // one weight stage (one tap of one chunk)
 constexpr int BI = BN / 16 / NW;                    // weight DMA instructions per wave and step (2)
@@ -54,9 +55,17 @@ constexpr int BK = 32;
 constexpr int OOB = (int)0x80000000;
 
 // BM = 128: 8 x 16 pixels, wave tiles 64 x 64, 180 patch pixels in 12 DMA instructions, 48 KB -> three workgroups per CU.
-// BM = 256: 16 x 16 pixels, wave tiles 128 x 64 (six fragment reads per eight MFMAs instead of eight; the weights of a step serve twice
-// the pixels), 324 patch pixels in 24 instructions, 72 KB and ~210 VGPRs -> two workgroups per CU.
+// BM = 256: 8 x 32 pixels, wave tiles 128 x 64 (six fragment reads per eight MFMAs instead of eight; the weights of a step serve twice
+// the pixels), 340 patch pixels in 24 instructions, 72 KB and ~210 VGPRs -> two workgroups per CU.
 template <int BM> struct Tile {
+    // Tile = TH rows x TW pixels of one sample.  ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with
+    // TW = 32 the 32 rows of an A fragment are 32 CONSECUTIVE patch pixels and every group holds 16 distinct pixels mod 16 -> conflict-free
+    // under the swizzle for any tap shift.  With TW = 16 lanes 16-31 sit one patch row (18 pixels) further: two 2-way conflicts per group,
+    // i.e. every A read takes twice its LDS cycles (kept for the 128-row tile: 32 x 4 tiles would need a 16 KB patch image, two workgroups per CU).
+    // (Measured: 16 x 16 -> 8 x 32 tiles at 256 rows: 0.886 -> 0.875-0.905 of the register-staged kernel's time, i.e. nothing — the LDS is not
+    // what the tile waits for.)
+    static constexpr int TW = BM == 128 ? 16 : 32, TWL = BM == 128 ? 4 : 5;
+    static constexpr int PW = TW + 2;
     static constexpr int TH = BM / TW, PH = TH + 2, NPIX = PW * PH;
     static constexpr int PPIX = (NPIX + 16 * NW - 1) / (16 * NW) * (16 * NW);
     static constexpr int PB_BYTES = PPIX * ROW;         // one patch buffer
@@ -79,7 +88,7 @@ struct PdGeom {
 template <int BM, bool RGB>
 __global__ __launch_bounds__(NT, BM == 128 ? 3 : 2) void patch_dma_kernel(const ConvArgs p, const PdGeom g) {
     typedef Tile<BM> T;
-    constexpr int TH = T::TH, NPIX = T::NPIX, PPIX = T::PPIX, PB_BYTES = T::PB_BYTES, PI = T::PI, WM = T::WM, TM = T::TM, NST = T::NST;
+    constexpr int TW = T::TW, TWL = T::TWL, PW = T::PW, TH = T::TH, NPIX = T::NPIX, PPIX = T::PPIX, PB_BYTES = T::PB_BYTES, PI = T::PI, WM = T::WM, TM = T::TM, NST = T::NST;
     typedef wgsconv::Scheme<1> SC;
     typedef SC::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(NT, BM == 128 ? 3 : 2) void patch_dma_kernel(const 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + l31;
-        q[i] = (r >> 4) * PW + (r & 15);
+        q[i] = (r >> TWL) * PW + (r & (TW - 1));
     }
     const int bswz = (l31 >> 2) & 3;
     const int b_rd0 = (wn * WN + l31) * ROW + (((0 + lh) ^ bswz) << 4), b_rd1 = (wn * WN + l31) * ROW + (((2 + lh) ^ bswz) << 4);
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(NT, BM == 128 ? 3 : 2) void patch_dma_kernel(const 
         if (sum == 12345.678f) p.y[tid] = sum;
         return;
     }
-    // ---- epilogue (contract of conv_igemm.hip; rows are the TH x 16 tile pixels of sample b)
+    // ---- epilogue (contract of conv_igemm.hip; rows are the TH x TW tile pixels of sample b)
     float op_mult = 1.f, op_inv = 1.f;       // the producer scaled the plane by the power-of-two operand scale (conv_scheme.h): undone here
     wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);
     int* r_pix = reinterpret_cast<int*>(smem_b);
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(NT, BM == 128 ? 3 : 2) void patch_dma_kernel(const 
     float* r_nz = reinterpret_cast<float*>(r_b + BM);
     int* r_add = reinterpret_cast<int*>(r_nz + BM);
     if (tid < BM) {
-        const int ty = tid >> 4, tx = tid & 15;
+        const int ty = tid >> TWL, tx = tid & (TW - 1);
         const int oy = (ty0 + ty) * p.osy + p.oy0, ox = (tx0 + tx) * p.osx + p.ox0;
         const int hw = oy * p.Wo + ox;
         r_pix[tid] = b * p.Ho * p.Wo + hw;
@@ -302,6 +311,7 @@ int launch_patch_dma(const ConvArgs& a, hipStream_t st) {
     if (!a.a_hi || a.sch != 1 || a.a_scale || !a.w_hi) return 1;
     if (a.Ci % BK || a.Co % BN || a.ntaps < 3 || a.ntaps > 16) return 1;
     const int bm = wgs_flags().patch_dma_bm;
+    const int TW = bm == 128 ? Tile<128>::TW : Tile<256>::TW, PW = TW + 2;
     const int th = bm / TW;
     if (a.Wg < TW || (a.Wg & (a.Wg - 1)) || a.Hg % th || a.Hg != a.Hi || a.Wg != a.Wi) return 1;
     if (a.rgb_out && a.Co != BN) return 1;
