@@ -72,8 +72,21 @@ def check(rc, what="wgs"):
         raise WgsError("%s failed (rc=%d): %s" % (what, rc, lib().wgs_last_error().decode()))
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def stream_id(device_index=None):
+    """hipStream_t (as an integer) of torch's current stream on the device (default: the current device).  Through torch's raw
+    accessors where this build has them: torch.cuda.current_stream() costs ~7 us per call in device-index resolution, and a training
+    step asks ~280 times (tools/host_cprofile.py)."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _RAW_STREAM(_RAW_DEVICE() if device_index is None else device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(stream_id())
 
 
 class StagedPass:
@@ -82,15 +95,15 @@ class StagedPass:
     stage's launches on another stream than the tensors they read were produced on."""
 
     def __init__(self, gen):
-        self.stream_id = torch.cuda.current_stream().cuda_stream
+        self.stream_id = stream_id()
         self.gen = gen
         next(gen)                      # the first stage
 
     def advance(self):
         """Enqueue the next stage: None while the pass is paused again, the image when it is complete."""
-        if torch.cuda.current_stream().cuda_stream != self.stream_id:
+        if stream_id() != self.stream_id:
             raise WgsError("a staged generator pass must be resumed under the stream it was begun on (begun on %#x, resumed on %#x)"
-                           % (self.stream_id, torch.cuda.current_stream().cuda_stream))
+                           % (self.stream_id, stream_id()))
         try:
             next(self.gen)
         except StopIteration as e:

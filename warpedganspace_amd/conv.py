@@ -221,7 +221,7 @@ _WS = {}
 
 def _workspace(device, nbytes=0):
     # one buffer per (device, stream): launches on different streams may run concurrently
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, L.stream_id(device.index))
     ws = _WS.get(key)
     need = max(WS_BYTES, nbytes)
     if ws is None or ws.numel() * 4 < need:
