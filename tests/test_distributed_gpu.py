@@ -297,3 +297,66 @@ def test_bench_eight_ranks_end_to_end_over_gloo(tmp_path):
     assert d['product']['value'] > 0
     full = json.load(open(side))
     assert full['host_pinning_plan'] and len(full['host_pinning_plan']) == 8          # the plan every rank would take under RCCL
+
+
+def _rccl_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        dist.init_process_group('nccl', rank=0, world_size=1)        # "nccl" is RCCL on ROCm
+        B = 2
+        e1, c = _build(dev, 11, 1, 0, B)
+        z, idx = c['z'][:B].to(dev), c['idx'][:B].to(dev)
+        mag = torch.tensor([0.3, -0.4]).to(dev)
+
+        def warm(e):
+            with torch.no_grad():
+                e.G(z)
+            torch.cuda.synchronize()
+            e.steps_done = 1
+        warm(e1)
+        e1.step(z, idx, mag)
+        torch.cuda.synchronize()
+        g1 = e1.bucket.grad.clone()
+        # the data-parallel branches (world = 2 as far as the engine knows) over a ONE-rank RCCL group: broadcasts, the two asynchronous
+        # all-reduces (side stream / main stream), their stream-ordered wait() in front of Adam — RCCL's semantics, not gloo's host-blocking ones
+        e2, _ = _build(dev, 11, 2, 0, B)
+        e2.comm_events = []
+        warm(e2)
+        for _ in range(3):
+            e2.step(z, idx, mag)
+        torch.cuda.synchronize()
+        e3, _ = _build(dev, 11, 2, 0, B)
+        warm(e3)
+        e3.step(z, idx, mag)
+        torch.cuda.synchronize()
+        scale = float(g1.abs().max())
+        err = float((e3.bucket.grad - g1).abs().max()) / scale      # a sum over one rank: the local gradient
+        st = e2.pop_stats()                                          # (an all-reduce of the statistics)
+        ok = bool(torch.isfinite(e2.bucket.flat).all()) and bool(torch.isfinite(torch.tensor(list(st.values()))).all())
+        waits = [a.elapsed_time(b) for a, b in e2.comm_events]
+        q.put((err, ok, len(waits), e2.allreduce_bytes, dist.get_backend(), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((None, None, None, None, None, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(600)
+def test_trainstep_data_parallel_branches_over_a_one_rank_rccl_group(dev):
+    """RCCL contact on the one GPU this box has: the engine's world > 1 branches (parameter broadcast, the asynchronous all-reduces of R's and
+    S's gradient groups, the stream-ordered wait in front of Adam, the statistics all-reduce) driven through a real `nccl` process group of
+    size 1.  The sum over one rank is the local gradient: compared with the world = 1 engine's; three consecutive steps stay finite."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    err, ok, n_ev, nbytes, backend, tb = q.get(timeout=500)
+    p.join(60)
+    assert tb is None, tb
+    print('one-rank RCCL group: gradient error vs the world-1 engine %.2e, all-reduce payload %d B per step' % (err, nbytes))
+    assert backend == 'nccl' and err < 2e-5 and ok and n_ev == 3 and nbytes > 0
+    assert p.exitcode == 0

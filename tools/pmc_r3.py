@@ -63,7 +63,7 @@ def summarise(d, out):
     for f in sorted(glob.glob(d + '/*/p_counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
-            mm = re.search(r'(igemm_\w+<[^>]*>|upconv_blur_kernel<[^>]*>|wino_f32_kernel<[^>]*>|halo3x3_kernel<[^>]*>)', kn)
+            mm = re.search(r'(igemm_\w+<[^>]*>|patch_dma_kernel<[^>]*>|upconv_blur_kernel<[^>]*>|wino_f32_kernel<[^>]*>|halo3x3_kernel<[^>]*>)', kn)
             if not mm:
                 continue
             key = (int(r['Dispatch_Id']), mm.group(1))

@@ -72,7 +72,7 @@ def check(rc, what="wgs"):
         raise WgsError("%s failed (rc=%d): %s" % (what, rc, lib().wgs_last_error().decode()))
 
 
-_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_STREAM = None if os.environ.get("WGS_TORCH_STREAM") else getattr(torch._C, "_cuda_getCurrentRawStream", None)    # WGS_TORCH_STREAM=1: development A/B
 _RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
 
 

@@ -30,7 +30,8 @@ void wgs_set_error(const char* fmt, ...);
     } while (0)
 
 // Development A/B switches (WGS_DMA_ALWAYS, WGS_PHASE_PATCH, WGS_NO_PATCH, WGS_PATCH_BM256, WGS_PATCH_TPS1, WGS_UP_GH16,
-// WGS_PATCH_NTF0, WGS_WGRAD_PER_TAP, WGS_PATCH_WIDE, WGS_F32_SMALL, WGS_F32_OLD, WGS_WINO_NARROW, WGS_WINO_SMALL): read from the
+// WGS_PATCH_NTF0, WGS_WGRAD_PER_TAP, WGS_PATCH_WIDE, WGS_F32_SMALL, WGS_F32_OLD, WGS_WINO_NARROW, WGS_WINO_SMALL, WGS_PATCH_NODMA,
+// WGS_PATCH_DMA_BM ...: the full list is wgs_flags()'s initialiser in core.hip): read from the
 // environment ONCE, when the first launch asks for them, and immutable afterwards — no getenv on launch paths, no mutable
 // global state.  All default to off = the measured-best path.
 struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap, patch_wide, f32_small, f32_old, wino_narrow, wino_small;
