@@ -141,3 +141,28 @@ def test_bn_backward_over_the_scratch_pair(dev):
             for u, v in zip(got, ref):
                 assert rel_err(u, v) < 1e-5
             a, b = b, a
+
+
+@pytest.mark.parametrize('precision', [0, 1])
+@pytest.mark.parametrize('B,Ci,Co,H', [(32, 128, 128, 32), (8, 256, 256, 64), (32, 64, 64, 64)])
+def test_column_sums_and_magnitude_bound_from_one_launch(dev, precision, B, Ci, Co, H):
+    """wgs_conv_desc.col_stats and .y_amax together, alone and neither: the epilogue has one copy of its store loop per combination (the sums
+    and the running maximum are computed where the value is, not behind the loop) — same y bits in all four, the right sums and maximum."""
+    torch.manual_seed(B + Ci + H)
+    x = torch.randn(B, H, H, Ci, device=dev)
+    w = torch.randn(Co, 9, Ci, device=dev) / (9 * Ci) ** 0.5
+    ref = C.conv2d(x, w, 3, pad=1, precision=precision)
+    ws = torch.zeros(64 * Co, dtype=torch.float64, device=dev)
+    am = torch.zeros(1, device=dev)
+    y_both = C.conv2d(x, w, 3, pad=1, precision=precision, col_stats=ws, y_amax=am)
+    am2 = torch.zeros(1, device=dev)
+    y_am = C.conv2d(x, w, 3, pad=1, precision=precision, y_amax=am2)
+    ws2 = torch.zeros(64 * Co, dtype=torch.float64, device=dev)
+    y_st = C.conv2d(x, w, 3, pad=1, precision=precision, col_stats=ws2)
+    assert torch.equal(y_both, ref) and torch.equal(y_am, ref) and torch.equal(y_st, ref)
+    assert am.item() == am2.item() == ref.abs().max().item()
+    yd = ref.double().reshape(-1, Co)
+    for buf in (ws, ws2):
+        s1, s2 = _sums(buf, Co)
+        assert float((s1 - yd.sum(0)).abs().max() / yd.sum(0).abs().max()) < 2e-5
+        assert float((s2 - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).abs().max()) < 2e-6

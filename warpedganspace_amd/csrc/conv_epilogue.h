@@ -7,6 +7,7 @@
 namespace wgsconv {
 
 typedef float epi_f32x16 __attribute__((ext_vector_type(16)));
+template <bool V> struct EpiTag { static constexpr bool value = V; };
 
 // Column statistics of a launch's output for the train-mode BatchNorm behind it (wgs_conv_desc.col_stats): a lane's partial sums of
 // column n over its rows (<= 64 values, fp32) -> the two half-waves hold the same columns: combined with one cross-half shuffle -> one
@@ -56,34 +57,50 @@ __device__ __forceinline__ void conv_epilogue_apply(const ConvArgs& p, epi_f32x1
             const int rowbytes = p.Co * 4;
             const float slope = p.act_slope, gain = p.gain;
             float vmax = 0.f;
-            float st1[TN], st2[TN];
+            // Two copies of the loop (with / without column statistics), and the running maximum pinned where it is computed: left to itself the
+            // compiler SINKS the max / sum updates into the `if (p.y_amax)` / `if (stats)` blocks behind the loop, i.e. it keeps all TM * TN * 16
+            // finished outputs alive to the end — 44 - 152 bytes of scratch per lane in every 256-row kernel (+16 % HBM writes in the counters,
+            // rounds 3 - 5), reloaded one by one behind s_waitcnt vmcnt(0), which also waits for the tile's output stores.
+            auto run = [&](auto stats_tag, auto amax_tag) {
+                constexpr bool STATS = decltype(stats_tag)::value, AMAX = decltype(amax_tag)::value;
+                float st1[TN], st2[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
-            const bool stats = p.col_stats != nullptr;
+                for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int pix = r_pix[row];
-                    const float nz = r_nz[row];
-                    const int ro = pix >= 0 ? pix * rowbytes : (int)0x80000000;
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int pix = r_pix[row];
+                        const float nz = r_nz[row];
+                        const int ro = pix >= 0 ? pix * rowbytes : (int)0x80000000;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        float v = acc[i][j][r] * alpha;
-                        v *= cs[j];
-                        v += nz + bs[j];
-                        v = fmaxf(v, v * slope) * gain;           // == (v > 0 ? v : v * slope) * gain for slope in [0, 1]
-                        vmax = fmaxf(vmax, pix >= 0 ? fabsf(v) : 0.f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)((unsigned)ro + (unsigned)noff[j]), 0, 0);
-                        if (stats) { const float u = pix >= 0 ? v : 0.f; st1[j] += u; st2[j] = fmaf(u, u, st2[j]); }
+                        for (int j = 0; j < TN; ++j) {
+                            float v = acc[i][j][r] * alpha;
+                            v *= cs[j];
+                            v += nz + bs[j];
+                            v = fmaxf(v, v * slope) * gain;           // == (v > 0 ? v : v * slope) * gain for slope in [0, 1]
+                            if (AMAX) {
+                                vmax = fmaxf(vmax, pix >= 0 ? fabsf(v) : 0.f);
+                                asm volatile("" : "+v"(vmax));
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)((unsigned)ro + (unsigned)noff[j]), 0, 0);
+                            if (STATS) {
+                                const float u = pix >= 0 ? v : 0.f;
+                                st1[j] += u; st2[j] = fmaf(u, u, st2[j]);
+                                asm volatile("" : "+v"(st1[j]), "+v"(st2[j]));
+                            }
+                        }
                     }
                 }
-            }
-            if (stats) {
+                if (STATS) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) col_stats_flush(p.col_stats, p.Co, n0 + wn * WN + j * 32 + l31, true, st1[j], st2[j], lh);
-            }
+                    for (int j = 0; j < TN; ++j) col_stats_flush(p.col_stats, p.Co, n0 + wn * WN + j * 32 + l31, true, st1[j], st2[j], lh);
+                }
+            };
+            if (p.col_stats) { if (p.y_amax) run(EpiTag<true>{}, EpiTag<true>{}); else run(EpiTag<true>{}, EpiTag<false>{}); }
+            else if (p.y_amax) run(EpiTag<false>{}, EpiTag<true>{});
+            else run(EpiTag<false>{}, EpiTag<false>{});
             if (p.y_amax) {      // magnitude bound for the next layer's fp16 operand scale: one atomic per wave
                 vmax = wave_max(vmax);
                 if (l31 == 0 && lh == 0) raise_amax(p.y_amax, vmax);
@@ -183,6 +200,7 @@ __device__ __forceinline__ void conv_epilogue_rgb(const ConvArgs& p, epi_f32x16 
                 v += nz + bs[j];
                 v = fmaxf(v, v * slope) * gain;
                 vmax = fmaxf(vmax, pix >= 0 ? fabsf(v) : 0.f);
+                asm volatile("" : "+v"(vmax));          // (computed here, not sunk into `if (p.y_amax)` with every output kept alive: see conv_epilogue_apply)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (int)((unsigned)ro + (unsigned)noff[j]), 0, 0);
                 t0 = fmaf(v, q0[j], t0); t1 = fmaf(v, q1[j], t1); t2 = fmaf(v, q2[j], t2);
             }
