@@ -5,7 +5,8 @@ style product and the rounding to fp16 having been done by the producing kernel)
   * same bits as the register-staged patch kernel it replaces (WGS_PATCH_NODMA=1: same tile, same order of the MFMA sums), for one to
     four 32-channel chunks, maps 16 .. 256 wide (one tile column, image borders on every side of a tile), odd batch sizes, both tile shapes;
   * against the convolution in fp64 within the plain-fp16 scheme's tolerance;
-  * launches the library declines for this kernel (too few tiles, Cout = 256) still run, through the other kernels."""
+  * 256 output columns per workgroup (Cout % 256 == 0, opt-in): same bits as the register-staged 256 x 256 patch tile, fp32-rounding close to the LDS-DMA kernel;
+  * launches the library declines for this kernel (too few tiles) still run, through the other kernels."""
 import os
 
 import pytest
@@ -66,7 +67,7 @@ def test_same_bits_as_the_register_staged_patch_kernel_and_close_to_fp64(dev, B,
     try:
         _flags(WGS_PLANE_PATCH_MAX_CO=100000, WGS_PATCH_DMA_BM=bm)
         got, am, sym = _run(plane, w, epi, B, H, Co, dev)
-        assert sym.startswith('patch_dma_kernel<%d, false>' % bm), sym
+        assert sym.startswith('patch_dma_kernel<%d, 128, false>' % bm), sym
         _flags(WGS_PATCH_NODMA=1)
         ref, am_ref, sym_ref = _run(plane, w, epi, B, H, Co, dev)
         assert sym_ref.startswith('igemm_patch_kernel<1, 128, 128'), sym_ref
@@ -96,6 +97,30 @@ def test_repeated_launches_return_the_same_bits(dev, bm):
             assert torch.equal(first, again), i
     finally:
         _flags(WGS_PATCH_DMA_BM=None)
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(32, 256, 256, 64), (16, 128, 512, 64), (13, 64, 256, 64), (4, 256, 256, 128)])
+def test_256_columns_per_workgroup(dev, B, Ci, Co, H):
+    """Cout % 256 == 0, WGS_PATCH_DMA_BN256=1: the 8-wave 256 x 256 tile (not the default route: 2-3 % slower than the LDS-DMA kernel).  Same bits as
+    the register-staged patch kernel's 256 x 256 tile (same order of the MFMA sums); within fp32 rounding of the LDS-DMA kernel (another order)."""
+    x, plane, w, demod, noise, bias, epi = _case(dev, B, Ci, Co, H, B + Ci + Co)
+    try:
+        _flags(WGS_PATCH_DMA_BN256=1)
+        got, am, sym = _run(plane, w, epi, B, H, Co, dev)
+        assert sym.startswith('patch_dma_kernel<256, 256, false>'), sym
+        _flags(WGS_PATCH_DMA_BN256=None, WGS_PATCH_NODMA=1, WGS_PLANE_PATCH_MAX_CO=100000)
+        ref, am_ref, sym_ref = _run(plane, w, epi, B, H, Co, dev)
+        assert sym_ref.startswith('igemm_patch_kernel<1, 256, 256'), sym_ref
+        _flags(WGS_PATCH_NODMA=None, WGS_PLANE_PATCH_MAX_CO=None)
+        dma, _, sym_dma = _run(plane, w, epi, B, H, Co, dev)
+        assert sym_dma.startswith('igemm_dma16_kernel'), sym_dma
+    finally:
+        _flags(WGS_PATCH_NODMA=None, WGS_PLANE_PATCH_MAX_CO=None, WGS_PATCH_DMA_BN256=None)
+    assert torch.equal(got, ref) and am.item() == am_ref.item()
+    assert (got - dma).abs().max() <= 2e-6 * dma.abs().max()
+    full = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double().reshape(Co, 3, 3, Ci).permute(0, 3, 1, 2), padding=1)
+    full = torch.nn.functional.leaky_relu(full * demod.double()[:, :, None, None] + 0.3 * noise.double().view(1, 1, H, H) + bias.double()[None, :, None, None], 0.2) * SQRT2
+    assert (got.double().permute(0, 3, 1, 2) - full).abs().max() <= 2e-3 * full.abs().max()
 
 
 @pytest.mark.parametrize('B,Ci,Co,H', [(1, 128, 128, 64), (8, 128, 256, 64)])

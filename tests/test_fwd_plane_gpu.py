@@ -206,7 +206,7 @@ def test_torgb_in_the_conv_epilogue(dev, B, Ci, Co, H, with_y):
         lib.wgs_dev_trace_kernels(0)
         # Cout = 128: the all-DMA patch kernel when its 256-pixel tiles fill the chip (>= 200 of them), else the register-staged one
         want = 'igemm_dma16_kernel<1, 256, 256, 2, 4, true>' if Co != 128 else \
-            ('patch_dma_kernel<256, true>' if B * (H // 16) ** 2 >= 200 else 'igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0, true, true>')
+            ('patch_dma_kernel<256, 128, true>' if B * (H // 16) ** 2 >= 200 else 'igemm_patch_kernel<1, 128, 128, 2, 2, 1, 0, true, true>')
         assert sym.startswith(want), sym
         if with_y:
             assert torch.equal(got, ref)

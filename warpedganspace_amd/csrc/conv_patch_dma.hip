@@ -46,18 +46,18 @@ using wgsconv::ConvArgs;
                              // i.e. with two steps of lead the DMAs' latency is covered)
 #endif
 
-constexpr int BN = 128, NW = 4, NT = 64 * NW;
-constexpr int WN = 64, TN = 2, WAVES_N = 2;
+constexpr int WN = 64, TN = 2;                      // wave tiles are 64 columns wide: BN / 64 wave columns x 2 wave rows
 constexpr int ROW = 64;                             // bytes per LDS row (32 fp16 channels), patch and weights
-constexpr int WST = BN * ROW;                       // one weight stage (one tap of one chunk)
-constexpr int BI = BN / 16 / NW;                    // weight DMA instructions per wave and step (2)
+constexpr int BI = 2;                               // weight DMA instructions per wave and step: BN / 16 rows-of-16 over BN / 32 waves
 constexpr int BK = 32;
 constexpr int OOB = (int)0x80000000;
 
 // BM = 128: 8 x 16 pixels, wave tiles 64 x 64, 180 patch pixels in 12 DMA instructions, 48 KB -> three workgroups per CU.
 // BM = 256: 8 x 32 pixels, wave tiles 128 x 64 (six fragment reads per eight MFMAs instead of eight; the weights of a step serve twice
 // the pixels), 340 patch pixels in 24 instructions, 72 KB and ~210 VGPRs -> two workgroups per CU.
-template <int BM> struct Tile {
+template <int BM, int BN> struct Tile {
+    static constexpr int WAVES_N = BN / WN, NW = 2 * WAVES_N, NT = 64 * NW;      // 128 columns: 4 waves; 256 columns: 8 waves (one workgroup per CU)
+    static constexpr int WST = BN * ROW;                // one weight stage (one tap of one chunk)
     // Tile = TH rows x TW pixels of one sample.  ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with
     // TW = 32 the 32 rows of an A fragment are 32 CONSECUTIVE patch pixels and every group holds 16 distinct pixels mod 16 -> conflict-free
     // under the swizzle for any tap shift.  With TW = 16 lanes 16-31 sit one patch row (18 pixels) further: two 2-way conflicts per group,
@@ -85,9 +85,11 @@ struct PdGeom {
     int tapw[16];        // byte offset of tap t's slab inside a weight row of the 16-bit plane
 };
 
-template <int BM, bool RGB>
-__global__ __launch_bounds__(NT, BM == 128 ? 3 : 2) void patch_dma_kernel(const ConvArgs p, const PdGeom g) {
-    typedef Tile<BM> T;
+template <int BM, int BN, bool RGB>
+__global__ __launch_bounds__(64 * 2 * (BN / 64), BN == 256 ? 1 : (BM == 128 ? 3 : 2)) void patch_dma_kernel(const ConvArgs p, const PdGeom g) {
+    typedef Tile<BM, BN> T;
+    constexpr int WAVES_N = T::WAVES_N, NW = T::NW, WST = T::WST;
+    static_assert(BN / 16 / NW == BI, "two weight DMA instructions per wave and step");
     constexpr int TW = T::TW, TWL = T::TWL, PW = T::PW, TH = T::TH, NPIX = T::NPIX, PPIX = T::PPIX, PB_BYTES = T::PB_BYTES, PI = T::PI, WM = T::WM, TM = T::TM, NST = T::NST;
     typedef wgsconv::Scheme<1> SC;
     typedef SC::frag frag;
@@ -306,15 +308,20 @@ namespace wgsconv {
 
 // 0 = launch taken.  a: as handed to the patch kernels (16-bit weight extents), fp16 activation plane, scheme 1; the caller has checked
 // stride 1 / same size / pre-split weights.  Taken for power-of-two maps >= 16 wide with a multiple of 8 rows, a 3x3 neighbourhood
-// (3 .. 16 taps inside dy, dx in -1 .. 1), Cin % 32 == 0, Cout % 128 == 0.
+// (3 .. 16 taps inside dy, dx in -1 .. 1), Cin % 32 == 0, Cout % 128 == 0 (256 columns per workgroup where Cout % 256 == 0).
 int launch_patch_dma(const ConvArgs& a, hipStream_t st) {
-    if (!a.a_hi || a.sch != 1 || a.a_scale || !a.w_hi) return 1;
-    if (a.Ci % BK || a.Co % BN || a.ntaps < 3 || a.ntaps > 16) return 1;
+    if (!a.a_hi || a.sch != 1 || a.a_scale || !a.w_hi || a.ups || a.isy != 1 || a.isx != 1) return 1;
+    if (a.Ci % BK || a.Co % 128 || a.ntaps < 3 || a.ntaps > 16) return 1;
     const int bm = wgs_flags().patch_dma_bm;
-    const int TW = bm == 128 ? Tile<128>::TW : Tile<256>::TW, PW = TW + 2;
+    // 256 output columns per workgroup (8 waves, one workgroup per CU; WGS_PATCH_DMA_BN256=1): a weight stage and a patch serve twice the MFMAs.
+    // Bit-identical to the register-staged 256 x 256 patch tile; measured against the LDS-DMA kernel that owns these launches (conv_igemm_dma.hip,
+    // whose two wave groups alternate between memory and MFMA phases): 512 -> 512 @64^2 0.596-0.604 vs 0.580-0.588 ms, 256 -> 256 @128^2 0.621-0.624
+    // vs 0.605-0.613 — 2-3 % slower, so it is not the default route.
+    const int bn = (bm == 256 && a.Co % 256 == 0 && wgs_flags().patch_dma_bn256) ? 256 : 128;
+    const int TW = bm == 128 ? Tile<128, 128>::TW : Tile<256, 128>::TW, PW = TW + 2;
     const int th = bm / TW;
     if (a.Wg < TW || (a.Wg & (a.Wg - 1)) || a.Hg % th || a.Hg != a.Hi || a.Wg != a.Wi) return 1;
-    if (a.rgb_out && a.Co != BN) return 1;
+    if (a.rgb_out && a.Co != bn) return 1;
     PdGeom g;
     for (int t = 0; t < 16; ++t) { g.tappix[t] = 0; g.tapw[t] = 0; }
     for (int t = 0; t < a.ntaps; ++t) {
@@ -325,19 +332,25 @@ int launch_patch_dma(const ConvArgs& a, hipStream_t st) {
     g.ntaps = a.ntaps;
     g.tiles_x = a.Wg / TW;
     g.tiles_per_img = (a.Hg / th) * g.tiles_x;
-    const int nblocks = a.B * g.tiles_per_img * (a.Co / BN);
+    const int nblocks = a.B * g.tiles_per_img * (a.Co / bn);
     if (nblocks < 200) return 1;
-    auto go = [&](auto k, int smem, const char* name) {
+    auto go = [&](auto k, int nt, int smem, const char* name) {
         wgs_note_kernel("%s", name);
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(NT), smem, st, a, g);
+        WGS_LAUNCH(k, dim3((unsigned)nblocks), dim3(nt), smem, st, a, g);
     };
-    if (bm == 256) {
-        if (a.rgb_out) go(patch_dma_kernel<256, true>, Tile<256>::SMEM, "patch_dma_kernel<256, true>");
-        else go(patch_dma_kernel<256, false>, Tile<256>::SMEM, "patch_dma_kernel<256, false>");
+    if (bn == 256) {
+        typedef Tile<256, 256> T;
+        if (a.rgb_out) go(patch_dma_kernel<256, 256, true>, T::NT, T::SMEM, "patch_dma_kernel<256, 256, true>");
+        else go(patch_dma_kernel<256, 256, false>, T::NT, T::SMEM, "patch_dma_kernel<256, 256, false>");
+    } else if (bm == 256) {
+        typedef Tile<256, 128> T;
+        if (a.rgb_out) go(patch_dma_kernel<256, 128, true>, T::NT, T::SMEM, "patch_dma_kernel<256, 128, true>");
+        else go(patch_dma_kernel<256, 128, false>, T::NT, T::SMEM, "patch_dma_kernel<256, 128, false>");
     } else {
-        if (a.rgb_out) go(patch_dma_kernel<128, true>, Tile<128>::SMEM, "patch_dma_kernel<128, true>");
-        else go(patch_dma_kernel<128, false>, Tile<128>::SMEM, "patch_dma_kernel<128, false>");
+        typedef Tile<128, 128> T;
+        if (a.rgb_out) go(patch_dma_kernel<128, 128, true>, T::NT, T::SMEM, "patch_dma_kernel<128, 128, true>");
+        else go(patch_dma_kernel<128, 128, false>, T::NT, T::SMEM, "patch_dma_kernel<128, 128, false>");
     }
     return 0;
 }

@@ -35,6 +35,7 @@ static WgsFlags read_flags() {
     g.patch_tps1 = getenv("WGS_PATCH_TPS1") != nullptr;
     g.up_gh16 = getenv("WGS_UP_GH16") != nullptr;
     g.patch_dma_bm = (getenv("WGS_PATCH_DMA_BM") && atoi(getenv("WGS_PATCH_DMA_BM")) == 128) ? 128 : 256;      // ... its tile rows (conv_patch_dma.hip: 256 measured best)
+    g.patch_dma_bn256 = getenv("WGS_PATCH_DMA_BN256") != nullptr;   // ... its 8-wave 256 x 256 tile for Cout % 256 == 0 (measured 2-3 % slower than the LDS-DMA kernel: off)
     g.patch_nodma = getenv("WGS_PATCH_NODMA") != nullptr;      // fp16-plane 128 x 128 tiles: the register-staged patch kernel instead of conv_patch_dma.hip
     g.up_gh8 = getenv("WGS_UP_GH8") != nullptr;      // fused up-sampling kernel: the 4-wave 14 x 6-cell tiles (two workgroups per CU) whatever the launch size
     g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
