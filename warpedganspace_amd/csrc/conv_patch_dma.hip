@@ -41,6 +41,10 @@ using wgsconv::ConvArgs;
                      // 7 no epilogue (the accumulators sunk into one conditional store)
 #endif
 
+#ifndef WGS_PD_PRIO
+#define WGS_PD_PRIO 0        // 1: raise the wave's priority for the MFMAs of a step — measured 0.707-0.718 vs 0.705-0.715 ms without: nothing
+#endif
+
 #ifndef WGS_PD_NST256
 #define WGS_PD_NST256 3      // weight stages of the 256-row tile (4 = 80 KB, two workgroups fill the CU's 160 KB exactly: measured 0.721 vs 0.722 ms,
                              // i.e. with two steps of lead the DMAs' latency is covered)
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), BN == 256 ? 1 : (BM == 128 ? 3 
         a_addr(c1 & 1, t1, aa);
         bb0 = r_n1 + b_rd0; bb1 = r_n1 + b_rd1;
         __builtin_amdgcn_sched_barrier(0);
+        if (WGS_PD_PRIO) __builtin_amdgcn_s_setprio(1);      // the wave that has its operands goes first on its SIMD (the other workgroup's wave is staging)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(64 * 2 * (BN / 64), BN == 256 ? 1 : (BM == 128 ? 3 
                     if (WGS_QABL == 4) { asm volatile("" :: "v"(af[ks][i]), "v"(bf[ks][j])); continue; }
                     acc[i][j] = SC::mma(&af[ks][i], &bf[ks][j], acc[i][j]);
                 }
+        if (WGS_PD_PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LATE) : "memory");      // step s + 1's weights (and everything older) have landed
         bar();
