@@ -62,7 +62,8 @@ F16_MFMA_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf16,
 MFMA_PER_PRODUCT = {'fp32': 1.0, 'fp32w': 16.0 / 36.0, 'bf16x3': 3.0, 'f16': 1.0, 'f16x2': 2.0}        # per launch label (a 'mixed' run has all three 16-bit kinds)
 DTYPE = {'fp32': 'fp32', 'fp32w': 'fp32', 'bf16x3': 'bf16x3 (split-bf16, fp32-class)', 'f16': 'fp16 operands, fp32 accumulate',
          'f16x2': 'fp16 x2 operands, fp32 accumulate', 'mixed': 'mixed fp16 / split-bf16 per layer, fp32 accumulate',
-         'mixed-strict': 'mixed fp16 x2 / split-bf16 per layer (strict table), fp32 accumulate'}
+         'mixed-strict': 'mixed fp16 x2 / split-bf16 per layer (strict table), fp32 accumulate',
+         'bf16x3w': 'bf16x3 (split-bf16, fp32-class), F(2,3) form of the 3x3 stride-1 convs'}
 DTYPE_TEXT = {
     'fp32': "fp32 everywhere (the reference's arithmetic): every conv of G and R, forward and backward, is f32-input MFMA "
             "(v_mfma_f32_32x32x2_f32) with fp32 accumulate; everything else fp32 VALU",
@@ -77,6 +78,7 @@ DTYPE_TEXT = {
              "3.2): fp16 operands (1 or 2 MFMAs per product) in the layers at >= 64x64, split-bf16 x3 (fp32-class) below; fp32 accumulate / "
              "demodulation / epilogue everywhere; dynamic power-of-two scale on every fp16 operand",
 }
+DTYPE_TEXT['bf16x3w'] = DTYPE_TEXT['bf16x3'] + "; the 3x3 stride-1 convs with their horizontal taps in the Winograd form F(2,3) (V and U split into bf16 hi+lo after the fp32 transforms: 2 MFMAs per direct product)"
 DTYPE_TEXT['mixed-strict'] = DTYPE_TEXT['mixed'] + " — per-layer table CALIBRATED on the engine's own generator (conv.STRICT_LADDER): the cheapest rung with no single image of a 2 304-code sample over 0.95e-3"
 R_TEXT = {(5, 5, 0): "; reconstructor (trained): fp32 MFMA, Winograd form of the 3x3 stride-1 forward / input-gradient convs, direct exact "
                      "fp32 for the rest and for every weight gradient; BatchNorm statistics in fp64 partials",

@@ -228,6 +228,22 @@ int wgs_conv_wino_layout(const wgs_conv_desc* desc);
 int wgs_conv_wino_weight(const wgs_conv_desc* desc, float* U, wgs_stream_t stream);
 int wgs_conv_wino(const wgs_conv_desc* desc, const float* U, wgs_stream_t stream);
 
+/* 3x3 stride-1 'same' convolutions in split-bf16 (the arithmetic of precision 1: fp32-class, ~2^-16 per product) with the horizontal
+ * taps in the Winograd form F(2, 3) and the vertical taps direct (conv_wino_bf16.hip): 12 instead of 18 products per pair of output
+ * pixels and input channel, i.e. two bf16 MFMAs per direct product instead of three; V = B^T (x * style) and U = G g are formed in fp32
+ * and split into bf16 hi + lo afterwards.  Same contract and epilogue as wgs_conv_igemm with precision 1 (a_scale, col_scale, noise,
+ * bias, leaky-relu, alpha, y_amax); results equal the direct split-bf16 kernels' up to that arithmetic's own rounding (1e-5 against
+ * fp64 convolutions).  Covered: all nine taps dy, dx in {-1, 0, 1} each exactly once (forward and input-gradient launches alike),
+ * isy = osy = 1, ups 0, Hi = Ho % 8 == 0, Wi = Wo % 32 == 0, Ci % 32 == 0, Co % 128 == 0, act 0, act_slope in [0, 1], no addend /
+ * x_f16 / rgb_out / col_stats / a_pixelnorm_eps, row strides of a_scale / col_scale % 4 == 0, a sample's tensors < 2 GiB, and at
+ * least 200 workgroups (B * Hi / 8 * Wi / 32 * Co / 128): wgs_conv_wino16_supported() tells (1 / 0).
+ * wgs_conv_wino16_weight: U (24 * Ci * Co uint16, caller-owned) = the launch's weights G g as bf16 hi / lo planes in the kernel's
+ * B-fragment order (one layout: reusable by every covered launch of the same weights and taps).  wgs_conv_wino16 runs the launch with
+ * it (desc->w is not read). */
+int wgs_conv_wino16_supported(const wgs_conv_desc* desc);
+int wgs_conv_wino16_weight(const wgs_conv_desc* desc, uint16_t* U, wgs_stream_t stream);
+int wgs_conv_wino16(const wgs_conv_desc* desc, const uint16_t* U, wgs_stream_t stream);
+
 /* Weight gradient of a (strided) conv:  dw[co*w_row_stride + wt[t]*w_tap_stride + ci] +=
  *   sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*isy + dy[t], ox*isx + dx[t], ci]
  * ACCUMULATED (atomicAdd across the K splits) into the caller-zeroed `dw`.

@@ -22,7 +22,15 @@ SHAPES = [('conv fp32w 512->512 @64x64 9 taps B32', 'conv', 'fp32w', 512, 512, 6
           ('conv f16x2 32->32 @1024x1024 9 taps B8', 'halo', 'f16x2', 32, 32, 1024),
           ('conv f16x2 64->64 @512x512 9 taps B8', 'halo', 'f16x2', 64, 64, 512),
           # round 5: the fused up-sampling kernel in split-bf16 (StyleGAN2-256's 32 -> 64 layer under the default policy)
-          ('conv bf16x3 512->512 @32x32 up-conv + blur fused B32', 'up', 'bf16x3', 512, 512, 32)]
+          ('conv bf16x3 512->512 @32x32 up-conv + blur fused B32', 'up', 'bf16x3', 512, 512, 32),
+          # round 6: the split-bf16 F(2,3) kernel (conv_wino_bf16.hip) and the direct split-bf16 patch kernel it replaces
+          ('conv bf16x3w 512->512 @64x64 9 taps B32', 'conv', 'bf16x3w', 512, 512, 64),
+          ('conv bf16x3w 256->256 @128x128 9 taps B32', 'conv', 'bf16x3w', 256, 256, 128),
+          ('conv bf16x3w 128->128 @256x256 9 taps B32', 'conv', 'bf16x3w', 128, 128, 256),
+          ('conv bf16x3 512->512 @64x64 9 taps B32', 'conv', 'bf16x3', 512, 512, 64),
+          ('conv bf16x3 256->256 @128x128 9 taps B32', 'conv', 'bf16x3', 256, 256, 128)]
+if os.environ.get('PMC_ONLY'):       # restrict a run AND its summary to the shapes whose label contains this text (tools/pmc_quick.sh)
+    SHAPES = [s_ for s_ in SHAPES if os.environ['PMC_ONLY'] in s_[0]]
 
 
 def run():
@@ -34,7 +42,7 @@ def run():
         B = 8 if kind == 'halo' else 32
         x = torch.randn(B, h, h, ci, device=dev); w = torch.randn(co, 9, ci, device=dev) / (9 * ci) ** 0.5
         s = torch.randn(B, ci, device=dev); dm = torch.rand(B, co, device=dev)
-        ws = C.SplitCache(w) if m == C.FP32W else (C.split_weight(w, m) if m else None)
+        ws = C.SplitCache(w) if m in (C.FP32W, C.BF16W) else (C.split_weight(w, m) if m else None)
         if kind in ('conv', 'halo'):
             y = torch.empty(B, h, h, co, device=dev)
             am = x.abs().amax().reshape(1)
@@ -63,7 +71,7 @@ def summarise(d, out):
     for f in sorted(glob.glob(d + '/*/p_counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
-            mm = re.search(r'(igemm_\w+<[^>]*>|patch_dma_kernel<[^>]*>|upconv_blur_kernel<[^>]*>|wino_f32_kernel<[^>]*>|halo3x3_kernel<[^>]*>)', kn)
+            mm = re.search(r'(igemm_\w+<[^>]*>|patch_dma_kernel<[^>]*>|upconv_blur_kernel<[^>]*>|wino_f32_kernel<[^>]*>|wino16_kernel<[^>]*>|halo3x3_kernel<[^>]*>)', kn)
             if not mm:
                 continue
             key = (int(r['Dispatch_Id']), mm.group(1))

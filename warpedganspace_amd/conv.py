@@ -61,13 +61,15 @@ class WgradDesc(ctypes.Structure):
 #              sample is over the 1e-3 gate (STRICT_LADDER; the default table holds the gate per batch tensor and per image at p99 - p99.9)
 #   5 'fp32w'  fp32 with the 3x3 stride-1 convs in Winograd F(2x2,3x3) form on the fp32 matrix cores (2.25x fewer multiplies, ~1e-6
 #              against the direct form, 3e-6 against fp64: no wider than the direct fp32 kernel); the rest as 'fp32'
+#   7 'bf16x3w' split-bf16 (the arithmetic of 'bf16x3': fp32-class) with the 3x3 stride-1 convs' horizontal taps in the Winograd form F(2,3)
+#              (csrc/conv_wino_bf16.hip: two bf16 MFMAs per direct product instead of three); launches it does not cover run 'bf16x3'
 #  -1 'auto'   per generator: the cheapest mode whose measured image error stays inside the north_star's 1e-3 gate for that
 #              architecture with margin (tests/test_precision_schemes_gpu.py): see AUTO_TABLE
 # There is NO process-wide arithmetic state: a mode is an attribute of a generator instance (`G.precision`), an argument of
 # its forward (`G(z, shift, precision=...)`) and of the step engine (`TrainStep(..., precision=..., r_precision=...)`); bare
 # conv calls without `precision=` run the reference's arithmetic (exact fp32).
-PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'mixed': 4, 'fp32w': 5, 'mixed-strict': 6}
-AUTO, MIXED, FP32W, MIXED_STRICT = -1, 4, 5, 6
+PRECISION_NAMES = {'auto': -1, 'fp32': 0, 'bf16x3': 1, 'f16': 2, 'f16x2': 3, 'mixed': 4, 'fp32w': 5, 'mixed-strict': 6, 'bf16x3w': 7}
+AUTO, MIXED, FP32W, MIXED_STRICT, BF16W = -1, 4, 5, 6, 7
 # default of the TRAINING CLIs (train.py, bench.py extra runs); the image-producing CLIs (traverse_latent_space.py,
 # sample_gan.py) default to IMAGE_DEFAULT_PRECISION, the fp32-class mode
 DEFAULT_PRECISION = 'auto'
@@ -154,6 +156,8 @@ def layer_precision(code, out_res, is_up, policy=None):
     """Concrete arithmetic of one StyleGAN2 layer's forward conv under mode `code`."""
     if code == FP32W:          # the Winograd form exists for the 3x3 stride-1 convs; the up-convs (1/2/2/4-tap phases) stay direct
         return 0 if is_up else FP32W
+    if code == BF16W:          # the F(2,3) form exists for the 3x3 stride-1 convs; the up-convs run the direct split-bf16 kernels
+        return 1 if is_up else BF16W
     if not is_mixed(code):
         return code
     return (policy or MIXED_256).fwd(out_res, is_up)
@@ -163,6 +167,8 @@ def layer_precision_bwd(code, out_res, is_up, policy=None):
     """Arithmetic of a layer's INPUT-GRADIENT conv under mode `code`."""
     if code == FP32W:
         return 0 if is_up else FP32W
+    if code == BF16W:
+        return 1 if is_up else BF16W
     if not is_mixed(code):
         return code
     return (policy or MIXED_256).bwd(out_res, is_up)
@@ -188,7 +194,7 @@ def is_f16_operand(code):
 
 def is_reduced(code):
     """Modes whose products are not exact fp32 MFMA: the ones the run-time image-error check applies to."""
-    return code in (1, 2, 3, MIXED, MIXED_STRICT)
+    return code in (1, 2, 3, MIXED, MIXED_STRICT, BF16W)
 
 
 def precision_name(code):
@@ -255,6 +261,8 @@ class SplitCache:
     def get(self, precision):
         if precision in (0, FP32W):
             return None
+        if precision == BF16W:     # the split-bf16 planes serve the launches the F(2,3) kernel does not cover
+            precision = 1
         if precision not in self.planes:
             self.planes[precision] = split_weight(self.w, precision)
         return self.planes[precision]
@@ -332,6 +340,8 @@ def _desc(x, w, y, taps, Hg, Wg, isy=1, osy=1, oy0=0, ox0=0, w_tap_stride=None, 
         prec = 3
     if prec == FP32W:          # launch() routes the launches the Winograd kernel covers; everything else is the direct fp32 form
         prec = 0
+    if prec == BF16W:          # likewise: what conv_wino_bf16.hip does not cover is a direct split-bf16 launch
+        prec = 1
     if grad_operand and prec >= 2 and a_amax is None:
         # an fp16 gradient operand needs a magnitude bound (5 exponent bits); without one the launch runs in split-bf16
         prec = 1
@@ -381,6 +391,19 @@ def _wino_weight(d, w, cache):
     return U
 
 
+def _wino16_weight(d, w, cache):
+    """U = G g of a launch's weights as bf16 hi / lo planes in conv_wino_bf16.hip's B-fragment order (wgs_conv_wino16_weight): kept in the
+    weight tensor's SplitCache when the caller has one (frozen generator weights), rebuilt per launch otherwise."""
+    key = ('wino16', d.w_tap_stride, d.w_row_stride, tuple((d.dy[i], d.dx[i], d.wt[i]) for i in range(9)))
+    if isinstance(cache, SplitCache) and not isinstance(cache, StepWinoCache) and key in cache.planes:
+        return cache.planes[key]
+    U = torch.empty(24 * d.Ci * d.Co, device=w.device, dtype=torch.int16)
+    L.check(L.lib().wgs_conv_wino16_weight(ctypes.byref(d), L.ptr(U, torch.int16), L.stream()), 'wgs_conv_wino16_weight')
+    if isinstance(cache, SplitCache) and not isinstance(cache, StepWinoCache):
+        cache.planes[key] = U
+    return U
+
+
 def pixelnorm_fused_ok(x, w, y, taps, Hg, Wg, **kw):
     """True when launch(..., pixelnorm_eps=eps) is covered: the conv's operand PixelNorm(x) is formed while the few-channel kernel stages
     its input patch (wgs_conv_desc.a_pixelnorm_eps), so the normalised tensor is never written (ProgGAN's 16- / 32-channel layers)."""
@@ -391,7 +414,18 @@ def pixelnorm_fused_ok(x, w, y, taps, Hg, Wg, **kw):
 
 
 def launch(x, w, y, taps, Hg, Wg, **kw):
-    """One implicit-GEMM launch (wgs_conv_igemm), or — precision 'fp32w' and a shape it covers — the Winograd kernel (wgs_conv_wino)."""
+    """One implicit-GEMM launch (wgs_conv_igemm), or — precision 'fp32w' / 'bf16x3w' and a shape they cover — the Winograd kernels
+    (wgs_conv_wino: F(2x2,3x3) in fp32; wgs_conv_wino16: F(2,3) x direct in split-bf16)."""
+    if kw.get('precision') == BF16W:
+        # decided before the weight planes are touched: a covered launch reads U only (no bf16 planes of w are built for it)
+        kw_ = {k: v for k, v in kw.items() if k != 'w_split'}
+        d, flops = _desc(x, w, y, taps, Hg, Wg, **kw_)
+        if L.lib().wgs_conv_wino16_supported(ctypes.byref(d)):
+            U = _wino16_weight(d, w, kw.get('w_split'))
+            kind = _kind(d, 1)
+            _timed(kind.replace('conv bf16x3 ', 'conv bf16x3w ', 1) if kind else None, flops, lambda: L.check(L.lib().wgs_conv_wino16(ctypes.byref(d), L.ptr(U, torch.int16), L.stream()), 'wgs_conv_wino16'))
+            return y
+        kw = dict(kw, precision=1)          # not covered: the direct split-bf16 launch it stands for
     d, flops = _desc(x, w, y, taps, Hg, Wg, **kw)
     if kw.get('precision') == FP32W and L.lib().wgs_conv_wino_supported(ctypes.byref(d)):
         U = _wino_weight(d, w, kw.get('w_split'))

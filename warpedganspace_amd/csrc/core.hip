@@ -36,6 +36,7 @@ static WgsFlags read_flags() {
     g.up_gh16 = getenv("WGS_UP_GH16") != nullptr;
     g.patch_dma_bm = (getenv("WGS_PATCH_DMA_BM") && atoi(getenv("WGS_PATCH_DMA_BM")) == 128) ? 128 : 256;      // ... its tile rows (conv_patch_dma.hip: 256 measured best)
     g.patch_dma_bn256 = getenv("WGS_PATCH_DMA_BN256") != nullptr;   // ... its 8-wave 256 x 256 tile for Cout % 256 == 0 (measured 2-3 % slower than the LDS-DMA kernel: off)
+    g.wino16_min_wg = getenv("WGS_WINO16_MIN_WG") ? atoi(getenv("WGS_WINO16_MIN_WG")) : 200;      // conv_wino_bf16.hip: launches with fewer workgroups are left to the direct kernels' split-K forms
     g.patch_nodma = getenv("WGS_PATCH_NODMA") != nullptr;      // fp16-plane 128 x 128 tiles: the register-staged patch kernel instead of conv_patch_dma.hip
     g.up_gh8 = getenv("WGS_UP_GH8") != nullptr;      // fused up-sampling kernel: the 4-wave 14 x 6-cell tiles (two workgroups per CU) whatever the launch size
     g.patch_ntf0 = getenv("WGS_PATCH_NTF0") != nullptr;
@@ -63,7 +64,7 @@ const WgsFlags& wgs_flags() { return flags_storage(); }
 
 extern "C" {
 const char* wgs_last_error(void) { return g_err; }
-int wgs_abi_version(void) { return 8; }      // 8: wgs_wgrad_desc.ws / ws_bytes (direct-fragment weight gradients); split-bf16 in wgs_sg2_upconv_blur_act.  7: wgs_sample_step; split-bf16 weight gradients with few input channels.  6: wgs_conv_wino_layout; fp16 activation planes
+int wgs_abi_version(void) { return 9; }      // 9: wgs_conv_wino16* (split-bf16 F(2,3) form of the 3x3 stride-1 convs).  8: wgs_wgrad_desc.ws / ws_bytes (direct-fragment weight gradients); split-bf16 in wgs_sg2_upconv_blur_act.  7: wgs_sample_step; split-bf16 weight gradients with few input channels.  6: wgs_conv_wino_layout; fp16 activation planes
 void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
 int64_t wgs_dev_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 void wgs_dev_trace_kernels(int on) { g_trace.store(on ? 1 : 0, std::memory_order_relaxed); g_kernel[0] = 0; }
