@@ -32,6 +32,11 @@ def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    # step engines built with precision 'auto' / 'mixed-strict' on a StyleGAN2-256 / -1024 calibrate their per-layer table on their generator
+    # (trainer.TrainStep.calibrate_strict: 2 304 / 576 latent codes by default): the suite's engines use a small sample (the calibration
+    # itself is tested with the full one in tests/test_precision_schemes_gpu.py)
+    from warpedganspace_amd.trainer import TrainStep
+    TrainStep.calibrate_images_default = 96
     return torch.device('cuda:0')
 
 

@@ -108,18 +108,20 @@ def _canned_full(bench, world=1):
             "exposed_wait_ms_per_step": 0.123, "per_gpu_images_per_sec": 71.59, "n1_same_job": {"value": 590.12, "ms_per_step": 54.23, "steps": 30},
             "note": "z" * 300} if world > 1 else None
     host = {"library_launches_per_step": 426.0, "host_enqueue_ms_per_step": 6.6, "host_enqueue_ms_per_step_mean": 7.0, "note": "n" * 200}
-    same = [dict({"config": "headline workload in the product's default arithmetic (--precision auto), same steps / warmup"}, precision='mixed', value=1145.0,
-                 ms_per_step=27.9, dtype=bench.DTYPE['mixed'], dtype_detail='d' * 500, roofline=dict(roof, kernel='igemm_patch_kernel<0, 256, 256, 2, 4, 1, 0>'),
+    same = [dict({"config": "headline workload in the product's default arithmetic (--precision auto), same steps / warmup"}, precision='mixed-strict', value=1145.0,
+                 ms_per_step=27.9, dtype=bench.DTYPE['mixed-strict'], dtype_detail='d' * 500, roofline=dict(roof, kernel='igemm_patch_kernel<0, 256, 256, 2, 4, 1, 0>'),
                  host=host, comm=comm, last_stats={}, n_gpus=world, steps=100,
-                 precision_check={"batch_max": 5.9e-4, "image_median": 4.1e-4, "image_p99": 8.4e-4, "image_max": 1.06e-3, "over_gate_frac": 0.0013, "gate": 1e-3, "n": 2304}),
+                 strict_calibration={"table": "128:w,3;256:w,3", "tried": [("default 128:2,3;256:2,3", 1.1e-3, 256), ("128:w,3;256:w,3", 8.1e-4, 2304)], "images": 2304,
+                                     "margin": 0.95, "gate": 1e-3, "fp16_layers": 2},
+                 precision_check={"batch_max": 5.9e-4, "image_median": 4.1e-4, "image_p99": 8.4e-4, "image_max": 9.06e-4, "over_gate_frac": 0.0, "gate": 1e-3, "n": 2304}),
             dict({"config": "headline workload in direct-form exact fp32 (--precision fp32: no Winograd), same steps / warmup"}, precision='fp32', value=410.0,
                  ms_per_step=78.0, dtype='fp32', dtype_detail='d' * 500, roofline=roof, host=host, last_stats={}, n_gpus=world, steps=100)]
     others = [dict({"config": e[0], "key": e[-1]}, precision=e[6], value=123.45, ms_per_step=1.0, r_arith=[1, 1, 1]) for e in bench.EXTRA]
     for o in others:
-        if o["key"] == "cfg3_mixed_strict":
-            o["precision_check"] = {"batch_max": 4.5e-4, "image_median": 3.5e-4, "image_p99": 6.5e-4, "image_max": 8.4e-4, "over_gate_frac": 0.0, "gate": 1e-3, "n": 2304}
-    assert bench.EXTRA[4][-1] == 'cfg3_auto_Rfp32'
-    others[4] = {"config": bench.EXTRA[4][0], "key": bench.EXTRA[4][-1], "precision": bench.EXTRA[4][6], "error": "RuntimeError('" + "e" * 300 + "')"}
+        if o["key"] == "cfg3_mixed_uncalibrated":
+            o["precision_check"] = {"batch_max": 8.5e-4, "image_median": 4.5e-4, "image_p99": 1.0e-3, "image_max": 1.3e-3, "over_gate_frac": 0.012, "gate": 1e-3, "n": 2304}
+    assert bench.EXTRA[5][-1] == 'cfg3_auto_Rfp32'
+    others[5] = {"config": bench.EXTRA[4][0], "key": bench.EXTRA[4][-1], "precision": bench.EXTRA[4][6], "error": "RuntimeError('" + "e" * 300 + "')"}
     args = types.SimpleNamespace(size=256, gan='stylegan2', K=128, N=32, batch=32, w_space=False, steps=100, warmup=20, precision='fp32w')
     head = {"value": 572.7, "ms_per_step": 55.9, "dtype": "fp32", "dtype_detail": bench.DTYPE_TEXT['fp32w'], "precision": "fp32w", "r_arith": [5, 5, 0],
             "roofline": roof, "host": host}
@@ -152,11 +154,13 @@ def test_final_line_is_under_4kb_and_round_trips(bench, world):
         assert c['value'] == 0.393 and c['cores'] == 128 and c['kind'] == 'port' and len(c['sample']) <= 300
         assert len(d['others_images_per_sec']) == len(bench.EXTRA) - 1 and 'error' in d['others_images_per_sec'].values()
         assert d['comm'] is None
-        # the measured image error of the timed arithmetic, and the strict policy's rate + error beside it
+        # the measured image error of the timed arithmetic — the table the engine calibrated on its own generator —
+        # and the un-calibrated default table's rate + error beside it
         pc = d['product']['precision_check']
-        assert pc['n'] == 2304 and pc['image_max'] == 1.06e-3 and pc['over_gate_frac'] == 0.0013 and pc['batch_max'] == 5.9e-4 and pc['image_p99'] == 8.4e-4
-        st = d['product']['strict']
-        assert st['precision'] == 'mixed-strict' and st['value'] == 123.45 and st['precision_check']['over_gate_frac'] == 0.0
+        assert pc['n'] == 2304 and pc['image_max'] == 9.06e-4 and pc['over_gate_frac'] == 0.0 and pc['batch_max'] == 5.9e-4 and pc['image_p99'] == 8.4e-4
+        assert d['product']['precision'] == 'mixed-strict' and d['product']['table'] == '128:w,3;256:w,3' and d['product']['fp16_layers'] == 2
+        un = d['product']['uncalibrated']
+        assert un['precision'] == 'mixed' and un['value'] == 123.45 and un['precision_check']['over_gate_frac'] == 0.012
     else:
         assert d['comm']['world_size_observed'] == 8 and d['comm']['exposed_wait_ms_per_step'] == 0.123 and d['product']['exposed_wait_ms_per_step'] == 0.123
         # VERDICT r4 #6c: the N = 1 rate of the same job beside the per-GPU rate and the exposed wait

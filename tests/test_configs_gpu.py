@@ -213,7 +213,7 @@ def test_cfg5_full_size_step_fp16_path(dev):
         res[mode] = (st, eng.argmax.cpu().clone(), eng.bucket.gview[id(eng.S.SUPPORT_SETS)].double().cpu().reshape(-1).clone())
         del eng, G, S, R
         torch.cuda.empty_cache()
-    assert C.resolve('auto', 'stylegan2', 1024) == C.MIXED
+    assert C.resolve('auto', 'stylegan2', 1024) == C.MIXED_STRICT       # the table the engine calibrated on this generator
     (s0, a0, g0), (s1, a1, g1) = res['fp32'], res['auto']
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
     print('cfg5 step (1024^2, K=200, N=64, B=8): loss fp32 %.6f mixed %.6f, dS cosine %.5f' % (s0[2], s1[2], cos))

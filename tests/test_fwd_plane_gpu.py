@@ -117,7 +117,7 @@ def test_conv_fed_with_the_plane_returns_the_same_bits(dev, B, C1, C2, H, route)
     assert (got.double().permute(0, 3, 1, 2) - full).abs().max() <= 2e-3 * full.abs().max()
 
 
-@pytest.mark.parametrize('size,prec', [(256, 'auto'), (128, 'f16')])
+@pytest.mark.parametrize('size,prec', [(256, 'mixed'), (128, 'f16')])
 def test_generator_same_image_and_gradient_with_and_without_forward_planes(dev, monkeypatch, size, prec):
     from tests import golden_inputs as GI
     from warpedganspace_amd.stylegan2 import Generator
@@ -125,7 +125,7 @@ def test_generator_same_image_and_gradient_with_and_without_forward_planes(dev, 
     G = Generator(size, 512, 8)
     G.load_state_dict(GI.fill_state_dict(G.state_dict(), 977))
     G = G.to(dev).eval()
-    G.precision = 'auto'
+    G.precision = prec
     B = 32 if size == 128 else 16
     z = torch.randn(B, 512, device=dev)
     imgs, grads, nograd = [], [], []
@@ -154,7 +154,7 @@ def test_generator_same_image_and_gradient_with_and_without_forward_planes(dev, 
 
 
 def test_the_route_is_taken_in_the_default_policy(dev):
-    """StyleGAN2-256 under 'auto' at the training batch: both plain-fp16 stride-1 convs (128^2, 256^2) read a producer-written plane."""
+    """StyleGAN2-256 under the default 'mixed' table at the training batch: both plain-fp16 stride-1 convs (128^2, 256^2) read a producer-written plane."""
     from warpedganspace_amd.gan_load import build_stylegan2
     torch.manual_seed(0)
     G = build_stylegan2(None, resolution=256).to(dev).eval()
@@ -163,7 +163,7 @@ def test_the_route_is_taken_in_the_default_policy(dev):
     L.lib().wgs_dev_trace_kernels(1)
     try:
         with torch.no_grad():
-            G(z, precision='auto')
+            G(z, precision='mixed')
         torch.cuda.synchronize()
         syms = [r[4] for r in C.PROFILE if r[0] and ' 9 taps' in r[0] and (r[0].startswith('conv f16 128->128 @256') or r[0].startswith('conv f16 256->256 @128'))]
     finally:
@@ -244,9 +244,9 @@ def test_generator_same_image_with_and_without_the_fused_torgb(dev, monkeypatch)
     for on in (True, False):
         monkeypatch.setattr(C, 'RGB_FUSED', on)
         with torch.no_grad():
-            a = G(z, precision='auto').clone()
+            a = G(z, precision='mixed').clone()
         zz = z.clone().requires_grad_(True)
-        img = G(zz, precision='auto')
+        img = G(zz, precision='mixed')
         img.backward(torch.linspace(-1, 1, img.numel(), device=dev).view_as(img))
         res[on] = (a, img.detach().clone(), zz.grad.clone())
     assert torch.equal(res[True][0], res[True][1])             # the pass that stores nothing and the pass that saves: same image

@@ -14,9 +14,10 @@ def test_precision_names_round_trip():
 
 
 def test_auto_resolves_per_architecture():
-    assert C.precision_name(C.resolve('auto', 'stylegan2', 256)) == 'mixed'
-    assert C.precision_name(C.resolve(None, 'stylegan2', 256)) == 'mixed'                # None = auto
-    assert C.precision_name(C.resolve('auto', 'stylegan2', 1024)) == 'mixed'
+    # StyleGAN2: the per-layer table CALIBRATED by the step engine on its own generator (round 6; the fixed 'mixed' table stays an explicit mode)
+    assert C.precision_name(C.resolve('auto', 'stylegan2', 256)) == 'mixed-strict'
+    assert C.precision_name(C.resolve(None, 'stylegan2', 256)) == 'mixed-strict'         # None = auto
+    assert C.precision_name(C.resolve('auto', 'stylegan2', 1024)) == 'mixed-strict'
     assert C.precision_name(C.resolve('auto', 'proggan', 256)) == 'f16'
     assert C.precision_name(C.resolve('auto', 'biggan', 128)) == 'bf16x3'
     assert C.precision_name(C.resolve('auto', 'sngan', 32)) == C.AUTO_FALLBACK
@@ -37,25 +38,26 @@ def test_no_process_wide_arithmetic_state():
     a, b = Generator(32, 512, 2), Generator(32, 512, 2)
     a.precision = 'f16'
     assert a.resolve_precision() == 2 and b.resolve_precision() == 0 and b.resolve_precision('mixed') == 4
-    assert Generator(256, 512, 2).resolve_precision('auto') == C.MIXED
+    assert Generator(256, 512, 2).resolve_precision('auto') == C.MIXED_STRICT
 
 
 def test_mixed_policy_per_layer():
-    M = C.MIXED
-    # StyleGAN2-256 (the default table): below 128 x 128 split-bf16, stride-1 convs fp16, up-sampling layers fp16 x2
-    assert C.layer_precision(M, 64, False) == 1 and C.layer_precision(M, 64, True) == 1 and C.layer_precision(M, 32, True) == 1
+    M, W16 = C.MIXED, C.BF16W
+    # StyleGAN2-256 (the default table): below 128 x 128 split-bf16 (stride-1 convs in the F(2,3) form where the kernel covers them: code 7
+    # falls back to a direct split-bf16 launch elsewhere), stride-1 convs fp16, up-sampling layers fp16 x2
+    assert C.layer_precision(M, 64, False) == W16 and C.layer_precision(M, 64, True) == 1 and C.layer_precision(M, 32, True) == 1 and C.layer_precision(M, 8, False) == W16
     assert C.layer_precision(M, 128, False) == 2 and C.layer_precision(M, 256, False) == 2
     assert C.layer_precision(M, 128, True) == 3 and C.layer_precision(M, 256, True) == 3
     # backward: the up-sampling layers' input-gradient convs in plain fp16, everything else as the forward
     assert C.layer_precision_bwd(M, 128, True) == 2
     assert C.layer_precision_bwd(M, 128, False) == 2 and C.layer_precision_bwd(M, 16, True) == 1
     # ... and the two 64 x 64 layers: split-bf16 forward (image gate), plain fp16 input-gradient convs (gradient gate)
-    assert C.layer_precision_bwd(M, 64, False) == 2 and C.layer_precision_bwd(M, 64, True) == 2 and C.layer_precision_bwd(M, 32, False) == 1
+    assert C.layer_precision_bwd(M, 64, False) == 2 and C.layer_precision_bwd(M, 64, True) == 2 and C.layer_precision_bwd(M, 32, False) == W16
     # StyleGAN2-1024: fp16 x2 in the HBM-bound 512^2 / 1024^2 layers only
     pol = C.mixed_policy(1024)
     assert pol is C.MIXED_1024 and C.mixed_policy(256) is C.MIXED_256
     assert C.layer_precision(M, 1024, False, pol) == 3 and C.layer_precision(M, 512, True, pol) == 3
-    assert C.layer_precision(M, 256, False, pol) == 1 and C.layer_precision(M, 64, True, pol) == 1
+    assert C.layer_precision(M, 256, False, pol) == W16 and C.layer_precision(M, 64, True, pol) == 1
     assert C.layer_precision_bwd(M, 1024, True, pol) == 2 and C.layer_precision_bwd(M, 1024, False, pol) == 3
     assert C.layer_precision_bwd(M, 256, False, pol) == 2 and C.layer_precision_bwd(M, 64, True, pol) == 2 and C.layer_precision_bwd(M, 32, True, pol) == 1
     # an explicit table, and a policy without the plain-fp16 backward rule
@@ -65,6 +67,17 @@ def test_mixed_policy_per_layer():
     # any fixed mode is the same for every layer, forward and backward
     for code in (0, 1, 2, 3):
         assert C.layer_precision(code, 8, True) == code and C.layer_precision_bwd(code, 256, True) == code
+    # 'bf16x3w': split-bf16 everywhere, the stride-1 layers carry code 7 to conv.launch (which routes what conv_wino_bf16.hip covers)
+    for res in (4, 64, 256):
+        assert C.layer_precision(W16, res, False) == W16 and C.layer_precision(W16, res, True) == 1
+        assert C.layer_precision_bwd(W16, res, False) == W16 and C.layer_precision_bwd(W16, res, True) == 1
+    assert C.is_reduced(W16) and not C.is_f16_operand(W16)
+    # the strict ladder (ordered by measured step time): starts at the default table, ends without any fp16-rounded layer; distinct names
+    for size, ladder in C.STRICT_LADDER.items():
+        sp = [pol_.spends() for _, pol_ in ladder]
+        assert ladder[0][1] is C.MIXED_POLICIES[size] and sp[0] == max(sp) and sp[-1] == 0, (size, sp)
+        assert len({n_ for n_, _ in ladder}) == len(ladder)
+        assert C.mixed_policy(size, C.MIXED_STRICT) in [pol_ for _, pol_ in ladder]
 
 
 def test_fused_upconv_selection():

@@ -250,7 +250,7 @@ def test_staged_pass_equals_the_plain_pass_and_hooks_fire_in_the_backward(dev, p
 
 
 def test_stylegan2_1024_torgb_in_the_few_channel_kernel(dev):
-    """StyleGAN2-1024 in its default arithmetic: the ToRGBs of the 64- / 32-channel layers at 512^2 / 1024^2 run in their conv's epilogue
+    """StyleGAN2-1024 under its default 'mixed' table: the ToRGBs of the 64- / 32-channel layers at 512^2 / 1024^2 run in their conv's epilogue
     (conv.rgb_halo_ok); same image and gradient as with the separate ToRGB launches."""
     from warpedganspace_amd import conv as C
     G, _ = build(1024, 77, dev)
@@ -263,10 +263,10 @@ def test_stylegan2_1024_torgb_in_the_few_channel_kernel(dev):
             C.RGB_FUSED = fused
             G._route = {}
             s = sh.clone().requires_grad_(True)
-            img = wrap(z, s, precision='auto')
+            img = wrap(z, s, precision='mixed')
             img.square().mean().backward()
             with torch.no_grad():
-                img0 = wrap(z, precision='auto')             # the pass that keeps nothing (its last layer's output is never stored)
+                img0 = wrap(z, precision='mixed')             # the pass that keeps nothing (its last layer's output is never stored)
             out[fused] = (img.detach().clone(), s.grad.clone(), img0.clone(), sum(bool(v) for k, v in G._route.items() if k[0] == 'rgb_halo'))
     finally:
         C.RGB_FUSED = True

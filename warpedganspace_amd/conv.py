@@ -76,7 +76,8 @@ DEFAULT_PRECISION = 'auto'
 IMAGE_DEFAULT_PRECISION = 'bf16x3'
 # (generator family, output resolution) -> mode for 'auto'; only entries with a measurement behind them
 # (profiles/r4_precision_schemes.json: ProgGAN-256 3.5e-4, ProgGAN-1024 9e-5 per image in f16); everything else falls back to the fp32-class mode.
-AUTO_TABLE = {('stylegan2', 256): 'mixed', ('stylegan2', 1024): 'mixed', ('proggan', 256): 'f16', ('proggan', 1024): 'f16'}
+# StyleGAN2: the CALIBRATED per-layer table (round 6; VERDICT r5 #1: the un-calibrated 'mixed' table sat ON the gate on bench.py's initialisation)
+AUTO_TABLE = {('stylegan2', 256): 'mixed-strict', ('stylegan2', 1024): 'mixed-strict', ('proggan', 256): 'f16', ('proggan', 1024): 'f16'}
 AUTO_FALLBACK = 'bf16x3'
 
 
@@ -84,17 +85,20 @@ class MixedPolicy:
     """Per-layer arithmetic of a StyleGAN2 generator under 'mixed': every fp16-rounded layer adds an independent ~2.5e-4 (both
     operands rounded, 'f16') or ~1.7e-4 (one operand, 'f16x2') to the image error, and the generator's MACs sit in the layers
     at >= 64x64; so those run in fp16 and the low-resolution layers (latency-bound) in split-bf16.
-    table: {output resolution: (stride-1 conv code, up-conv code)}; resolutions not listed run `below` (bf16x3).
+    table: {output resolution: (stride-1 conv code, up-conv code)}; resolutions not listed run `below` — a code, or a (stride-1, up-conv)
+    pair; default (BF16W, 1): fp32-class split-bf16, the stride-1 convs in the F(2,3) form where conv_wino_bf16.hip covers them (maps
+    >= 32 x 32 that fill the chip; the rest are direct split-bf16 launches).
     bwd_up_f16: the up-sampling layers' INPUT-GRADIENT convs run in plain f16 when their forward is f16x2 (the two-MFMA form
     exists for the image-error budget; the gradient has its own gate, the shared-gate gradient error).
     bwd_table: explicit arithmetic of the input-gradient convs of the listed resolutions."""
 
-    def __init__(self, table, below=1, bwd_up_f16=True, bwd_table=None):
-        self.table, self.below, self.bwd_up_f16 = dict(table), below, bwd_up_f16
+    def __init__(self, table, below=(BF16W, 1), bwd_up_f16=True, bwd_table=None):
+        self.table, self.bwd_up_f16 = dict(table), bwd_up_f16
+        self.below = tuple(below) if isinstance(below, (tuple, list)) else (below, below)
         self.bwd_table = dict(bwd_table or {})     # {output resolution: (stride-1, up-conv)} arithmetic of the INPUT-GRADIENT convs only
 
     def fwd(self, out_res, is_up):
-        s1, up = self.table.get(out_res, (self.below, self.below))
+        s1, up = self.table.get(out_res, self.below)
         return up if is_up else s1
 
     def bwd(self, out_res, is_up):
@@ -104,6 +108,10 @@ class MixedPolicy:
         lp = self.fwd(out_res, is_up)
         return 2 if (is_up and lp == 3 and self.bwd_up_f16) else lp
 
+    def spends(self):
+        """Number of layers that round an operand to fp16 in the forward pass (what the image-error budget is spent on)."""
+        return sum((s1 in (2, 3)) + (up in (2, 3)) for s1, up in self.table.values())
+
 
 # Chosen from measured sweeps (tools/policy_sweep.py, profiles/r3_policy_sweep.md): per-image error of every candidate over 384
 # (256^2) / 64 (1024^2) latent codes and two weight fills, against the exact-fp32 kernels, and the step time under it.
@@ -111,34 +119,49 @@ class MixedPolicy:
 # 384 images within 1e-3 (max 8.5e-4, p99 7.3e-4, batch tensors <= 5.2e-4).  Round 2's table also ran the two 64^2 layers in fp16
 # (10 % faster, but p99 1.0e-3 and 1 % of single images over the gate).  Their INPUT-GRADIENT convs do run in plain fp16 (bwd_table):
 # the image gate is a forward matter, the gradient has its own (shared-gate gradient error vs the fp64 oracle, 1e-3).
-MIXED_256 = MixedPolicy({128: (2, 3), 256: (2, 3)}, bwd_table={64: (2, 2)})
+# Round 6: the split-bf16 stride-1 layers (64^2 and below) take the F(2,3) form (BF16W): same error class, two MFMAs per product instead of three.
+W = BF16W
+MIXED_256 = MixedPolicy({64: (W, 1), 128: (2, 3), 256: (2, 3)}, bwd_table={64: (2, 2)})
 # StyleGAN2-1024 (17 layers): fp16 x2 in the four HBM-bound layers at 512^2 / 1024^2 (64 / 32 channels: the 3-MFMA split-bf16 form
 # is what costs there, not the second fp16 MFMA), split-bf16 everywhere else: 12 % faster than split-bf16 everywhere, every
 # measured image within 1e-3 (max 8.5e-4).  fp16 in the 64^2 .. 256^2 layers as well measures 1.1e-3 .. 1.4e-3 at this depth.
 MIXED_1024 = MixedPolicy({512: (3, 3), 1024: (3, 3)}, bwd_table={64: (2, 2), 128: (2, 2), 256: (2, 2)})
 MIXED_POLICIES = {256: MIXED_256, 1024: MIXED_1024}
-# 'mixed-strict' (VERDICT r4 #7): NO single image over the 1e-3 gate.  Which table achieves that depends on the weights: the sweep's
-# well-conditioned fills (profiles/r5_policy_sweep.md: 4 fills x 576 codes) put the default table at max 1.06e-3 / 0.1 % over and table `f`
-# below at 9.3e-4 / none over, but on bench.py's raw constructor initialisation (a mapping network that collapses every z onto nearly one
-# w) the same tables measure 1.27e-3 / 1.0 % and 1.11e-3 / 0.09 %.  So the strict mode is CALIBRATED: a step engine built with
-# 'mixed-strict' measures the ladder below on its own generator (trainer.TrainStep.calibrate_strict: 2 304 codes against the exact-fp32
+# 'mixed-strict' (VERDICT r4 #7, r5 #1): NO single image over the 1e-3 gate.  Which table achieves that depends on the weights: the sweep's
+# well-conditioned fills (profiles/r5_policy_sweep.md: 4 fills x 576 codes) put the default table at max 1.06e-3 / 0.1 % over, but on
+# bench.py's raw constructor initialisation (a mapping network that collapses every z onto nearly one w) the same table measures
+# 1.27e-3 / 1.0 %.  So the strict mode is CALIBRATED: a step engine built with 'mixed-strict' — what 'auto' means for StyleGAN2 since
+# round 6 — measures the ladder below on its own generator (trainer.TrainStep.calibrate_strict: 2 304 codes against the exact-fp32
 # kernels) and takes the first — cheapest — table whose worst single image stays under 0.95 x the gate; the last rung is split-bf16
-# everywhere.  Backward arithmetic is the default table's on every rung (the gradient has its own gate, section 3.2 of DESIGN.md).
+# everywhere.  Round 6: the rungs keep the stride-1 layers they take out of fp16 in the F(2,3) split-bf16 form (W: fp32-class at 2 MFMAs
+# per product), so the budget is spent on the up-sampling layers, where fp16 buys most.  Backward arithmetic is the default table's on
+# every rung (the gradient has its own gate, section 3.2 of DESIGN.md).  Order = measured step time (tools/policy_sweep.py, profiles/r6_policy_sweep.md).
 _BWD_256 = {64: (2, 2), 128: (2, 2), 256: (2, 2)}
 _BWD_1024 = {64: (2, 2), 128: (2, 2), 256: (2, 2), 512: (3, 2), 1024: (3, 2)}
+def _p256(table):
+    return MixedPolicy(table, bwd_table=_BWD_256)
+
+
+# 256: ordered by the measured step time on bench.py's generator (profiles/r6_policy_sweep.md, same box: 23.8 / 24.5 / 24.7 / 24.9 / 25.0 / 25.4 / 25.6 /
+# 26.0 / 26.4 / 26.7 ms; worst single image of 2 304: 1.28e-3 / 1.19e-3 / 1.09e-3 / 9.5e-4 / 1.06e-3 / 8.2e-4 / 8.1e-4 / 6.6e-4 / 4.7e-4 / 4.4e-5)
 STRICT_LADDER = {
     256: [('default 128:2,3;256:2,3', MIXED_256),
-          ('k 128:2,3;256:3,3', MixedPolicy({128: (2, 3), 256: (3, 3)}, bwd_table=_BWD_256)),
-          ('f 128:3,3;256:3,3', MixedPolicy({128: (3, 3), 256: (3, 3)}, bwd_table=_BWD_256)),
-          ('e 256:2,3', MixedPolicy({256: (2, 3)}, bwd_table=_BWD_256)),
-          ('256:3,3', MixedPolicy({256: (3, 3)}, bwd_table=_BWD_256)),
-          ('bf16x3 everywhere', MixedPolicy({}, bwd_table=_BWD_256))],
+          ('128:2,2;256:w,3', _p256({128: (2, 2), 256: (W, 3)})),
+          ('128:w,3;256:2,3', _p256({128: (W, 3), 256: (2, 3)})),
+          ('128:w,2;256:w,2', _p256({128: (W, 2), 256: (W, 2)})),
+          ('128:2,3;256:w,3', _p256({128: (2, 3), 256: (W, 3)})),
+          ('128:w,2;256:w,3', _p256({128: (W, 2), 256: (W, 3)})),
+          ('128:w,3;256:w,2', _p256({128: (W, 3), 256: (W, 2)})),
+          ('128:w,3;256:w,3', _p256({128: (W, 3), 256: (W, 3)})),
+          ('128:w,1;256:w,3', _p256({256: (W, 3)})),
+          ('bf16x3w everywhere', _p256({}))],
     1024: [('default 512:3,3;1024:3,3', MIXED_1024),
            ('1024:3,3', MixedPolicy({1024: (3, 3)}, bwd_table=_BWD_1024)),
-           ('bf16x3 everywhere', MixedPolicy({}, bwd_table=_BWD_1024))],
+           ('bf16x3w everywhere', MixedPolicy({}, bwd_table=_BWD_1024))],
 }
+STRICT_IMAGES = {256: 2304, 1024: 576}       # latent codes of a calibration (72 batches of the configurations' 32 / 8 images)
 # before an engine has calibrated (a bare generator call with precision='mixed-strict'): the most conservative fp16 rung
-MIXED_256_STRICT = STRICT_LADDER[256][4][1]
+MIXED_256_STRICT = STRICT_LADDER[256][8][1]
 MIXED_STRICT_POLICIES = {256: MIXED_256_STRICT, 1024: STRICT_LADDER[1024][1][1]}
 
 

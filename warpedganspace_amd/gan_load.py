@@ -24,25 +24,27 @@ class StyleGAN2Wrapper(nn.Module):
         """Z-space codes [B,512] -> W-space codes [B,512] (mapping network)."""
         return self.G.get_latent(z)
 
-    def forward(self, z, shift=None, latent_is_w=False, precision=None):
+    def forward(self, z, shift=None, latent_is_w=False, precision=None, policy=None):
         """z: latent codes (Z space, or W space when `latent_is_w`); shift: shift vectors in the space
         selected by `shift_in_w_space`.  Returns images [B, 3, res, res] (NCHW, un-clamped).
-        precision (extension): arithmetic of this call's convs (conv.PRECISION_NAMES); default: the generator's `precision`."""
+        precision (extension): arithmetic of this call's convs (conv.PRECISION_NAMES); default: the generator's `precision`.
+        policy (extension): conv.MixedPolicy of this call under a 'mixed' mode (a step engine passes the table it calibrated)."""
+        kw = dict(precision=precision, policy=policy)
         if self.shift_in_w_space:
             if latent_is_w:
-                return self.G([z if shift is None else z + shift], input_is_latent=True, precision=precision)[0]
+                return self.G([z if shift is None else z + shift], input_is_latent=True, **kw)[0]
             w = self.G.get_latent(z)
-            return self.G([w if shift is None else w + shift], input_is_latent=True, precision=precision)[0]
-        return self.G([z if shift is None else z + shift], input_is_latent=False, precision=precision)[0]
+            return self.G([w if shift is None else w + shift], input_is_latent=True, **kw)[0]
+        return self.G([z if shift is None else z + shift], input_is_latent=False, **kw)[0]
 
     def resolve_precision(self, requested=None):
         return self.G.resolve_precision(requested)
 
     # -- the un-shifted pass G(z) in two stages (extension; trainer.TrainStep) ------------------------------------------------------
-    def begin(self, z, precision=None, pause_res=32):
+    def begin(self, z, precision=None, pause_res=32, policy=None):
         """Enqueue the mapping network and the synthesis layers up to `pause_res` for G(z) (no shift, nothing saved): a handle."""
         w, _ = self.G._mapping_fwd(z, save=False)
-        return self.G.synthesis_begin(w, self.G.resolve_precision(precision), pause_res)
+        return self.G.synthesis_begin(w, self.G.resolve_precision(precision), pause_res, policy)
 
     def advance(self, handle):
         """Enqueue the layers up to the next pause resolution (`pause_res` a tuple): None while paused again, else the image."""

@@ -143,9 +143,9 @@ class _Mapping(torch.autograd.Function):
 
 class _Synthesis(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, G, w, prec):
-        ctx.prec = prec                                      # the backward runs in the arithmetic its forward ran in
-        img, saved = G._synthesis_fwd(w, ctx.needs_input_grad[1], prec)
+    def forward(ctx, G, w, prec, policy=None):
+        ctx.prec, ctx.policy = prec, policy                  # the backward runs in the arithmetic (and per-layer table) its forward ran in
+        img, saved = G._synthesis_fwd(w, ctx.needs_input_grad[1], prec, policy)
         ctx.G, ctx.saved = G, saved
         # side work for THIS forward's backward (Generator.bwd_hooks): the list object is bound to this autograd node and taken off the
         # generator, so that another forward / backward of the same generator in between neither sees nor consumes it
@@ -159,7 +159,7 @@ class _Synthesis(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gimg):
         hooks, ctx.hooks = ctx.hooks, None
-        return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous(), ctx.prec, hooks), None
+        return None, ctx.G._synthesis_bwd(ctx.saved, gimg.contiguous(), ctx.prec, hooks, ctx.policy), None, None
 
 
 class Generator(nn.Module):
@@ -340,20 +340,20 @@ class Generator(nn.Module):
         return gz
 
     # -- synthesis network, model.py:389-403 ---------------------------------------------------------------
-    def _synthesis_fwd(self, w, save, prec):
-        g = self._synthesis_gen(w, save, prec, None)
+    def _synthesis_fwd(self, w, save, prec, policy=None):
+        g = self._synthesis_gen(w, save, prec, None, policy)
         try:
             next(g)
         except StopIteration as e:
             return e.value
         raise L.WgsError("synthesis generator paused without a pause resolution")
 
-    def synthesis_begin(self, w, prec, pause_res):
+    def synthesis_begin(self, w, prec, pause_res, policy=None):
         """Enqueue the synthesis layers whose output is <= pause_res (nothing saved) and return a handle for synthesis_advance() /
         synthesis_finish().  `pause_res` may be a tuple of ascending resolutions: the pass then pauses before the first layer above
         each.  The low-resolution layers are latency-bound (a tenth of the FLOPs, a quarter of the pass's time): the training step
         runs them for the NEXT batch's un-shifted pass next to the same layers of this batch's shifted pass (trainer.TrainStep)."""
-        return L.StagedPass(self._synthesis_gen(w.contiguous(), False, prec, pause_res))
+        return L.StagedPass(self._synthesis_gen(w.contiguous(), False, prec, pause_res, policy))
 
     @staticmethod
     def synthesis_advance(handle):
@@ -365,11 +365,12 @@ class Generator(nn.Module):
         """Enqueue everything that is left: the image."""
         return handle.finish()
 
-    def _synthesis_gen(self, w, save, prec, pause_res):
+    def _synthesis_gen(self, w, save, prec, pause_res, policy=None):
         """The synthesis pass as a Python generator: yields before the first layer whose output exceeds `pause_res` (an int, or a tuple of
         ascending resolutions with one pause each; None: never; at least once when a pause resolution is given) and returns (image, saved)."""
         P = self._prepare()
-        pol = self.mixed_policy or C.mixed_policy(self.size, prec)
+        # per-layer table of the 'mixed' modes: this call's (a step engine passes its calibrated one), else the instance's override, else the default
+        pol = policy or self.mixed_policy or C.mixed_policy(self.size, prec)
         lib, st = L.lib(), L.stream()
         w = w.contiguous()
         B = w.shape[0]
@@ -419,6 +420,8 @@ class Generator(nn.Module):
                 paused = True
                 yield None
             lp = C.layer_precision(prec, 2 * H if ly['up'] else H, ly['up'], pol)      # 'mixed': per-layer arithmetic
+            if lp == C.BF16W and Co % 128:       # the F(2,3) split-bf16 form covers >= 128 output channels: the few-channel layers are plain split-bf16 launches
+                lp = 1
             sc_kw = dict(a_amax=xmax[i], a_amax2=smax) if (f16_chain and lp in (2, 3)) else {}
             ymax = xmax[i + 1] if f16_chain else None
             rgbp = None
@@ -500,10 +503,10 @@ class Generator(nn.Module):
             yield None                    # (a generator smaller than the pause resolution: everything ran in the first stage)
         return skip, saved
 
-    def _synthesis_bwd(self, saved, dimg, prec, hooks=None):
+    def _synthesis_bwd(self, saved, dimg, prec, hooks=None, policy=None):
         """d image [B,3,S,S] -> d latent [B, style_dim] (all n_latent copies of w summed)."""
         P = self._prepare()
-        pol = self.mixed_policy or C.mixed_policy(self.size, prec)
+        pol = policy or self.mixed_policy or C.mixed_policy(self.size, prec)
         lib, st = L.lib(), L.stream()
         S, outs, demods, B = saved
         dev = dimg.device
@@ -550,6 +553,8 @@ class Generator(nn.Module):
             sR = S[:, r['off']:] if has_rgb else None
             lp = C.layer_precision_bwd(prec, Hc, ly['up'], pol)
             wino, lp = lp == C.FP32W, (0 if lp == C.FP32W else lp)       # 'fp32w': fp32 throughout, Winograd form of the stride-1 gradient conv
+            if lp == C.BF16W and ly['Ci'] % 128:
+                lp = 1
             # a stride-1 layer's dy has ONE consumer, its gradient conv: in the plain-fp16 launches that fill the chip it is stored
             # only as that conv's fp16 operand plane, scaled from an a-priori bound of its magnitude (its own maximum is not known
             # before the kernel has run): max|gA| from the producing conv's epilogue, max|drgb| <= 4^levels * max|dimg|
@@ -632,17 +637,18 @@ class Generator(nn.Module):
         return _Mapping.apply(self, input)
 
     def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
-                input_is_latent=False, noise=None, randomize_noise=False, precision=None):
+                input_is_latent=False, noise=None, randomize_noise=False, precision=None, policy=None):
         """Same call signature as the reference (model.py:359-408).  Supported on the HIP path: a single
         style code, the registered noise buffers, no truncation — i.e. exactly what StyleGAN2Wrapper
-        (models/gan_load.py:157-179) issues.  `precision` (extension): arithmetic of this call's convs, default self.precision."""
+        (models/gan_load.py:157-179) issues.  `precision` (extension): arithmetic of this call's convs, default self.precision;
+        `policy` (extension): conv.MixedPolicy of this call under a 'mixed' mode (default: self.mixed_policy, else the architecture's table)."""
         if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise or truncation < 1:
             raise NotImplementedError("HIP StyleGAN2 path supports one style code, registered noise, truncation=1")
         s = styles[0]
         if s.ndim != 2:
             raise NotImplementedError("per-layer (W+) latents are not supported on the HIP path")
         w = s if input_is_latent else _Mapping.apply(self, s)
-        img = _Synthesis.apply(self, w, self.resolve_precision(precision))
+        img = _Synthesis.apply(self, w, self.resolve_precision(precision), policy)
         if return_latents:
             return img, w.unsqueeze(1).repeat(1, self.n_latent, 1)
         return img, None

@@ -130,7 +130,8 @@ class TrainStep:
     """One optimisation step of lib/trainer.py:190-261 on this rank's share of the batch."""
 
     def __init__(self, generator, support_sets, reconstructor, params, local_batch, device, world=1, seed=None, rank=0,
-                 start_iter=0, precision=None, r_precision='auto', two_streams=True, defer_wgrad=True, prefetch=True, priority_main=True):
+                 start_iter=0, precision=None, r_precision='auto', two_streams=True, defer_wgrad=True, prefetch=True, priority_main=True,
+                 calibrate_images=None):
         """precision: arithmetic of the frozen generator's convs (conv.PRECISION_NAMES; None = the generator's own `precision`
         attribute, whose default is the reference's fp32).  r_precision: 'fp32' | 'bf16x3' | 'auto' | reconstructor.RArith —
         arithmetic of the trained Reconstructor's convs ('auto': exact fp32 when the generator runs exact fp32, the fp32-class
@@ -200,7 +201,12 @@ class TrainStep:
         self.argmax = torch.empty(local_batch, dtype=torch.int64, device=device)
         self.loss_ws = torch.empty(2 * local_batch, device=device)
         self.w_space = bool(getattr(params, 'shift_in_w_space', False))
-        self.strict_calibration = None
+        # 'mixed-strict' (what 'auto' resolves to for StyleGAN2): the per-layer table this engine calibrated on its generator's weights.  It
+        # belongs to the ENGINE and travels with every generator call it makes (G(..., policy=)): the generator object is not touched, so
+        # other engines / callers sharing it keep their own arithmetic.
+        self.strict_calibration, self._policy = None, None
+        self.calibrate_images = calibrate_images if calibrate_images is not None else getattr(TrainStep, 'calibrate_images_default', None)   # None: conv.STRICT_IMAGES
+        self._checks = 0                     # run-time precision checks done so far (the check's sample is a function of this count only)
         if self.precision == C.MIXED_STRICT:
             self.calibrate_strict()
         self.comm_events = None      # set to a list to collect (start, end) HIP events around the all-reduce waits
@@ -231,8 +237,13 @@ class TrainStep:
             self._r_precision = r_precision
         self.r_arith = r_arith(self._r_precision, self.precision)
         self._pre, self._cold = None, True
+        self._policy, self.strict_calibration = None, None
         if self.precision == C.MIXED_STRICT:
             self.calibrate_strict()
+
+    def _gkw(self):
+        """Extra keyword arguments of this engine's generator calls: the calibrated per-layer table, when there is one."""
+        return {'policy': self._policy} if self._policy is not None else {}
 
     def check_precision(self, gate=1e-3, batches=1):
         """Run-time guard of a 16-bit generator mode (the per-architecture policy tables were calibrated on random-init weights):
@@ -242,7 +253,11 @@ class TrainStep:
         if not C.is_reduced(self.precision):
             return None
         g = torch.Generator(device=self.dev)
-        g.manual_seed(0x5DEECE66D + self.steps_done)       # the same codes on every rank: every rank takes the same decision
+        # the same codes on every rank (every rank takes the same decision), and a function of the number of checks made so far only: the
+        # record of an engine's first check does not depend on how many steps ran before it (with `+ steps_done` the bench's
+        # verdict flipped with --steps)
+        g.manual_seed(0x5DEECE66D + self._checks)
+        self._checks += 1
         per, bat = [], []
         for _ in range(max(1, int(batches))):
             z = sample_z(self.B, self.G.dim_z, truncation=getattr(self.p, 'z_truncation', None), device=self.dev, generator=g)
@@ -255,7 +270,7 @@ class TrainStep:
                 kw['classes'] = pool[torch.randint(0, pool.numel(), (self.B,), device=self.dev, generator=g)]
             with torch.no_grad():
                 ref = self.G(z, precision='fp32', **kw)
-                img = self.G(z, precision=self.precision, **kw)
+                img = self.G(z, precision=self.precision, **kw, **self._gkw())
                 d, m = (img - ref).abs().flatten(1).amax(1), ref.abs().flatten(1).amax(1)
                 per.append(d / m.clamp_min(1e-30))
                 bat.append(d.max() / m.max().clamp_min(1e-30))
@@ -266,39 +281,67 @@ class TrainStep:
         return {'precision': C.precision_name(self.precision), 'batch': batch, 'batch_median': float(bat.median()),
                 'per_image_median': float(per.median()), 'per_image_p99': float(per.quantile(0.99)), 'per_image_max': float(per.max()),
                 'over_gate_frac': float((per > gate).float().mean()), 'gate': gate, 'ok': bool(batch < gate and batch == batch),
+                'policy': (self.strict_calibration or {}).get('table'),
                 'n': int(per.numel())}
 
-    def calibrate_strict(self, images=2304, margin=0.95, gate=1e-3, seed=0x51C7):
+    def calibrate_strict(self, images=None, margin=0.95, gate=1e-3, seed=0x51C7, ref_cache_bytes=4 << 30):
         """'mixed-strict': measure conv.STRICT_LADDER on THIS generator's weights (per-image max-norm error against the exact-fp32 kernels over
         `images` latent codes, identical on every rank) and adopt the first — cheapest — table whose worst single image is under
-        margin * gate.  Returns the calibration record (also kept as self.strict_calibration)."""
+        margin * gate.  The table is kept on the engine (self._policy) and passed with every generator call; the generator object is not
+        modified.  The fp32 reference images are kept on the device only while they fit `ref_cache_bytes` (StyleGAN2-1024: 2 304 images
+        are 29 GB) — beyond that each rung recomputes them batch by batch; a rung stops at its first batch over the limit.  With several
+        ranks, rank 0's choice is broadcast.  Returns the calibration record (also kept as self.strict_calibration)."""
         inner = getattr(self.G, 'G', None)
-        ladder = C.STRICT_LADDER.get(getattr(inner, 'size', None))
+        size = getattr(inner, 'size', None)
+        ladder = C.STRICT_LADDER.get(size)
         if self.precision != C.MIXED_STRICT or ladder is None or not hasattr(inner, 'mixed_policy'):
             return None
+        images = images if images is not None else self.calibrate_images
+        images = int(images if images is not None else C.STRICT_IMAGES.get(size, 576))
         nb = max(1, images // self.B)
         g = torch.Generator(device=self.dev)
         g.manual_seed(seed)
         zs = [sample_z(self.B, self.G.dim_z, truncation=getattr(self.p, 'z_truncation', None), device=self.dev, generator=g) for _ in range(nb)]
+        keep = nb * self.B * 3 * size * size * 4 <= ref_cache_bytes
+        refs = {}
+
+        def ref_of(k):
+            if k in refs:
+                return refs[k]
+            r = self.G(zs[k], precision='fp32')
+            r = (r, r.abs().flatten(1).amax(1).clamp_min(1e-30))
+            if keep:
+                refs[k] = r
+            return r
         tried, chosen = [], None
+        limit = margin * gate
         with torch.no_grad():
-            refs = [self.G(z, precision='fp32') for z in zs]
-            mx = [r.abs().flatten(1).amax(1).clamp_min(1e-30) for r in refs]
-            for name, pol in ladder:
-                inner.mixed_policy = pol
-                worst = torch.zeros((), device=self.dev)
-                for z, r, m in zip(zs, refs, mx):
-                    worst = torch.maximum(worst, ((self.G(z, precision=self.precision) - r).abs().flatten(1).amax(1) / m).max())
-                w = float(worst)
-                tried.append((name, w))
-                if w == w and w < margin * gate:
-                    chosen = name
+            for ri, (name, pol) in enumerate(ladder):
+                worst, seen, pend = 0.0, 0, None
+                for k in range(nb):
+                    r, m = ref_of(k)
+                    e = ((self.G(zs[k], precision=self.precision, policy=pol) - r).abs().flatten(1).amax(1) / m).max()
+                    pend = e if pend is None else torch.maximum(pend, e)
+                    seen += 1
+                    if k % 8 == 7 or k == nb - 1:                 # one host sync per eight batches; a rung stops at its first group over the limit
+                        v, pend = float(pend), None
+                        worst = v if v != v else max(worst, v)
+                        if not (worst < limit):
+                            break
+                tried.append((name, worst, seen * self.B))
+                if worst == worst and worst < limit:
+                    chosen = ri
                     break
         if chosen is None:       # (cannot happen with a split-bf16 last rung unless the generator overflows: keep it anyway)
-            chosen = ladder[-1][0]
-            inner.mixed_policy = ladder[-1][1]
+            chosen = len(ladder) - 1
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            t = torch.tensor([chosen], dtype=torch.int64, device=self.dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.broadcast(t, 0)
+            chosen = int(t.item())
+        self._policy = ladder[chosen][1]
         self._pre, self._cold = None, True
-        self.strict_calibration = {'table': chosen, 'tried': [(n, float('%.3g' % w)) for n, w in tried], 'images': nb * self.B, 'margin': margin, 'gate': gate}
+        self.strict_calibration = {'table': ladder[chosen][0], 'tried': [(n, float('%.3g' % w), ni) for n, w, ni in tried], 'images': nb * self.B,
+                                   'margin': margin, 'gate': gate, 'fp16_layers': self._policy.spends()}
         return self.strict_calibration
 
     def _out_size(self):
@@ -374,17 +417,17 @@ class TrainStep:
         # those must be produced on the main stream, ahead of everything that reads them)
         side = self.side_stream if (self.two_streams and not self._cold) else None
         self._cold = False
-        prec = self.precision
+        prec, gkw = self.precision, self._gkw()
         pre_img = img is not None           # G(z) of this batch was generated during the previous step (see below)
         if pre_img:
             img.record_stream(cur)          # (the wait for it sits in front of the Reconstructor, its only reader)
         elif side is not None:
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
-                img = G(z, precision=prec)
+                img = G(z, precision=prec, **gkw)
         with torch.no_grad():
             if img is None:
-                img = G(z, precision=prec)                                                    # :200, nothing saved
+                img = G(z, precision=prec, **gkw)                                             # :200, nothing saved
             code = G.get_w(z) if self.w_space else z                          # :236
         # Derived forms of R's trained weights (transposed copies for its input-gradient convs, Winograd operands in 'fp32w'): fixed since
         # the last Adam update, re-derived now on the side stream instead of launch by launch inside R's forward / backward
@@ -416,7 +459,7 @@ class TrainStep:
                 tail_res = self.tail_pause_res or min(self._out_size() // 2, 256)      # (1024^2 generators: 512 / 256 / 128 measured 32.7 / 32.3 / 32.3 ms at cfg5)
                 pauses = (self.split_pause_res, tail_res) if (self.tail_prefetch and tail_res > self.split_pause_res) else self.split_pause_res
                 with torch.cuda.stream(self.pre_stream), torch.no_grad():
-                    handle = G.begin(zn, precision=prec, pause_res=pauses)
+                    handle = G.begin(zn, precision=prec, pause_res=pauses, **gkw)
                 zn.record_stream(self.pre_stream)
             nxt = (zn, idxn, magn, handle)
         # shift = mag * S(mask, code)   (:235) — fused scale
@@ -443,7 +486,7 @@ class TrainStep:
         if hookable:
             inner.bwd_hooks = hooks
         try:
-            img_shifted = G(z, shift, precision=prec)                                         # :239, input-gradient only
+            img_shifted = G(z, shift, precision=prec, **gkw)                                  # :239, input-gradient only
         finally:
             if hookable:
                 inner.bwd_hooks = None      # (taken by the forward; cleared here if it failed or kept nothing)
@@ -459,7 +502,7 @@ class TrainStep:
             self.pre_stream.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(self.pre_stream), torch.no_grad():
                 if handle is None:
-                    imgn = G(zn, precision=prec)
+                    imgn = G(zn, precision=prec, **gkw)
                 elif self.tail_prefetch:
                     imgn = G.advance(handle)            # None: paused in front of the tail layers
                 else:
