@@ -235,7 +235,8 @@ int wgs_conv_wino(const wgs_conv_desc* desc, const float* U, wgs_stream_t stream
  * bias, leaky-relu, alpha, y_amax); results equal the direct split-bf16 kernels' up to that arithmetic's own rounding (1e-5 against
  * fp64 convolutions).  Covered: all nine taps dy, dx in {-1, 0, 1} each exactly once (forward and input-gradient launches alike),
  * isy = osy = 1, ups 0, Hi = Ho % 8 == 0, Wi = Wo % 32 == 0, Ci % 32 == 0, Co % 128 == 0, act 0, act_slope in [0, 1], no addend /
- * x_f16 / rgb_out / col_stats / a_pixelnorm_eps, row strides of a_scale / col_scale % 4 == 0, a sample's tensors < 2 GiB, and at
+ * x_f16 / col_stats / a_pixelnorm_eps; rgb_out (ToRGB in the epilogue, y then optional) with Co == 128 only (one tile holds every channel
+ * of its pixels); row strides of a_scale / col_scale % 4 == 0, a sample's tensors < 2 GiB, and at
  * least 200 workgroups (B * Hi / 8 * Wi / 32 * Co / 128): wgs_conv_wino16_supported() tells (1 / 0).
  * wgs_conv_wino16_weight: U (24 * Ci * Co uint16, caller-owned) = the launch's weights G g as bf16 hi / lo planes in the kernel's
  * B-fragment order (one layout: reusable by every covered launch of the same weights and taps).  wgs_conv_wino16 runs the launch with
@@ -456,7 +457,9 @@ int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, 
  * on exit (zero it once when allocating it; one buffer serves any sequence of wgs_bn_fwd / wgs_bn_bwd / wgs_colsum calls on one
  * stream, with any C): the launch that sums the replicas zeroes them again, so no reduction needs a memset.  A buffer that is NOT zero
  * (never zeroed, a call cut short, two streams sharing it) gives wrong statistics without an error; WGS_CHECK_WS=1 in the environment
- * makes every call verify it first (synchronously: debugging only).  C % 4 == 0. */
+ * makes every call verify it first (synchronously: debugging only).  C % 4 == 0.  The fused launches (wgs_bn_fwd_fused / wgs_bn_bwd_fused)
+ * zero max(4096, 2 * C) doubles of the buffer they leave clean whatever the current C >= 64, so one pair sized for the widest layer serves
+ * any sequence of widths in [64, ...]; calls with C < 64 must not share a pair with calls of another width. */
 #define WGS_BN_WS_DOUBLES(C) (64 * (C))
 int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,

@@ -143,6 +143,31 @@ def test_bn_backward_over_the_scratch_pair(dev):
             a, b = b, a
 
 
+def test_scratch_pair_shared_by_layers_of_different_widths(dev):
+    """the fused apply launches zero a C-independent extent of the buffer they leave clean, so a producer of ANOTHER width finds it
+    zero: widths 64 (32 replicas: 4096 doubles), 96 (21 replicas: 4032), 512 (4 replicas) and 2304 (one replica of 4608 doubles) in turn over
+    one pair sized for the widest."""
+    torch.manual_seed(5)
+    pair = [torch.zeros(64 * 2304, dtype=torch.float64, device=dev) for _ in range(2)]
+    k = 0
+    for N, Cn in ((512, 64), (300, 2304), (256, 96), (64, 512), (128, 64), (100, 2304), (700, 128)):
+        x, dyA = torch.randn(N, Cn, device=dev), torch.randn(N, Cn, device=dev)
+        mean, invstd = x.mean(0), 1.0 / (x.var(0, unbiased=False) + 1e-5).sqrt()
+        g = torch.rand(Cn, device=dev) + 0.5
+        ref = [torch.empty_like(x), torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)]
+        ws = torch.zeros(64 * Cn, dtype=torch.float64, device=dev)
+        L.check(L.lib().wgs_bn_bwd(L.ptr(x), L.ptr(dyA), None, None, L.ptr(mean), L.ptr(invstd), L.ptr(g), L.ptr(ref[0]), None,
+                                   L.ptr(ref[1]), L.ptr(ref[2]), L.rawptr(ws), L.c_int64(N), Cn, 1, L.stream()), 'bn_bwd')
+        a, b = pair[k], pair[k ^ 1]
+        k ^= 1
+        assert float(a.abs().max()) == 0.0, (N, Cn)               # what the previous launch left for this producer
+        got = [torch.empty_like(x), torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)]
+        L.check(L.lib().wgs_bn_bwd_fused(L.ptr(x), L.ptr(dyA), None, None, L.ptr(mean), L.ptr(invstd), L.ptr(g), L.ptr(got[0]), None,
+                                         L.ptr(got[1]), L.ptr(got[2]), L.rawptr(a), L.rawptr(b), L.c_int64(N), Cn, L.stream()), 'bn_bwd_fused')
+        for u, v in zip(got, ref):
+            assert rel_err(u, v) < 1e-5, (N, Cn)
+
+
 @pytest.mark.parametrize('precision', [0, 1])
 @pytest.mark.parametrize('B,Ci,Co,H', [(32, 128, 128, 32), (8, 256, 256, 64), (32, 64, 64, 64)])
 def test_column_sums_and_magnitude_bound_from_one_launch(dev, precision, B, Ci, Co, H):

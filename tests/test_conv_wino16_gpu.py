@@ -54,7 +54,7 @@ def test_wino16_styled_forward_vs_float64(dev, B, H, W, ci, co):
     got = C.conv2d(xg, wp, 3, pad=1, precision=C.BF16W, y_amax=ymax, **epi)
     assert float(ymax) == float(got.abs().max())           # the magnitude scalar the fp16 chains read (exact: a maximum, not a sum)
     sym = L.lib().wgs_dev_last_kernel().decode()
-    assert sym == 'wino16_kernel<true>', sym
+    assert sym == 'wino16_kernel<true, false>', sym
     direct = C.conv2d(xg, wp, 3, pad=1, precision=1, **epi)
     assert 'wino16' not in L.lib().wgs_dev_last_kernel().decode()
     L.lib().wgs_dev_trace_kernels(0)
@@ -78,7 +78,7 @@ def test_wino16_input_gradient_form_vs_float64(dev, B, H, ci, co):
     L.lib().wgs_dev_trace_kernels(1)
     got = C.conv2d_dgrad(dy.to(dev), wt, (H, H), 3, pad=1, precision=C.BF16W, w_split=cache, alpha=1.0)
     sym = L.lib().wgs_dev_last_kernel().decode()
-    assert sym == 'wino16_kernel<false>', sym
+    assert sym == 'wino16_kernel<false, false>', sym
     L.lib().wgs_dev_trace_kernels(0)
     assert rel_err(got, ref) < 2e-5
     assert len(cache.planes) == 1           # U is kept with the weight tensor
@@ -127,3 +127,30 @@ def test_wino16_repeated_launches_are_bit_identical_under_other_traffic(dev):
             junk = junk * 1.0001
         assert torch.equal(first, C.conv2d(x, wp, 3, pad=1, precision=C.BF16W, a_scale=s, w_split=cache))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('keep_y', [True, False])
+def test_wino16_torgb_in_the_epilogue(dev, keep_y):
+    """wgs_conv_desc.rgb_out with 128 output channels: the three channel sums of models/StyleGAN2/model.py:270-282 from the finished values,
+    y stored only when asked for — against the unfused launch + a float64 ToRGB."""
+    torch.manual_seed(21)
+    B, H, ci, co = 4, 64, 64, 128
+    x = torch.randn(B, H, H, ci, device=dev)
+    wp = C.pack_weight(torch.randn(co, ci, 3, 3, device=dev) / (9 * ci) ** 0.5)
+    s, dm = torch.randn(B, ci, device=dev) + 1.0, torch.rand(B, co, device=dev) + 0.5
+    bias, noise, nw = torch.randn(co, device=dev), torch.randn(H * H, device=dev), torch.tensor([0.37], device=dev)
+    srgb = torch.randn(B, 300, device=dev)            # a wider style matrix: row stride 300, the layer's slice at column 100
+    wrgb = torch.randn(3, co, device=dev)
+    epi = dict(a_scale=s, col_scale=dm, bias=bias, noise=noise, noise_w=nw, act_slope=0.2, gain=2 ** 0.5)
+    assert C.rgb_wino16_ok(x, wp, **epi)
+    plain = C.conv2d(x, wp, 3, pad=1, precision=C.BF16W, **epi)
+    rgb = torch.full((B, H, H, 4), 7.0, device=dev)
+    L.lib().wgs_dev_trace_kernels(1)
+    y = C.conv2d(x, wp, 3, pad=1, precision=C.BF16W, out=None if keep_y else C.NoOutput(B, H, H, co),
+                 rgb=dict(out=rgb, s=srgb[:, 100:], ld=300, w=wrgb, scale=0.25), **epi)
+    assert L.lib().wgs_dev_last_kernel().decode() == 'wino16_kernel<true, true>'
+    L.lib().wgs_dev_trace_kernels(0)
+    if keep_y:
+        assert torch.equal(y, plain)
+    ref = 0.25 * torch.einsum('bhwn,bn,on->bhwo', plain.double(), srgb[:, 100:100 + co].double(), wrgb.double())
+    assert rel_err(rgb[..., :3], ref) < 2e-6 and float(rgb[..., 3].abs().max()) == 0.0

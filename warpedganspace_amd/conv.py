@@ -581,6 +581,21 @@ def rgb_halo_ok(x, w_packed, lp, **epi):
     return bool(L.lib().wgs_conv_rgb_supported(ctypes.byref(d)))
 
 
+def rgb_wino16_ok(x, w_packed, **epi):
+    """ToRGB may run in the epilogue of this stride-1 3x3 launch in the F(2,3) split-bf16 form ('bf16x3w'): 128 output channels, i.e. one
+    tile of conv_wino_bf16.hip holds every channel of its pixels (StyleGAN2-256's last layer), and the kernel covers the launch."""
+    B, H, W, Ci = x.shape
+    Co = w_packed.shape[0]
+    if not (RGB_FUSED and Co == 128):
+        return False
+    taps = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
+    epi = {k: v for k, v in epi.items() if k != 'w_split'}
+    dummy = torch.empty(1, device=x.device)
+    d, _ = _desc(x, w_packed, NoOutput(B, H, W, Co), taps, H, W, w_tap_stride=Ci, w_row_stride=9 * Ci, precision=BF16W,
+                 rgb=dict(out=dummy, s=dummy, w=dummy, scale=1.0, ld=Co), **epi)
+    return bool(L.lib().wgs_conv_wino16_supported(ctypes.byref(d)))
+
+
 def fwd_plane_ok(B, Hout, C, Co_next, lp_next):
     """the up-conv's output [B,Hout,Hout,C] may be handed to the next (stride-1, plain fp16) conv as its operand plane"""
     return FWD_PLANE and lp_next == 2 and C % 32 == 0 and Co_next % 128 == 0 and _plane_fits(B, Hout, Hout, C) and \

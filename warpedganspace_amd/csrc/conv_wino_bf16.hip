@@ -30,10 +30,12 @@
 //   * U never passes through LDS: wino16_weight_kernel writes it in the main kernel's B-fragment order, a wave streams the 4 KB of its
 //     (position, channel half) per (chunk, kernel row) straight into registers one kernel row ahead.
 //   * epilogue: the four positions of a pixel pair live in four waves: one exchange through LDS per channel half ([pair][position][64
-//     channels] fp32, 128 KB), then thread = (pair, channel quad): y0 / y1, demodulation, noise, bias, leaky-relu, two 16-byte stores.
+//     channels] fp32, 128 KB), then thread = (pair, channel quad): y0 / y1, demodulation, noise, bias, leaky-relu, two 16-byte stores;
+//     with 128 output channels optionally ToRGB (wgs_conv_desc.rgb_out) from the finished values, and then y need not be stored at all.
 #include <type_traits>
 #include "wgs_common.h"
 #include "conv_scheme.h"
+#include "conv_epilogue.h"
 #include "../../include/wgs.h"
 
 namespace {
@@ -76,6 +78,7 @@ struct W16Args {
     const float* noise;
     const float* noise_w;
     float* y_amax;
+    float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int rgb_ld;      // ToRGB in the epilogue (wgs_conv_desc.rgb_out; Co == 128: the tile holds every channel)
     int B, H, W, Ci, Co, a_ld, col_ld;
     float alpha, act_slope, gain;
 };
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void wino16_weight_kernel(const float* __restr
     }
 }
 
-template <bool STY>
+template <bool STY, bool RGB>
 __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -332,7 +335,17 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
     const float nw = p.noise ? p.noise_w[0] : 0.f;
     const float slope = p.act_slope, gain = p.gain;
     float vmax = 0.f;
-    float* yb = p.y + (size_t)b * p.H * p.W * p.Co;
+    float* yb = p.y ? p.y + (size_t)b * p.H * p.W * p.Co : nullptr;
+    // ToRGB (models/StyleGAN2/model.py:270-282) in this epilogue: a thread's partial channel sums of its 4 x 2 pixels over both channel halves,
+    // then one sum over the 16 lanes (channel quads) of a pixel pair on the vector ALU (DPP row) and one 16-byte pixel store; y itself is
+    // stored only when the caller wants it (a pass that keeps nothing never writes the layer's output)
+    float racc[RGB ? 4 : 1][2][3];
+    if (RGB) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) racc[k][j][0] = racc[k][j][1] = racc[k][j][2] = 0.f;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (nh == h && WGS_W16ABL != 4) {
@@ -351,6 +364,15 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
         if (p.col_scale) cs = *reinterpret_cast<const f32x4*>(p.col_scale + (size_t)b * p.col_ld + co);
         if (p.bias) bs = *reinterpret_cast<const f32x4*>(p.bias + co);
         cs *= p.alpha;
+        float q[3][4];
+        if (RGB) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sr = p.rgb_s[(size_t)b * p.rgb_ld + co + c] * p.rgb_scale;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) q[o][c] = p.rgb_w[o * p.Co + co + c] * sr;
+            }
+        }
         __syncthreads();
         if (WGS_W16ABL != 4) {
 #pragma unroll
@@ -369,13 +391,31 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
                     v0 = fmaxf(v0, v0 * slope) * gain; v1 = fmaxf(v1, v1 * slope) * gain;
                     y0[c] = v0; y1[c] = v1;
                     vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
+                    if (RGB) {
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) { racc[k][0][o] = __builtin_fmaf(v0, q[o][c], racc[k][0][o]); racc[k][1][o] = __builtin_fmaf(v1, q[o][c], racc[k][1][o]); }
+                    }
                 }
-                float* dst = yb + ((size_t)oy * p.W + ox) * p.Co + co;
-                *reinterpret_cast<f32x4*>(dst) = y0;
-                *reinterpret_cast<f32x4*>(dst + p.Co) = y1;
+                if (!RGB || yb) {
+                    float* dst = yb + ((size_t)oy * p.W + ox) * p.Co + co;
+                    *reinterpret_cast<f32x4*>(dst) = y0;
+                    *reinterpret_cast<f32x4*>(dst + p.Co) = y1;
+                }
             }
         }
         if (h == 0) __syncthreads();
+    }
+    if (RGB) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int T = (tid >> 4) + 32 * k;
+            const int oy = by * TR + (T >> 4), ox = bx * 32 + 2 * (T & 15);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float t0 = wgsconv::dpp_sum16(racc[k][j][0]), t1 = wgsconv::dpp_sum16(racc[k][j][1]), t2 = wgsconv::dpp_sum16(racc[k][j][2]);
+                if (cq == 0) *reinterpret_cast<f32x4*>(p.rgb_out + ((size_t)b * p.H * p.W + (size_t)oy * p.W + ox + j) * 4) = (f32x4){t0, t1, t2, 0.f};
+            }
+        }
     }
     if (p.y_amax) {
         vmax = wave_max(vmax);
@@ -397,7 +437,8 @@ bool w16_taps(const wgs_conv_desc* d, W16Taps& tp) {
 }
 
 bool w16_ok(const wgs_conv_desc* d) {
-    if (!d || !d->x || !d->w || !d->y || d->x_f16 || d->rgb_out || d->col_stats || d->a_pixelnorm_eps > 0.f) return false;
+    if (!d || !d->x || !d->w || d->x_f16 || d->col_stats || d->a_pixelnorm_eps > 0.f) return false;
+    if (d->rgb_out ? !(d->Co == 128 && d->rgb_s && d->rgb_w && d->rgb_ld >= d->Co) : !d->y) return false;       // ToRGB in the epilogue: one tile holds every channel; y optional
     W16Taps tp;
     if (!w16_taps(d, tp)) return false;
     if (!(d->isy == 1 && d->isx == 1 && d->osy == 1 && d->osx == 1 && d->oy0 == 0 && d->ox0 == 0 && d->ups == 0 && d->Hg == d->Hi && d->Wg == d->Wi &&
@@ -431,22 +472,22 @@ int wgs_conv_wino16(const wgs_conv_desc* d, const uint16_t* U, wgs_stream_t stre
     W16Args a;
     a.x = d->x; a.U = U; a.y = d->y; a.a_scale = d->a_scale; a.col_scale = d->col_scale; a.bias = d->bias; a.noise = d->noise; a.noise_w = d->noise_w;
     a.y_amax = d->y_amax;
+    a.rgb_out = d->rgb_out; a.rgb_s = d->rgb_s; a.rgb_w = d->rgb_w; a.rgb_scale = d->rgb_scale; a.rgb_ld = d->rgb_ld;
     a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.Ci = d->Ci; a.Co = d->Co;
     a.a_ld = d->a_ld > 0 ? d->a_ld : d->Ci; a.col_ld = d->col_ld > 0 ? d->col_ld : d->Co;
     a.alpha = d->alpha != 0.f ? d->alpha : 1.f; a.act_slope = d->act_slope; a.gain = d->gain;
     const unsigned grid = (unsigned)((long)d->B * (d->Hi / TR) * (d->Wi / 32) * (d->Co / 128));
     hipStream_t st = (hipStream_t)stream;
-    if (d->a_scale) {
-        auto k = wino16_kernel<true>;
-        wgs_note_kernel("wino16_kernel<true>");
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        WGS_LAUNCH(k, dim3(grid), dim3(512), SMEM, st, a);
-    } else {
-        auto k = wino16_kernel<false>;
-        wgs_note_kernel("wino16_kernel<false>");
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        WGS_LAUNCH(k, dim3(grid), dim3(512), SMEM, st, a);
+#define WGS_W16_LAUNCH(STY, RGB)                                                                                     \
+    {                                                                                                                \
+        auto k = wino16_kernel<STY, RGB>;                                                                            \
+        wgs_note_kernel("wino16_kernel<%s, %s>", STY ? "true" : "false", RGB ? "true" : "false");                    \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);                  \
+        WGS_LAUNCH(k, dim3(grid), dim3(512), SMEM, st, a);                                                           \
     }
+    if (d->rgb_out) { if (d->a_scale) WGS_W16_LAUNCH(true, true) else WGS_W16_LAUNCH(false, true) }
+    else { if (d->a_scale) WGS_W16_LAUNCH(true, false) else WGS_W16_LAUNCH(false, false) }
+#undef WGS_W16_LAUNCH
     WGS_CHECK_LAUNCH("wino16_kernel");
     return WGS_OK;
 }

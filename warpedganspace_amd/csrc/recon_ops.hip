@@ -266,6 +266,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // channels into LDS; workgroup 0 also writes what the finalise / collapse launches wrote), and the scratch is a PAIR: this launch reads
 // `ws`, and leaves the OTHER scratch `wz` zero for the next producer (it was dirtied two producers ago; nothing else touches it now) —
 // so neither a finalise / collapse launch nor a memset sits between a reduction and its apply.
+// Doubles of the OTHER scratch buffer that a fused apply launch zeroes.  The footprint of a producer is wgs_bn_nrep(C') * 2 * C' doubles of ITS
+// channel count: <= 4096 for 64 <= C' <= 2048, 2 * C' above.  A scratch pair is shared by BatchNorms of different widths (ResNet-18: 64 .. 512), so
+// the extent must not depend on the CURRENT C (zeroing nrep(C) * 2 * C left a tail of a wider / narrower predecessor's sums — silently
+// wrong statistics).  Below 64 channels a buffer holds only WGS_BN_WS_DOUBLES(C) = 64 * C doubles: such calls must not share a pair with other widths.
+__device__ __forceinline__ int bn_zero_extent(int C) { return C >= 64 ? (2 * C > 4096 ? 2 * C : 4096) : wgs_bn_nrep(C) * 2 * C; }
+
 __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ ws, double* __restrict__ wz,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ res, float* __restrict__ y,
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __rest
     }
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0 && nbt) nbt[0] += 1;
-        for (int i = threadIdx.x; i < nrep * 2 * C; i += 256) wz[i] = 0.0;
+        for (int i = threadIdx.x; i < bn_zero_extent(C); i += 256) wz[i] = 0.0;
     }
     __syncthreads();
     const int c4n = C >> 2;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
         if (blockIdx.x == 0) { dbeta[c] = f1; dgamma[c] = f2; }
     }
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < nrep * 2 * C; i += 256) wz[i] = 0.0;
+        for (int i = threadIdx.x; i < bn_zero_extent(C); i += 256) wz[i] = 0.0;
     __syncthreads();
     const int c4n = C >> 2;
     const int64_t total = N * c4n;

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void sample_step_kernel(float* __restrict__ z,
         const u4 r = draw(seed, step, 2u, (unsigned)i);
         const float u = u01(r.x);
         pool[i] = i < B ? (lo - hi) * u - lo : (lo - hi) * u + hi;
-        const float e = fmaxf(-__logf(u01(draw(seed, step, 3u, (unsigned)i).x)), 1.17549435e-38f);     // > 0: no 0 / 0 for entry 0, no inf key
+        // > 0: no 0 / 0 for entry 0; and large enough that i / e stays finite for the largest i (2047 / 1e-30 = 2e33): with FLT_MIN here every
+        // i >= 4 overflowed to +inf whenever the fast log returned <= 0 for a u just below 1 (~2^-24 per draw), and several inf keys tie
+        const float e = fmaxf(-__logf(u01(draw(seed, step, 3u, (unsigned)i).x)), 1e-30f);
         key[i] = (float)i / e;                     // weight i: entry 0 has key 0 and is never among the B largest
     }
     __syncthreads();

@@ -321,6 +321,23 @@ class Reconstructor(nn.Module):
 
     # -- explicit schedule -------------------------------------------------------------------------------
     def _forward_impl(self, x1, x2, save=True, arith=None, sw=None):
+        """The forward schedule.  An exception anywhere in it (out of memory, a WgsError, KeyboardInterrupt) may leave a BatchNorm scratch buffer
+        holding a conv's sums with no apply launch behind it: the scratch pairs are cleared before it propagates, so that a later step does
+        not silently compute its statistics on top of them."""
+        try:
+            return self._forward_body(x1, x2, save, arith, sw)
+        except BaseException:
+            self._reset_bn_scratch()
+            raise
+
+    def _reset_bn_scratch(self):
+        for pair in self.__dict__.get('_bn_pairs', {}).values():
+            try:
+                pair.reset()
+            except Exception:  # noqa: BLE001  (a device that is gone: nothing left to protect)
+                pass
+
+    def _forward_body(self, x1, x2, save=True, arith=None, sw=None):
         if self.reconstructor_type == 'LeNet':
             from . import lenet
             return lenet.forward_impl(self, x1, x2, save)
@@ -340,9 +357,12 @@ class Reconstructor(nn.Module):
         if est and BN_FUSED_APPLY:
             # ... and finished in the apply kernel's prologue over a scratch PAIR (_BNScratch): conv -> apply, one BatchNorm launch instead of
             # three; the backward's three launches become two the same way
-            pair = self.__dict__.get('_bn_pair')
-            if pair is None or pair.buf[0].device != dev:
-                pair = self.__dict__['_bn_pair'] = _BNScratch(dev)
+            # one pair per (device, stream): two engines / streams driving the same Reconstructor do not share accumulators
+            pairs = self.__dict__.setdefault('_bn_pairs', {})
+            key = (dev.index, L.stream_id(dev.index))
+            pair = pairs.get(key)
+            if pair is None:
+                pair = pairs[key] = _BNScratch(dev)
             ws = pair
         cs = (lambda: dict(col_stats=ws.cur() if isinstance(ws, _BNScratch) else ws)) if est else (lambda: {})
         # The stem (7 x 7, stride 2, 2c = 6 input channels): SPACE-TO-DEPTH.  The image pair is packed as
@@ -402,6 +422,13 @@ class Reconstructor(nn.Module):
         return logits, mag.reshape(B) if B > 1 else mag.squeeze(), saved
 
     def _backward_impl(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None, wt=None, sw=None):
+        try:
+            return self._backward_body(S, dlogits, dmag, need_x, gbuf, deferred, wt, sw)
+        except BaseException:
+            self._reset_bn_scratch()          # (see _forward_impl)
+            raise
+
+    def _backward_body(self, S, dlogits, dmag, need_x=(False, True), gbuf=None, deferred=None, wt=None, sw=None):
         """Returns ({id(param): grad}, d_x1 or None, d_x2 or None).  With `gbuf` ({id(param): zero-initialised
         buffer in the parameter's MEMORY layout, conv weights packed [Co,T,Ci]}) gradients are written /
         accumulated straight into those buffers (the trainer's flat gradient bucket)."""

@@ -463,7 +463,18 @@ class Generator(nn.Module):
                            gain=SQRT2, w_split=ly['wp_s'], y_amax=ymax, **sc_kw)
                 rgb_kw, keep = {}, True
                 key = ('rgb_halo', i, B, lp)
-                if i % 2 == 0 and Co <= 64:
+                if i % 2 == 0 and lp == C.BF16W and Co == 128:
+                    # the F(2,3) split-bf16 kernel holds all 128 output channels of its pixels (StyleGAN2-256's last layer): ToRGB in its epilogue,
+                    # and without a backward to feed the layer's output is not stored at all
+                    key = ('rgb_w16', i, B)
+                    if key not in self._route:
+                        self._route[key] = C.rgb_wino16_ok(x, ly['wp'], **ckw)
+                    if self._route[key]:
+                        r_ = P['rgbs'][i // 2]
+                        rgbp = torch.empty(B, H, H, 4, device=dev)
+                        rgb_kw = dict(rgb=dict(out=rgbp, s=S[:, r_['off']:], ld=sumC, w=r_['w'], scale=r_['scale']))
+                        keep = save or i + 1 < len(P['layers'])
+                elif i % 2 == 0 and Co <= 64:
                     # StyleGAN2-1024's 64- / 32-channel layers at 512^2 / 1024^2: ToRGB in the few-channel kernel's epilogue (decided once per
                     # (layer, batch, arithmetic)); without a backward to feed, the last layer's output is not stored at all
                     if key not in self._route:
