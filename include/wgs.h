@@ -459,7 +459,7 @@ int wgs_stem_weight_s2d(const float* src, float* dst, int Co, int Ci, int back, 
  * (never zeroed, a call cut short, two streams sharing it) gives wrong statistics without an error; WGS_CHECK_WS=1 in the environment
  * makes every call verify it first (synchronously: debugging only).  C % 4 == 0.  The fused launches (wgs_bn_fwd_fused / wgs_bn_bwd_fused)
  * zero max(4096, 2 * C) doubles of the buffer they leave clean whatever the current C >= 64, so one pair sized for the widest layer serves
- * any sequence of widths in [64, ...]; calls with C < 64 must not share a pair with calls of another width. */
+ * any sequence of widths in [64, 2048]; calls with C < 64 or C > 2048 must not share a pair with calls of another width. */
 #define WGS_BN_WS_DOUBLES(C) (64 * (C))
 int wgs_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* save_mean,
                float* save_invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, double* ws,

@@ -145,12 +145,12 @@ def test_bn_backward_over_the_scratch_pair(dev):
 
 def test_scratch_pair_shared_by_layers_of_different_widths(dev):
     """the fused apply launches zero a C-independent extent of the buffer they leave clean, so a producer of ANOTHER width finds it
-    zero: widths 64 (32 replicas: 4096 doubles), 96 (21 replicas: 4032), 512 (4 replicas) and 2304 (one replica of 4608 doubles) in turn over
-    one pair sized for the widest."""
+    zero: widths 64 (32 replicas: 4096 doubles), 96 (21 replicas: 4032), 512 (4 replicas) and 2048 (one replica) in turn over one pair sized
+    for the widest.  (Widths below 64 or above 2048 have their own footprint rule and must not share a pair with others: include/wgs.h.)"""
     torch.manual_seed(5)
-    pair = [torch.zeros(64 * 2304, dtype=torch.float64, device=dev) for _ in range(2)]
+    pair = [torch.zeros(64 * 2048, dtype=torch.float64, device=dev) for _ in range(2)]
     k = 0
-    for N, Cn in ((512, 64), (300, 2304), (256, 96), (64, 512), (128, 64), (100, 2304), (700, 128)):
+    for N, Cn in ((512, 64), (300, 2048), (256, 96), (64, 512), (128, 64), (100, 2048), (700, 128)):
         x, dyA = torch.randn(N, Cn, device=dev), torch.randn(N, Cn, device=dev)
         mean, invstd = x.mean(0), 1.0 / (x.var(0, unbiased=False) + 1e-5).sqrt()
         g = torch.rand(Cn, device=dev) + 0.5

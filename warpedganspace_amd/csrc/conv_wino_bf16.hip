@@ -53,7 +53,8 @@ typedef wgsconv::sch_bf16x8 frag;
 #define WGS_W16ORD 0     // 1: channel-block-major workgroup order (development A/B)
 #endif
 #ifndef WGS_W16ABL
-#define WGS_W16ABL 0     // development ablations (tools/build_abl.sh w16abl): 1 no MFMAs, 2 no staging (loads, transform, LDS stores), 3 no U loads, 4 no epilogue exchange / stores
+#define WGS_W16ABL 0     // development ablations (tools/build_abl.sh w16abl): 1 no MFMAs, 2 no staging (loads, transform, LDS stores), 3 no U loads, 4 no epilogue exchange / stores,
+                         // 5 no barrier in the chunk loop, 6 staging without its global loads, 7 staging loads only (no transform, no LDS stores)
 #endif
 
 constexpr int KC = 16;                   // input channels per chunk = the k of one MFMA
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
     f32x4 ra[4], rq[2], rsv = {1.f, 1.f, 1.f, 1.f};
     auto load_A = [&](int c) {
         const int cb = min(c, nchunks - 1) * (KC * 4);         // past the end: the last chunk again (stored into a dead buffer)
-        if (WGS_W16ABL == 2) { ra[0] = ra[1] = ra[2] = ra[3] = rq[0] = rq[1] = (f32x4){1.f, 2.f, 3.f, 4.f}; return; }
+        if (WGS_W16ABL == 2 || WGS_W16ABL == 6) { ra[0] = ra[1] = ra[2] = ra[3] = rq[0] = rq[1] = (f32x4){1.f, 2.f, 3.f, 4.f}; return; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[j] = buf_load4(rx, a_off[j], cb);
         rq[0] = buf_load4(rx, q_off[0], cb);
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
     // the halo row's position: V = s * d[ja] + sgn * s * d[jb]
     auto stage_halo = [&](int buf) {
         if (WGS_W16ABL == 2) return;
+        if (WGS_W16ABL == 7) { asm volatile("" :: "v"(rq[0]), "v"(rq[1])); return; }
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
     // positions 2 * half, 2 * half + 1 of the own row: transform (style folded in), split, two 8-byte stores per plane
     auto stage_pair = [&](int buf, int half) {
         if (WGS_W16ABL == 2) return;
+        if (WGS_W16ABL == 7) { if (half) asm volatile("" :: "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(rsv)); return; }
         f32x4 va, vb;
         if (half == 0) {
             if (STY) { ra[1] = rsv * ra[1]; ra[2] = rsv * ra[2]; }
@@ -252,6 +255,12 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
     // Chunk kt multiplies LDS buffer kt & 1 in 12 units (kernel row ky, row block i) of 6 MFMAs; the B fragments of kernel row ky sit in
     // ring slot ky, and at the head of each group of four units the fragments of the group after the next are requested (an L2 round
     // trip under load is about one group long).  The staging work of chunk kt + 1 and the requests of chunk kt + 2 are spread over the units.
+    // Measured and left out (round 6, same box, 512 -> 512 @64^2 at 1.07 ms): a two-deep instead of a three-deep B ring (+-0); the next chunk's first B
+    // request in front of the patch requests, loads returning in order (-0.5 %); an L2 warm-up load of the patch two chunks ahead (+3 %); the
+    // two waves of a SIMD staging in different thirds of the chunk (+2 %); the instruction-mix hints below (+-1 % between any two forms, no
+    // hints +4 %).  What the ablations say: without the patch requests -8 %, without the transform + split behind them a further -20 %,
+    // without the U requests -21 %, without the chunk barrier -1.5 %, without MFMAs -46 %: the kernel runs at 1.74 GHz under its power cap
+    // (GRBM_GUI_ACTIVE / time), and what removing work buys is the energy of that work — re-arranging the same work buys nothing.
     auto mma_chunk = [&](int kt) {
         const int cur = kt & 1, nxt = cur ^ 1;
         const unsigned char* base = smem + cur * STAGE + a_rd;
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
     __syncthreads();
     for (int kt = 0; kt < nchunks; ++kt) {
         mma_chunk(kt);
-        __syncthreads();
+        if (WGS_W16ABL != 5) __syncthreads();
     }
 
     // ---- epilogue: per channel half h the four position waves exchange their accumulators through LDS, then every thread finishes

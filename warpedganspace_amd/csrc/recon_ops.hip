@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // Doubles of the OTHER scratch buffer that a fused apply launch zeroes.  The footprint of a producer is wgs_bn_nrep(C') * 2 * C' doubles of ITS
 // channel count: <= 4096 for 64 <= C' <= 2048, 2 * C' above.  A scratch pair is shared by BatchNorms of different widths (ResNet-18: 64 .. 512), so
 // the extent must not depend on the CURRENT C (zeroing nrep(C) * 2 * C left a tail of a wider / narrower predecessor's sums — silently
-// wrong statistics).  Below 64 channels a buffer holds only WGS_BN_WS_DOUBLES(C) = 64 * C doubles: such calls must not share a pair with other widths.
+// wrong statistics).  Below 64 channels a buffer holds only WGS_BN_WS_DOUBLES(C) = 64 * C doubles, above 2048 the footprint is 2 * C: such calls must
+// not share a pair with other widths (include/wgs.h).
 __device__ __forceinline__ int bn_zero_extent(int C) { return C >= 64 ? (2 * C > 4096 ? 2 * C : 4096) : wgs_bn_nrep(C) * 2 * C; }
 
 __global__ __launch_bounds__(256) void bn_apply_fused_kernel(const float* __restrict__ x, const double* __restrict__ ws, double* __restrict__ wz,
