@@ -32,7 +32,7 @@ def parse(spec):
         r, m = e.split(':')
         s1, up = m.split(',')
         table[int(r)] = tuple(C.BF16W if v == 'w' else int(v) for v in (s1, up))
-    return name, 'mixed', C.MixedPolicy(table, bwd_table={64: (2, 2), 128: (2, 2), 256: (2, 2)}, **({'below': 1} if os.environ.get('BELOW') == '1' else {}))
+    return name, 'mixed', C.MixedPolicy(table, bwd_table=({64: (2, 2), 128: (2, 2), 256: (2, 2)} if size <= 256 else {64: (2, 2), 128: (2, 2), 256: (2, 2), 512: (3, 2), 1024: (3, 2)}), **({'below': 1} if os.environ.get('BELOW') == '1' else {}))
 
 
 cands = []

@@ -155,8 +155,10 @@ STRICT_LADDER = {
           ('128:w,3;256:w,3', _p256({128: (W, 3), 256: (W, 3)})),
           ('128:w,1;256:w,3', _p256({256: (W, 3)})),
           ('bf16x3w everywhere', _p256({}))],
+    # 1024 (profiles/r6_policy_sweep.md, bench.py's generator, B = 8): 30.6 / 30.9 / 30.8 ms, worst single image of 576: 1.02e-3 / 4.9e-4 / 4.6e-5 — with the
+    # F(2,3) form in the 64^2 .. 256^2 layers the fp16 layers at 512^2 / 1024^2 (HBM-bound) buy nothing any more
     1024: [('default 512:3,3;1024:3,3', MIXED_1024),
-           ('1024:3,3', MixedPolicy({1024: (3, 3)}, bwd_table=_BWD_1024)),
+           ('512:1,3;1024:1,3', MixedPolicy({512: (1, 3), 1024: (1, 3)}, bwd_table=_BWD_1024)),
            ('bf16x3w everywhere', MixedPolicy({}, bwd_table=_BWD_1024))],
 }
 STRICT_IMAGES = {256: 2304, 1024: 576}       # latent codes of a calibration (72 batches of the configurations' 32 / 8 images)

@@ -284,12 +284,12 @@ class TrainStep:
                 'policy': (self.strict_calibration or {}).get('table'),
                 'n': int(per.numel())}
 
-    def calibrate_strict(self, images=None, margin=0.95, gate=1e-3, seed=0x51C7, ref_cache_bytes=4 << 30):
+    def calibrate_strict(self, images=None, margin=0.95, gate=1e-3, seed=0x51C7, ref_cache_bytes=8 << 30):
         """'mixed-strict': measure conv.STRICT_LADDER on THIS generator's weights (per-image max-norm error against the exact-fp32 kernels over
         `images` latent codes, identical on every rank) and adopt the first — cheapest — table whose worst single image is under
         margin * gate.  The table is kept on the engine (self._policy) and passed with every generator call; the generator object is not
-        modified.  The fp32 reference images are kept on the device only while they fit `ref_cache_bytes` (StyleGAN2-1024: 2 304 images
-        are 29 GB) — beyond that each rung recomputes them batch by batch; a rung stops at its first batch over the limit.  With several
+        modified.  The fp32 reference images are kept on the device only while they fit `ref_cache_bytes` (StyleGAN2-1024: 576 images are
+        7 GB, 2 304 would be 29 GB) — beyond that each rung recomputes them batch by batch; a rung stops at its first batch over the limit.  With several
         ranks, rank 0's choice is broadcast.  Returns the calibration record (also kept as self.strict_calibration)."""
         inner = getattr(self.G, 'G', None)
         size = getattr(inner, 'size', None)
