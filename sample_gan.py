@@ -53,7 +53,7 @@ def parse(argv=None):
     ext.add_argument('--random-init-generator', action='store_true')
     ext.add_argument('--seed', type=int, default=None, help="seed of the latent-code sampler")
     ext.add_argument('--batch-size', type=int, default=32, help="codes rendered per generator call")
-    ext.add_argument('--precision', choices=('auto', 'fp32', 'fp32w', 'bf16x3', 'f16', 'f16x2', 'mixed', 'mixed-strict'), default=None,
+    ext.add_argument('--precision', choices=('auto', 'fp32', 'fp32w', 'bf16x3', 'bf16x3w', 'f16', 'f16x2', 'mixed', 'mixed-strict'), default=None,
                      help="arithmetic of the generator's convs (default: the fp32-class bf16x3; fp32 = the reference's)")
     ext.add_argument('--root', type=str, default='experiments', help="root of the experiments tree")
     return p, p.parse_args(argv)

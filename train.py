@@ -51,7 +51,7 @@ def parse(argv=None):
     ext = p.add_argument_group('extensions (not stored in args.json)')
     ext.add_argument('--random-init-generator', action='store_true')
     ext.add_argument('--seed', type=int, default=None)
-    ext.add_argument('--precision', choices=('auto', 'fp32', 'fp32w', 'bf16x3', 'f16', 'f16x2', 'mixed', 'mixed-strict'), default=None,
+    ext.add_argument('--precision', choices=('auto', 'fp32', 'fp32w', 'bf16x3', 'bf16x3w', 'f16', 'f16x2', 'mixed', 'mixed-strict'), default=None,
                      help="arithmetic of the frozen generator's convs (default: warpedganspace_amd.conv.DEFAULT_PRECISION = auto: the "
                           "cheapest mode measured inside the 1e-3 image-error gate for the architecture, else the fp32-class bf16x3; "
                           "fp32 = the reference's arithmetic everywhere)")

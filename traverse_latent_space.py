@@ -51,7 +51,7 @@ def main(argv=None):
     p.add_argument('--no-cuda', dest='cuda', action='store_false')
     p.add_argument('--random-init-generator', action='store_true', help="extension: no pre-trained generator file")
     p.add_argument('--pool-root', type=str, default=osp.join('experiments', 'latent_codes'))
-    p.add_argument('--precision', choices=('auto', 'fp32', 'fp32w', 'bf16x3', 'f16', 'f16x2', 'mixed', 'mixed-strict'), default=None,
+    p.add_argument('--precision', choices=('auto', 'fp32', 'fp32w', 'bf16x3', 'bf16x3w', 'f16', 'f16x2', 'mixed', 'mixed-strict'), default=None,
                    help="extension: arithmetic of the generator's convs (default: the fp32-class bf16x3; fp32 = the reference's)")
     p.set_defaults(cuda=True)
     args = p.parse_args(argv)
