@@ -21,7 +21,7 @@ def test_auto_resolves_per_architecture():
     assert C.precision_name(C.resolve('auto', 'proggan', 256)) == 'f16'
     assert C.precision_name(C.resolve('auto', 'biggan', 128)) == 'bf16x3'
     assert C.precision_name(C.resolve('auto', 'sngan', 32)) == C.AUTO_FALLBACK
-    assert C.precision_name(C.resolve('auto', 'stylegan2', 64)) == C.AUTO_FALLBACK      # no measurement behind it: fp32-class
+    assert C.precision_name(C.resolve('auto', 'stylegan2', 64)) == 'bf16x3w'            # no measurement behind it: fp32-class (StyleGAN2: with the F(2,3) form)
     assert C.resolve('fp32', 'stylegan2', 256) == 0 and C.resolve(3, 'proggan', 256) == 3   # an explicit mode wins everywhere
     for key, name in C.AUTO_TABLE.items():
         assert name in C.PRECISION_NAMES and name != 'auto', key

@@ -79,6 +79,8 @@ IMAGE_DEFAULT_PRECISION = 'bf16x3'
 # StyleGAN2: the CALIBRATED per-layer table (round 6; VERDICT r5 #1: the un-calibrated 'mixed' table sat ON the gate on bench.py's initialisation)
 AUTO_TABLE = {('stylegan2', 256): 'mixed-strict', ('stylegan2', 1024): 'mixed-strict', ('proggan', 256): 'f16', ('proggan', 1024): 'f16'}
 AUTO_FALLBACK = 'bf16x3'
+# ... StyleGAN2 (any size): the same arithmetic with the F(2,3) form of its stride-1 3x3 convs (conv_wino_bf16.hip; what the kernel does not cover is a bf16x3 launch)
+AUTO_FALLBACK_BY_FAMILY = {'stylegan2': 'bf16x3w'}
 
 
 class MixedPolicy:
@@ -231,7 +233,7 @@ def resolve(requested, family, resolution):
     code = AUTO if requested is None else precision_code(requested)
     if code != AUTO:
         return code
-    return PRECISION_NAMES[AUTO_TABLE.get((family, resolution), AUTO_FALLBACK)]
+    return PRECISION_NAMES[AUTO_TABLE.get((family, resolution), AUTO_FALLBACK_BY_FAMILY.get(family, AUTO_FALLBACK))]
 
 
 # Profiling hook (bench.py): set to a list to collect (shape label, algorithmic FLOPs, start event, end event, kernel symbol) per

@@ -735,13 +735,14 @@ class Trainer(object):
         if r is None:
             return None
         if self.rank == 0:
-            print("#. Precision check @ iteration {}: {} image error vs exact fp32: batch {:.2e}, single image median {:.2e} / max {:.2e} "
+            print("#. Precision check @ iteration {}: {} image error vs exact fp32: batch {:.2e}, single image median {:.2e} / max {:.2e}, {:.2%} over "
                   "(gate {:.0e}, {} codes) -- {}".format(iteration, r['precision'], r['batch'], r['per_image_median'], r['per_image_max'],
-                                                          r['gate'], r['n'], 'ok' if r['ok'] else 'OVER THE GATE'))
-        if not r['ok'] and engine.precision != C.PRECISION_NAMES[C.AUTO_FALLBACK]:
-            engine.set_precision(C.AUTO_FALLBACK)
+                                                          r['over_gate_frac'], r['gate'], r['n'], 'ok' if r['ok'] else 'OVER THE GATE'))
+        fb = C.AUTO_FALLBACK_BY_FAMILY['stylegan2'] if hasattr(getattr(engine.G, 'G', None), 'mixed_policy') else C.AUTO_FALLBACK
+        if not r['ok'] and engine.precision not in (C.PRECISION_NAMES[C.AUTO_FALLBACK], C.PRECISION_NAMES[fb]):
+            engine.set_precision(fb)
             if self.rank == 0:
-                print("#. Generator arithmetic switched to {} (fp32-class) for the rest of the run".format(C.AUTO_FALLBACK))
+                print("#. Generator arithmetic switched to {} (fp32-class) for the rest of the run".format(fb))
         return r
 
     def train(self, generator, support_sets, reconstructor):
@@ -773,6 +774,11 @@ class Trainer(object):
         engine = TrainStep(generator, support_sets, reconstructor, p, p.batch_size // self.world, dev, world=self.world,
                            seed=getattr(p, 'seed', None), rank=self.rank, start_iter=starting_iter,
                            precision=getattr(p, 'precision', None), r_precision=getattr(p, 'r_precision', 'auto'))
+        if engine.strict_calibration and self.rank == 0:
+            c = engine.strict_calibration
+            print("#. Generator arithmetic calibrated on this generator ({} latent codes against the exact-fp32 kernels): per-layer table '{}' "
+                  "({} fp16-rounded layer(s)); rungs tried (worst single image, codes seen): {}".format(
+                      c['images'], c['table'], c['fp16_layers'], ', '.join("%s %.2e (%d)" % tuple(t) for t in c['tried'])))
         if getattr(self, 'resume_optim', None) is not None and engine.load_optim_state(self.resume_optim) and self.rank == 0:
             print("#. Restored Adam moments (step {}) from the checkpoint".format(engine.bucket.step_count))
         if self.rank == 0:
