@@ -13,7 +13,7 @@ if os.path.exists(side):
     shutil.copy(side, os.path.join(pr, rnd + '_bench_extra.json'))
 names = {'fp32w': ('fp32w', 'fp32 everywhere, Winograd F(2x2,3x3) form of the 3x3 stride-1 convs (the headline arithmetic)', '--precision fp32w', line),
          'fp32': ('fp32', 'direct-form exact fp32 everywhere (`direct_fp32` of the bench line)', '--precision fp32', line.get('direct_fp32') or {}),
-         'auto': ('mixed', "the product's default arithmetic (auto = mixed fp16 / split-bf16 per layer; `product` of the bench line)", '--precision auto', line.get('product') or {})}
+         'auto': ('auto', "the product's default arithmetic (auto = the per-layer table the engine calibrated on its own generator; `product` of the bench line; steps only: the calibration's launches are not counted)", '--precision auto', line.get('product') or {})}
 for mode, (out, what, flag, rec) in names.items():
     for kind, title in (('step', 'per-kernel time of the training step'), ('phases', 'phases of one single-stream training step')):
         src = os.path.join(go, '%s_%s_%s%s.md' % (tag, kind, mode, '_kernel_stats' if kind == 'step' else ''))

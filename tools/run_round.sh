@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools/run_round.sh <tag> [notests] — GPU test suite, default bench line (+ side file), rocprofv3 kernel tables and phase
+# usage: bash tools/run_round.sh <tag> [notests|tests] [lite] — GPU test suite, default bench line (+ side file), rocprofv3 kernel tables and phase
 # breakdowns of the fp32w / fp32 / auto step, PMC passes of the dominant conv kernels, host-enqueue measurement with 8 processes
 TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -13,7 +13,7 @@ timeout 900 python bench.py --extra-out gpurun_out/${TAG}_bench_extra.json > gpu
 tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; wc -c gpurun_out/${TAG}_bench.json
 for mode in fp32w fp32 auto; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$mode -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-product-run --single-stream --precision $mode --extra-out gpurun_out/prof_${TAG}_${mode}_extra.json > gpurun_out/prof_${TAG}_$mode.log 2>&1
-  python tools/prof_summary.py gpurun_out/prof_${TAG}_$mode 12 > gpurun_out/${TAG}_step_${mode}_kernel_stats.md
+  python tools/prof_summary.py gpurun_out/prof_${TAG}_$mode 12 $([ $mode = auto ] && echo --steps-only) > gpurun_out/${TAG}_step_${mode}_kernel_stats.md
   python tools/phase_breakdown.py gpurun_out/prof_${TAG}_$mode 8 > gpurun_out/${TAG}_phases_${mode}.md 2>&1
   find gpurun_out/prof_${TAG}_$mode -name "*kernel_trace.csv" -delete
   head -12 gpurun_out/${TAG}_step_${mode}_kernel_stats.md | cut -c1-160
@@ -26,6 +26,7 @@ for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 find gpurun_out/pmc_${TAG} -name "*kernel_trace.csv" -delete
 python tools/pmc_r3.py --summarise gpurun_out/pmc_${TAG} gpurun_out/${TAG}_conv_pmc | tail -16 | cut -c1-220
+if [ "$3" = "lite" ]; then exit 0; fi
 timeout 900 python tools/host_enqueue_n.py 8 auto | tail -1 > gpurun_out/${TAG}_host_enqueue_8.json
 # round 5: weight-gradient kernels (micro-benchmark + PMC passes), the reported-only rows of the precision table
 timeout 600 python tools/bench_wgrad_direct.py ksweep > gpurun_out/${TAG}_wgrad_bench.txt 2>&1

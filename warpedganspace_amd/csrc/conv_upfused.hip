@@ -37,7 +37,14 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int ROW = 64;                  // bytes per LDS row of a weight plane (DMA: unpadded, XOR-swizzled 16-B slots)
-constexpr int PROW = 80;                 // bytes per LDS row of the patch (padded, linear)
+constexpr int PROW = 80;                 // bytes per patch pixel in LDS (32 channels of one 16-bit plane + 16 B)
+// Patch ROWS are PW pixels + PPAD bytes apart (round 6).  An A fragment's 32 GEMM rows are consecutive grid positions, and the grid is GX = PW - 1
+// wide: where a fragment runs from one grid row into the next the pixel index jumps by 2.  ds_read_b128 is served in the lane groups
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), a group is conflict-free iff its 16 addresses differ mod 256 B, i.e. iff 5 * pixel is a
+// bijection mod 16 over the group: true for consecutive pixels, false behind a jump of 2 (both groups of nearly every fragment: 2-way, 24 - 27 %
+// of this kernel's LDS cycles in profiles/r5_conv_pmc.md).  With (row stride / 16 - 5 (GX - 1)) = 5 (mod 16) a row change looks like one pixel
+// step to the banks: 11 extra 16-B slots per patch row for both tile shapes (18- and 16-wide grids).
+constexpr int PPAD = 176;
 // (round 5, measured and reverted: unpadded 64-byte rows with an XOR swizzle make room for all nine products of an fp16 x2 chunk in ONE weight
 //  stage — one full-drain barrier per chunk instead of two: 0.940 -> 0.936 ms at 512 -> 256 @64, 1.034 -> 1.055 ms at 256 -> 128 @128.  The barriers
 //  are not what the kernel waits for either; neither are the 4-wave tiles at two workgroups per CU (WGS_UP_GH8: 1.05 / 1.24 ms).)
@@ -52,7 +59,7 @@ __device__ constexpr int T_PH[9] = {0, 1, 2, 3, 0, 2, 0, 1, 0};
 __device__ constexpr int T_SH[9] = {0, 0, 0, 0, 1, 1, 2, 2, 3};
 constexpr int T_W_HOST[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8};
 // patch row shift of the four (dy, dx) groups, in patch pixels (PW = patch width of the tile shape)
-__device__ constexpr int sh_off(int sh, int PW) { return sh == 0 ? PW + 1 : (sh == 1 ? PW : (sh == 2 ? 1 : 0)); }
+__device__ constexpr int sh_off(int sh, int PRS) { return sh == 0 ? PRS + PROW : (sh == 1 ? PRS : (sh == 2 ? PROW : 0)); }   // in bytes (PRS: patch row stride)
 
 struct UpArgs {
     const float* x; const unsigned short* w_hi; const unsigned short* w_lo; float* y;
@@ -85,7 +92,9 @@ struct UpCfg {
     // products per weight stage (split-bf16: two planes of BOTH operands — three products fit beside the patch planes, one in the two-per-CU form)
     static constexpr int TS = GH == 16 ? (NA * NB == 1 ? 9 : (NA * NB == 2 ? 5 : 3)) : (NA * NB == 1 ? 5 : (NA * NB == 2 ? 3 : 1));
     static constexpr int NSTEP = (9 + TS - 1) / TS;
-    static constexpr int P_BYTES = PALLOC * PROW;
+    static constexpr int PRS = PW * PROW + PPAD;                       // bytes between patch rows
+    static_assert(((PRS / 16 - 5 * (GX - 1)) & 15) == 5, "patch row stride: a grid-row change must look like one pixel step to the LDS banks");
+    static constexpr int P_BYTES = PH * PRS;
     static constexpr int B_BYTES = BN * ROW, B_TAP = NB * B_BYTES, B_STAGE = TS * B_TAP;
     static constexpr int K_BYTES = 2 * NA * P_BYTES + 2 * B_STAGE;
     static constexpr int T_BYTES = TW * TH * 32 * 4;                   // t tile: TH x TW positions x 32 channels fp32
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     constexpr int WM = 32, TN = 2;              // a wave: 32 grid rows x all 64 channels x 4 phases = 128 accumulator registers
     constexpr int TS = CF::TS, NSTEP = CF::NSTEP;
     constexpr int P_BYTES = CF::P_BYTES, B_BYTES = CF::B_BYTES, B_TAP = CF::B_TAP, B_STAGE = CF::B_STAGE;
-    constexpr int PALLOC = CF::PALLOC, NPIX = CF::NPIX;
+    constexpr int PALLOC = CF::PALLOC, NPIX = CF::NPIX, PRS = CF::PRS;
     constexpr int NPL = (PALLOC * 8 + NT - 1) / NT;     // float4 patch loads per thread and chunk (5)
     constexpr int OR = CF::OR, OW = CF::OW, GX = CF::GX, GY = CF::GY, PW = CF::PW, TW = CF::TW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
 
     // ---- patch staging: element e = tid + j*NT -> patch pixel e / 8, float4 q = e % 8
     const int q = tid & 7;
-    int p_goff[NPL];
+    int p_goff[NPL], p_loff[NPL];
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
         const int pp = (tid + j * NT) >> 3;
@@ -147,8 +156,8 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         const int iy = y0 - 2 + pr, ix = x0 - 2 + pc;
         const bool v = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.H;
         p_goff[j] = v ? (((b * p.H + iy) * p.H + ix) * p.Ci + q * 4) * 4 : OOB;
+        p_loff[j] = pp < NPIX ? pr * PRS + pc * PROW + q * 8 : -1;
     }
-    const int p_lbase = (tid >> 3) * PROW + q * 8;
     float op_mult = 1.f, op_inv = 1.f;
     if (SCH != 0) wgsconv::operand_scale(p.a_amax, p.a_amax2, p.a_bound, op_mult, op_inv);      // (bf16 has fp32's exponent range: no operand scale)
     const int cpt = p.Ci / BK;
@@ -177,9 +186,9 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             const f32x4 f = {v.x, v.y, v.z, v.w};
             uint2 h, l;
             SC::cvt4(f, h, l);
-            if (((tid + j * NT) >> 3) < PALLOC) {
-                *reinterpret_cast<uint2*>(pb + p_lbase + j * (NT / 8) * PROW) = h;
-                if (NA == 2) *reinterpret_cast<uint2*>(pb + P_BYTES + p_lbase + j * (NT / 8) * PROW) = l;
+            if (p_loff[j] >= 0) {
+                *reinterpret_cast<uint2*>(pb + p_loff[j]) = h;
+                if (NA == 2) *reinterpret_cast<uint2*>(pb + P_BYTES + p_loff[j]) = l;
             }
         }
     };
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     const int l31 = lane & 31, lh = lane >> 5;
     const int m_a = wm * WM + l31;
     const int m_c = m_a < GX * GY ? m_a : GX * GY - 1;       // GEMM rows past the grid (252..255) shadow its last position
-    const int pa0 = ((m_c / GX) * PW + (m_c % GX)) * PROW + lh * 16;
+    const int pa0 = (m_c / GX) * PRS + (m_c % GX) * PROW + lh * 16;
     const int bswz = (l31 >> 2) & 3;
     const int b_rd = l31 * ROW;
     const int bk0 = ((0 + lh) ^ bswz) << 4, bk1 = ((2 + lh) ^ bswz) << 4;
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
         auto ld_a = [&](int q, frag* a) {
             const int ks = q / TS, t = s * TS + q % TS;
 #pragma unroll
-            for (int pl = 0; pl < NA; ++pl) a[pl] = *reinterpret_cast<const frag*>(pb + pl * P_BYTES + pa0 + sh_off(T_SH[t], PW) * PROW + ks * 32);
+            for (int pl = 0; pl < NA; ++pl) a[pl] = *reinterpret_cast<const frag*>(pb + pl * P_BYTES + pa0 + sh_off(T_SH[t], PRS) + ks * 32);
         };
         auto ld_b = [&](int q, frag (*b)[NB]) {
             const int ks = q / TS, u = q % TS;
