@@ -235,8 +235,10 @@ int wgs_conv_wino(const wgs_conv_desc* desc, const float* U, wgs_stream_t stream
  * bias, leaky-relu, alpha, y_amax); results equal the direct split-bf16 kernels' up to that arithmetic's own rounding (1e-5 against
  * fp64 convolutions).  Covered: all nine taps dy, dx in {-1, 0, 1} each exactly once (forward and input-gradient launches alike),
  * isy = osy = 1, ups 0, Hi = Ho % 8 == 0, Wi = Wo % 32 == 0, Ci % 32 == 0, Co % 128 == 0, act 0, act_slope in [0, 1], no addend /
- * x_f16 / col_stats / a_pixelnorm_eps; rgb_out (ToRGB in the epilogue, y then optional) with Co == 128 only (one tile holds every channel
- * of its pixels); row strides of a_scale / col_scale % 4 == 0, a sample's tensors < 2 GiB, and at
+ * x_f16 / col_stats / a_pixelnorm_eps; rgb_out (ToRGB in the epilogue, y then optional) with Co <= 512: a tile holds 128 channels of its
+ * pixels, so rgb_out is [B, Ho * Wo, 4 * Co / 128] — the 16-byte slot of channel block j at floats 4 j .. 4 j + 3 holds that block's partial
+ * sums (the whole sum at Co == 128); wgs_sg2_torgb_up_fwd(x = rgb_out, C = 4 * Co / 128, unit style, weight [3, C] with ones at [o, 4 j + o])
+ * adds the slots, the bias and the up-sampled skip; row strides of a_scale / col_scale % 4 == 0, a sample's tensors < 2 GiB, and at
  * least 200 workgroups (B * Hi / 8 * Wi / 32 * Co / 128): wgs_conv_wino16_supported() tells (1 / 0).
  * wgs_conv_wino16_weight: U (24 * Ci * Co uint16, caller-owned) = the launch's weights G g as bf16 hi / lo planes in the kernel's
  * B-fragment order (one layout: reusable by every covered launch of the same weights and taps).  wgs_conv_wino16 runs the launch with

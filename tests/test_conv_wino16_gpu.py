@@ -154,3 +154,44 @@ def test_wino16_torgb_in_the_epilogue(dev, keep_y):
         assert torch.equal(y, plain)
     ref = 0.25 * torch.einsum('bhwn,bn,on->bhwo', plain.double(), srgb[:, 100:100 + co].double(), wrgb.double())
     assert rel_err(rgb[..., :3], ref) < 2e-6 and float(rgb[..., 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('co', [256, 512])
+def test_wino16_torgb_partial_sums_per_channel_block(dev, co):
+    """rgb_out with 256 / 512 output channels: one 16-byte slot of partial channel sums per 128-channel block and pixel; the finishing launch
+    (wgs_sg2_torgb_up_fwd with C = 4 * Co / 128, unit style, tiled identity weight) adds the slots, the bias and the up-sampled skip — against the
+    stand-alone ToRGB launch on the layer's output."""
+    torch.manual_seed(22)
+    B, H, ci = 4, 64, 64
+    nb = co // 128
+    x = torch.randn(B, H, H, ci, device=dev)
+    wp = C.pack_weight(torch.randn(co, ci, 3, 3, device=dev) / (9 * ci) ** 0.5)
+    s, dm = torch.randn(B, ci, device=dev) + 1.0, torch.rand(B, co, device=dev) + 0.5
+    bias, noise, nw = torch.randn(co, device=dev), torch.randn(H * H, device=dev), torch.tensor([0.37], device=dev)
+    srgb = torch.randn(B, 1100, device=dev)
+    wrgb = torch.randn(3, co, device=dev)
+    epi = dict(a_scale=s, col_scale=dm, bias=bias, noise=noise, noise_w=nw, act_slope=0.2, gain=2 ** 0.5)
+    assert C.rgb_wino16_ok(x, wp, **epi)
+    plain = C.conv2d(x, wp, 3, pad=1, precision=C.BF16W, **epi)
+    rgb = torch.full((B, H, H, 4 * nb), 7.0, device=dev)
+    L.lib().wgs_dev_trace_kernels(1)
+    y = C.conv2d(x, wp, 3, pad=1, precision=C.BF16W, rgb=dict(out=rgb, s=srgb[:, 100:], ld=1100, w=wrgb, scale=0.25), **epi)
+    assert L.lib().wgs_dev_last_kernel().decode() == 'wino16_kernel<true, true>'
+    L.lib().wgs_dev_trace_kernels(0)
+    assert torch.equal(y, plain)
+    part = rgb.view(B, H, H, nb, 4)
+    ref = 0.25 * torch.einsum('bhwjn,bjn,ojn->bhwjo', plain.double().view(B, H, H, nb, 128), srgb[:, 100:100 + co].double().view(B, nb, 128),
+                              wrgb.double().view(3, nb, 128))
+    assert rel_err(part[..., :3], ref) < 2e-6 and float(part[..., 3].abs().max()) == 0.0
+    # the finishing launch against the stand-alone ToRGB (+ bias + up-sampled skip) on the stored output
+    rb, skip = torch.randn(3, device=dev), torch.randn(B, 3, H // 2, H // 2, device=dev)
+    k1 = torch.tensor([1., 3., 3., 1.], device=dev)
+    upk = (k1[:, None] * k1[None, :] / 64 * 4).contiguous()
+    img_a, img_b = torch.empty(B, 3, H, H, device=dev), torch.empty(B, 3, H, H, device=dev)
+    ones, eye = torch.ones(B, 4 * nb, device=dev), torch.eye(3, 4, device=dev).repeat(1, nb).contiguous()
+    st = L.stream()
+    L.check(L.lib().wgs_sg2_torgb_up_fwd(L.ptr(rgb), L.ptr(ones), 4 * nb, L.ptr(eye), L.ptr(rb), L.ptr(skip), L.ptr(upk), L.ptr(img_a),
+                                         B, H, H, 4 * nb, L.c_float(1.0), st), 'finish')
+    L.check(L.lib().wgs_sg2_torgb_up_fwd(L.ptr(plain), L.rawptr(srgb[:, 100:]), 1100, L.ptr(wrgb), L.ptr(rb), L.ptr(skip), L.ptr(upk), L.ptr(img_b),
+                                         B, H, H, co, L.c_float(0.25), st), 'torgb')
+    assert rel_err(img_a, img_b) < 2e-6

@@ -590,7 +590,7 @@ def rgb_wino16_ok(x, w_packed, **epi):
     tile of conv_wino_bf16.hip holds every channel of its pixels (StyleGAN2-256's last layer), and the kernel covers the launch."""
     B, H, W, Ci = x.shape
     Co = w_packed.shape[0]
-    if not (RGB_FUSED and Co == 128):
+    if not (RGB_FUSED and Co in (128, 256, 512)):        # (Co > 128: one partial sum per 128-channel block, rgb out = [B,H,W,4 * Co / 128])
         return False
     taps = [(ky - 1, kx - 1, ky * 3 + kx) for ky in range(3) for kx in range(3)]
     epi = {k: v for k, v in epi.items() if k != 'w_split'}

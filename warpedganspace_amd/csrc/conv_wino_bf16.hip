@@ -31,7 +31,8 @@
 //     (position, channel half) per (chunk, kernel row) straight into registers one kernel row ahead.
 //   * epilogue: the four positions of a pixel pair live in four waves: one exchange through LDS per channel half ([pair][position][64
 //     channels] fp32, 128 KB), then thread = (pair, channel quad): y0 / y1, demodulation, noise, bias, leaky-relu, two 16-byte stores;
-//     with 128 output channels optionally ToRGB (wgs_conv_desc.rgb_out) from the finished values, and then y need not be stored at all.
+//     optionally ToRGB (wgs_conv_desc.rgb_out) from the finished values — at 128 output channels the whole sum, and then y need not be stored at all;
+//     at 256 / 512 the 128-channel block's partial sum (a 16-byte slot per pixel and block; the caller's finishing launch adds the slots).
 #include <type_traits>
 #include "wgs_common.h"
 #include "conv_scheme.h"
@@ -79,7 +80,7 @@ struct W16Args {
     const float* noise;
     const float* noise_w;
     float* y_amax;
-    float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int rgb_ld;      // ToRGB in the epilogue (wgs_conv_desc.rgb_out; Co == 128: the tile holds every channel)
+    float* rgb_out; const float* rgb_s; const float* rgb_w; float rgb_scale; int rgb_ld;      // ToRGB in the epilogue (wgs_conv_desc.rgb_out [B,H,W,4 * Co / 128]: one partial sum per 128-channel block)
     int B, H, W, Ci, Co, a_ld, col_ld;
     float alpha, act_slope, gain;
 };
@@ -422,7 +423,8 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float t0 = wgsconv::dpp_sum16(racc[k][j][0]), t1 = wgsconv::dpp_sum16(racc[k][j][1]), t2 = wgsconv::dpp_sum16(racc[k][j][2]);
-                if (cq == 0) *reinterpret_cast<f32x4*>(p.rgb_out + ((size_t)b * p.H * p.W + (size_t)oy * p.W + ox + j) * 4) = (f32x4){t0, t1, t2, 0.f};
+                // (Co > 128: this channel block's PARTIAL sums, pixel = 4 * Co / 128 floats, block nb at floats 4 nb .. 4 nb + 3; the finishing launch adds them)
+                if (cq == 0) *reinterpret_cast<f32x4*>(p.rgb_out + (((size_t)b * p.H * p.W + (size_t)oy * p.W + ox + j) * ntn + nb) * 4) = (f32x4){t0, t1, t2, 0.f};
             }
         }
     }
@@ -447,7 +449,8 @@ bool w16_taps(const wgs_conv_desc* d, W16Taps& tp) {
 
 bool w16_ok(const wgs_conv_desc* d) {
     if (!d || !d->x || !d->w || d->x_f16 || d->col_stats || d->a_pixelnorm_eps > 0.f) return false;
-    if (d->rgb_out ? !(d->Co == 128 && d->rgb_s && d->rgb_w && d->rgb_ld >= d->Co) : !d->y) return false;       // ToRGB in the epilogue: one tile holds every channel; y optional
+    // ToRGB in the epilogue: a tile holds 128 channels of its pixels — every channel at Co == 128, else one of Co / 128 partial sums per pixel; y optional
+    if (d->rgb_out ? !(d->Co <= 512 && d->rgb_s && d->rgb_w && d->rgb_ld >= d->Co) : !d->y) return false;
     W16Taps tp;
     if (!w16_taps(d, tp)) return false;
     if (!(d->isy == 1 && d->isx == 1 && d->osy == 1 && d->osx == 1 && d->oy0 == 0 && d->ox0 == 0 && d->ups == 0 && d->Hg == d->Hi && d->Wg == d->Wi &&

@@ -277,7 +277,8 @@ class Generator(nn.Module):
             P['map'] = [(l.weight.contiguous(), l.bias.contiguous(), l.scale, l.lr_mul) for l in list(self.style)[1:]]
             P['const'] = self.input.input[0].permute(1, 2, 0).contiguous()       # [4,4,C] NHWC
             P['const_amax'] = P['const'].abs().max().reshape(1).contiguous()     # magnitude bound of the first layer's input
-            P['rgb_finish'] = (torch.ones(1024, 4, device=dev), torch.eye(3, 4, device=dev).contiguous())   # unit style / identity weight of a fused ToRGB's finish
+            # unit style / identity weight of a fused ToRGB's finish, per number of floats per pixel (4 per 128-channel block of partial sums)
+            P['rgb_finish'] = {nc: (torch.ones(1024, nc, device=dev), torch.eye(3, 4, device=dev).repeat(1, nc // 4).contiguous()) for nc in (4, 8, 16)}
         self._prep = P
         return P
 
@@ -463,15 +464,16 @@ class Generator(nn.Module):
                            gain=SQRT2, w_split=ly['wp_s'], y_amax=ymax, **sc_kw)
                 rgb_kw, keep = {}, True
                 key = ('rgb_halo', i, B, lp)
-                if i % 2 == 0 and lp == C.BF16W and Co == 128:
-                    # the F(2,3) split-bf16 kernel holds all 128 output channels of its pixels (StyleGAN2-256's last layer): ToRGB in its epilogue,
-                    # and without a backward to feed the layer's output is not stored at all
+                if i % 2 == 0 and lp == C.BF16W and Co in (128, 256, 512):
+                    # the F(2,3) split-bf16 kernel holds 128 output channels of its pixels: ToRGB in its epilogue — the whole sum at 128 channels
+                    # (StyleGAN2-256's last layer: without a backward to feed, the layer's output is not stored at all), one partial sum per
+                    # 128-channel block at 256 / 512 (the finishing launch adds them: the layer's output is not read back by a ToRGB launch)
                     key = ('rgb_w16', i, B)
                     if key not in self._route:
                         self._route[key] = C.rgb_wino16_ok(x, ly['wp'], **ckw)
                     if self._route[key]:
                         r_ = P['rgbs'][i // 2]
-                        rgbp = torch.empty(B, H, H, 4, device=dev)
+                        rgbp = torch.empty(B, H, H, 4 * (Co // 128), device=dev)
                         rgb_kw = dict(rgb=dict(out=rgbp, s=S[:, r_['off']:], ld=sumC, w=r_['w'], scale=r_['scale']))
                         keep = save or i + 1 < len(P['layers'])
                 elif i % 2 == 0 and Co <= 64:
@@ -495,11 +497,12 @@ class Generator(nn.Module):
                 img = torch.empty(B, 3, Hc, Hc, device=dev)
                 if rgbp is not None:
                     # the channel sums came out of the conv's epilogue: bias + up-sampled skip through the same kernel (C = 4, unit style)
-                    one4, eye34 = P['rgb_finish']
+                    nc = rgbp.shape[3]              # 4 floats per 128-channel block of the producing conv
+                    one4, eye34 = P['rgb_finish'][nc]
                     if B > one4.shape[0]:
-                        one4 = torch.ones(B, 4, device=dev)
-                    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(rgbp), L.ptr(one4[:B]), 4, L.ptr(eye34), L.ptr(r['bias']), L.ptr(skip),
-                                                     L.ptr(r['upk']), L.ptr(img), B, Hc, Hc, 4, L.c_float(1.0), st), 'torgb_finish')
+                        one4 = torch.ones(B, nc, device=dev)
+                    L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(rgbp), L.ptr(one4[:B]), nc, L.ptr(eye34), L.ptr(r['bias']), L.ptr(skip),
+                                                     L.ptr(r['upk']), L.ptr(img), B, Hc, Hc, nc, L.c_float(1.0), st), 'torgb_finish')
                 elif skip is not None:    # + Upsample(skip) (model.py:279-281), evaluated inside the ToRGB kernel's epilogue
                     L.check(lib.wgs_sg2_torgb_up_fwd(L.ptr(x), L.rawptr(S[:, r['off']:]), sumC, L.ptr(r['w']), L.ptr(r['bias']), L.ptr(skip),
                                                      L.ptr(r['upk']), L.ptr(img), B, Hc, Hc, r['C'], L.c_float(r['scale']), st), 'torgb_up')
