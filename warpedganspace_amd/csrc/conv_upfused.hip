@@ -178,11 +178,13 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     auto store_patch = [&](int buf) {
         if (WGS_UABL == 8 || WGS_UABL == 9) { asm volatile("" :: "v"(pr_[0].x), "v"(pr_[NPL - 1].w)); return; }
         unsigned char* pb = patch + buf * NA * P_BYTES;
+        // the power-of-two operand scale folded into the style HERE (not where the style is loaded: a use there waits for the chunk's loads at
+        // their issue): fl(x * s) * 2^k == fl(x * (s * 2^k)) bit for bit, both scalings are exact
+        const float4 scm = make_float4(sc.x * op_mult, sc.y * op_mult, sc.z * op_mult, sc.w * op_mult);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             float4 v = pr_[j];
-            v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
-            v.x *= op_mult; v.y *= op_mult; v.z *= op_mult; v.w *= op_mult;      // power of two: exact
+            v.x = __fmul_rn(v.x, scm.x); v.y = __fmul_rn(v.y, scm.y); v.z = __fmul_rn(v.z, scm.z); v.w = __fmul_rn(v.w, scm.w);
             const f32x4 f = {v.x, v.y, v.z, v.w};
             uint2 h, l;
             SC::cvt4(f, h, l);
@@ -358,6 +360,13 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             dev = fmaxf(dev, fabsf(kf[i] - kv[i >> 2] * kh[i & 3]));
         }
         sep = sep && dev <= 2e-7f * kmax;
+        // uniform values: as scalar registers the eight taps feed the packed FMAs through op_sel (no {k, k} vector pairs: 16 registers fewer in
+        // the blur, which runs while the other channel half's 64 accumulators are still live)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kh[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kh[i])));
+            kv[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kv[i])));
+        }
     }
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y ? p.y : reinterpret_cast<float*>(p.y_f16), 0, p.y ? p.y_bytes : 0, 0x00020000);
     // The consumer's fp16 operand plane, written here: f16_rn(y * style_next * 2^k).  k comes from an A-PRIORI bound of |y * style_next|
@@ -378,33 +387,40 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     const int lx = bslot % OW, strip = bslot / OW;
     const bool bl_live = bslot < OW * NSTRIP;
     float vmax = 0.f;
+    // T-tile byte offset of this lane's 16 accumulator rows (grid position of row r, phase (0, 0), channel l31), computed ONCE: the four phases
+    // and both channel halves add compile-time constants.  (Round 6: the offsets used to be re-derived — two wrap tests, a bound test under a
+    // saved exec mask, a 64-bit multiply-add — in front of every one of the 128 stores of a lane; now per group of four rows, 4 x 2 times per tile: ~1 500 of a wave's ~3 200 vector instructions
+    // per tile.)  GEMM rows past the grid (252 .. 255 of the 18 x 14 grid) shadow its last position in the A-fragment reads, so their
+    // accumulators ARE that position's values: they are stored to its slot (same bits from two lanes) instead of being masked out.
+    const int mb_t = wm * WM + 4 * lh;                   // this lane's first grid row; its 16 rows are mb_t + (r & 3) + 8 * (r >> 2)
+    auto t_off = [&](int r) {
+        int m = mb_t + (r & 3) + 8 * (r >> 2);
+        m = m < GX * GY ? m : GX * GY - 1;
+        const int gy = m / GX, gx = m - gy * GX;
+        return ((2 * gy * TW + 2 * gx) * 32 + l31) * 4;
+    };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (n0 + half * 32 >= p.Co) break;               // a half-filled column tile (Co = 32)
         {
             const float cs = aux_cs[half * 32 + l31];
             const float al = p.alpha * op_inv;
-            const int mb = wm * WM + 4 * lh;                 // this lane's first grid row; its 16 rows are mb + (r & 3) + 8 * (r >> 2)
-            const int mbq = mb / GX, mbr = mb - mbq * GX;
 #pragma unroll
-            for (int ph = 0; ph < 4; ++ph)
+            for (int rg = 0; rg < 16; rg += 4) {
+                const int o0 = t_off(rg), o1 = t_off(rg + 1), o2 = t_off(rg + 2), o3 = t_off(rg + 3);
 #pragma unroll
-                for (int r2 = 0; r2 < 16; r2 += 2) {
+                for (int ph = 0; ph < 4; ++ph) {
+                    const int po = ((ph >> 1) * TW + (ph & 1)) * 128;        // the phase's position offset: an immediate of the store
+                    unsigned char* tb = reinterpret_cast<unsigned char*>(T) + po;
                     // (acc * alpha) * column scale for two rows per packed multiply
-                    const f32x2 tv = f32x2{half ? acc[ph][1][r2] : acc[ph][0][r2], half ? acc[ph][1][r2 + 1] : acc[ph][0][r2 + 1]} * al * cs;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int r = r2 + e;
-                        const int cr = (r & 3) + 8 * (r >> 2);       // compile-time row offset (<= 27)
-                        int gx = mbr + cr, gy = mbq;
-                        if (gx >= GX) { gx -= GX; ++gy; }
-                        if (gx >= GX) { gx -= GX; ++gy; }
-                        if (gy < GY) {
-                            const int pos = (2 * gy + (ph >> 1)) * TW + 2 * gx + (ph & 1);
-                            T[pos * 32 + l31] = e ? tv.y : tv.x;
-                        }
-                    }
+                    const f32x2 ta = f32x2{half ? acc[ph][1][rg] : acc[ph][0][rg], half ? acc[ph][1][rg + 1] : acc[ph][0][rg + 1]} * al * cs;
+                    const f32x2 tc = f32x2{half ? acc[ph][1][rg + 2] : acc[ph][0][rg + 2], half ? acc[ph][1][rg + 3] : acc[ph][0][rg + 3]} * al * cs;
+                    *reinterpret_cast<float*>(tb + o0) = ta.x;
+                    *reinterpret_cast<float*>(tb + o1) = ta.y;
+                    *reinterpret_cast<float*>(tb + o2) = tc.x;
+                    *reinterpret_cast<float*>(tb + o3) = tc.y;
                 }
+            }
         }
         __syncthreads();
         if (bl_live) {
@@ -416,17 +432,25 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
             // (two channels per instruction throughout: v_pk_add / v_pk_mul; the leaky ReLU as max(a, 0.2 a), which equals the
             //  select for every finite a, signed zeros included)
             const f32x2 bv0 = {bv.x, bv.y}, bv1 = {bv.z, bv.w}, sn0 = {sn.x, sn.y}, sn1 = {sn.z, sn.w};
-            auto emit = [&](f32x2 a0, f32x2 a1, int ly) {
-                const int oy = 2 * y0 + ly;
-                const bool ok = oy < Ho && ox < Ho;
-                const float nz = aux_nz[ly * OW + lx];
+            // per-thread row base of the output address, the noise slot and the row bound: a row of the strip then costs one add, one
+            // compare and one select (round 6: each emit used to rebuild its address with a 64-bit multiply-add and a 32-bit multiply
+            // under a saved exec mask)
+            const int oy_s = 2 * y0 + strip * RS;                                  // first output row of this thread's strip
+            const int rstride = Ho * p.Co * 4;                                     // bytes between output rows (uniform)
+            const int off_s = ox < Ho ? (((b * Ho + oy_s) * Ho + ox) * p.Co + c) * 4 : OOB;
+            const int rows_ok = ox < Ho ? Ho - oy_s : 0;                           // rows k of the strip with k < rows_ok lie inside the image
+            const float* nz_s = aux_nz + strip * RS * OW + lx;
+            auto emit = [&](f32x2 a0, f32x2 a1, int k) {                           // k: row of the strip (compile-time at every call site)
+                const bool ok = k < rows_ok;
+                const float nz = nz_s[k * OW];
                 const f32x2 nz2 = {nz, nz};
                 a0 += nz2 + bv0; a1 += nz2 + bv1;
                 const f32x2 s0 = a0 * 0.2f, s1 = a1 * 0.2f;
                 a0 = f32x2{fmaxf(a0.x, s0.x), fmaxf(a0.y, s0.y)} * 1.4142135623730951f;
                 a1 = f32x2{fmaxf(a1.x, s1.x), fmaxf(a1.y, s1.y)} * 1.4142135623730951f;
-                if (ok) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a0.x), fabsf(a0.y))), fmaxf(fabsf(a1.x), fabsf(a1.y)));
-                const int off = ok ? (((b * Ho + oy) * Ho + ox) * p.Co + c) * 4 : OOB;
+                const float rmax = fmaxf(fmaxf(fmaxf(fabsf(a0.x), fabsf(a0.y)), fabsf(a1.x)), fabsf(a1.y));
+                vmax = fmaxf(vmax, ok ? rmax : 0.f);
+                const int off = ok ? off_s + k * rstride : OOB;
                 const u32x4 sv = {__float_as_uint(a0.x), __float_as_uint(a0.y), __float_as_uint(a1.x), __float_as_uint(a1.y)};
                 if (WGS_UABL == 7) { asm volatile("" :: "v"(sv), "v"(off)); return; }
                 __builtin_amdgcn_raw_buffer_store_b128(sv, ry, off, 0, 0);          // (y == NULL: zero-extent descriptor, the store is dropped)
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
                             a0 = __builtin_elementwise_fma(hlo[(rr - 3 + ky) & 3], kk, a0);
                             a1 = __builtin_elementwise_fma(hhi[(rr - 3 + ky) & 3], kk, a1);
                         }
-                        emit(a0, a1, strip * RS + rr - 3);
+                        emit(a0, a1, rr - 3);
                     }
                 }
             } else {
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
                                 const float4 v = win[(rr - 3 + ky) & 3][kx];
                                 a.x = fmaf(v.x, wv, a.x); a.y = fmaf(v.y, wv, a.y); a.z = fmaf(v.z, wv, a.z); a.w = fmaf(v.w, wv, a.w);
                             }
-                        emit(f32x2{a.x, a.y}, f32x2{a.z, a.w}, strip * RS + rr - 3);
+                        emit(f32x2{a.x, a.y}, f32x2{a.z, a.w}, rr - 3);
                     }
                 }
             }
