@@ -359,15 +359,19 @@ __global__ __launch_bounds__(512, 1) void wino16_kernel(const W16Args p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (nh == h && WGS_W16ABL != 4) {
+            // pair T = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh: the lane part and the column block in one of four base registers (row blocks
+            // 0 - 1 / 2 - 3 are 64 KB apart), the rest a multiple of 1 KB below 64 KB — an immediate of the store (ds_write2st64_b32 takes two of
+            // them; with one base the compiler spent a vector add per store on the offsets beyond a ds_write's 16 bits)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int jl = 0; jl < 2; ++jl)
 #pragma unroll
-                for (int jl = 0; jl < 2; ++jl)
+                for (int i = 0; i < 4; ++i) {
+                    int eo = (i < 2 ? 0 : 65536) + (4 * lh) * 1024 + pw * 256 + (jl * 32 + l31) * 4;
+                    asm volatile("" : "+v"(eo));        // (opaque: otherwise the two column blocks' stores are paired as ds_write2_b32, whose 8-bit offsets need an add per pair)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int T = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        *reinterpret_cast<float*>(smem + T * 1024 + pw * 256 + (jl * 32 + l31) * 4) = acc[i][jl][r];
-                    }
+                    for (int r = 0; r < 16; ++r)
+                        *reinterpret_cast<float*>(smem + eo + ((i & 1) * 32 + (r & 3) + 8 * (r >> 2)) * 1024) = acc[i][jl][r];
+                }
         }
         const int co = (nb << 7) + h * 64 + cq * 4;
         f32x4 cs = {1.f, 1.f, 1.f, 1.f}, bs = {0.f, 0.f, 0.f, 0.f};
