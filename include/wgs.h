@@ -349,6 +349,12 @@ int wgs_sg2_blur_noise_bias_act(const float* x, const float* kernel4x4, const fl
  * kernel4x4: the 16 taps as wgs_upfirdn2d takes them for that call. */
 int wgs_sg2_blur_bwd_f16(const float* dy, const float* kernel4x4, uint16_t* dt_hi, const float* a_amax, float a_bound,
                          int B, int H, int W, int C, wgs_stream_t stream);
+/* (ABI 10) The same with dy ALREADY an fp16 plane, dy_hi = f16_rn(dy * 2^k1), k1 from a_amax alone (a_bound 1: the plane wgs_sg2_act_bwd_f16
+ * writes with dy_bound = a_amax): the activation backward of an up-sampling layer (models/StyleGAN2/op/fused_act.py:19-48) then stores 2
+ * instead of 4 bytes per element and this pass reads 2 instead of 4.  Fed the same values, dt_hi is bit for bit what wgs_sg2_blur_bwd_f16
+ * makes of the fp32 tensor; against the fp32 route the gradient sees one more fp16 rounding in front of a 16-tap average. */
+int wgs_sg2_blur_bwd_f16_x16(const uint16_t* dy_hi, const float* kernel4x4, uint16_t* dt_hi, const float* a_amax, float a_bound,
+                             int B, int H, int W, int C, wgs_stream_t stream);
 
 /* The whole up-sampling StyledConv in one launch (fp16 operand schemes): modulated stride-2 transposed 3x3 conv
  * (ModulatedConv2d.forward upsample branch, models/StyleGAN2/model.py:201-212: F.conv_transpose2d + Blur(pad (1,1))),

@@ -74,6 +74,7 @@ def test_generator_backward_same_gradient(dev, monkeypatch):
     G = G.to(dev).eval()
     z = torch.randn(32, 512, device=dev)
     outs = []
+    monkeypatch.setattr(C, 'DY_PLANE_UP', False)      # (the route of the test below is not bit-identical to the fp32 route)
     for on in (True, False):
         monkeypatch.setattr(C, 'BLUR_BWD_F16', on)
         zz = z.clone().requires_grad_(True)
@@ -84,6 +85,47 @@ def test_generator_backward_same_gradient(dev, monkeypatch):
     assert torch.isfinite(outs[0]).all()
     # (the style-gradient reductions behind z use fp32 atomics: two runs of the SAME route differ in the last bits)
     assert (outs[0] - outs[1]).abs().max() <= 1e-5 * outs[1].abs().max()
+
+
+@pytest.mark.parametrize('B,C_,H,mag', [(8, 64, 64, 1.0), (4, 128, 32, 3e-6), (2, 32, 40, 7e4)])
+def test_plane_from_a_plane_has_the_bits_of_the_fp32_route(dev, B, C_, H, mag):
+    """wgs_sg2_blur_bwd_f16_x16: dy handed over as the fp16 plane f16_rn(dy * 2^k1) (k1 from a_amax alone) gives bit for bit the plane that
+    wgs_sg2_blur_bwd_f16 makes of the fp32 tensor holding the same (fp16-representable) values."""
+    torch.manual_seed(B * 10 + H)
+    dy = (torch.randn(B, H, H, C_, device=dev) * mag)
+    am = dy.abs().amax().reshape(1) * 1.7            # a bound, not the maximum
+    k1 = 12 - (torch.floor(torch.log2(am)).item() + 1)      # am * 2^k1 in [2^11, 2^12)
+    dyq = (dy * 2.0 ** k1).half()                            # the plane sg2_act_bwd_f16 would write
+    dy_vals = (dyq.float() * 2.0 ** -k1).contiguous()        # the values it holds
+    kf = blur_f().to(dev)
+    want = C.blur_bwd_f16(dy_vals, kf, am, 4.0)
+    got = C.blur_bwd_f16(dyq.view(torch.int16).contiguous(), kf, am, 4.0)
+    assert got.dtype == torch.int16 and torch.equal(got, want)
+
+
+def test_generator_backward_with_the_up_layers_dy_as_fp16_planes(dev, monkeypatch):
+    """conv.DY_PLANE_UP: the activation backward of an up-sampling layer stores its dy as an fp16 plane for the transposed blur.  One more fp16
+    rounding in front of a 16-tap average: the gradient moves by less than a fifth of the default arithmetic's own distance from the oracle
+    (3.8e-4 / 6.0e-4)."""
+    from tests import golden_inputs as GI
+    from warpedganspace_amd.stylegan2 import Generator
+    torch.manual_seed(0)
+    G = Generator(128, 512, 8)
+    G.load_state_dict(GI.fill_state_dict(G.state_dict(), 977))
+    G = G.to(dev).eval()
+    z = torch.randn(32, 512, device=dev)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(C, 'DY_PLANE_UP', on)
+        zz = z.clone().requires_grad_(True)
+        img = G([zz], precision='f16')[0]
+        gi = torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)
+        img.backward(gi)
+        outs.append(zz.grad.clone())
+    assert torch.isfinite(outs[0]).all()
+    d = float((outs[0] - outs[1]).abs().max() / outs[1].abs().max())
+    print('DY_PLANE_UP on vs off: %.2e' % d)
+    assert 0.0 < d <= 1.2e-4
 
 
 @pytest.mark.parametrize('with_gA,with_rgb', [(True, True), (True, False), (False, True)])

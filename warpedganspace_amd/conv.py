@@ -656,6 +656,13 @@ BLUR_BWD_F16 = True
 # The same for the stride-1 layers: sg2_act_bwd stores dy only as the fp16 plane of the gradient conv (wgs_sg2_act_bwd_f16), scaled
 # from an a-priori magnitude bound (wgs_sg2_dy_bound) since its own maximum is not known before it has run.
 DY_PLANE = True
+# Round 6, measured and left OFF: an UP-sampling layer's dy as an fp16 plane as well, where its transposed blur writes the gradient conv's plane
+# anyway (blur_bwd_f16_ok): sg2_act_bwd stores 2 instead of 4 bytes per element and the blur reads 2 instead of 4 (wgs_sg2_blur_bwd_f16_x16:
+# bit for bit the plane the fp32-input blur makes of the same values; the generator's gradient moves by 5e-5, one more fp16 rounding in front
+# of a 16-tap average).  Same-box A/B of the auto step, three alternations: 25.32 - 25.42 ms with the route, 25.13 - 25.37 ms without — the
+# 1.9 GB it removes were served from the memory-side cache (the blur reads what sg2_act_bwd has just written), and the route adds a bound launch
+# per layer.  tests/test_blur_bwd_f16_gpu.py keeps both forms covered.
+DY_PLANE_UP = False
 DY_PLANE_MIN_CO = 128       # (round 3: 256 — the plane then had only the LDS-DMA kernel, which re-reads every activation row nine times from L2;
                             #  planes of stride-1 launches with < 512 output columns now go through the patch kernel's XF16 form)
 # The LDS-DMA kernel addresses an fp16 operand plane through one buffer descriptor: its extent (2 bytes per element) must stay
@@ -682,10 +689,16 @@ def dy_plane_ok(B, Hc, Ci_dgrad, Co_dgrad, precision):
 
 
 def blur_bwd_f16(dy, blur_f, a_amax, a_bound):
+    """dt = transposed blur of dy as the fp16 operand plane of the stride-2 gradient conv; dy fp32, or (int16) the fp16 plane
+    sg2_act_bwd_f16 wrote with dy_bound = a_amax (wgs_sg2_blur_bwd_f16_x16)"""
     B, H, W, Cc = dy.shape
     dt = torch.empty(B, H + 1, W + 1, Cc, device=dy.device, dtype=torch.int16)
-    L.check(L.lib().wgs_sg2_blur_bwd_f16(L.ptr(dy), L.ptr(blur_f), L.ptr(dt, torch.int16), L.rawptr(a_amax), L.c_float(a_bound),
-                                         B, H, W, Cc, L.stream()), 'wgs_sg2_blur_bwd_f16')
+    if dy.dtype == torch.int16:
+        L.check(L.lib().wgs_sg2_blur_bwd_f16_x16(L.ptr(dy, torch.int16), L.ptr(blur_f), L.ptr(dt, torch.int16), L.rawptr(a_amax), L.c_float(a_bound),
+                                                 B, H, W, Cc, L.stream()), 'wgs_sg2_blur_bwd_f16_x16')
+    else:
+        L.check(L.lib().wgs_sg2_blur_bwd_f16(L.ptr(dy), L.ptr(blur_f), L.ptr(dt, torch.int16), L.rawptr(a_amax), L.c_float(a_bound),
+                                             B, H, W, Cc, L.stream()), 'wgs_sg2_blur_bwd_f16')
     return dt
 
 

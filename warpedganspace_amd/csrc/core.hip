@@ -64,7 +64,7 @@ const WgsFlags& wgs_flags() { return flags_storage(); }
 
 extern "C" {
 const char* wgs_last_error(void) { return g_err; }
-int wgs_abi_version(void) { return 9; }      // 9: wgs_conv_wino16* (split-bf16 F(2,3) form of the 3x3 stride-1 convs).  8: wgs_wgrad_desc.ws / ws_bytes (direct-fragment weight gradients); split-bf16 in wgs_sg2_upconv_blur_act.  7: wgs_sample_step; split-bf16 weight gradients with few input channels.  6: wgs_conv_wino_layout; fp16 activation planes
+int wgs_abi_version(void) { return 10; }     // 10: wgs_sg2_blur_bwd_f16_x16 (transposed blur of an fp16 gradient plane).  9: wgs_conv_wino16* (split-bf16 F(2,3) form of the 3x3 stride-1 convs).  8: wgs_wgrad_desc.ws / ws_bytes (direct-fragment weight gradients); split-bf16 in wgs_sg2_upconv_blur_act.  7: wgs_sample_step; split-bf16 weight gradients with few input channels.  6: wgs_conv_wino_layout; fp16 activation planes
 void wgs_dev_reload_flags(void) { flags_storage() = read_flags(); }
 int64_t wgs_dev_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
 void wgs_dev_trace_kernels(int on) { g_trace.store(on ? 1 : 0, std::memory_order_relaxed); g_kernel[0] = 0; }

@@ -10,6 +10,9 @@
 // F16 (without EPI): the result is stored as the fp16 operand plane of the consuming conv, hi = f16_rn(out * 2^k) with the
 // power of two of conv_scheme.h's operand_scale(a_amax, a_bound) — exactly what that conv's own staging (or the LDS-DMA
 // pre-pass) would make of the fp32 tensor, which is then never written: half the store bytes, no pre-pass.
+// XF16 (with F16, round 6): the INPUT is an fp16 plane too, f16_rn(in * 2^k1) with k1 from operand_scale(a_amax, 1) (sg2_act_bwd's dy as the
+// plane it writes for a gradient conv): read as 8 bytes per four channels, filtered in fp32, rescaled by the exact power of two 2^(k - k1).  Fed
+// the same values, bit for bit the plane the fp32-input form writes (a power-of-two scaling commutes with every rounding of the filter).
 #pragma once
 #include "wgs_common.h"
 #include "conv_scheme.h"
@@ -18,15 +21,21 @@ namespace wgsfir {
 
 constexpr int TY = 16;
 
-template <bool EPI, bool F16 = false>
+template <bool EPI, bool F16 = false, bool XF16 = false>
 __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, const float* __restrict__ kern,
                                                    float* __restrict__ y, int B, int Hin, int Win, int Ho, int Wo, int C,
                                                    int py0, int px0, const float* __restrict__ noise,
                                                    const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                    float* __restrict__ y_amax, const float* __restrict__ a_amax, float a_bound) {
     static_assert(!(EPI && F16), "the fp16 plane is the operand of a gradient conv: no epilogue");
+    static_assert(!XF16 || F16, "an fp16 input plane is filtered into an fp16 output plane");
     float op_mult = 1.f, op_inv = 1.f;
     if (F16) wgsconv::operand_scale(a_amax, nullptr, a_bound, op_mult, op_inv);
+    if (XF16) {       // the input carries 2^k1: what is left to apply is 2^(k - k1)
+        float in_mult, in_inv;
+        wgsconv::operand_scale(a_amax, nullptr, 1.f, in_mult, in_inv);
+        op_mult *= in_inv;
+    }
     float kf[16];
     float vmax = 0.f;
 #pragma unroll
@@ -48,6 +57,7 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI) bv = *reinterpret_cast<const float4*>(bias + c);
     const float* xb = x + (size_t)b * Hin * Win * C + c;
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x) + (size_t)b * Hin * Win * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
     const int ix0 = ox - px0;
     float4 win[4][5];
@@ -59,7 +69,13 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
         for (int kx = 0; kx < 5; ++kx) {
             const int ix = ix0 + kx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowok && ix >= 0 && ix < Win) v = *reinterpret_cast<const float4*>(xb + ((size_t)iy * Win + ix) * C);
+            if (rowok && ix >= 0 && ix < Win) {
+                if (XF16) {
+                    const uint2 h = *reinterpret_cast<const uint2*>(xh + ((size_t)iy * Win + ix) * C);
+                    const wgsconv::sch_f16x4 hv = __builtin_bit_cast(wgsconv::sch_f16x4, h);
+                    v = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+                } else v = *reinterpret_cast<const float4*>(xb + ((size_t)iy * Win + ix) * C);
+            }
             win[rr & 3][kx] = v;
         }
         if (rr >= 3) {
@@ -105,13 +121,13 @@ __global__ __launch_bounds__(256) void fir4_kernel(const float* __restrict__ x, 
     }
 }
 
-template <bool EPI, bool F16 = false>
+template <bool EPI, bool F16 = false, bool XF16 = false>
 inline void launch_fir4(const float* x, const float* kern, float* y, int B, int Hin, int Win, int Ho, int Wo, int C, int py0,
                         int px0, const float* noise, const float* noise_w, const float* bias, hipStream_t st, float* y_amax = nullptr,
                         const float* a_amax = nullptr, float a_bound = 1.f) {
     const int strips = (Ho + TY - 1) / TY;
     const long total = (long)B * strips * ((Wo + 1) / 2) * (C / 4);
-    WGS_LAUNCH((fir4_kernel<EPI, F16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
+    WGS_LAUNCH((fir4_kernel<EPI, F16, XF16>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, kern, y, B, Hin, Win, Ho, Wo,
                        C, py0, px0, noise, noise_w, bias, y_amax, a_amax, a_bound);
 }
 

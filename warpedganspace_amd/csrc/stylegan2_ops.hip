@@ -930,6 +930,17 @@ int wgs_sg2_blur_bwd_f16(const float* dy, const float* kernel4x4, uint16_t* dt_h
     return WGS_OK;
 }
 
+int wgs_sg2_blur_bwd_f16_x16(const uint16_t* dy_hi, const float* kernel4x4, uint16_t* dt_hi, const float* a_amax, float a_bound,
+                             int B, int H, int W, int C, wgs_stream_t stream) {
+    WGS_CHECK_ARG(dy_hi && kernel4x4 && dt_hi && a_amax, "wgs_sg2_blur_bwd_f16_x16: null pointer");
+    WGS_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "wgs_sg2_blur_bwd_f16_x16: bad sizes (C %% 4)");
+    WGS_CHECK_ARG(a_bound > 0.f, "wgs_sg2_blur_bwd_f16_x16: a_bound must be positive");
+    wgsfir::launch_fir4<false, true, true>(reinterpret_cast<const float*>(dy_hi), kernel4x4, reinterpret_cast<float*>(dt_hi), B, H, W, H + 1, W + 1, C,
+                                           2, 2, nullptr, nullptr, nullptr, (hipStream_t)stream, nullptr, a_amax, a_bound);
+    WGS_CHECK_LAUNCH("fir4_kernel<f16 plane from an f16 plane>");
+    return WGS_OK;
+}
+
 int wgs_sg2_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, const float* skip, float* img,
                       int B, int P, int C, float wscale, wgs_stream_t stream) {
     WGS_CHECK_ARG(x && s && w && bias && img, "wgs_sg2_torgb_fwd: null pointer");

@@ -573,6 +573,10 @@ class Generator(nn.Module):
             # only as that conv's fp16 operand plane, scaled from an a-priori bound of its magnitude (its own maximum is not known
             # before the kernel has run): max|gA| from the producing conv's epilogue, max|drgb| <= 4^levels * max|dimg|
             plane = (not ly['up']) and C.dy_plane_ok(B, Hc, Co, ly['Ci'], lp) and (gA is None or gA_amax is not None)
+            # an up-sampling layer's dy has one consumer too, the transposed blur: where that writes the gradient conv's fp16 plane, dy reaches it
+            # as an fp16 plane as well (same a-priori bound; conv.DY_PLANE_UP)
+            if ly['up'] and C.DY_PLANE_UP and C.blur_bwd_f16_ok(B, Hc, Co, ly['Ci'], lp) and (gA is None or gA_amax is not None):
+                plane = True
             rgb_args = (L.ptr(dskip if has_rgb else None), L.ptr(r['w']) if has_rgb else None, L.rawptr(sR),
                         L.c_float(r['scale'] if has_rgb else 0.0))
             if plane:
