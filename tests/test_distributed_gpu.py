@@ -23,6 +23,14 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _failure_text(r):
+    """what a failed launcher run said: the lines that name a cause (a rank's traceback, a GPU memory fault, an HSA status) from anywhere in
+    its stderr — the runtime's queue dump behind a fault is thousands of lines long and used to push them out of the tail — then the tails"""
+    import re
+    key = [ln for ln in r.stderr.splitlines() if re.search(r'fault|HSA_STATUS|hipError|Traceback|Error:|error:|Aborted|out of memory', ln)]
+    return '\n'.join(key[:40]) + '\n--- stdout tail ---\n' + r.stdout[-1500:] + '\n--- stderr head ---\n' + r.stderr[:1500] + '\n--- stderr tail ---\n' + r.stderr[-1500:]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -170,7 +178,7 @@ def _bench_two_ranks(backend, tmp_path):
     cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--dist-backend', backend, '--steps', '3', '--warmup', '2', '--batch', '4',
            '--size', '32', '-K', '16', '-N', '4', '--no-cpu-baseline', '--no-extra', '--extra-out', side]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=repo))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0, _failure_text(r)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 alone prints the record
     assert len(lines[0]) < 4096                               # the driver keeps ~8 KB of stdout: the N > 1 line obeys the size cap too
@@ -286,7 +294,7 @@ def test_bench_eight_ranks_end_to_end_over_gloo(tmp_path):
     cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8', '--dist-backend', 'gloo', '--steps', '2', '--warmup', '1', '--batch', '2',
            '--size', '32', '-K', '16', '-N', '4', '--no-cpu-baseline', '--no-extra', '--no-direct-run', '--extra-out', side]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, PYTHONPATH=repo))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0, _failure_text(r)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1 and len(lines[0]) < 4096
     d = json.loads(lines[0])
