@@ -44,7 +44,8 @@ if os.path.exists(pmc):
 he = os.path.join(go, tag + '_host_enqueue_8.json')
 if os.path.exists(he) and os.path.getsize(he) > 10:
     shutil.copy(he, os.path.join(pr, rnd + '_host_enqueue_8_processes.json'))
-for src, dst in ((tag + '_wgrad_bench.txt', rnd + '_wgrad_bench.txt'), (tag + '_wgrad_pmc.txt', rnd + '_wgrad_pmc.txt'),
+for src, dst in ((tag + '_wino16_bench.txt', rnd + '_wino16_bench.txt'), (tag + '_ab_schedule.txt', rnd + '_ab_schedule.txt'),
+                 (tag + '_upfused_bench.txt', rnd + '_upfused_bench.txt'), (tag + '_wgrad_bench.txt', rnd + '_wgrad_bench.txt'), (tag + '_wgrad_pmc.txt', rnd + '_wgrad_pmc.txt'),
                  (tag + '_precision_schemes.json', rnd + '_precision_schemes.json')):
     if os.path.exists(os.path.join(go, src)) and os.path.getsize(os.path.join(go, src)) > 10:
         shutil.copy(os.path.join(go, src), os.path.join(pr, dst))

@@ -26,6 +26,10 @@ for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 find gpurun_out/pmc_${TAG} -name "*kernel_trace.csv" -delete
 python tools/pmc_r3.py --summarise gpurun_out/pmc_${TAG} gpurun_out/${TAG}_conv_pmc | tail -16 | cut -c1-220
+# round 6: the F(2,3) split-bf16 kernel against the direct kernels, and the schedule A/B of the auto step (the critical chain alone)
+timeout 300 python tools/bench_wino16.py > gpurun_out/${TAG}_wino16_bench.txt 2>&1
+timeout 600 python tools/ab_tail.py --precision auto --rounds 2 --only "baseline,chain only (static un-shifted batch: NOT training),mid stage behind R,baseline again" > gpurun_out/${TAG}_ab_schedule.txt 2>&1
+timeout 300 python tools/bench_upfused.py f16 f16x2 bf16x3 > gpurun_out/${TAG}_upfused_bench.txt 2>&1
 if [ "$3" = "lite" ]; then exit 0; fi
 timeout 900 python tools/host_enqueue_n.py 8 auto | tail -1 > gpurun_out/${TAG}_host_enqueue_8.json
 # round 5: weight-gradient kernels (micro-benchmark + PMC passes), the reported-only rows of the precision table
