@@ -228,7 +228,9 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     // ---- operand fragment addressing
     const int l31 = lane & 31, lh = lane >> 5;
     const int m_a = wm * WM + l31;
-    const int m_c = m_a < GX * GY ? m_a : GX * GY - 1;       // GEMM rows past the grid (252..255) shadow its last position
+    // GEMM rows past the grid (252 .. 255 of the 18 x 14 grid) shadow the position 16 rows back: the same addresses as lanes 12 - 15, which
+    // ds_read_b128 serves in the OTHER lane group — shadowing the last position (251) put four lanes on the bank slot of lane 11 (row 235)
+    const int m_c = m_a < GX * GY ? m_a : m_a - 16;
     const int pa0 = (m_c / GX) * PRS + (m_c % GX) * PROW + lh * 16;
     const int bswz = (l31 >> 2) & 3;
     const int b_rd = l31 * ROW;
@@ -390,12 +392,12 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     // T-tile byte offset of this lane's 16 accumulator rows (grid position of row r, phase (0, 0), channel l31), computed ONCE: the four phases
     // and both channel halves add compile-time constants.  (Round 6: the offsets used to be re-derived — two wrap tests, a bound test under a
     // saved exec mask, a 64-bit multiply-add — in front of every one of the 128 stores of a lane; now per group of four rows, 4 x 2 times per tile: ~1 500 of a wave's ~3 200 vector instructions
-    // per tile.)  GEMM rows past the grid (252 .. 255 of the 18 x 14 grid) shadow its last position in the A-fragment reads, so their
+    // per tile.)  GEMM rows past the grid (252 .. 255 of the 18 x 14 grid) shadow the position 16 rows back in the A-fragment reads, so their
     // accumulators ARE that position's values: they are stored to its slot (same bits from two lanes) instead of being masked out.
     const int mb_t = wm * WM + 4 * lh;                   // this lane's first grid row; its 16 rows are mb_t + (r & 3) + 8 * (r >> 2)
     auto t_off = [&](int r) {
         int m = mb_t + (r & 3) + 8 * (r >> 2);
-        m = m < GX * GY ? m : GX * GY - 1;
+        m = m < GX * GY ? m : m - 16;
         const int gy = m / GX, gx = m - gy * GX;
         return ((2 * gy * TW + 2 * gx) * 32 + l31) * 4;
     };
