@@ -54,3 +54,35 @@ def test_patch_rows_are_conflict_free_for_both_tile_shapes():
 def test_the_unpadded_layout_has_the_conflicts_the_counters_showed():
     prow = _const('PROW')
     assert _worst_conflict(18, 14, prow, 0) == 2 and _worst_conflict(16, 8, prow, 0) == 2
+
+
+def _store_groups_without_conflict(gx, gy, prow, ppad, nt, permute):
+    """share of the patch staging's ds_write_b64 lane groups (16 contiguous lanes, 8 bytes each, bank = (address / 4) mod 32) that touch 32
+    different banks; pixel of an 8-lane group as in the kernel: within an aligned run of eight pixels in the order 0 4 1 5 2 6 3 7"""
+    pw, ph = gx + 1, gy + 1
+    prs = pw * prow + ppad
+    npix = pw * ph
+    palloc = (npix + 7) // 8 * 8
+    good = total = 0
+    for j in range((palloc * 8 + nt - 1) // nt):
+        for g0 in range(0, nt, 16):
+            banks, n = set(), 0
+            for tid in range(g0, g0 + 16):
+                pl = (tid + j * nt) >> 3
+                pp = (pl & ~7) | ((pl & 7) >> 1) | ((pl & 1) << 2) if permute else pl
+                if pp >= npix:
+                    continue
+                a = (pp // pw) * prs + (pp % pw) * prow + (tid & 7) * 8
+                banks.update({(a // 4) % 32, (a // 4 + 1) % 32})
+                n += 2
+            if n:
+                total += 1
+                good += len(banks) == n
+    return good / total
+
+
+def test_patch_stores_pair_pixels_sixteen_banks_apart():
+    prow, ppad = _const('PROW'), _const('PPAD')
+    for gx, gy, nt in ((18, 14, 512), (16, 8, 256)):
+        assert _store_groups_without_conflict(gx, gy, prow, ppad, nt, False) <= 0.05         # adjacent pixels (80 B) overlap on 4 banks
+        assert _store_groups_without_conflict(gx, gy, prow, ppad, nt, True) >= 0.75          # (what is left: pairs that straddle a padded patch row)

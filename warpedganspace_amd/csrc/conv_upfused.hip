@@ -151,7 +151,10 @@ __global__ __launch_bounds__(32 * GH, GH == 8 ? 2 : 1) void upconv_blur_kernel(c
     int p_goff[NPL], p_loff[NPL];
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-        const int pp = (tid + j * NT) >> 3;
+        // pixel of this 8-lane group: within every aligned run of eight pixels the groups take them in the order 0 4 1 5 2 6 3 7, so that the two pixels
+        // of a ds_write_b64 lane group are 4 pixels = 320 B = 16 banks (mod 32) apart: adjacent pixels (80 B) overlapped on 4 of the 32 banks
+        const int pl = (tid + j * NT) >> 3;
+        const int pp = (pl & ~7) | ((pl & 7) >> 1) | ((pl & 1) << 2);
         const int pr = pp / PW, pc = pp - pr * PW;
         const int iy = y0 - 2 + pr, ix = x0 - 2 + pc;
         const bool v = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.H;
