@@ -429,13 +429,13 @@ EXTRA = [
     ("cfg3 StyleGAN2-256 mixed: the UN-calibrated default table (reported only: on this initialisation single images sit on the 1e-3 gate)", 'stylegan2', 256, 128, 32, 32, 'mixed', 'auto', False, 30, 'stylegan2-256', 'cfg3_mixed_uncalibrated'),
     ("cfg3 StyleGAN2-256 auto, reconstructor convs in exact fp32 [R fp32]", 'stylegan2', 256, 128, 32, 32, 'auto', 'fp32', False, 20, 'stylegan2-256', 'cfg3_auto_Rfp32'),
     ("cfg3 StyleGAN2-256 auto, W-space", 'stylegan2', 256, 128, 32, 32, 'auto', 'auto', True, 10, 'stylegan2-256', 'cfg3_auto_Wspace'),
-    ("cfg2 ProgGAN native 1024, K=64 N=16 B=32, auto", 'proggan', 1024, 64, 16, 32, 'auto', 'auto', False, 10, 'proggan-1024', 'cfg2_proggan1024_auto'),
+    ("cfg2 ProgGAN native 1024, K=64 N=16 B=32, auto", 'proggan', 1024, 64, 16, 32, 'auto', 'auto', False, 12, 'proggan-1024', 'cfg2_proggan1024_auto'),
     ("cfg2' ProgGAN truncated to 256 (first 14 blocks), K=64 N=16 B=32, auto", 'proggan', 256, 64, 16, 32, 'auto', 'auto', False, 8, 'proggan-256', 'cfg2_proggan256_auto'),
     ("cfg4 BigGAN-128 (the reference's architecture), K=128 N=32 B=16, auto", 'biggan', 128, 128, 32, 16, 'auto', 'auto', False, 8, 'biggan-128', 'cfg4_biggan128_auto'),
     ("cfg4' BigGAN-256 (generator_arch 256, class-conditional), K=128 N=32 B=16, auto", 'biggan', 256, 128, 32, 16, 'auto', 'auto', False, 6, None, 'cfg4_biggan256_auto'),
     ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp32 with the Winograd form (fp32w)", 'stylegan2', 1024, 200, 64, 8, 'fp32w', 'auto', False, 6, 'stylegan2-1024', 'cfg5_sg1024_fp32w'),
     ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, direct-form exact fp32", 'stylegan2', 1024, 200, 64, 8, 'fp32', 'auto', False, 3, 'stylegan2-1024', 'cfg5_sg1024_fp32'),
-    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, fp16 MFMA path = auto (this architecture's mixed policy: fp16 x2 in the 512^2 / 1024^2 layers)", 'stylegan2', 1024, 200, 64, 8, 'auto', 'auto', False, 12, 'stylegan2-1024', 'cfg5_sg1024_auto'),
+    ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, 16-bit MFMA path = auto (the table the engine calibrates on its generator; on this initialisation: split-bf16, the stride-1 layers in the F(2,3) form)", 'stylegan2', 1024, 200, 64, 8, 'auto', 'auto', False, 12, 'stylegan2-1024', 'cfg5_sg1024_auto'),
     ("cfg5 StyleGAN2-1024, K=200 N=64 B=8, bf16x3 everywhere", 'stylegan2', 1024, 200, 64, 8, 'bf16x3', 'auto', False, 6, 'stylegan2-1024', 'cfg5_sg1024_bf16x3'),
 ]
 
