@@ -35,8 +35,10 @@ def _run_launcher(cmd, timeout, repo):
     """bench.py through its launcher with N rank processes on ONE device.  With several rank processes SHARING a GPU (its hardware queues are then
     oversubscribed and the kernel driver time-slices them) about one launcher run in twenty loses a rank to `HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION`
     (measured in round 6: 1 / 20 and 1 / 12 with eight ranks, 3 / 6 on one box; the same with the library built from the round's first commit; 0 / 34
-    with HIP_LAUNCH_BLOCKING=1; never in hundreds of one-process-per-device runs).  That configuration exists only in these tests — a
-    deployment has one process per GPU — so THAT abort, and only that, is retried (twice); every other failure is reported at once."""
+    with HIP_LAUNCH_BLOCKING=1; never in hundreds of one-process-per-device runs; and never WITHOUT torch.distributed: eight concurrent processes
+    on one GPU ran 31 000 training steps of the same small engine and conv-only loops with no abort, tools/oversub_probe.py — it needs gloo
+    all-reducing device tensors through its host staging).  That configuration exists only in these tests — a deployment has one process
+    per GPU and RCCL — so THAT abort, and only that, is retried (twice); every other failure is reported at once."""
     import subprocess
     for attempt in range(3):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, PYTHONPATH=repo))
