@@ -44,6 +44,7 @@ static WgsFlags read_flags() {
     g.patch_wide = getenv("WGS_PATCH_WIDE") != nullptr;
     g.f32_small = getenv("WGS_F32_SMALL") != nullptr;      // exact fp32: 4-wave 128-row tiles only (no 8-wave tiles, no merged up-conv phases)
     g.wino_small = getenv("WGS_WINO_SMALL") != nullptr;      // Winograd fp32: 4-wave workgroups of 32 tiles x 64 channels, two per CU
+    g.wino_uord = !(getenv("WGS_WINO_UORD") && atoi(getenv("WGS_WINO_UORD")) == 0);      // Winograd fp32: an XCD's workgroups share one channel block of U instead of one input patch (0: the round-3 order)
     g.wino_narrow = getenv("WGS_WINO_NARROW") != nullptr;    // Winograd fp32: the 64-tile x 64-channel workgroup shape even where Cout % 128 == 0
     g.halo_min_tiles = getenv("WGS_HALO_MIN_TILES") ? atoi(getenv("WGS_HALO_MIN_TILES")) : 512;      // (tests: 1 = every covered shape)
     g.rbf_split = getenv("WGS_RBF_SPLIT") != nullptr;      // RBF forward as two launches (support vectors split over workgroups + finish)

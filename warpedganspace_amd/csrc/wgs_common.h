@@ -35,7 +35,8 @@ void wgs_set_error(const char* fmt, ...);
 // environment ONCE, when the first launch asks for them, and immutable afterwards — no getenv on launch paths, no mutable
 // global state.  All default to off = the measured-best path.
 struct WgsFlags { bool dma_always, phase_patch, no_patch, patch_bm256, patch_tps1, up_gh16, patch_ntf0, wgrad_per_tap, patch_wide, f32_small, f32_old, wino_narrow, wino_small;
-                  bool no_halo, rbf_split, check_ws, wgrad_staged, up_gh8, patch_nodma, patch_dma_bn256; int plane_patch_max_co, halo_min_tiles, patch_dma_bm, wino16_min_wg; };
+                  bool no_halo, rbf_split, check_ws, wgrad_staged, up_gh8, patch_nodma, patch_dma_bn256; int plane_patch_max_co, halo_min_tiles, patch_dma_bm, wino16_min_wg;
+                  bool wino_uord; };
 const WgsFlags& wgs_flags();
 
 // Launch accounting for bench.py (statistics only; nothing reads them on a launch path):
