@@ -51,7 +51,9 @@ typedef wgsconv::sch_bf16x8 frag;
                          // 3 = with DS / VMEM groups 1101, 4 = none 1145 — where an instruction sits inside a unit is not the lever
 #endif
 #ifndef WGS_W16ORD
-#define WGS_W16ORD 0     // 1: channel-block-major workgroup order (development A/B)
+#define WGS_W16ORD 1     // 1: channel-block-major workgroup order — an XCD's workgroups share one 128-channel slab of U instead of one input patch.  Alone the
+                         // launch is +-1 % either way; in the auto step (other streams competing for the memory system) 24.66 / 24.69 / 24.65 -> 24.59 / 24.59 / 24.55 ms,
+                         // same box, three alternations (round 6).  0: pixel tile major
 #endif
 #ifndef WGS_W16ABL
 #define WGS_W16ABL 0     // development ablations (tools/build_abl.sh w16abl): 1 no MFMAs, 2 no staging (loads, transform, LDS stores), 3 no U loads, 4 no epilogue exchange / stores,
